@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py — decode-step throughput of the MI355X paged-attention hot path.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1: plain python;
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   for N>1)
+
+One "step" = one decode step of ONE transformer layer's attention over one batch of synthetic
+input, i.e. the reference's per-layer call pair (vllmini/model/gpt2.py:44 then :62):
+    cache_ops.reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, "auto", 1.0)
+    paged_attention_v1(out, query, key_cache, value_cache, ...)
+through the drop-in Python surface -> C-ABI -> HIP kernels.  Inputs are resident in HBM before
+the timed region.  Default workload = BASELINE.json configs[2] ("cfg3": GPT-2 small heads,
+batch 256, seq 1024, block 16, num_blocks 32768), the configuration the metric is quoted on.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      achieved = algorithmic bytes of paged_attention_v1 / mean kernel
+                duration from HIP events recorded around every attention launch inside the timed
+                region, on the launch stream; peak = 8000 GB/s (MI355X HBM3E spec)
+  cpu_baseline  the reference's CPU fallback — PyTorch eager attention over the gathered pages
+                (oracle/eager.py, restating vllmini/model/gpt2.py:71-78) — timed on this box's host
+                cores on the same synthetic workload (rank 0, N=1 only)
+
+Multi-GPU: sequences are sharded over ranks as independent KV pools (weak scaling: `batch`
+sequences per GPU), no data-path collective; ranks only meet at the timing barriers.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from vllmini_amd import cache_ops, ops  # noqa: E402
+from vllmini_amd.workload import CONFIGS, make_workload  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--variant", type=int, default=0, help="force a kernel work decomposition (0 = heuristic)")
+    ap.add_argument("--sweep", action="store_true", help="time every kernel variant, write gpurun_out/sweep.json")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--sequential-tables", action="store_true",
+                    help="physically sequential pages instead of a random permutation (diagnostic)")
+    ap.add_argument("--ragged", action="store_true", help="seq_lens ~ U{1..L} (diagnostic)")
+    return ap.parse_args()
+
+
+def init_dist(n_gpus: int):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if n_gpus > 1 or world > 1:
+        import torch.distributed as dist
+
+        if world != n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                             f"--nproc-per-node {n_gpus}")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,  # "nccl" IS RCCL on ROCm
+                                device_id=torch.device("cuda", local_rank))
+        return dist, rank, world, local_rank
+    torch.cuda.set_device(0)
+    return None, 0, 1, 0
+
+
+def one_step(wl, out, i, variant):
+    """The reference's per-layer decode call pair, in its call order (gpt2.py:44, :62)."""
+    t = i % len(wl.tables)
+    c = wl.cfg
+    cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
+    ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
+                           wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0,
+                           0, 0, 1, 1, 0, _variant=variant)
+
+
+def time_steps(wl, out, steps, warmup, variant, dist, dev):
+    """W untimed steps, then EXACTLY K timed steps between barrier+synchronize pairs."""
+    c = wl.cfg
+    for i in range(warmup):
+        one_step(wl, out, i, variant)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        t = i % len(wl.tables)
+        cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
+        ev[i][0].record()  # HIP events on the launch stream (torch's current stream)
+        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
+                               wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0,
+                               0, 0, 1, 1, 0, _variant=variant)
+        ev[i][1].record()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    return elapsed, kern_ms
+
+
+def cpu_baseline(wl, steps):
+    """Reference CPU fallback: eager attention (gather by block_tables -> matmul/softmax/matmul)."""
+    from oracle.eager import torch_eager_decode  # checker/baseline only; never on the product path
+
+    c = wl.cfg
+    torch.set_num_threads(os.cpu_count() or 1)
+    kc, vc = wl.key_cache.cpu(), wl.value_cache.cpu()
+    q = wl.query.cpu().contiguous()
+    tab = wl.tables[0].cpu()
+    # bound the sample to ~10-30 s of CPU work: time one step, then decide how many to run
+    t0 = time.perf_counter()
+    torch_eager_decode(q, kc, vc, wl.scale, tab, c.seq_len, dtype=torch.float32)
+    first = time.perf_counter() - t0
+    n = max(1, min(steps, int(20.0 / max(first, 1e-3))))
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        torch_eager_decode(q, kc, vc, wl.scale, tab, c.seq_len, dtype=torch.float32)
+        ts.append(time.perf_counter() - t0)
+    med = statistics.median(ts)
+    return {
+        "value": c.batch / med, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "ms_per_step": med * 1e3,
+        "sample": f"full {c.name} batch ({c.batch} seqs x {c.seq_len} tokens, H{c.num_heads} D{c.head_size}), "
+                  f"fp32 torch eager incl. page gather, median of {n} steps after 1 warm-up, "
+                  f"{torch.get_num_threads()} threads",
+    }
+
+
+def main():
+    args = parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path exists for the product kernels)")
+    dist, rank, world, local_rank = init_dist(args.gpus)
+    dev = torch.device("cuda", local_rank)
+    cfg = CONFIGS[args.config]
+    wl = make_workload(cfg, dev, seed=1234 + rank, table_sets=2, ragged=args.ragged)
+    if args.sequential_tables:
+        for t, tab in enumerate(wl.tables):
+            per = cfg.num_blocks // len(wl.tables)
+            seq = torch.arange(cfg.batch * cfg.blocks_per_seq, dtype=torch.int32, device=dev) + t * per
+            tab[:, : cfg.blocks_per_seq] = seq.view(cfg.batch, cfg.blocks_per_seq)
+    out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
+
+    if args.sweep:
+        names = ops.variant_names()
+        res = []
+        for vid, name in enumerate(names, start=1):
+            if not name.startswith(f"d{cfg.head_size}_"):
+                continue
+            try:
+                _, kern_ms = time_steps(wl, out, args.steps, args.warmup, vid, dist, dev)
+            except RuntimeError as e:
+                res.append({"variant": vid, "name": name, "error": str(e)})
+                continue
+            us = statistics.mean(kern_ms) * 1e3
+            res.append({"variant": vid, "name": name, "us_mean": us, "us_median": statistics.median(kern_ms) * 1e3,
+                        "us_min": min(kern_ms) * 1e3, "gbps": cfg.algorithmic_bytes() / (us * 1e-6) / 1e9})
+            if rank == 0:
+                print(json.dumps(res[-1]), file=sys.stderr, flush=True)
+        if rank == 0:
+            os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(REPO, "gpurun_out", f"sweep_{cfg.name}.json"), "w") as f:
+                json.dump({"config": cfg.name, "picked": ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size,
+                                                                           cfg.seq_len), "results": res}, f, indent=1)
+        return
+
+    elapsed, kern_ms = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor([statistics.mean(kern_ms)], dtype=torch.float64, device=dev)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kern_mean_ms = float(k.item())
+    else:
+        kern_mean_ms = statistics.mean(kern_ms)
+
+    tokens = cfg.batch * world * args.steps          # one new token per sequence per step
+    ms_per_step = elapsed / args.steps * 1e3
+    achieved = cfg.algorithmic_bytes() / (kern_mean_ms * 1e-3) / 1e9
+    vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len)
+    line = {
+        "metric": "decode_tokens_per_sec_paged_attention_v1_per_layer",
+        "value": tokens / elapsed,
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{cfg.name}: paged_attention_v1+reshape_and_cache decode step, batch {cfg.batch}/GPU, "
+                        f"seq_len {cfg.seq_len}, {cfg.num_heads} heads x {cfg.head_size}, block_size {cfg.block_size}, "
+                        f"num_blocks {cfg.num_blocks}/GPU, fp16 KV, random-permutation block tables"
+                        + (" (SEQUENTIAL tables)" if args.sequential_tables else "")
+                        + (" (ragged lens)" if args.ragged else ""),
+            "global_batch": cfg.batch * world,
+            "seq_len": cfg.seq_len,
+            "parallelism": f"dp{world} (independent KV pools, no data-path collective)",
+            "kernel_variant": ops.variant_names()[vid - 1],
+        },
+        "paged_attention_v1_us_per_step": kern_mean_ms * 1e3,
+        "paged_attention_v1_us_median": statistics.median(kern_ms) * 1e3,
+        "paged_attention_v1_us_min": min(kern_ms) * 1e3,
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "kernel": "pa_v1_kernel",
+            "algorithmic_bytes_per_launch": cfg.algorithmic_bytes(),
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

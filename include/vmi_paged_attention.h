@@ -1,0 +1,143 @@
+/*
+ * vmi_paged_attention.h — C-ABI of the MI355X (gfx950) paged-attention decode path.
+ *
+ * This is the drop-in boundary for the two operators the reference's Python stack
+ * calls through its `paged_attention_cuda` extension module:
+ *
+ *   paged_attention_v1(...)            reference binding: paged_attention_ext/paged_attention_cuda/
+ *                                      paged_attention_cuda.cpp:7-25, :52 ; host entry
+ *                                      attention_kernels.cu:805-826 ; launcher :690-767
+ *   cache_ops.reshape_and_cache(...)   reference binding: paged_attention_cuda.cpp:58 ,
+ *                                      cache_kernels.h:11-14 ; host entry cache_kernels.cu:256-281
+ *
+ * The reference host entries take torch::Tensor and read sizes/strides from them
+ * (attention_kernels.cu:701-707, cache_kernels.cu:265-272).  Here every one of
+ * those values is an explicit argument: plain device pointers, sizes and element
+ * strides — no torch / pybind types.  The Python mirror (vllmini_amd/ops.py, re-exported
+ * under the reference's import name `paged_attention_cuda`) extracts them from the
+ * tensors exactly where the reference launcher does.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers on HIP device `device`;
+ *   - strides are in ELEMENTS (fp16 halves), as `tensor.stride(i)` reports them;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - calls are asynchronous: they enqueue kernels on `stream` and never synchronise;
+ *   - nothing is retained after return (no hidden workspace, no cached pointers);
+ *   - return value: 0 = launched; >0 = VMI_E_* validation code; <0 = -(hipError_t).
+ *     `vmi_last_error_string()` describes the last non-zero return on the calling thread.
+ *
+ * KV-cache layout (reference: vllmini/kv_cache.py:13-14, cache_kernels.cu:187-194):
+ *   key_cache   [num_blocks, num_kv_heads, head_size/x, block_size, x]   x = 8 halves (16 B)
+ *   value_cache [num_blocks, num_kv_heads, head_size,   block_size]
+ *   kv_block_stride = key_cache.stride(0), kv_head_stride = key_cache.stride(1) are applied
+ *   to BOTH caches, as the reference launcher does (attention_kernels.cu:706-707, 273-275, 402-403).
+ */
+#ifndef VMI_PAGED_ATTENTION_H
+#define VMI_PAGED_ATTENTION_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMI_ABI_VERSION 1
+
+/* validation codes (positive); HIP runtime errors are returned negated */
+enum {
+  VMI_OK = 0,
+  VMI_E_NULL_POINTER = 1,        /* a required pointer is NULL                                        */
+  VMI_E_HEAD_SIZE = 2,           /* "Unsupported head size"   (ref: attention_kernels.cu:763-765)     */
+  VMI_E_BLOCK_SIZE = 3,          /* "Unsupported block size"  (ref: attention_kernels.cu:800-802)     */
+  VMI_E_KV_HEADS = 4,            /* num_heads % num_kv_heads != 0 or non-positive                     */
+  VMI_E_ALIGNMENT = 5,           /* pointer/stride not 16-byte aligned where the kernel needs it      */
+  VMI_E_SHAPE = 6,               /* negative or inconsistent size                                     */
+  VMI_E_MAX_SEQ_LEN = 7,         /* logits for max_seq_len do not fit in the 160 KiB LDS of one CU    */
+  VMI_E_VARIANT = 8,             /* unknown tuning variant id                                         */
+  VMI_E_X = 9                    /* key_cache innermost dimension is not 8 halves                     */
+};
+
+/* Library identity / diagnostics. */
+int vmi_abi_version(void);
+const char* vmi_last_error_string(void);
+/* Compiled-for architecture string, e.g. "gfx950". */
+const char* vmi_target_arch(void);
+
+/*
+ * paged_attention_v1, fp16 query/out, fp16 ("auto") KV cache.
+ *
+ * Replaces: paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale,
+ *           block_tables, seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
+ *           kv_scale, tp_rank, blocksparse_*)          — attention_kernels.cu:805-826.
+ * The kv_cache_dtype/kv_scale/tp_rank/blocksparse arguments have no C counterpart: the
+ * Python mirror rejects every value other than the ones the reference callers pass
+ * ("auto", block-sparse disabled; vllmini/model/gpt2.py:94-113) before calling in.
+ *
+ *   out            [num_seqs, num_heads, head_size] fp16, contiguous          (written)
+ *   query          [num_seqs, num_heads, head_size] fp16, row stride q_stride (may be 3*hidden)
+ *   block_tables   [num_seqs, max_num_blocks_per_seq] int32; entries >= ceil(seq_len/block_size)
+ *                  are never read (the reference pads them with -1)
+ *   seq_lens       [num_seqs] int32; 0 => that sequence's output rows are zero
+ *   max_seq_len    upper bound on seq_lens[] (sizes the per-workgroup logits buffer in LDS,
+ *                  like the reference's dynamic shared memory, attention_kernels.cu:725-732)
+ *   alibi_slopes   [num_heads] fp32 or NULL
+ *
+ * Supported: head_size in {64, 128}, block_size == 16, x == 8.
+ */
+int vmi_paged_attention_v1_f16(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream);
+
+/*
+ * Same operator with an explicit tuning variant (work decomposition only — results are
+ * identical across variants up to fp32 summation order).  variant = 0 selects the
+ * built-in heuristic, i.e. exactly what vmi_paged_attention_v1_f16 runs.
+ * Used by bench.py / tests to sweep decompositions; not part of the reference surface.
+ */
+int vmi_paged_attention_v1_f16_variant(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream, int32_t variant);
+
+/* Number of tuning variants (valid ids are 1..count) and a short name for each. */
+int vmi_paged_attention_v1_variant_count(void);
+const char* vmi_paged_attention_v1_variant_name(int32_t variant);
+/* Variant id the heuristic would choose for this shape (>=1). */
+int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                        int32_t max_seq_len);
+
+/*
+ * cache_ops.reshape_and_cache, fp16 key/value into fp16 ("auto") caches.
+ *
+ * Replaces: reshape_and_cache(key, value, key_cache, value_cache, slot_mapping,
+ *           kv_cache_dtype, kv_scale)                   — cache_kernels.cu:256-281.
+ *
+ *   key, value     [num_tokens, num_heads, head_size] fp16, row strides key_stride / value_stride
+ *   slot_mapping   [num_tokens] int64; slot < 0 => token skipped (cache_kernels.cu:165-169);
+ *                  block = slot / block_size, offset = slot % block_size (cache_kernels.cu:172-173)
+ *   x              key_cache.size(4); must be 8
+ * Caches are dense in the layout above (the reference computes dense offsets from
+ * num_heads/head_size/block_size/x, cache_kernels.cu:187-194).
+ */
+int vmi_reshape_and_cache_f16(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping,
+    int32_t num_tokens, int32_t num_heads, int32_t head_size, int32_t block_size, int32_t x,
+    int64_t key_stride, int64_t value_stride,
+    int32_t device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMI_PAGED_ATTENTION_H */

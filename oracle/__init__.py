@@ -1,0 +1,27 @@
+"""CPU oracle for the paged-attention decode path — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this package,
+and only as the checker.  vllmini_amd/ (the product) never does.
+
+  kernel_model   C restatement of the reference CUDA kernel's arithmetic and rounding points
+                 (oracle/pa_kernel_model.c; attention_kernels.cu:86-496, cache_kernels.cu:152-207)
+  eager          numpy/torch restatement of the eager attention the reference tests its kernel
+                 against and uses where it has no kernel (vllmini/model/gpt2.py:71-78,
+                 vllmini/tests/kernels/paged_attention.py:102-110)
+
+Pin status: see pa_kernel_model.c header and DESIGN.md — "parity unpinned" against the CUDA
+kernel's own outputs (cannot be produced here), pinned against the reference's Python eager
+path via tests/golden/.
+"""
+from .kernel_model import (  # noqa: F401
+    build,
+    f2h,
+    h2f,
+    paged_attention_v1,
+    reshape_and_cache,
+)
+from .eager import (  # noqa: F401
+    eager_paged_attention,
+    gather_kv,
+    torch_eager_decode,
+)

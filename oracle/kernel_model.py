@@ -1,0 +1,132 @@
+"""ctypes wrapper around oracle/pa_kernel_model.c (numpy in, numpy out).  Test infrastructure."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_DIR, "pa_kernel_model.c")
+_OUT = os.path.join(_DIR, "_build", "liboracle_pa.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """gcc-compile the C restatement if missing/stale; returns the .so path."""
+    if force or not os.path.exists(_OUT) or os.path.getmtime(_OUT) < os.path.getmtime(_SRC):
+        os.makedirs(os.path.dirname(_OUT), exist_ok=True)
+        tmp = _OUT + ".tmp"
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+               _SRC, "-o", tmp, "-lm"]
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f"oracle build failed:\n{proc.stderr}")
+        os.replace(tmp, _OUT)
+    return _OUT
+
+
+def _load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        lib = ctypes.CDLL(build())
+        vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+        lib.vmi_oracle_paged_attention_v1_f16.restype = ctypes.c_int
+        lib.vmi_oracle_paged_attention_v1_f16.argtypes = [
+            vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, vp, i64, i64, i64, i32, i32]
+        lib.vmi_oracle_reshape_and_cache_f16.restype = ctypes.c_int
+        lib.vmi_oracle_reshape_and_cache_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64]
+        lib.vmi_oracle_f2h.restype = ctypes.c_uint16
+        lib.vmi_oracle_f2h.argtypes = [f32]
+        lib.vmi_oracle_h2f.restype = f32
+        lib.vmi_oracle_h2f.argtypes = [ctypes.c_uint16]
+        lib.vmi_oracle_hmul.restype = ctypes.c_uint16
+        lib.vmi_oracle_hmul.argtypes = [ctypes.c_uint16, ctypes.c_uint16]
+        lib.vmi_oracle_hadd.restype = ctypes.c_uint16
+        lib.vmi_oracle_hadd.argtypes = [ctypes.c_uint16, ctypes.c_uint16]
+        _lib = lib
+    return _lib
+
+
+def f2h(x: float) -> int:
+    return int(_load().vmi_oracle_f2h(float(x)))
+
+
+def h2f(h: int) -> float:
+    return float(_load().vmi_oracle_h2f(int(h)))
+
+
+def _elem_strides(a: np.ndarray) -> tuple[int, ...]:
+    return tuple(s // a.itemsize for s in a.strides)
+
+
+def _base_ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def paged_attention_v1(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
+                       num_kv_heads: int, scale: float, block_tables: np.ndarray,
+                       seq_lens: np.ndarray, block_size: int,
+                       alibi_slopes: np.ndarray | None = None, threads: int = 1) -> np.ndarray:
+    """Kernel-model output [num_seqs, num_heads, head_size] float16.
+
+    `query` may be a strided view (row stride = query.strides[0]); caches are float16 arrays in
+    the reference layout; block_tables int32 [S, MB]; seq_lens int32 [S].
+    """
+    assert query.dtype == np.float16 and key_cache.dtype == np.float16 and value_cache.dtype == np.float16
+    assert query.ndim == 3 and key_cache.ndim == 5 and value_cache.ndim == 4
+    S, H, D = query.shape
+    qs = _elem_strides(query)
+    assert qs[2] == 1 and qs[1] == D, "query must be dense in its last two dims"
+    key_cache = np.ascontiguousarray(key_cache)
+    value_cache = np.ascontiguousarray(value_cache)
+    block_tables = np.ascontiguousarray(block_tables, dtype=np.int32)
+    seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    assert block_tables.shape[0] == S and seq_lens.shape[0] == S
+    kb, kh = _elem_strides(key_cache)[:2]
+    out = np.zeros((S, H, D), dtype=np.float16)
+    alibi = None
+    if alibi_slopes is not None:
+        alibi = np.ascontiguousarray(alibi_slopes, dtype=np.float32)
+    lib = _load()
+
+    def run(lo: int, hi: int) -> int:
+        return lib.vmi_oracle_paged_attention_v1_f16(
+            _base_ptr(out), _base_ptr(query), _base_ptr(key_cache), _base_ptr(value_cache),
+            S, H, D, int(num_kv_heads), float(scale), _base_ptr(block_tables), _base_ptr(seq_lens),
+            int(block_size), int(block_tables.shape[1]),
+            None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh), lo, hi)
+
+    threads = max(1, min(int(threads), S))
+    if threads == 1:
+        rcs = [run(0, S)]
+    else:
+        bounds = np.linspace(0, S, threads + 1).astype(int)
+        with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL during the call
+            rcs = list(ex.map(lambda i: run(int(bounds[i]), int(bounds[i + 1])), range(threads)))
+    for rc in rcs:
+        if rc == 1:
+            raise RuntimeError(f"Unsupported head size / block size: {D} / {block_size}")
+        if rc != 0:
+            raise MemoryError("oracle allocation failed")
+    return out
+
+
+def reshape_and_cache(key: np.ndarray, value: np.ndarray, key_cache: np.ndarray,
+                      value_cache: np.ndarray, slot_mapping: np.ndarray) -> None:
+    """In-place scatter into contiguous float16 caches (reference layout)."""
+    assert key.dtype == np.float16 and value.dtype == np.float16
+    assert key_cache.dtype == np.float16 and value_cache.dtype == np.float16
+    assert key_cache.flags.c_contiguous and value_cache.flags.c_contiguous
+    T, H, D = key.shape
+    ks, vs = _elem_strides(key), _elem_strides(value)
+    assert ks[2] == 1 and ks[1] == D and vs[2] == 1 and vs[1] == D
+    slot_mapping = np.ascontiguousarray(slot_mapping, dtype=np.int64)
+    assert slot_mapping.shape == (T,)
+    rc = _load().vmi_oracle_reshape_and_cache_f16(
+        _base_ptr(key), _base_ptr(value), _base_ptr(key_cache), _base_ptr(value_cache),
+        _base_ptr(slot_mapping), T, H, D, int(key_cache.shape[3]), int(key_cache.shape[4]),
+        int(ks[0]), int(vs[0]))
+    assert rc == 0

@@ -1,0 +1,450 @@
+"""GPU parity: the HIP kernels, called through the drop-in Python surface -> C-ABI, against the CPU
+oracle (oracle/, checker only) on identical seeded inputs, plus the golden fixtures produced by the
+reference's own Python (tests/golden/), plus size-independent properties at BASELINE.json sizes.
+
+Tolerance (north_star: "within 1e-3 fp16" of the reference kernel): |hip - kernel_model| <= 1e-3
+absolute everywhere.  In practice the HIP kernel reproduces every fp16 rounding point of the
+reference, so most outputs are bit-identical and the rest differ by one fp16 ulp; the tests also
+assert that tighter, structural bound (<= 2 ulp of fp16 at the output's magnitude, or 2e-4 abs).
+
+Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import BS, make_case, ulp16
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-3          # north_star bound vs the reference kernel (model)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _ext():
+    import paged_attention_cuda as ext  # reference import name -> HIP build
+
+    from vllmini_amd import _lib
+
+    _lib.load()  # native library must be present: no fallback exists
+    return ext
+
+
+def run_hip(case, variant=0, out_shape=None, max_seq_len=None, alibi=None):
+    ext = _ext()
+    from vllmini_amd import ops
+
+    dev = _dev()
+    S, H, D = case["q"].shape
+    qbuf = torch.from_numpy(case["qbuf"]).to(dev)
+    q = qbuf[:, : H * D].view(S, H, D)
+    kc = torch.from_numpy(case["kc"]).to(dev)
+    vc = torch.from_numpy(case["vc"]).to(dev)
+    tab = torch.from_numpy(case["tables"]).to(dev)
+    lens = torch.from_numpy(case["lens"]).to(dev)
+    out = torch.full(out_shape or (S, H, D), float("nan"), dtype=torch.float16, device=dev)
+    msl = int(max_seq_len if max_seq_len is not None else max(int(case["lens"].max()), 1))
+    al = None if alibi is None else torch.from_numpy(alibi).to(dev)
+    if variant:
+        ops.paged_attention_v1(out, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, BS, msl, al,
+                               "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+    else:
+        ext.paged_attention_v1(out, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, BS, msl, al,
+                               "auto", 1.0, 0, 0, 1, 1, 0)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().reshape(S, H, D)
+
+
+def run_model(case, alibi=None):
+    return oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], case["num_kv_heads"], case["scale"],
+                                     case["tables"], case["lens"], BS, alibi_slopes=alibi, threads=8)
+
+
+def assert_close(got, ref, what=""):
+    got64, ref64 = got.astype(np.float64), ref.astype(np.float64)
+    assert np.isfinite(got64).all(), f"{what}: non-finite output"
+    d = np.abs(got64 - ref64)
+    assert d.max() <= ATOL, f"{what}: max|hip-model| = {d.max():.3e} > {ATOL}"
+    tight = np.maximum(2 * ulp16(ref64), 2e-4)
+    bad = d > tight
+    assert not bad.any(), f"{what}: {bad.sum()} outputs off by more than 2 fp16 ulp (max {d.max():.3e})"
+    return d.max(), float((d == 0).mean())
+
+
+# ------------------------------------------------------------------------------------------------
+# paged_attention_v1 vs the kernel model
+# ------------------------------------------------------------------------------------------------
+SHAPES = [
+    # (num_seqs, H, D, lens)
+    (1, 12, 64, [3]),                       # the reference test's own shape (tests/kernels/paged_attention.py:7-24)
+    (1, 12, 64, [32]),                      # BASELINE configs[0]
+    (6, 12, 64, [1, 15, 16, 17, 31, 33]),   # block-boundary edge cases
+    (4, 12, 64, [100, 1, 64, 257]),
+    (3, 12, 64, [1023, 1024, 513]),
+    (2, 32, 128, [40, 300]),                # Llama-shaped heads (configs[3] shape, small)
+    (5, 3, 64, [7, 70, 700, 16, 48]),       # num_heads not a multiple of 4
+    (2, 8, 128, [2048, 1999]),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: f"S{s[0]}_H{s[1]}_D{s[2]}_L{max(s[3])}")
+def test_pa_v1_matches_kernel_model_default_variant(shape):
+    S, H, D, lens = shape
+    rng = np.random.default_rng(1000 + S * 7 + H + D + sum(lens))
+    case = make_case(rng, S, H, D, lens, q_row_pad=2)  # q strided like the fused qkv view
+    got = run_hip(case)
+    ref = run_model(case)
+    assert_close(got, ref, f"shape {shape}")
+
+
+def _variants_for(D):
+    from vllmini_amd import ops
+
+    return [(i + 1, n) for i, n in enumerate(ops.variant_names()) if n.startswith(f"d{D}_")]
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_pa_v1_every_variant_matches_kernel_model(D):
+    """All work decompositions (heads/waves per workgroup, unroll depth, nt loads) give the same
+    result up to fp32 summation order."""
+    H = 8
+    lens = [1, 16, 17, 100, 333, 1024, 47, 2]
+    rng = np.random.default_rng(77 + D)
+    case = make_case(rng, len(lens), H, D, lens, q_row_pad=2, poison_tail=True)
+    ref = run_model(case)
+    for vid, name in _variants_for(D):
+        got = run_hip(case, variant=vid)
+        assert_close(got, ref, f"variant {name}")
+
+
+def test_pa_v1_nan_in_unowned_and_tail_slots_never_leaks():
+    rng = np.random.default_rng(5)
+    lens = [1, 5, 16, 21, 250]
+    case = make_case(rng, len(lens), 12, 64, lens, poison_tail=True, max_blocks=32)
+    got = run_hip(case, max_seq_len=32 * BS)  # capacity-style max_seq_len (scheduler.py:97)
+    ref = run_model(case)
+    assert_close(got, ref, "poisoned tails")
+
+
+def test_pa_v1_seq_len_zero_gives_zero_rows():
+    rng = np.random.default_rng(6)
+    case = make_case(rng, 3, 12, 64, [0, 20, 0], max_blocks=4)
+    got = run_hip(case, max_seq_len=64)
+    ref = run_model(case)
+    assert (got[0] == 0).all() and (got[2] == 0).all()
+    assert_close(got, ref, "L=0 rows")
+
+
+def test_pa_v1_out_with_extra_unit_dim_like_reference_test():
+    # reference test passes out as [S, H, 1, D] (tests/kernels/paged_attention.py:114)
+    rng = np.random.default_rng(7)
+    case = make_case(rng, 1, 12, 64, [3], max_blocks=4)
+    case["tables"][0] = [0, -1, -1, -1]  # the reference test's literal block table (:59)
+    case["kc"][0] = rng.standard_normal(case["kc"][0].shape).astype(np.float16)
+    case["vc"][0] = rng.standard_normal(case["vc"][0].shape).astype(np.float16)
+    got = run_hip(case, out_shape=(1, 12, 1, 64), max_seq_len=3)
+    ref = run_model(case)
+    assert_close(got, ref, "reference-test shape")
+    # and the reference test's own assertion: vs eager attention at atol 1e-2 (:138)
+    eager = oracle.eager_paged_attention(case["q"], case["kc"], case["vc"], 12, case["scale"], case["tables"],
+                                         case["lens"])
+    assert np.abs(got.astype(np.float64) - eager).max() <= 1e-2
+
+
+def test_pa_v1_gqa_and_alibi():
+    rng = np.random.default_rng(8)
+    lens = [33, 200, 16]
+    case = make_case(rng, 3, 8, 64, lens, num_kv_heads=2)
+    alibi = (2.0 ** -np.arange(1, 9)).astype(np.float32)
+    got = run_hip(case, alibi=alibi)
+    ref = run_model(case, alibi=alibi)
+    assert_close(got, ref, "gqa+alibi")
+
+
+def test_pa_v1_vs_exact_fp64_within_reference_tolerances():
+    """Sanity against the exact result: the reference's own bar is atol 1e-2 vs eager."""
+    rng = np.random.default_rng(9)
+    lens = [3, 32, 512, 1024]
+    case = make_case(rng, 4, 12, 64, lens, kv="normal")
+    got = run_hip(case).astype(np.float64)
+    exact = oracle.eager_paged_attention(case["q"], case["kc"], case["vc"], 12, case["scale"], case["tables"],
+                                         case["lens"])
+    d = np.abs(got - exact)
+    assert d.max() <= 1e-2
+    assert (d <= 1e-3 + 2e-3 * np.abs(exact)).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# reshape_and_cache: bit-exact
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,H,D,strided", [(1, 12, 64, True), (5, 12, 64, True), (37, 12, 64, False),
+                                           (256, 12, 64, True), (9, 32, 128, True), (4, 3, 80, False)])
+def test_reshape_and_cache_bit_exact(T, H, D, strided):
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(T * 131 + H + D)
+    NB = max(8, (T + BS - 1) // BS + 3)
+    kc = rng.standard_normal((NB, H, D // 8, BS, 8)).astype(np.float16)
+    vc = rng.standard_normal((NB, H, D, BS)).astype(np.float16)
+    width = 3 * H * D if strided else H * D
+    kbuf = rng.standard_normal((T, width)).astype(np.float16)
+    vbuf = rng.standard_normal((T, width)).astype(np.float16)
+    off = H * D if strided else 0
+    key = kbuf[:, off:off + H * D].reshape(T, H, D)
+    val = vbuf[:, off:off + H * D].reshape(T, H, D)
+    slots = rng.permutation(NB * BS)[:T].astype(np.int64)
+    if T >= 5:
+        slots[[1, 3]] = -1  # padding tokens are skipped (cache_kernels.cu:165-169)
+    t_kc, t_vc = torch.from_numpy(kc).to(dev), torch.from_numpy(vc).to(dev)
+    t_k = torch.from_numpy(kbuf).to(dev)[:, off:off + H * D].view(T, H, D)
+    t_v = torch.from_numpy(vbuf).to(dev)[:, off:off + H * D].view(T, H, D)
+    ext.cache_ops.reshape_and_cache(t_k, t_v, t_kc, t_vc, torch.from_numpy(slots).to(dev), "auto", 1.0)
+    torch.cuda.synchronize()
+    oracle.reshape_and_cache(key, val, kc, vc, slots)
+    assert np.array_equal(t_kc.cpu().numpy().view(np.uint16), kc.view(np.uint16))
+    assert np.array_equal(t_vc.cpu().numpy().view(np.uint16), vc.view(np.uint16))
+    # the reference test's own round-trip reading (tests/kernels/paged_attention.py:63-82)
+    got_k = t_kc.cpu().numpy()
+    for t in range(T):
+        if slots[t] < 0:
+            continue
+        b, o = divmod(int(slots[t]), BS)
+        assert np.array_equal(got_k[b, :, :, o, :].reshape(H, D), key[t])
+
+
+def test_reshape_and_cache_unaligned_rows_use_scalar_path():
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    T, H, D, NB = 6, 12, 64, 8
+    kc = np.zeros((NB, H, D // 8, BS, 8), dtype=np.float16)
+    vc = np.zeros((NB, H, D, BS), dtype=np.float16)
+    buf = rng.standard_normal((T, 2 * H * D + 4)).astype(np.float16)  # row stride not a multiple of 8
+    key = buf[:, 2:2 + H * D].reshape(T, H, D)                        # base not 16-byte aligned
+    val = buf[:, 2 + H * D:2 + 2 * H * D].reshape(T, H, D)
+    slots = np.array([0, 17, 33, 34, 100, 127], dtype=np.int64)
+    t_buf = torch.from_numpy(buf).to(dev)
+    t_kc, t_vc = torch.from_numpy(kc).to(dev), torch.from_numpy(vc).to(dev)
+    ext.cache_ops.reshape_and_cache(t_buf[:, 2:2 + H * D].view(T, H, D), t_buf[:, 2 + H * D:2 + 2 * H * D].view(T, H, D),
+                                    t_kc, t_vc, torch.from_numpy(slots).to(dev), "auto", 1.0)
+    torch.cuda.synchronize()
+    oracle.reshape_and_cache(key, val, kc, vc, slots)
+    assert np.array_equal(t_kc.cpu().numpy().view(np.uint16), kc.view(np.uint16))
+    assert np.array_equal(t_vc.cpu().numpy().view(np.uint16), vc.view(np.uint16))
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures generated from the reference's Python
+# ------------------------------------------------------------------------------------------------
+def test_golden_ref_eager_through_both_ops(golden_dir):
+    """key/value rows from the fixture go through reshape_and_cache, then paged_attention_v1, and the
+    result is compared with what the REFERENCE's eager attention produced for the same rows
+    (atol 1e-2 is the reference test's own bar; 2e-3 is what fp16 p.v rounding allows)."""
+    ext = _ext()
+    dev = _dev()
+    z = np.load(os.path.join(golden_dir, "ref_eager.npz"))
+    names = sorted({k.rsplit("/", 2)[0] for k in z.files})
+    rng = np.random.default_rng(11)
+    for name in names:
+        n_seq = len({k.split("/")[1] for k in z.files if k.startswith(name + "/")})
+        keys = [z[f"{name}/{s}/key"] for s in range(n_seq)]
+        H, D = keys[0].shape[1:]
+        lens = np.array([k.shape[0] for k in keys], dtype=np.int32)
+        nblk = (lens + BS - 1) // BS
+        NB = int(nblk.sum()) + 4
+        mb = int(nblk.max()) + 1
+        perm = rng.permutation(NB)
+        tables = np.full((n_seq, mb), -1, dtype=np.int32)
+        t_kc = torch.full((NB, H, D // 8, BS, 8), float("nan"), dtype=torch.float16, device=dev)
+        t_vc = torch.full((NB, H, D, BS), float("nan"), dtype=torch.float16, device=dev)
+        pos = 0
+        q = np.stack([z[f"{name}/{s}/query"][0] for s in range(n_seq)])
+        for s in range(n_seq):
+            tables[s, : nblk[s]] = perm[pos:pos + nblk[s]]
+            pos += nblk[s]
+            slots = (tables[s, np.arange(lens[s]) // BS].astype(np.int64) * BS + np.arange(lens[s]) % BS)
+            ext.cache_ops.reshape_and_cache(torch.from_numpy(keys[s]).to(dev),
+                                            torch.from_numpy(z[f"{name}/{s}/value"]).to(dev), t_kc, t_vc,
+                                            torch.from_numpy(slots).to(dev), "auto", 1.0)
+        out = torch.empty((n_seq, H, D), dtype=torch.float16, device=dev)
+        ext.paged_attention_v1(out, torch.from_numpy(q).to(dev), t_kc, t_vc, H, float(z[f"{name}/0/scale"]),
+                               torch.from_numpy(tables).to(dev), torch.from_numpy(lens).to(dev), BS,
+                               int(lens.max()), None, "auto", 1.0, 0, 0, 1, 1, 0)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().astype(np.float64)
+        for s in range(n_seq):
+            ref32 = z[f"{name}/{s}/ref_eager_fp32"].astype(np.float64)
+            ref16 = z[f"{name}/{s}/ref_eager_fp16"].astype(np.float64)
+            assert np.abs(got[s] - ref16).max() <= 1e-2, name          # the reference test's assertion
+            assert np.abs(got[s] - ref32).max() <= 2.5e-3, name
+
+
+def test_golden_seam_trace_replay(golden_dir):
+    """Replay every call the reference's Scheduler/BlockManager/GPT-2 made at the seam for config 1
+    (B=1, 5 -> 32 tokens): reshape_and_cache must leave the caches bit-identical to the trace's final
+    state, and each paged_attention_v1 must match the kernel model on the same inputs."""
+    ext = _ext()
+    dev = _dev()
+    z = np.load(os.path.join(golden_dir, "seam_trace.npz"))
+    meta = json.loads(str(z["meta"]))
+    H, D, NB = meta["num_heads"], meta["head_size"], meta["num_blocks"]
+    t_kc = torch.zeros((NB, H, D // 8, BS, 8), dtype=torch.float16, device=dev)   # kv_cache.py:13-14
+    t_vc = torch.zeros((NB, H, D, BS), dtype=torch.float16, device=dev)
+    worst = 0.0
+    n_pa = 0
+    for i in range(meta["num_calls"]):
+        op = str(z[f"call{i:04d}/op"])
+        if op == "reshape_and_cache":
+            key, value = z[f"call{i:04d}/key"], z[f"call{i:04d}/value"]
+            T = key.shape[0]
+            row = int(z[f"call{i:04d}/key_strides"][0])          # 3*hidden: strided views of fused qkv
+            buf = torch.zeros((T, row), dtype=torch.float16, device=dev)
+            kview = buf[:, : H * D].view(T, H, D)
+            vbuf = torch.zeros((T, row), dtype=torch.float16, device=dev)
+            vview = vbuf[:, : H * D].view(T, H, D)
+            kview.copy_(torch.from_numpy(key).to(dev))
+            vview.copy_(torch.from_numpy(value).to(dev))
+            assert kview.stride(0) == row
+            ext.cache_ops.reshape_and_cache(kview, vview, t_kc, t_vc,
+                                            torch.from_numpy(z[f"call{i:04d}/slot_mapping"]).to(dev), "auto", 1.0)
+        else:
+            q = z[f"call{i:04d}/query"]
+            row = int(z[f"call{i:04d}/query_strides"][0])
+            S = q.shape[0]
+            buf = torch.zeros((S, row), dtype=torch.float16, device=dev)
+            qview = buf[:, : H * D].view(S, H, D)
+            qview.copy_(torch.from_numpy(q).to(dev))
+            nkv, bs, msl = (int(v) for v in z[f"call{i:04d}/scalars"])
+            out = torch.empty((S, H, D), dtype=torch.float16, device=dev)
+            ext.paged_attention_v1(out, qview, t_kc, t_vc, nkv, float(z[f"call{i:04d}/scale"]),
+                                   torch.from_numpy(z[f"call{i:04d}/block_tables"]).to(dev),
+                                   torch.from_numpy(z[f"call{i:04d}/seq_lens"]).to(dev), bs, msl, None, "auto",
+                                   1.0, 0, 0, 1, 1, 0)
+            got = out.cpu().numpy().astype(np.float64)
+            ref = z[f"call{i:04d}/oracle_out"].astype(np.float64)
+            worst = max(worst, float(np.abs(got - ref).max()))
+            n_pa += 1
+    torch.cuda.synchronize()
+    assert n_pa == meta["num_decode_steps"] * meta["num_layers"]
+    assert worst <= ATOL, f"seam replay: max|hip-model| = {worst:.3e}"
+    assert np.array_equal(t_kc.cpu().numpy().view(np.uint16), z["final_key_cache"].view(np.uint16))
+    assert np.array_equal(t_vc.cpu().numpy().view(np.uint16), z["final_value_cache"].view(np.uint16))
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties + a sampled oracle check
+# ------------------------------------------------------------------------------------------------
+def _full_size_checks(cfg_name, sample_seqs):
+    from vllmini_amd import ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    dev = _dev()
+    cfg = CONFIGS[cfg_name]
+    wl = make_workload(cfg, dev, seed=3, table_sets=2)
+    out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
+
+    def attend(q, table, variant=0):
+        ops.paged_attention_v1(out, q, wl.key_cache, wl.value_cache, cfg.num_heads, wl.scale, table, wl.seq_lens,
+                               cfg.block_size, cfg.seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+        torch.cuda.synchronize()
+        return out.clone()
+
+    base = attend(wl.query, wl.tables[0])
+    assert torch.isfinite(base).all()
+    # (1) determinism / idempotence
+    assert torch.equal(base, attend(wl.query, wl.tables[0]))
+    # (2) output is a convex combination of V rows, and V ~ U(-1,1): |out| <= 1
+    assert float(base.abs().max()) <= 1.0 + 1e-3
+    # (3) permutation equivariance over sequences (independent units: grid is (heads, seqs))
+    perm = torch.randperm(cfg.batch, device=dev)
+    permuted = attend(wl.qkv[perm][:, : cfg.num_heads * cfg.head_size].view(cfg.batch, cfg.num_heads, cfg.head_size),
+                      wl.tables[0][perm])
+    assert torch.equal(permuted, base[perm])
+    # (4) all work decompositions agree to fp32-summation-order effects
+    for vid, name in _variants_for(cfg.head_size)[:6]:
+        other = attend(wl.query, wl.tables[0], variant=vid)
+        assert float((other.float() - base.float()).abs().max()) <= 1e-3, name
+    # (5) write-then-read: reshape_and_cache of a huge-norm key makes its token dominate the softmax
+    t = 1
+    key = wl.key.clone()
+    q = wl.query
+    big = (q.float() * 64.0).clamp(-60000, 60000).to(torch.float16)  # k = 64*q  ->  logit = 64*|q|^2*scale
+    vals = torch.full_like(big, 0.5)
+    cache_kc, cache_vc = wl.key_cache, wl.value_cache
+    from vllmini_amd import cache_ops
+    cache_ops.reshape_and_cache(big, vals, cache_kc, cache_vc, wl.slots[t], "auto", 1.0)
+    dominated = attend(q, wl.tables[t])
+    assert float((dominated.float() - 0.5).abs().max()) <= 2e-3
+    del key
+    # (6) sampled sequences against the kernel model (CPU, seconds): only the sampled sequences'
+    #     pages are brought to the host, re-indexed into a small pool
+    idx = np.linspace(0, cfg.batch - 1, sample_seqs).astype(int)
+    for which, got in ((0, base), (t, dominated)):
+        tab_dev = wl.tables[which][torch.from_numpy(idx).to(dev)][:, : cfg.blocks_per_seq]
+        flat = tab_dev.reshape(-1).to(torch.int64)
+        kc = wl.key_cache[flat].cpu().numpy()
+        vc = wl.value_cache[flat].cpu().numpy()
+        small_tab = np.arange(flat.numel(), dtype=np.int32).reshape(len(idx), cfg.blocks_per_seq)
+        qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
+        ref = oracle.paged_attention_v1(qn, kc, vc, cfg.num_heads, wl.scale, small_tab,
+                                        wl.seq_lens.cpu().numpy()[idx], cfg.block_size, threads=8)
+        assert_close(got.cpu().numpy()[idx], ref, f"{cfg_name} sampled vs model (tables[{which}])")
+
+
+def test_full_size_cfg2_properties():
+    _full_size_checks("cfg2", sample_seqs=4)
+
+
+def test_full_size_cfg3_roofline_config_properties():
+    _full_size_checks("cfg3", sample_seqs=3)
+
+
+def test_full_size_cfg4_properties():
+    _full_size_checks("cfg4", sample_seqs=2)
+
+
+# ------------------------------------------------------------------------------------------------
+# error behaviour at the seam (reference: TORCH_CHECK -> RuntimeError)
+# ------------------------------------------------------------------------------------------------
+def test_errors_raise_runtimeerror():
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(0)
+
+    def call(case, **over):
+        S, H, D = case["q"].shape
+        a = dict(out=torch.empty((S, H, D), dtype=torch.float16, device=dev), q=torch.from_numpy(case["q"].copy()).to(dev),
+                 kc=torch.from_numpy(case["kc"]).to(dev), vc=torch.from_numpy(case["vc"]).to(dev), nkv=case["num_kv_heads"],
+                 scale=case["scale"], tab=torch.from_numpy(case["tables"]).to(dev), lens=torch.from_numpy(case["lens"]).to(dev),
+                 bs=BS, msl=64, alibi=None, kvd="auto", kvs=1.0, vert=1)
+        a.update(over)
+        ext.paged_attention_v1(a["out"], a["q"], a["kc"], a["vc"], a["nkv"], a["scale"], a["tab"], a["lens"], a["bs"],
+                               a["msl"], a["alibi"], a["kvd"], a["kvs"], 0, 0, a["vert"], 1, 0)
+
+    good = make_case(rng, 2, 4, 64, [5, 40], max_blocks=4)
+    call(good)  # sanity: valid call passes
+    with pytest.raises(RuntimeError, match="Unsupported head size"):
+        call(make_case(rng, 1, 4, 80, [5], max_blocks=4))            # attention_kernels.cu:763-765
+    with pytest.raises(RuntimeError, match="kv cache"):
+        call(good, kvd="fp8")                                        # quant_utils.cuh:538
+    with pytest.raises(RuntimeError, match="kv cache"):
+        call(good, kvd="int4")                                       # quant_utils.cuh:564
+    with pytest.raises(RuntimeError, match="block-sparse"):
+        call(good, vert=2)
+    with pytest.raises(RuntimeError, match="int32"):
+        call(good, lens=torch.from_numpy(good["lens"].astype(np.int64)).to(dev))
+    with pytest.raises(RuntimeError, match="Unsupported input type"):
+        call(good, q=torch.from_numpy(good["q"].astype(np.float32)).to(dev))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        call(good, q=torch.from_numpy(good["q"].copy()))
+    torch.cuda.synchronize()

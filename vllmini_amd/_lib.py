@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI shared library (include/vmi_paged_attention.h).
+
+There is NO fallback: if the HIP library is missing or does not export the declared
+symbols, loading raises.  The operators in ops.py never route around it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+from . import build as _build
+
+_c_void_p = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+_f32 = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/vmi_paged_attention.h one to one
+_PA_ARGS = [
+    _c_void_p, _c_void_p, _c_void_p, _c_void_p,      # out, query, key_cache, value_cache
+    _i32, _i32, _i32, _i32,                          # num_seqs, num_heads, head_size, num_kv_heads
+    _f32,                                            # scale
+    _c_void_p, _c_void_p,                            # block_tables, seq_lens
+    _i32, _i32, _i32,                                # block_size, max_seq_len, max_num_blocks_per_seq
+    _c_void_p,                                       # alibi_slopes
+    _i64, _i64, _i64,                                # q_stride, kv_block_stride, kv_head_stride
+    _i32, _c_void_p,                                 # device, stream
+]
+
+SIGNATURES = {
+    "vmi_abi_version": (ctypes.c_int, []),
+    "vmi_last_error_string": (ctypes.c_char_p, []),
+    "vmi_target_arch": (ctypes.c_char_p, []),
+    "vmi_paged_attention_v1_f16": (ctypes.c_int, list(_PA_ARGS)),
+    "vmi_paged_attention_v1_f16_variant": (ctypes.c_int, list(_PA_ARGS) + [_i32]),
+    "vmi_paged_attention_v1_variant_count": (ctypes.c_int, []),
+    "vmi_paged_attention_v1_variant_name": (ctypes.c_char_p, [_i32]),
+    "vmi_paged_attention_v1_pick_variant": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
+    "vmi_reshape_and_cache_f16": (ctypes.c_int, [
+        _c_void_p, _c_void_p, _c_void_p, _c_void_p,  # key, value, key_cache, value_cache
+        _c_void_p,                                   # slot_mapping
+        _i32, _i32, _i32, _i32, _i32,                # num_tokens, num_heads, head_size, block_size, x
+        _i64, _i64,                                  # key_stride, value_stride
+        _i32, _c_void_p,                             # device, stream
+    ]),
+}
+
+ABI_VERSION = 1
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP extension is missing / stale / does not match the header."""
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = False) -> ctypes.CDLL:
+    """Load (once) and type the shared library.  Raises NativeLibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            if build_if_missing:
+                _build.build()
+            else:
+                raise NativeLibraryError(
+                    f"{path} not found: build it with `python -m vllmini_amd.build` "
+                    "(or __graft_entry__.build()). There is no CPU/torch fallback for these ops.")
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError as e:  # missing libamdhip64 etc.
+            raise NativeLibraryError(f"cannot load {path}: {e}") from e
+        for name, (restype, argtypes) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{path} does not export {name}") from e
+            fn.restype = restype
+            fn.argtypes = argtypes
+        got = lib.vmi_abi_version()
+        if got != ABI_VERSION:
+            raise NativeLibraryError(f"{path}: ABI version {got}, Python side expects {ABI_VERSION}")
+        _lib = lib
+        return _lib
+
+
+def last_error() -> str:
+    s = load().vmi_last_error_string()
+    return s.decode("utf-8", "replace") if s else ""

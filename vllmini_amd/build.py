@@ -1,0 +1,76 @@
+"""Build the gfx950 shared library (C-ABI, include/vmi_paged_attention.h) in-tree with hipcc.
+
+The reference builds its kernels as a torch CUDAExtension for sm_70..sm_89
+(paged_attention_ext/setup.py:21-46, build.sh:3-5).  Here there is no torch/pybind in the
+native code at all: one `hipcc --offload-arch=gfx950 -shared -fPIC` producing
+vllmini_amd/_C/libvmi_paged_attention.so, loaded through ctypes (vllmini_amd/_lib.py).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so is
+git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+SRC = os.path.join(PKG_DIR, "csrc", "paged_attention.hip")
+INCLUDE = os.path.join(REPO_ROOT, "include")
+OUT_DIR = os.path.join(PKG_DIR, "_C")
+LIB_NAME = "libvmi_paged_attention.so"
+LIB_PATH = os.path.join(OUT_DIR, LIB_NAME)
+
+ARCH = "gfx950"
+# -ffp-contract=off: the fp16 p*v products must be rounded before the fp16 adds (reference
+# rounding points, dtype_float16.cuh:252-260, 451-457) — no v_pk_fma_f16 contraction.
+HIPCC_FLAGS = [
+    f"--offload-arch={ARCH}",
+    "-O3",
+    "-std=c++17",
+    "-ffp-contract=off",
+    "-fPIC",
+    "-shared",
+    "-fno-gpu-rdc",
+    f"-I{INCLUDE}",
+]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (expected on PATH or at /opt/rocm/bin/hipcc)")
+    return exe
+
+
+def _deps() -> list[str]:
+    return [SRC, os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.abspath(__file__)]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the library if missing or older than its sources; return its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(OUT_DIR, exist_ok=True)
+    tmp = LIB_PATH + ".tmp"
+    cmd = [_hipcc(), *HIPCC_FLAGS, SRC, "-o", tmp]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,260 @@
+"""Python operator surface of the MI355X paged-attention decode path.
+
+Mirrors, name for name and argument for argument, what the reference's pybind module
+`paged_attention_cuda` exports and its Python stack calls:
+
+  paged_attention_v1(...18 positional args...)      paged_attention_cuda.cpp:7-25,:52 ;
+                                                    call site vllmini/model/gpt2.py:94-113
+  cache_ops.reshape_and_cache(...7 positional...)   cache_kernels.h:11-14 ; paged_attention_cuda.cpp:58 ;
+                                                    call site vllmini/model/gpt2.py:81-89
+
+Each function reads sizes and strides off the tensors at the same places the reference
+launchers do (attention_kernels.cu:701-707, cache_kernels.cu:265-272) and forwards raw device
+pointers to the C-ABI (include/vmi_paged_attention.h) on torch's CURRENT stream, without
+synchronising — same async contract as the reference (attention_kernels.cu:736-737).
+
+Error behaviour: the reference raises RuntimeError through TORCH_CHECK for an unsupported
+head size / block size / dtype / kv-cache dtype (attention_kernels.cu:764, 801; quant_utils.cuh:538,
+564) and validates nothing else.  Here the same cases raise RuntimeError with the same message
+stem, and malformed shapes/dtypes/devices (undefined behaviour in the reference) raise too.
+
+There is no CPU or torch fallback: tensors must live on a HIP device and the HIP library must
+be loadable, otherwise these functions raise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "paged_attention_v1",
+    "paged_attention_v2",
+    "reshape_and_cache",
+    "pick_variant",
+    "variant_names",
+]
+
+_SUPPORTED_KV_CACHE_DTYPES = ("auto",)
+_FP8_KV_CACHE_DTYPES = ("fp8", "fp8_e4m3", "fp8_e5m2")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _check_kv_cache_dtype(kv_cache_dtype: str) -> None:
+    if kv_cache_dtype in _SUPPORTED_KV_CACHE_DTYPES:
+        return
+    if kv_cache_dtype in _FP8_KV_CACHE_DTYPES:
+        raise RuntimeError(
+            f"Unsupported data type of kv cache: {kv_cache_dtype} (fp8 KV cache is not built; the "
+            "reference build never defines ENABLE_FP8 either, paged_attention_ext/setup.py:30-45)")
+    raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+
+
+def _check_device(name: str, t: torch.Tensor, device: torch.device) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must be a HIP device tensor (got {t.device}); this operator has no CPU path")
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+
+
+def _raise_native(code: int) -> None:
+    raise RuntimeError(f"{_lib.last_error()} (vmi code {code})")
+
+
+def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens,
+               block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
+               blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+               blocksparse_head_sliding_step):
+    """Validate and flatten the 18 reference arguments into the C-ABI argument tuple."""
+    if query.dim() != 3:
+        raise RuntimeError(f"query must be [num_seqs, num_heads, head_size], got {tuple(query.shape)}")
+    if query.dtype != torch.float16:
+        # reference dispatches float/half/bf16 (quant_utils.cuh:529-566); only fp16 is built here,
+        # which is the only dtype its callers use (gpt2.py, scheduler.py:13)
+        raise RuntimeError(f"Unsupported input type of paged attention: {query.dtype}")
+    _check_kv_cache_dtype(kv_cache_dtype)
+    if int(blocksparse_vert_stride) > 1:
+        raise RuntimeError("block-sparse paged attention (blocksparse_vert_stride > 1) is not "
+                           "supported; reference callers always pass vert_stride=1 (gpt2.py:109-112)")
+    dev = query.device
+    _check_device("query", query, dev)
+    for name, t in (("out", out), ("key_cache", key_cache), ("value_cache", value_cache),
+                    ("block_tables", block_tables), ("seq_lens", seq_lens)):
+        _check_device(name, t, dev)
+    if key_cache.dtype != torch.float16 or value_cache.dtype != torch.float16:
+        raise RuntimeError("key_cache/value_cache must be float16 for kv_cache_dtype='auto'")
+    if out.dtype != torch.float16:
+        raise RuntimeError(f"out must be float16, got {out.dtype}")
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("block_tables and seq_lens must be int32")
+
+    num_seqs, num_heads, head_size = (int(s) for s in query.shape)  # attention_kernels.cu:701-703
+    if key_cache.dim() != 5 or value_cache.dim() != 4:
+        raise RuntimeError("key_cache must be [num_blocks, num_kv_heads, head_size/x, block_size, x] "
+                           "and value_cache [num_blocks, num_kv_heads, head_size, block_size]")
+    x = int(key_cache.shape[4])
+    if x != 8:
+        raise RuntimeError(f"key_cache innermost dimension must be 8 (16 bytes of fp16), got {x}")
+    if int(key_cache.shape[3]) != int(block_size) or int(value_cache.shape[3]) != int(block_size):
+        raise RuntimeError(f"block_size={block_size} does not match the cache tensors "
+                           f"({key_cache.shape[3]}, {value_cache.shape[3]})")
+    if int(key_cache.shape[2]) * x != head_size or int(value_cache.shape[2]) != head_size:
+        raise RuntimeError("cache head_size does not match query head_size")
+    if int(key_cache.shape[1]) != int(num_kv_heads) or int(value_cache.shape[1]) != int(num_kv_heads):
+        raise RuntimeError("cache num_kv_heads does not match num_kv_heads argument")
+    if query.stride(2) != 1 or query.stride(1) != head_size:
+        raise RuntimeError("query must be contiguous in its last two dimensions")
+    if not key_cache[0].is_contiguous() or not value_cache[0].is_contiguous():
+        raise RuntimeError("each cache block must be dense")
+    if value_cache.stride(0) != key_cache.stride(0) or value_cache.stride(1) != key_cache.stride(1):
+        # the reference applies key_cache's strides to both tensors (attention_kernels.cu:706-707)
+        raise RuntimeError("key_cache and value_cache must have identical block/head strides")
+    if not out.is_contiguous() or out.numel() != num_seqs * num_heads * head_size:
+        # reference tests pass out as [S, H, 1, D] (tests/kernels/paged_attention.py:114)
+        raise RuntimeError("out must be contiguous with num_seqs*num_heads*head_size elements")
+    if block_tables.dim() != 2 or int(block_tables.shape[0]) != num_seqs or block_tables.stride(1) != 1:
+        raise RuntimeError("block_tables must be [num_seqs, max_num_blocks_per_seq] with unit inner stride")
+    if block_tables.stride(0) != block_tables.shape[1] and num_seqs > 1:
+        raise RuntimeError("block_tables must be row-contiguous")
+    if seq_lens.dim() != 1 or int(seq_lens.shape[0]) != num_seqs or not seq_lens.is_contiguous():
+        raise RuntimeError("seq_lens must be a contiguous [num_seqs] tensor")
+    alibi_ptr = None
+    if alibi_slopes is not None:
+        _check_device("alibi_slopes", alibi_slopes, dev)
+        if alibi_slopes.dtype != torch.float32 or alibi_slopes.numel() != num_heads or \
+                not alibi_slopes.is_contiguous():
+            raise RuntimeError("alibi_slopes must be a contiguous float32 [num_heads] tensor")
+        alibi_ptr = alibi_slopes.data_ptr()
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    return (
+        out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        num_seqs, num_heads, head_size, int(num_kv_heads), float(scale),
+        block_tables.data_ptr(), seq_lens.data_ptr(),
+        int(block_size), int(max_seq_len), int(block_tables.shape[1]),   # attention_kernels.cu:704
+        alibi_ptr,
+        int(query.stride(0)), int(key_cache.stride(0)), int(key_cache.stride(1)),  # :705-707
+        dev.index if dev.index is not None else torch.cuda.current_device(), stream,
+    )
+
+
+def paged_attention_v1(
+    out: torch.Tensor,
+    query: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    num_kv_heads: int,
+    scale: float,
+    block_tables: torch.Tensor,
+    seq_lens: torch.Tensor,
+    block_size: int,
+    max_seq_len: int,
+    alibi_slopes: Optional[torch.Tensor],
+    kv_cache_dtype: str,
+    kv_scale: float,
+    tp_rank: int = 0,
+    blocksparse_local_blocks: int = 0,
+    blocksparse_vert_stride: int = 1,
+    blocksparse_block_size: int = 1,
+    blocksparse_head_sliding_step: int = 0,
+    *,
+    _variant: int = 0,
+) -> None:
+    """Decode attention over the paged KV cache; writes `out` in place, returns None.
+
+    Reference: attention_kernels.cu:805-826 (host), :86-496 (kernel).  `_variant` (keyword only,
+    not part of the reference surface) forces a work decomposition for tuning/tests.
+    """
+    args = _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                      seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale,
+                      tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
+                      blocksparse_block_size, blocksparse_head_sliding_step)
+    lib = _lib.load()
+    if _variant:
+        rc = lib.vmi_paged_attention_v1_f16_variant(*args, int(_variant))
+    else:
+        rc = lib.vmi_paged_attention_v1_f16(*args)
+    if rc != 0:
+        _raise_native(rc)
+    return None
+
+
+def paged_attention_v2(*args, **kwargs) -> None:
+    """Exported by the reference (paged_attention_cuda.cpp:53) but never called from its Python
+    (SURVEY.md §2 #7).  The split-KV variant is a 'next' row, not built yet."""
+    raise NotImplementedError(
+        "paged_attention_v2 (split-KV) is not implemented in this build; the reference stack only "
+        "calls paged_attention_v1 (vllmini/model/gpt2.py:94)")
+
+
+def reshape_and_cache(
+    key: torch.Tensor,
+    value: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    slot_mapping: torch.Tensor,
+    kv_cache_dtype: str,
+    kv_scale: float,
+) -> None:
+    """Scatter new-token K/V rows into the paged caches at `slot_mapping`; in place, returns None.
+
+    Reference: cache_kernels.cu:256-281 (host), :152-207 (kernel).
+    """
+    _check_kv_cache_dtype(kv_cache_dtype)
+    if key.dim() != 3 or value.dim() != 3 or key.shape != value.shape:
+        raise RuntimeError("key and value must both be [num_tokens, num_heads, head_size]")
+    if key.dtype != torch.float16 or value.dtype != torch.float16:
+        raise RuntimeError(f"Unsupported input type of reshape_and_cache: {key.dtype}")
+    dev = key.device
+    for name, t in (("key", key), ("value", value), ("key_cache", key_cache),
+                    ("value_cache", value_cache), ("slot_mapping", slot_mapping)):
+        _check_device(name, t, dev)
+    if key_cache.dtype != torch.float16 or value_cache.dtype != torch.float16:
+        raise RuntimeError("key_cache/value_cache must be float16 for kv_cache_dtype='auto'")
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("slot_mapping must be int64")
+    num_tokens, num_heads, head_size = (int(s) for s in key.shape)       # cache_kernels.cu:265-267
+    if key_cache.dim() != 5 or value_cache.dim() != 4:
+        raise RuntimeError("key_cache must be [num_blocks, num_heads, head_size/x, block_size, x] "
+                           "and value_cache [num_blocks, num_heads, head_size, block_size]")
+    block_size = int(key_cache.shape[3])                                  # cache_kernels.cu:268
+    x = int(key_cache.shape[4])                                           # cache_kernels.cu:269
+    if not key_cache.is_contiguous() or not value_cache.is_contiguous():
+        # the reference computes dense offsets (cache_kernels.cu:187-194)
+        raise RuntimeError("key_cache and value_cache must be contiguous")
+    if int(key_cache.shape[1]) != num_heads or int(key_cache.shape[2]) * x != head_size or \
+            tuple(value_cache.shape[1:]) != (num_heads, head_size, block_size):
+        raise RuntimeError("cache shapes do not match key/value shapes")
+    if key.stride(2) != 1 or key.stride(1) != head_size or value.stride(2) != 1 or \
+            value.stride(1) != head_size:
+        raise RuntimeError("key/value must be contiguous in their last two dimensions")
+    if slot_mapping.numel() != num_tokens or not slot_mapping.is_contiguous():
+        raise RuntimeError("slot_mapping must be a contiguous [num_tokens] tensor")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = _lib.load().vmi_reshape_and_cache_f16(
+        key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
+        int(key.stride(0)), int(value.stride(0)),                         # cache_kernels.cu:271-272
+        dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+    if rc != 0:
+        _raise_native(rc)
+    return None
+
+
+# ---- tuning helpers (not part of the reference surface) --------------------------------------
+
+def variant_names() -> list[str]:
+    lib = _lib.load()
+    n = lib.vmi_paged_attention_v1_variant_count()
+    return [lib.vmi_paged_attention_v1_variant_name(i + 1).decode() for i in range(n)]
+
+
+def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int) -> int:
+    return int(_lib.load().vmi_paged_attention_v1_pick_variant(num_seqs, num_heads, head_size,
+                                                                max_seq_len))
