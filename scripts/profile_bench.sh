@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 evidence for bench.py's roofline numbers (run on the GPU box via gpurun).
+#   pass 1: --kernel-trace --stats  -> per-kernel durations (must agree with bench.py's HIP-event mean)
+#   pass 2: --pmc FETCH_SIZE        -> HBM read traffic   (own pass; never combined with trace domains other than kernel-trace)
+#   pass 3: --pmc WRITE_SIZE
+# Usage: scripts/profile_bench.sh <tag> [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ARGS="--steps 50 --warmup 10 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python bench.py $ARGS > "$OUT/bench_under_trace.json" 2> "$OUT/trace.stderr"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- python bench.py $ARGS > "$OUT/bench_under_pmc_fetch.json" 2> "$OUT/pmc_fetch.stderr"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o write -- python bench.py $ARGS > "$OUT/bench_under_pmc_write.json" 2> "$OUT/pmc_write.stderr"
+python scripts/summarize_prof.py "$OUT" > "$OUT/summary.json" 2> "$OUT/summary.stderr"
+cat "$OUT/summary.json"

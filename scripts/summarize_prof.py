@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output dirs (kernel-trace stats + PMC csv) into one small JSON for profiles/."""
+import csv, glob, json, os, sys, statistics
+
+out = sys.argv[1]
+res = {"dir": out}
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+# kernel stats
+for f in find("trace/**/*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    res["kernel_stats"] = [
+        {k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")}
+        for r in rows[:8]]
+# per-dispatch durations of the attention kernel (skip warm-up dispatches)
+for f in find("trace/**/*kernel_trace.csv"):
+    rows = [r for r in csv.DictReader(open(f)) if "pa_v1_kernel" in r.get("Kernel_Name", "")]
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    if d:
+        tail = d[10:] if len(d) > 20 else d
+        res["pa_v1_dispatches"] = {"n": len(d), "mean_us_all": statistics.mean(d) / 1e3,
+                                   "mean_us_after_warmup": statistics.mean(tail) / 1e3,
+                                   "median_us": statistics.median(tail) / 1e3, "min_us": min(tail) / 1e3,
+                                   "vgpr": rows[0].get("VGPR_Count"), "sgpr": rows[0].get("SGPR_Count"),
+                                   "lds": rows[0].get("LDS_Block_Size"), "wg": rows[0].get("Workgroup_Size"),
+                                   "grid": rows[0].get("Grid_Size")}
+# PMC
+for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    for f in find(f"{sub}/**/*counter_collection.csv"):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                if "pa_v1_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == name]
+        if vals:
+            tail = vals[10:] if len(vals) > 20 else vals
+            res[name] = {"n": len(vals), "mean_raw_KiB_units": statistics.mean(tail),
+                         "mean_bytes_uncorrected": statistics.mean(tail) * 1024}
+print(json.dumps(res, indent=1))

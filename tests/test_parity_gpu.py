@@ -375,8 +375,7 @@ def _full_size_checks(cfg_name, sample_seqs):
         other = attend(wl.query, wl.tables[0], variant=vid)
         assert float((other.float() - base.float()).abs().max()) <= 1e-3, name
     # (5) write-then-read: reshape_and_cache of a huge-norm key makes its token dominate the softmax
-    t = 1
-    key = wl.key.clone()
+    t = len(wl.tables) - 1
     q = wl.query
     big = (q.float() * 64.0).clamp(-60000, 60000).to(torch.float16)  # k = 64*q  ->  logit = 64*|q|^2*scale
     vals = torch.full_like(big, 0.5)
@@ -385,11 +384,10 @@ def _full_size_checks(cfg_name, sample_seqs):
     cache_ops.reshape_and_cache(big, vals, cache_kc, cache_vc, wl.slots[t], "auto", 1.0)
     dominated = attend(q, wl.tables[t])
     assert float((dominated.float() - 0.5).abs().max()) <= 2e-3
-    del key
     # (6) sampled sequences against the kernel model (CPU, seconds): only the sampled sequences'
     #     pages are brought to the host, re-indexed into a small pool
     idx = np.linspace(0, cfg.batch - 1, sample_seqs).astype(int)
-    for which, got in ((0, base), (t, dominated)):
+    for which, got in ((0, base), (t, dominated)) if t != 0 else ((t, dominated),):
         tab_dev = wl.tables[which][torch.from_numpy(idx).to(dev)][:, : cfg.blocks_per_seq]
         flat = tab_dev.reshape(-1).to(torch.int64)
         kc = wl.key_cache[flat].cpu().numpy()

@@ -12,8 +12,8 @@
 //   * a K tile (one physical block, one kv head) is D*16*2 bytes, contiguous
 //     ([D/8][16 tok][8 halves]); a wave reads it as D/32 fully coalesced 1-KiB
 //     global_load_dwordx4 (16 B per lane); lane = (chunk&3)*16 + tok holds 8 consecutive
-//     dims of one token, so q.k is 4 v_dot2_f32_f16 per load followed by a 2-step
-//     butterfly over the 4 chunk lanes;
+//     dims of one token, so q.k is 8 v_fma_mix_f32 per load (fp16 operands, fp32 FMA — the
+//     reference's arithmetic) followed by a 2-step butterfly over the 4 chunk lanes;
 //   * a V tile is [D][16 tok] halves, also D/32 coalesced 1-KiB loads; lane = row*2 + half
 //     holds 8 consecutive tokens of one dim row, so p.v is 4 v_pk_mul_f16 + 3 v_pk_add_f16;
 //   * block-table entries are loaded once per 64 blocks into a VGPR (lane j = j-th block)
@@ -48,6 +48,8 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// LDS logits are written as float and re-read 4 at a time: the vector view must alias float
+typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));
 
 static thread_local char g_err[512] = "";
 
@@ -207,15 +209,22 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       const int idx = g * U + j;
       if (idx < nmy) {  // wave-uniform
         const int b = sub + idx * WPH;
-        float acc = 0.f;
+        // q.k over this lane's 8*NL dims: fp16 operands converted to fp32, fp32 FMA chain
+        // (v_fma_mix_f32) — the reference's arithmetic (dtype_float16.cuh:292-298, 399-404).
+        // One accumulator per load keeps NL independent dependency chains in flight.
+        float accv[NL];
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
+          const h16x8 qh = __builtin_bit_cast(h16x8, qreg[i]);
+          const h16x8 kh = __builtin_bit_cast(h16x8, r[j][i]);
+          float a = (float)qh[0] * (float)kh[0];
 #pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, qreg[i][w]),
-                                         __builtin_bit_cast(h16x2, r[j][i][w]), acc, false);
-          }
+          for (int e = 1; e < 8; ++e) a = __builtin_fmaf((float)qh[e], (float)kh[e], a);
+          accv[i] = a;
         }
+        float acc = accv[0];
+#pragma unroll
+        for (int i = 1; i < NL; ++i) acc += accv[i];
         acc += __shfl_xor(acc, 16);
         acc += __shfl_xor(acc, 32);
         const int token = b * BS + tk;
@@ -285,8 +294,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       if (idx < nmy) {  // wave-uniform
         const int b = sub + idx * WPH;
         const int token0 = b * BS + hf * 8;
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(logits + token0);
-        const f32x4 e1 = *reinterpret_cast<const f32x4*>(logits + token0 + 4);
+        const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(logits + token0);
+        const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(logits + token0 + 4);
         h16x8 pv;
         pv[0] = (h16)(e0[0] * inv_sum);
         pv[1] = (h16)(e0[1] * inv_sum);
@@ -461,15 +470,15 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int max_seq_
   while (wph < 16 && units * wph < 2048 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   int v = 0;
   if (head_size == 64) {
-    if (wph == 1) v = find_variant(64, (num_heads % 4 == 0) ? 4 : 1, 1, 4, false);
+    if (wph == 1) v = find_variant(64, (num_heads % 4 == 0) ? 4 : 1, 1, 4, true);
     else if (wph == 2) v = find_variant(64, 1, 2, 4, true);
-    else if (wph == 4) v = find_variant(64, 1, 4, 4, false);
+    else if (wph == 4) v = find_variant(64, 1, 4, 4, true);
     else if (wph == 8) v = find_variant(64, 1, 8, 2, false);
     else v = find_variant(64, 1, 16, 1, false);
     if (!v) v = find_variant(64, 1, 1, 4, false);
   } else {
-    if (wph == 1) v = find_variant(128, (num_heads % 4 == 0) ? 4 : 1, 1, 2, false);
-    else if (wph <= 4) v = find_variant(128, 1, 4, 2, false);
+    if (wph == 1) v = find_variant(128, (num_heads % 4 == 0) ? 4 : 1, 1, 2, true);
+    else if (wph <= 4) v = find_variant(128, 1, 4, 2, true);
     else if (wph == 8) v = find_variant(128, 1, 8, 2, false);
     else v = find_variant(128, 1, 16, 1, false);
     if (!v) v = find_variant(128, 1, 1, 2, false);

@@ -46,7 +46,7 @@ CONFIGS = {
     "cfg1": DecodeConfig("cfg1", 1, 12, 64, 32, 64),
     "cfg2": DecodeConfig("cfg2", 32, 12, 64, 512, 4096),
     "cfg3": DecodeConfig("cfg3", 256, 12, 64, 1024, 32768),
-    "cfg4": DecodeConfig("cfg4", 128, 32, 128, 2048, 16384 + 2048),
+    "cfg4": DecodeConfig("cfg4", 128, 32, 128, 2048, 32768),   # 2 disjoint table sets of 16384 blocks
     "cfg5": DecodeConfig("cfg5", 256, 12, 64, 1024, 65536),
 }
 
