@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--variant", type=int, default=0, help="force a kernel work decomposition (0 = heuristic)")
     ap.add_argument("--sweep", action="store_true", help="time every kernel variant, write gpurun_out/sweep.json")
+    ap.add_argument("--diag", action="store_true",
+                    help="report the plain 16-B/lane read bandwidth of this box over the K pool (stderr + gpurun_out/diag.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--sequential-tables", action="store_true",
@@ -161,6 +163,35 @@ def main():
             seq = torch.arange(cfg.batch * cfg.blocks_per_seq, dtype=torch.int32, device=dev) + t * per
             tab[:, : cfg.blocks_per_seq] = seq.view(cfg.batch, cfg.blocks_per_seq)
     out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
+
+    if args.diag:
+        from vllmini_amd import _lib
+        lib = _lib.load()
+        sink = torch.zeros(1, dtype=torch.int32, device=dev)
+        src = wl.key_cache
+        nbytes = src.numel() * 2
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        res = []
+        for nt in (0, 1):
+            for blocks in (1024, 2048, 4096, 8192, 16384):
+                for _ in range(3):
+                    lib.vmi_diag_stream_read(src.data_ptr(), nbytes, sink.data_ptr(), blocks, nt, local_rank, stream)
+                evs = []
+                for i in range(20):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s_ = wl.value_cache if i % 2 else wl.key_cache   # alternate pools: defeat the 256 MiB MALL
+                    a.record()
+                    lib.vmi_diag_stream_read(s_.data_ptr(), nbytes, sink.data_ptr(), blocks, nt, local_rank, stream)
+                    b.record()
+                    evs.append((a, b))
+                torch.cuda.synchronize(dev)
+                ms = statistics.median(a.elapsed_time(b) for a, b in evs)
+                res.append({"nt": nt, "blocks": blocks, "bytes": nbytes, "us": ms * 1e3, "gbps": nbytes / (ms * 1e-3) / 1e9})
+                print(json.dumps(res[-1]), file=sys.stderr, flush=True)
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", "diag.json"), "w") as f:
+            json.dump(res, f, indent=1)
+        return
 
     if args.sweep:
         names = ops.variant_names()

@@ -137,6 +137,15 @@ int vmi_reshape_and_cache_f16(
     int64_t key_stride, int64_t value_stride,
     int32_t device, void* stream);
 
+/*
+ * Diagnostic (no reference counterpart): plain coalesced 16-B/lane read of `bytes` from `src`
+ * with `blocks` workgroups of 256 threads; nt != 0 uses non-temporal loads.  `sink` is a 4-byte
+ * device word that is (practically) never written.  bench.py --diag uses it to report the read
+ * bandwidth this box sustains, next to the attention kernel's achieved figure.
+ */
+int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blocks, int32_t nt,
+                         int32_t device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
