@@ -38,7 +38,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from vllmini_amd import cache_ops, ops  # noqa: E402
+from vllmini_amd import cache_ops, ops, shard  # noqa: E402
 from vllmini_amd.workload import CONFIGS, make_workload  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -93,17 +93,12 @@ def one_step(wl, out, i, variant):
 
 
 def time_steps(wl, out, steps, warmup, variant, dist, dev):
-    """W untimed steps, then EXACTLY K timed steps between barrier+synchronize pairs."""
+    """W untimed steps, then EXACTLY K timed steps between barrier+synchronize pairs
+    (vllmini_amd/shard.py:timed_steps — the same code the 2-rank gloo test exercises)."""
     c = wl.cfg
-    for i in range(warmup):
-        one_step(wl, out, i, variant)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(steps):
+
+    def timed(i):
         t = i % len(wl.tables)
         cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
         ev[i][0].record()  # HIP events on the launch stream (torch's current stream)
@@ -111,11 +106,9 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev):
                                wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0,
                                0, 0, 1, 1, 0, _variant=variant)
         ev[i][1].record()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+
+    elapsed = shard.timed_steps(lambda i: one_step(wl, out, i, variant), steps, warmup, dist,
+                                sync=lambda: torch.cuda.synchronize(dev), timed_step=timed)
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     return elapsed, kern_ms
 
@@ -217,15 +210,8 @@ def main():
         return
 
     elapsed, kern_ms = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([statistics.mean(kern_ms)], dtype=torch.float64, device=dev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kern_mean_ms = float(k.item())
-    else:
-        kern_mean_ms = statistics.mean(kern_ms)
+    elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    kern_mean_ms = shard.max_over_ranks(statistics.mean(kern_ms), dist, dev)
 
     tokens = cfg.batch * world * args.steps          # one new token per sequence per step
     ms_per_step = elapsed / args.steps * 1e3

@@ -1,0 +1,174 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/*.h
+declares (no compute calls without a GPU), the Python mirror carries the reference's operator
+surface, and the product path fails loudly instead of falling back."""
+from __future__ import annotations
+
+import ctypes
+import glob
+import inspect
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = []
+    for h in glob.glob(os.path.join(REPO, "include", "*.h")):
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"\b(vmi_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from vllmini_amd import _lib, build
+
+    path = build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    declared = _declared_symbols()
+    assert {"vmi_paged_attention_v1_f16", "vmi_reshape_and_cache_f16", "vmi_last_error_string",
+            "vmi_abi_version"} <= set(declared)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
+    assert set(_lib.SIGNATURES) <= set(declared)
+    typed = _lib.load()
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 1
+    assert typed.vmi_target_arch() == b"gfx950"
+
+
+def test_library_is_gfx950_only_and_has_no_torch_dependency():
+    from vllmini_amd import build
+
+    path = build.build()
+    out = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+    assert "libamdhip64" in out
+    assert "torch" not in out and "c10" not in out and "python" not in out.lower()
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if os.path.exists(objdump):
+        r = subprocess.run([objdump, "--offloading", path], capture_output=True, text=True)
+        archs = set(re.findall(r"gfx[0-9a-f]+", r.stdout))
+        if archs:
+            assert archs == {"gfx950"}, archs
+
+
+def test_python_surface_matches_reference_signatures():
+    """Names, arity and order of paged_attention_cuda.paged_attention_v1 / cache_ops.reshape_and_cache
+    (paged_attention_cuda.cpp:7-25, cache_kernels.h:11-14)."""
+    import paged_attention_cuda as ext
+
+    assert set(ext.__all__) == {"paged_attention_v1", "paged_attention_v2", "cache_ops"}     # ext/__init__.py:4-8
+    pa = [p.name for p in inspect.signature(ext.paged_attention_v1).parameters.values()
+          if p.kind is not inspect.Parameter.KEYWORD_ONLY]
+    assert pa == ["out", "query", "key_cache", "value_cache", "num_kv_heads", "scale", "block_tables", "seq_lens",
+                  "block_size", "max_seq_len", "alibi_slopes", "kv_cache_dtype", "kv_scale", "tp_rank",
+                  "blocksparse_local_blocks", "blocksparse_vert_stride", "blocksparse_block_size",
+                  "blocksparse_head_sliding_step"]
+    rc = list(inspect.signature(ext.cache_ops.reshape_and_cache).parameters)
+    assert rc == ["key", "value", "key_cache", "value_cache", "slot_mapping", "kv_cache_dtype", "kv_scale"]
+    for name in ("swap_blocks", "copy_blocks", "reshape_and_cache_flash", "convert_fp8"):          # .cpp:56-61
+        assert hasattr(ext.cache_ops, name)
+    with pytest.raises(NotImplementedError):
+        ext.paged_attention_v2()
+
+
+def _cpu_args(D=64, dtype=torch.float16):
+    S, H, NB = 2, 4, 8
+    return dict(out=torch.empty(S, H, D, dtype=dtype), q=torch.zeros(S, H, D, dtype=dtype),
+                kc=torch.zeros(NB, H, D // 8, 16, 8, dtype=torch.float16), vc=torch.zeros(NB, H, D, 16, dtype=torch.float16),
+                tab=torch.zeros(S, 4, dtype=torch.int32), lens=torch.ones(S, dtype=torch.int32), H=H)
+
+
+def test_no_cpu_fallback_ops_raise_on_host_tensors():
+    import paged_attention_cuda as ext
+
+    a = _cpu_args()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.paged_attention_v1(a["out"], a["q"], a["kc"], a["vc"], a["H"], 0.125, a["tab"], a["lens"], 16, 64, None,
+                               "auto", 1.0, 0, 0, 1, 1, 0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.cache_ops.reshape_and_cache(a["q"], a["q"], a["kc"], a["vc"], torch.zeros(2, dtype=torch.int64), "auto", 1.0)
+
+
+def test_argument_validation_before_any_launch():
+    import paged_attention_cuda as ext
+
+    a = _cpu_args()
+    call = lambda **o: ext.paged_attention_v1(  # noqa: E731
+        o.get("out", a["out"]), o.get("q", a["q"]), a["kc"], a["vc"], a["H"], 0.125, a["tab"], a["lens"], 16, 64, None,
+        o.get("kvd", "auto"), 1.0, 0, 0, o.get("vert", 1), 1, 0)
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache: fp8"):
+        call(kvd="fp8")                                      # quant_utils.cuh:538 (ENABLE_FP8 never defined)
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache: int8"):
+        call(kvd="int8")                                     # quant_utils.cuh:564
+    with pytest.raises(RuntimeError, match="Unsupported input type"):
+        call(q=a["q"].float())
+    with pytest.raises(RuntimeError, match="block-sparse"):
+        call(vert=2)
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
+        ext.cache_ops.reshape_and_cache(a["q"], a["q"], a["kc"], a["vc"], torch.zeros(2, dtype=torch.int64), "fp8_e5m2", 1.0)
+
+
+def test_native_library_missing_is_a_loud_error(tmp_path, monkeypatch):
+    from vllmini_amd import _lib, build
+
+    monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.NativeLibraryError, match="no CPU/torch fallback"):
+        _lib.load()
+
+
+def test_c_abi_validation_codes_without_gpu():
+    """Argument validation in the C entry points runs before any HIP call, so it is testable here."""
+    from vllmini_amd import _lib
+
+    lib = _lib.load()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    args = lambda hs=64, bs=16, nkv=4, ptr=p16, qs=256: (  # noqa: E731
+        p16, ptr, p16, p16, 1, 4, hs, nkv, 0.125, p16, p16, bs, 16, 1, None, qs, 4096, 1024, 0, None)
+    assert lib.vmi_paged_attention_v1_f16(*args(hs=80)) == 2
+    assert b"Unsupported head size: 80" in lib.vmi_last_error_string()
+    assert lib.vmi_paged_attention_v1_f16(*args(bs=64)) == 3
+    assert b"Unsupported block size: 64" in lib.vmi_last_error_string()
+    assert lib.vmi_paged_attention_v1_f16(*args(nkv=3)) == 4
+    assert lib.vmi_paged_attention_v1_f16(*args(ptr=p16 + 2)) == 5
+    assert lib.vmi_paged_attention_v1_f16(*args(qs=257)) == 5
+    assert lib.vmi_paged_attention_v1_f16(None, *args()[1:]) == 1
+    a = list(args())
+    a[4] = 0                                                   # num_seqs == 0: nothing to do, no HIP call
+    assert lib.vmi_paged_attention_v1_f16(*a) == 0
+    assert lib.vmi_paged_attention_v1_f16_variant(*args(), 9999) == 8
+    assert lib.vmi_reshape_and_cache_f16(p16, p16, p16, p16, p16, 1, 4, 64, 16, 4, 256, 256, 0, None) == 9
+    assert lib.vmi_reshape_and_cache_f16(p16, p16, p16, p16, p16, 0, 4, 64, 16, 8, 256, 256, 0, None) == 0
+    assert lib.vmi_paged_attention_v1_pick_variant(256, 12, 64, 1024) >= 1
+    assert lib.vmi_paged_attention_v1_pick_variant(1, 12, 80, 64) == 0
+    n = lib.vmi_paged_attention_v1_variant_count()
+    names = [lib.vmi_paged_attention_v1_variant_name(i + 1).decode() for i in range(n)]
+    assert len(set(names)) == n and all(nm.startswith(("d64_", "d128_")) for nm in names)
+
+
+def test_workload_builder_matches_survey_byte_counts():
+    from vllmini_amd.workload import CONFIGS, DecodeConfig, make_workload
+
+    assert CONFIGS["cfg2"].algorithmic_bytes() == 50_434_176
+    assert CONFIGS["cfg3"].algorithmic_bytes() == 806_159_360
+    assert CONFIGS["cfg4"].algorithmic_bytes() == 4_297_130_496
+    wl = make_workload(DecodeConfig("t", 3, 12, 64, 40, 64), "cpu", seed=0, table_sets=2, ragged=True)
+    c = wl.cfg
+    assert wl.key_cache.shape == (c.num_blocks, 12, 8, 16, 8) and wl.value_cache.shape == (c.num_blocks, 12, 64, 16)
+    assert wl.query.stride(0) == 3 * 12 * 64 and wl.key.data_ptr() - wl.query.data_ptr() == 12 * 64 * 2
+    t0, t1 = (t[t >= 0] for t in wl.tables)
+    assert len(set(t0.tolist())) == len(t0) and not set(t0.tolist()) & set(t1.tolist())   # distinct, disjoint
+    lens = wl.seq_lens.to(torch.int64)
+    for tab, slot in zip(wl.tables, wl.slots):
+        blk = tab[torch.arange(c.batch), (lens - 1) // 16].to(torch.int64)
+        assert torch.equal(slot, blk * 16 + (lens - 1) % 16)

@@ -194,9 +194,13 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       int idx = g * U + j;
       idx = idx < nmy ? idx : nmy - 1;  // padding slots re-read my last block (never OOB)
       const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
-      const h16* ptr = base + phys * p.kv_block_stride;
+      // (sc0/sc1 cache-policy bits and buffer- vs flat-addressed loads were measured neutral on
+      //  this stream; only `nt` pays: profiles/r01_cfg3_sweep_cache_policy_bits.json)
+      {
+        const h16* ptr = base + phys * p.kv_block_stride;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(ptr + i * 512);
+        for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(ptr + i * 512);
+      }
     }
   };
 

@@ -1,0 +1,97 @@
+"""Sharding of the decode path over the GPUs of one node.
+
+The path partitions into independent units: a sequence touches only its own KV pages, and the
+operator's grid is (heads, sequences) with no cross-sequence reduction (attention_kernels.cu:734).
+So: one process per GPU, every rank owns a PRIVATE KV pool, free list and block tables, and a
+contiguous slice of the global batch.  There is NO collective on the data path.  The only exchange a
+decode loop needs is the per-step hand-back of sampled token ids (8 bytes per sequence) — an
+all_gather over `torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in CPU tests).
+The reference has no distributed layer at all (last row).
+
+Timing helpers implement bench.py's contract: W untimed warm-up steps, then exactly K steps between
+a barrier + device synchronise on both sides, and the MAX over ranks.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous balanced slice [lo, hi) of n_items for `rank` (first n_items % world ranks get one more)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} not in [0, {world})")
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def owner_of(index: int, n_items: int, world: int) -> int:
+    """Rank whose shard_range contains `index`."""
+    q, r = divmod(n_items, world)
+    boundary = r * (q + 1)
+    if index < boundary:
+        return index // (q + 1)
+    return r + (index - boundary) // q if q else world - 1
+
+
+def barrier_sync(dist, sync: Optional[Callable[[], None]]) -> None:
+    if sync is not None:
+        sync()
+    if dist is not None:
+        dist.barrier()
+    if sync is not None:
+        sync()
+
+
+def timed_steps(step: Callable[[int], None], steps: int, warmup: int, dist=None,
+                sync: Optional[Callable[[], None]] = None,
+                timed_step: Optional[Callable[[int], None]] = None) -> float:
+    """Run `warmup` untimed then exactly `steps` timed calls of step(i); returns local elapsed seconds.
+    `sync` = device synchronise (torch.cuda.synchronize on GPU ranks, None on CPU).  `timed_step`, if
+    given, replaces `step` inside the timed region (same work plus per-launch event records)."""
+    for i in range(warmup):
+        step(i)
+    barrier_sync(dist, sync)
+    t0 = time.perf_counter()
+    body = timed_step or step
+    for i in range(steps):
+        body(i)
+    barrier_sync(dist, sync)
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(value: float, dist=None, device: torch.device | str = "cpu") -> float:
+    if dist is None:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_token_ids(local_ids: torch.Tensor, global_batch: int, dist=None) -> torch.Tensor:
+    """all_gather the int64 ids each rank sampled for its slice into the global [B] order.
+    Slices may differ by one element, so every rank pads to the largest slice (8 bytes/sequence:
+    latency-bound, nowhere near a 153 GB/s xGMI link)."""
+    if dist is None:
+        return local_ids
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(global_batch, rank, world)
+    assert local_ids.dtype == torch.int64 and local_ids.numel() == hi - lo
+    width = -(-global_batch // world)
+    padded = torch.zeros(width, dtype=torch.int64, device=local_ids.device)
+    padded[: hi - lo] = local_ids
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded)
+    parts = []
+    for r in range(world):
+        a, b = shard_range(global_batch, r, world)
+        parts.append(out[r][: b - a])
+    return torch.cat(parts)
+
+
+def shard_rows(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    lo, hi = shard_range(x.shape[0], rank, world)
+    return x[lo:hi]
