@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--sweep", action="store_true", help="time every kernel variant, write gpurun_out/sweep.json")
     ap.add_argument("--diag", action="store_true",
                     help="report the plain 16-B/lane read bandwidth of this box over the K pool (stderr + gpurun_out/diag.json)")
+    ap.add_argument("--e2e", action="store_true",
+                    help="end-to-end GPT-2 small decode (12 layers, random weights) on the batched harness: "
+                         "extra JSON line on stderr + gpurun_out/e2e.json")
+    ap.add_argument("--e2e-context", type=int, default=1008, help="context length the e2e sequences start at")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--sequential-tables", action="store_true",
@@ -142,6 +146,56 @@ def cpu_baseline(wl, steps):
     }
 
 
+def run_e2e(args, dist, rank, world, local_rank, dev):
+    """GPT-2 small, `batch` sequences per GPU at ~seq_len context, one token per sequence per step,
+    through vllmini_amd.gpt2_decode (hipGraph replay of the whole step).  KV is synthetic: pages are
+    filled with random fp16 and sequences are registered at the target context length."""
+    import numpy as np
+
+    from vllmini_amd.gpt2_decode import GPT2Dims, GPT2PagedDecoder, random_state_dict
+    from vllmini_amd.kv_pool import PagedKVPool
+
+    cfg = CONFIGS[args.config]
+    # GPT-2 small with the position table extended past 1024 so contexts can cross seq_len 1024
+    dims = GPT2Dims(n_positions=2048)
+    assert (cfg.num_heads, cfg.head_size) == (dims.n_head, dims.head_size)
+    ctx0 = args.e2e_context
+    total_steps = args.warmup + args.steps + 2
+    mb = -(-(ctx0 + total_steps) // cfg.block_size) + 1
+    blocks_needed = cfg.batch * dims.n_layer * (mb - 1)
+    pool = PagedKVPool(blocks_needed + 64, dims.n_head, dims.head_size, cfg.block_size, mb, dims.n_layer, device=dev,
+                       max_seqs=cfg.batch, multi_block_prefill=True)
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    pool.key_cache.uniform_(-1, 1, generator=g)
+    pool.value_cache.uniform_(-1, 1, generator=g)
+    # shuffle the free list so pages are scattered like a long-running pool's
+    perm = np.random.default_rng(rank).permutation(pool.num_blocks)
+    pool.free_blocks = perm.tolist()
+    for s in range(cfg.batch):
+        pool.allocate_for_prefill(s, ctx0)           # bookkeeping only: the pages already hold synthetic KV
+    dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool)
+    ids = list(range(cfg.batch))
+    tok = torch.randint(0, dims.vocab_size, (cfg.batch,), device=dev, generator=g)
+
+    def step(i):
+        nonlocal tok
+        logits = dec.decode(ids, tok, use_graph=True)
+        tok = logits.argmax(-1)                       # greedy: stays on the device, no host sync
+
+    elapsed = shard.timed_steps(step, args.steps, args.warmup, dist, sync=lambda: torch.cuda.synchronize(dev))
+    elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    res = {"metric": "gpt2_small_decode_tokens_per_sec_end_to_end", "value": cfg.batch * world * args.steps / elapsed,
+           "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "context": ctx0, "batch_per_gpu": cfg.batch,
+           "data": "synthetic KV + random-init GPT-2 small weights", "dtype": "f16",
+           "note": "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy"}
+    if rank == 0:
+        print(json.dumps(res), file=sys.stderr, flush=True)
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", "e2e.json"), "w") as f:
+            json.dump(res, f, indent=1)
+
+
 def main():
     args = parse_args()
     if not torch.cuda.is_available():
@@ -149,6 +203,11 @@ def main():
     dist, rank, world, local_rank = init_dist(args.gpus)
     dev = torch.device("cuda", local_rank)
     cfg = CONFIGS[args.config]
+    if args.e2e:
+        run_e2e(args, dist, rank, world, local_rank, dev)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     wl = make_workload(cfg, dev, seed=1234 + rank, table_sets=2, ragged=args.ragged)
     if args.sequential_tables:
         for t, tab in enumerate(wl.tables):

@@ -24,6 +24,10 @@ Fixtures written:
                     32 tokens, block 16, max_blocks_per_seq 4), with strides, plus the allocator state
                     (free list, block tables) after every decode step -> pins the host-side
                     mirror and replays reference-produced inputs through the HIP kernels.
+  gpt2_tiny_decode.npz  the reference's GPT2LMHeadModel + BlockManager (tiny random-weight config, fp16,
+                    prompt of 6 tokens then 30 forced decode tokens crossing two block boundaries): weights,
+                    tokens and the logits of every step -> pins the batched decode harness
+                    (vllmini_amd/gpt2_decode.py) as a caller of the ops.
   ref_selftest.json result of running the reference's OWN unittest (tests/kernels/paged_attention.py)
                     against the oracle-backed stub on CPU.
 """
@@ -255,6 +259,55 @@ def gen_seam_trace(out_path: str, rec: SeamRecorder):
 
 
 # ------------------------------------------------------------------------------------------------
+# fixture 3: the reference model as the caller (tiny GPT-2, forced tokens)
+# ------------------------------------------------------------------------------------------------
+def gen_gpt2_tiny(out_path: str):
+    from transformers import GPT2Config
+    from vllmini.block_manager import BlockManager
+    from vllmini.model.gpt2 import GPT2LMHeadModel
+    from vllmini.model.helpers.generate_triangular_mask import generate_triangular_mask
+
+    torch.manual_seed(1)
+    cfg = GPT2Config(vocab_size=512, n_positions=64, n_embd=128, n_layer=2, n_head=2)
+    model = GPT2LMHeadModel(cfg).eval().to(torch.float16)           # scheduler.py:13
+    H, D = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    num_blocks, block_size, mb = 32, 16, 4
+    bm = BlockManager(num_blocks, block_size, H, D, mb)
+    g = torch.Generator().manual_seed(2)
+    prompt = torch.randint(0, cfg.vocab_size, (1, 6), generator=g)
+    forced = torch.randint(0, cfg.vocab_size, (30,), generator=g)
+    seq_id = 5
+    logits_steps = []
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        # prefill exactly as Scheduler.add_sequence does (scheduler.py:33-47)
+        _, _, slot_mappings, tables = bm.allocate_for_prefill(seq_id, cfg.num_hidden_layers, prompt.shape[1])
+        mask = generate_triangular_mask(1, H, prompt.shape[1])
+        logits, _ = model(input_ids=prompt, position_ids=torch.arange(prompt.shape[1]), attention_mask=mask,
+                          use_cache=True, key_cache=bm.kv_cache.key_cache, value_cache=bm.kv_cache.value_cache,
+                          slot_mappings=slot_mappings, block_tables=tables)
+        logits_steps.append(logits[0, -1].float().numpy())
+        cur_len = prompt.shape[1]
+        for tok in forced:                                          # decode exactly as Scheduler.run does (:81-98)
+            tables, new_slots = bm.decode_step(seq_id, 1)
+            logits, _ = model(input_ids=tok.view(1, 1), position_ids=torch.tensor([cur_len]), attention_mask=None,
+                              use_cache=True, is_prefill=False, key_cache=bm.kv_cache.key_cache,
+                              value_cache=bm.kv_cache.value_cache, slot_mappings=new_slots, block_tables=tables,
+                              seq_lens=torch.tensor([cur_len], dtype=torch.int32), max_seq_len=mb * block_size)
+            logits_steps.append(logits[0, -1].float().numpy())
+            cur_len += 1
+    arrays = {"meta": np.array(json.dumps({
+        "vocab_size": cfg.vocab_size, "n_positions": cfg.n_positions, "n_embd": cfg.n_embd, "n_layer": cfg.n_layer,
+        "n_head": cfg.n_head, "layer_norm_epsilon": cfg.layer_norm_epsilon, "num_blocks": num_blocks,
+        "block_size": block_size, "max_blocks_per_seq": mb, "seq_id": seq_id})),
+        "prompt": prompt.numpy(), "forced": forced.numpy(), "logits": np.stack(logits_steps),
+        "final_table": np.stack([t.numpy() for t in bm.kv_cache.paged_attention_block_tables[seq_id]])}
+    for k, v in model.state_dict().items():
+        arrays["sd/" + k] = v.numpy()
+    np.savez_compressed(out_path, **arrays)
+    print(f"wrote {out_path}: {len(logits_steps)} logit rows of {cfg.vocab_size}")
+
+
+# ------------------------------------------------------------------------------------------------
 # pin 3: the reference's own unittest, run against the oracle-backed stub
 # ------------------------------------------------------------------------------------------------
 def run_reference_selftest(out_path: str):
@@ -293,6 +346,7 @@ def main():
     with CudaToCpu():
         gen_ref_eager(os.path.join(HERE, "ref_eager.npz"))
         gen_seam_trace(os.path.join(HERE, "seam_trace.npz"), rec)
+        gen_gpt2_tiny(os.path.join(HERE, "gpt2_tiny_decode.npz"))
         run_reference_selftest(os.path.join(HERE, "ref_selftest.json"))
 
 

@@ -44,7 +44,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert typed.vmi_target_arch() == b"gfx950"
 
 
-def test_library_is_gfx950_only_and_has_no_torch_dependency():
+def test_library_is_gfx950_only_and_has_no_torch_dependency(tmp_path):
+    import shutil
+
     from vllmini_amd import build
 
     path = build.build()
@@ -53,7 +55,9 @@ def test_library_is_gfx950_only_and_has_no_torch_dependency():
     assert "torch" not in out and "c10" not in out and "python" not in out.lower()
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if os.path.exists(objdump):
-        r = subprocess.run([objdump, "--offloading", path], capture_output=True, text=True)
+        copy = str(tmp_path / "lib.so")          # --offloading extracts the code objects next to its input
+        shutil.copy(path, copy)
+        r = subprocess.run([objdump, "--offloading", copy], capture_output=True, text=True, cwd=str(tmp_path))
         archs = set(re.findall(r"gfx[0-9a-f]+", r.stdout))
         if archs:
             assert archs == {"gfx950"}, archs

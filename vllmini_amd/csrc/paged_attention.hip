@@ -140,7 +140,17 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   const int head = blockIdx.x * HPW + hl;
   if (WPH == 1 && head >= p.num_heads) return;  // host guarantees H % HPW == 0 when WPH > 1
 
-  const int L = p.seq_lens[seq];
+  // The first 64 block-table entries of this wave are requested BEFORE seq_len is known (any entry
+  // inside the row is readable; entries past the context are simply never used), so the table,
+  // seq_len and q loads overlap instead of forming a chain in front of the first page load.
+  const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
+  int bt_sg = 0;  // which 64-entry slice of my blocks is in bt_reg
+  int32_t bt_reg = (sub + lane * WPH < p.max_blocks_per_seq) ? bt[sub + lane * WPH] : 0;
+
+  // seq_len > max_seq_len overflows the logits buffer in the reference (undefined behaviour,
+  // attention_kernels.cu:725-732); here the context is truncated to the LDS that was reserved.
+  int L = p.seq_lens[seq];
+  L = L > p.lpad ? p.lpad : L;
   const int nblk = (L + BS - 1) / BS;
 
   float* logits = reinterpret_cast<float*>(smem) + (size_t)hl * p.lpad;
@@ -174,15 +184,11 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   // ---- my share of the blocks: b = sub + idx*WPH, idx in [0, nmy) -----------------------
   const int nmy = nblk > sub ? (nblk - sub + WPH - 1) / WPH : 0;
   const int ngroups = (nmy + U - 1) / U;
-  const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
-
-  int bt_sg = -1;      // which 64-entry slice of my blocks is in bt_reg
-  int32_t bt_reg = 0;  // lane j: physical id of my block (bt_sg*64 + j)
-  auto table_for = [&](int g) {
+  auto table_for = [&](int g) {  // lane j: physical id of my block (bt_sg*64 + j)
     const int sg = (g * U) >> 6;
     if (sg != bt_sg) {
-      const int myidx = sg * 64 + lane;
-      bt_reg = (myidx < nmy) ? bt[sub + myidx * WPH] : 0;
+      const int b = sub + (sg * 64 + lane) * WPH;
+      bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
       bt_sg = sg;
     }
   };
@@ -619,11 +625,20 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   p.kv_head_stride = kv_head_stride;
   p.lpad = lpad;
 
-  dim3 grid((num_heads + v.HPW - 1) / v.HPW, num_seqs, 1);
   dim3 block(v.HPW * v.WPH * 64);
-  hipLaunchKernelGGL(v.fn, grid, block, lds, static_cast<hipStream_t>(stream), p);
-  e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 launch");
+  // gridDim.y is limited to 65535: longer batches go out as consecutive launches over slices
+  for (int32_t s0 = 0; s0 < num_seqs; s0 += 65535) {
+    const int32_t ns = (num_seqs - s0) < 65535 ? (num_seqs - s0) : 65535;
+    PAParams ps = p;
+    ps.out = p.out + (int64_t)s0 * num_heads * head_size;
+    ps.q = p.q + (int64_t)s0 * q_stride;
+    ps.block_tables = p.block_tables + (int64_t)s0 * max_num_blocks_per_seq;
+    ps.seq_lens = p.seq_lens + s0;
+    dim3 grid((num_heads + v.HPW - 1) / v.HPW, ns, 1);
+    hipLaunchKernelGGL(v.fn, grid, block, lds, static_cast<hipStream_t>(stream), ps);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 launch");
+  }
   return VMI_OK;
 }
 

@@ -1,0 +1,208 @@
+"""Batched GPT-2 decode harness around the paged-attention ops.
+
+Counterpart of the reference's callers of the hot path — GPT2Attention.forward / _cache_kv /
+_paged_attention (vllmini/model/gpt2.py:21-115), GPT2Block/GPT2Model/GPT2LMHeadModel
+(gpt2.py:130-273) and the decode part of Scheduler.run (vllmini/scheduler.py:76-100) — written
+for what the operators are actually batched over:
+
+  * the reference decodes ONE sequence per step (scheduler.py:55-115) and rebuilds its metadata
+    with per-element device syncs; here a step advances B sequences at once from host-side
+    bookkeeping (kv_pool.PagedKVPool.decode_step_batch) with a single upload;
+  * q/k/v are strided views of the fused c_attn output (row stride 3*hidden), exactly the views
+    the reference hands to the ops (gpt2.py:35-41);
+  * everything around the two ops is plain torch (F.linear -> hipBLASLt, layer_norm, gelu):
+    library GEMMs, not part of the hot path.
+
+`reference_off_by_one=True` reproduces the reference caller's seq_lens (length BEFORE the new
+token, scheduler.py:96, so the newest token is not attended); the default attends to it.
+
+Weights use the reference's state_dict names (nn.Linear layout [out, in]; lm_head tied to wte,
+gpt2.py:240-241) so a reference checkpoint loads unchanged.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import cache_ops, ops
+from .kv_pool import PagedKVPool
+
+
+@dataclasses.dataclass(frozen=True)
+class GPT2Dims:
+    vocab_size: int = 50257
+    n_positions: int = 1024
+    n_embd: int = 768
+    n_layer: int = 12
+    n_head: int = 12
+    layer_norm_epsilon: float = 1e-5
+    eos_token_id: int = 50256
+
+    @property
+    def head_size(self) -> int:
+        return self.n_embd // self.n_head
+
+
+def random_state_dict(dims: GPT2Dims, device, dtype=torch.float16, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init weights of the GPT-2 architecture (no checkpoints exist offline), std 0.02."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    E = dims.n_embd
+
+    def w(*shape, std=0.02):
+        return (torch.randn(*shape, generator=g) * std).to(device=device, dtype=dtype)
+
+    sd = {"transformer.wte.weight": w(dims.vocab_size, E), "transformer.wpe.weight": w(dims.n_positions, E, std=0.01),
+          "transformer.ln_f.weight": torch.ones(E, device=device, dtype=dtype),
+          "transformer.ln_f.bias": torch.zeros(E, device=device, dtype=dtype)}
+    for i in range(dims.n_layer):
+        p = f"transformer.h.{i}."
+        sd[p + "ln_1.weight"] = torch.ones(E, device=device, dtype=dtype)
+        sd[p + "ln_1.bias"] = torch.zeros(E, device=device, dtype=dtype)
+        sd[p + "attn.c_attn.weight"] = w(3 * E, E)
+        sd[p + "attn.c_attn.bias"] = w(3 * E)
+        sd[p + "attn.c_proj.weight"] = w(E, E)
+        sd[p + "attn.c_proj.bias"] = w(E)
+        sd[p + "ln_2.weight"] = torch.ones(E, device=device, dtype=dtype)
+        sd[p + "ln_2.bias"] = torch.zeros(E, device=device, dtype=dtype)
+        sd[p + "mlp.c_fc.weight"] = w(4 * E, E)
+        sd[p + "mlp.c_fc.bias"] = w(4 * E)
+        sd[p + "mlp.c_proj.weight"] = w(E, 4 * E)
+        sd[p + "mlp.c_proj.bias"] = w(E)
+    sd["lm_head.weight"] = sd["transformer.wte.weight"]     # tied (gpt2.py:241)
+    return sd
+
+
+class GPT2PagedDecoder:
+    """Prefill + batched decode of GPT-2 over a PagedKVPool, calling the two hot-path ops."""
+
+    def __init__(self, dims: GPT2Dims, state_dict: Dict[str, torch.Tensor], pool: PagedKVPool,
+                 reference_off_by_one: bool = False):
+        assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
+        assert pool.head_size == dims.head_size
+        self.dims, self.sd, self.pool = dims, state_dict, pool
+        self.reference_off_by_one = reference_off_by_one
+        self.scale = dims.head_size ** -0.5                    # gpt2.py:13
+        self.device = pool.device
+        self.max_seq_len = pool.max_blocks_per_seq * pool.block_size   # capacity, like scheduler.py:97
+        self._static: Optional[dict] = None
+        self._graph = None
+
+    # ---- pieces shared by prefill and decode --------------------------------------------------------
+    def _ln(self, x, prefix):
+        return F.layer_norm(x, (self.dims.n_embd,), self.sd[prefix + ".weight"], self.sd[prefix + ".bias"],
+                            self.dims.layer_norm_epsilon)
+
+    def _mlp(self, x, p):                                      # gpt2.py:117-128 (nn.GELU = exact erf form)
+        h = F.linear(x, self.sd[p + "mlp.c_fc.weight"], self.sd[p + "mlp.c_fc.bias"])
+        return F.linear(F.gelu(h), self.sd[p + "mlp.c_proj.weight"], self.sd[p + "mlp.c_proj.bias"])
+
+    def _qkv(self, h, p):
+        E, H, D = self.dims.n_embd, self.dims.n_head, self.dims.head_size
+        qkv = F.linear(h, self.sd[p + "attn.c_attn.weight"], self.sd[p + "attn.c_attn.bias"])   # [T, 3E]
+        T = qkv.shape[0]
+        # strided views of the fused projection, row stride 3E (gpt2.py:35-41)
+        return (qkv[:, :E].view(T, H, D), qkv[:, E:2 * E].view(T, H, D), qkv[:, 2 * E:].view(T, H, D))
+
+    # ---- prefill (one sequence; eager causal attention like the reference, gpt2.py:46-58, 71-78) ------
+    @torch.no_grad()
+    def prefill(self, seq_id: int, input_ids: Sequence[int]) -> torch.Tensor:
+        """Allocates the sequence, writes its K/V through reshape_and_cache, returns last-token logits [V]."""
+        ids = torch.as_tensor(list(input_ids), dtype=torch.long, device=self.device)
+        T = ids.numel()
+        _, slots, _ = self.pool.allocate_for_prefill(seq_id, T)
+        slots_dev = torch.from_numpy(slots).to(self.device)
+        H = self.dims.n_head
+        x = self.sd["transformer.wte.weight"][ids] + self.sd["transformer.wpe.weight"][torch.arange(T, device=self.device)]
+        mask = torch.triu(torch.full((T, T), float("-inf"), dtype=x.dtype, device=self.device), diagonal=1)
+        for i in range(self.dims.n_layer):
+            p = f"transformer.h.{i}."
+            q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)
+            cache_ops.reshape_and_cache(k, v, self.pool.key_cache, self.pool.value_cache, slots_dev[i], "auto", 1.0)
+            qh, kh, vh = (t.transpose(0, 1) for t in (q, k, v))                       # [H, T, D]
+            w = torch.matmul(qh, kh.transpose(-1, -2)) * self.scale + mask            # gpt2.py:72-74
+            a = torch.matmul(F.softmax(w, dim=-1), vh)                                 # gpt2.py:76-78
+            a = a.transpose(0, 1).reshape(T, H * self.dims.head_size)
+            x = x + F.linear(a, self.sd[p + "attn.c_proj.weight"], self.sd[p + "attn.c_proj.bias"])
+            x = x + self._mlp(self._ln(x, p + "ln_2"), p)
+        x = self._ln(x[-1:], "transformer.ln_f")
+        return F.linear(x, self.sd["lm_head.weight"])[0]
+
+    # ---- batched decode -------------------------------------------------------------------------------
+    def _forward_decode(self, st: dict) -> torch.Tensor:
+        """One decode step for B sequences from static device buffers (graph-capturable: no allocation
+        of metadata, no host sync)."""
+        d, pool = self.dims, self.pool
+        B = st["input_ids"].shape[0]
+        x = self.sd["transformer.wte.weight"][st["input_ids"]] + self.sd["transformer.wpe.weight"][st["position_ids"]]
+        for i in range(d.n_layer):
+            p = f"transformer.h.{i}."
+            q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)
+            cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i], "auto", 1.0)  # gpt2.py:44
+            out = torch.empty((B, d.n_head, d.head_size), dtype=q.dtype, device=q.device)   # empty_like(q) is contiguous, gpt2.py:93
+            ops.paged_attention_v1(out, q, pool.key_cache, pool.value_cache, d.n_head, self.scale, st["tables"][i],
+                                   st["seq_lens"], pool.block_size, self.max_seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0)
+            x = x + F.linear(out.view(B, d.n_embd), self.sd[p + "attn.c_proj.weight"], self.sd[p + "attn.c_proj.bias"])
+            x = x + self._mlp(self._ln(x, p + "ln_2"), p)
+        return F.linear(self._ln(x, "transformer.ln_f"), self.sd["lm_head.weight"])   # [B, V]
+
+    def _ensure_static(self, B: int) -> dict:
+        if self._static is None or self._static["input_ids"].shape[0] != B:
+            L, MB, dev = self.dims.n_layer, self.pool.max_blocks_per_seq, self.device
+            self._static = {
+                "input_ids": torch.zeros(B, dtype=torch.long, device=dev),
+                "position_ids": torch.zeros(B, dtype=torch.long, device=dev),
+                "tables": torch.full((L, B, MB), -1, dtype=torch.int32, device=dev),
+                "slots": torch.zeros((L, B), dtype=torch.int64, device=dev),
+                "seq_lens": torch.zeros(B, dtype=torch.int32, device=dev),
+            }
+            self._graph = None
+        return self._static
+
+    def stage_step(self, seq_ids: Sequence[int], input_ids) -> dict:
+        """Host bookkeeping for one step + ONE upload per array into the static device buffers."""
+        B = len(seq_ids)
+        st = self._ensure_static(B)
+        positions = np.fromiter((self.pool.seq_len(s) for s in seq_ids), dtype=np.int64, count=B)  # scheduler.py:81
+        tables, slots, ctx = self.pool.decode_step_batch(seq_ids)
+        lens = ctx - 1 if self.reference_off_by_one else ctx
+        st["tables"].copy_(torch.from_numpy(np.ascontiguousarray(tables)), non_blocking=True)
+        st["slots"].copy_(torch.from_numpy(np.ascontiguousarray(slots)), non_blocking=True)
+        st["seq_lens"].copy_(torch.from_numpy(np.ascontiguousarray(lens.astype(np.int32))), non_blocking=True)
+        st["position_ids"].copy_(torch.from_numpy(positions), non_blocking=True)
+        if isinstance(input_ids, torch.Tensor):
+            st["input_ids"].copy_(input_ids.to(torch.long), non_blocking=True)
+        else:
+            st["input_ids"].copy_(torch.as_tensor(list(input_ids), dtype=torch.long), non_blocking=True)
+        return st
+
+    @torch.no_grad()
+    def decode(self, seq_ids: Sequence[int], input_ids, use_graph: bool = False) -> torch.Tensor:
+        """Feed one token per sequence; returns logits [B, V].  With use_graph the step's ~150 kernel
+        launches are replayed from one hipGraph (captured on first use for this batch size)."""
+        st = self.stage_step(seq_ids, input_ids)
+        if not use_graph:
+            return self._forward_decode(st)
+        if self._graph is None:
+            s = torch.cuda.Stream(self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):          # warm-up outside capture (library handles, LDS attributes)
+                self._forward_decode(st)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._graph_out = self._forward_decode(st)
+        self._graph.replay()
+        return self._graph_out
+
+    # ---- sampling (scheduler.py:144-153: temperature 1.0, top-k 50, multinomial) -------------------------
+    @staticmethod
+    def sample_top_k(logits: torch.Tensor, top_k: int = 50, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        vals, idx = torch.topk(logits.float(), top_k, dim=-1)
+        probs = F.softmax(vals, dim=-1)
+        choice = torch.multinomial(probs, num_samples=1, generator=generator)
+        return idx.gather(-1, choice).squeeze(-1)

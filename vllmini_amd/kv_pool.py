@@ -9,19 +9,24 @@ Reference:
 
 The reference keeps one int32 [1, max_blocks] table PER (sequence, layer) on the device and scans
 it element by element (a device->host sync per element, block_manager.py:36-39).  Here the same
-state lives in host numpy arrays — tables[layer][seq_row] — and one [B, max_blocks] int32 tensor and
-one [B] int64 slot tensor per layer are produced per decode step for a whole BATCH of sequences,
-which is the shape paged_attention_v1 / reshape_and_cache are batched over.  For any single sequence
-the block ids, their order, the slots and the free-list order are exactly the reference's
-(tests/test_kv_pool.py replays the reference's own allocator trace from tests/golden/seam_trace.npz).
+state lives in host numpy arrays with one ROW per live sequence —
+    tables [layers, rows, max_blocks] int32,  nblocks / filled [layers, rows]
+— and a decode step for a whole batch is a handful of vectorised numpy operations that emit
+one [layers, B, max_blocks] int32 table tensor and one [layers, B] int64 slot tensor, the shapes
+paged_attention_v1 / reshape_and_cache are batched over.  No device round trip is involved.
+
+For any single sequence the block ids, their order, the slots and the free-list order are exactly
+the reference's (tests/test_kv_pool.py replays the reference's own allocator trace from
+tests/golden/seam_trace.npz); for a batch, new blocks are handed out in the order the reference
+would use if it stepped the sequences one after the other (sequence-major, then layer).
 
 Reference quirks that are reproduced or flagged, not silently changed:
   * prefill hands out exactly one block per layer, so prompts longer than block_size are rejected
     here (the reference would silently write into the next block, which belongs to another layer:
-    kv_cache.py:25-35, SURVEY.md §3B);
+    kv_cache.py:25-35, SURVEY.md §3B) unless `multi_block_prefill=True` (this build's extension);
   * decode_step needs a trailing -1 in the table to find the last block (block_manager.py:36-39), so a
-    sequence can use at most max_blocks_per_seq-1 blocks per layer; exceeding that raises here
-    (the reference dies with UnboundLocalError);
+    sequence can use at most max_blocks_per_seq-1 blocks per layer before the next step fails; that
+    raises here (the reference dies with UnboundLocalError);
   * exhaustion raises RuntimeError with the reference's messages (kv_cache.py:22-23, 57-58).
 """
 from __future__ import annotations
@@ -37,7 +42,7 @@ X = 8  # halves per 16-byte K chunk (kv_cache.py:13: head_size // 8, ..., 8)
 class PagedKVPool:
     def __init__(self, num_blocks: int, num_heads: int, head_size: int, block_size: int,
                  max_blocks_per_seq: int, num_layers: int, device: torch.device | str = "cuda",
-                 allocate_tensors: bool = True):
+                 allocate_tensors: bool = True, max_seqs: int = 64, multi_block_prefill: bool = False):
         self.num_blocks = num_blocks
         self.num_heads = num_heads
         self.head_size = head_size
@@ -45,6 +50,7 @@ class PagedKVPool:
         self.max_blocks_per_seq = max_blocks_per_seq
         self.num_layers = num_layers
         self.device = torch.device(device)
+        self.multi_block_prefill = multi_block_prefill
         if allocate_tensors:
             # kv_cache.py:13-14 — ONE pool shared by all layers
             self.key_cache = torch.zeros(num_blocks, num_heads, head_size // X, block_size, X,
@@ -55,73 +61,129 @@ class PagedKVPool:
             self.key_cache = self.value_cache = None
         self.free_blocks: List[int] = list(range(num_blocks))          # kv_cache.py:16, FIFO
         self.allocated_blocks: Dict[int, List[int]] = {}               # kv_cache.py:17
-        # per sequence: [layers, max_blocks] int32 table (-1 padded) and per-layer fill of the last block
-        self._tables: Dict[int, np.ndarray] = {}
-        self._nblocks: Dict[int, np.ndarray] = {}                      # [layers] blocks in use
-        self._filled: Dict[int, np.ndarray] = {}                       # [layers] tokens in the last block
-        self._seq_len: Dict[int, int] = {}
+        self._row_of: Dict[int, int] = {}
+        self._free_rows: List[int] = []
+        self._rows = 0
+        self._alloc_rows(max_seqs)
+
+    # ---- row storage -----------------------------------------------------------------------------
+    def _alloc_rows(self, n: int) -> None:
+        L, MB = self.num_layers, self.max_blocks_per_seq
+        tables = np.full((L, n, MB), -1, dtype=np.int32)
+        nblocks = np.zeros((L, n), dtype=np.int64)
+        filled = np.zeros((L, n), dtype=np.int64)
+        seq_len = np.zeros(n, dtype=np.int64)
+        if self._rows:
+            tables[:, : self._rows] = self._tables
+            nblocks[:, : self._rows] = self._nblocks
+            filled[:, : self._rows] = self._filled
+            seq_len[: self._rows] = self._seq_len
+        self._free_rows.extend(range(self._rows, n))
+        self._tables, self._nblocks, self._filled, self._seq_len = tables, nblocks, filled, seq_len
+        self._rows = n
+
+    def _new_row(self, seq_id: int) -> int:
+        if not self._free_rows:
+            self._alloc_rows(max(2 * self._rows, 1))
+        row = self._free_rows.pop(0)
+        self._row_of[seq_id] = row
+        return row
+
+    def _take(self, n: int) -> List[int]:
+        taken = self.free_blocks[:n]                                    # kv_cache.py:25-26 / pop(0) :60
+        del self.free_blocks[:n]
+        return taken
 
     # ---- reference-compatible per-sequence operations -------------------------------------------
     def allocate_for_prefill(self, seq_id: int, seq_len: int) -> Tuple[List[int], np.ndarray, np.ndarray]:
         """-> (allocated block ids, slot mappings [layers, seq_len] int64, tables [layers, MB] int32)."""
         if seq_id in self.allocated_blocks:
             raise ValueError(f"sequence {seq_id} already allocated")
-        if len(self.free_blocks) < self.num_layers:
+        bs, L = self.block_size, self.num_layers
+        per_layer = 1
+        if seq_len > bs:
+            if not self.multi_block_prefill:
+                raise RuntimeError(
+                    f"prefill of {seq_len} tokens does not fit the single block per layer the reference "
+                    f"allocates (block_size={bs}; kv_cache.py:25-35)")
+            per_layer = -(-seq_len // bs)
+            if per_layer > self.max_blocks_per_seq - 1:
+                raise RuntimeError(f"prefill of {seq_len} tokens needs {per_layer} blocks per layer, table "
+                                   f"holds {self.max_blocks_per_seq - 1} usable entries")
+        if len(self.free_blocks) < L * per_layer:
             raise RuntimeError("Not enough free blocks for prefill allocation")   # kv_cache.py:22-23
-        if seq_len > self.block_size:
-            raise RuntimeError(
-                f"prefill of {seq_len} tokens does not fit the single block per layer the reference "
-                f"allocates (block_size={self.block_size}; kv_cache.py:25-35)")
-        allocated = self.free_blocks[: self.num_layers]                # kv_cache.py:25-26
-        self.free_blocks = self.free_blocks[self.num_layers:]
+        allocated = self._take(L * per_layer)
         self.allocated_blocks[seq_id] = list(allocated)
-        tab = np.full((self.num_layers, self.max_blocks_per_seq), -1, dtype=np.int32)
-        tab[:, 0] = allocated                                          # kv_cache.py:31
-        self._tables[seq_id] = tab
-        self._nblocks[seq_id] = np.ones(self.num_layers, dtype=np.int64)
-        self._filled[seq_id] = np.full(self.num_layers, min(seq_len, self.block_size), dtype=np.int64)  # :30
-        self._seq_len[seq_id] = seq_len
-        slots = (np.arange(seq_len, dtype=np.int64)[None, :] +
-                 np.asarray(allocated, dtype=np.int64)[:, None] * self.block_size)   # kv_cache.py:35
-        return list(allocated), slots, tab.copy()
+        row = self._new_row(seq_id)
+        # layer l gets blocks [l, L + l, 2L + l, ...]: the first L are the reference's one-per-layer
+        blocks = np.asarray(allocated, dtype=np.int32).reshape(per_layer, L).T        # [L, per_layer]
+        self._tables[:, row, :] = -1
+        self._tables[:, row, :per_layer] = blocks                       # kv_cache.py:31
+        self._nblocks[:, row] = per_layer
+        self._filled[:, row] = seq_len - (per_layer - 1) * bs           # kv_cache.py:30 (min(seq_len, bs))
+        self._seq_len[row] = seq_len
+        pos = np.arange(seq_len, dtype=np.int64)
+        slots = blocks.astype(np.int64)[:, pos // bs] * bs + pos % bs   # kv_cache.py:35
+        return list(allocated), slots, self._tables[:, row, :].copy()
 
     def decode_step(self, seq_id: int, input_len: int = 1) -> Tuple[np.ndarray, np.ndarray]:
-        """One new token for one sequence -> (tables [layers, MB] int32, slots [layers] int64).
-        Layer by layer, like block_manager.py:34-59 (so a shared free list hands blocks out in the
-        reference's order)."""
-        tab, nb, filled = self._tables[seq_id], self._nblocks[seq_id], self._filled[seq_id]
-        slots = np.empty(self.num_layers, dtype=np.int64)
-        for layer in range(self.num_layers):
-            if nb[layer] >= self.max_blocks_per_seq:
-                # the reference finds the last block by looking for the first -1 (block_manager.py:36-39)
-                raise RuntimeError(
-                    f"sequence {seq_id} layer {layer}: table of {self.max_blocks_per_seq} entries is full; "
-                    "the reference needs a trailing -1 (block_manager.py:36-39)")
-            last_block = int(tab[layer, nb[layer] - 1])
-            num_filled = int(filled[layer])
-            if num_filled == self.block_size:                           # block_manager.py:48-53
-                if len(self.free_blocks) == 0:
-                    raise RuntimeError("No free blocks available")      # kv_cache.py:57-58
-                new_block = self.free_blocks.pop(0)                     # kv_cache.py:60
-                self.allocated_blocks[seq_id].append(new_block)
-                tab[layer, nb[layer]] = new_block                       # kv_cache.py:64-70
-                nb[layer] += 1
-                last_block, num_filled = new_block, 0
-            slots[layer] = last_block * self.block_size + num_filled    # block_manager.py:55
-            filled[layer] = num_filled + input_len                      # block_manager.py:59
-        self._seq_len[seq_id] += input_len
-        return tab.copy(), slots
+        """One new token for one sequence -> (tables [layers, MB] int32, slots [layers] int64)
+        (block_manager.py:28-63)."""
+        tables, slots, _ = self._step_rows(np.array([self._row_of[seq_id]]), [seq_id], input_len)
+        return tables[:, 0, :], slots[:, 0]
 
     def free(self, seq_id: int) -> None:
         if seq_id in self.allocated_blocks:                             # kv_cache.py:81-86
             self.free_blocks.extend(self.allocated_blocks[seq_id])
             del self.allocated_blocks[seq_id]
-            del self._tables[seq_id], self._nblocks[seq_id], self._filled[seq_id], self._seq_len[seq_id]
+            row = self._row_of.pop(seq_id)
+            self._tables[:, row, :] = -1
+            self._nblocks[:, row] = 0
+            self._free_rows.append(row)
 
     def seq_len(self, seq_id: int) -> int:
-        return self._seq_len[seq_id]
+        return int(self._seq_len[self._row_of[seq_id]])
 
-    # ---- batched view: what the batched operators consume -----------------------------------------
+    def table(self, seq_id: int) -> np.ndarray:
+        return self._tables[:, self._row_of[seq_id], :].copy()
+
+    # ---- batched step: what the batched operators consume -----------------------------------------
+    def _step_rows(self, rows: np.ndarray, seq_ids: Sequence[int], input_len: int):
+        bs, MB = self.block_size, self.max_blocks_per_seq
+        nb = self._nblocks[:, rows]                                     # [L, B]
+        filled = self._filled[:, rows]
+        if (nb >= MB).any():
+            # the reference finds the last block by looking for the first -1 (block_manager.py:36-39)
+            l, b = np.argwhere(nb >= MB)[0]
+            raise RuntimeError(
+                f"sequence {seq_ids[b]} layer {l}: table of {MB} entries is full; "
+                "the reference needs a trailing -1 (block_manager.py:36-39)")
+        need = filled == bs                                             # block_manager.py:48
+        n_new = int(need.sum())
+        if n_new:
+            # reference order: sequence by sequence, layer by layer within a sequence
+            order = np.argwhere(need.T)                                 # rows of (b, l), b-major
+            if n_new > len(self.free_blocks):
+                # hand out what the reference would have handed out before failing
+                order = order[: len(self.free_blocks)]
+            new_blocks = self._take(len(order))
+            for (b, l), blk in zip(order, new_blocks):
+                r = rows[b]
+                self._tables[l, r, self._nblocks[l, r]] = blk           # kv_cache.py:64-70
+                self._nblocks[l, r] += 1
+                self._filled[l, r] = 0
+                self.allocated_blocks[seq_ids[b]].append(blk)
+            if len(order) < n_new:
+                raise RuntimeError("No free blocks available")          # kv_cache.py:57-58
+            nb = self._nblocks[:, rows]
+            filled = self._filled[:, rows]
+        tables = self._tables[:, rows, :]                               # [L, B, MB] (copy: fancy index)
+        last = np.take_along_axis(tables, (nb - 1)[:, :, None], axis=2)[:, :, 0].astype(np.int64)
+        slots = last * bs + filled                                      # block_manager.py:55
+        self._filled[:, rows] = filled + input_len                      # block_manager.py:59
+        self._seq_len[rows] += input_len
+        return tables, slots, self._seq_len[rows].astype(np.int32)
+
     def decode_step_batch(self, seq_ids: Sequence[int]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """One new token for EVERY sequence in `seq_ids` (in that order) ->
              tables  [layers, B, MB] int32, slots [layers, B] int64, context_lens [B] int32
@@ -129,19 +191,11 @@ class PagedKVPool:
         reference passes the length BEFORE the new token, scheduler.py:96 vs block_manager.py:55 — an
         off-by-one in its caller that makes the newest token invisible; pass context_lens-1 as
         seq_lens to reproduce that.)"""
-        B = len(seq_ids)
-        tables = np.empty((self.num_layers, B, self.max_blocks_per_seq), dtype=np.int32)
-        slots = np.empty((self.num_layers, B), dtype=np.int64)
-        lens = np.empty(B, dtype=np.int32)
-        for i, sid in enumerate(seq_ids):
-            t, s = self.decode_step(sid, 1)
-            tables[:, i, :] = t
-            slots[:, i] = s
-            lens[i] = self._seq_len[sid]
-        return tables, slots, lens
+        rows = np.fromiter((self._row_of[s] for s in seq_ids), dtype=np.int64, count=len(seq_ids))
+        return self._step_rows(rows, seq_ids, 1)
 
     def upload(self, tables: np.ndarray, slots: np.ndarray, lens: np.ndarray):
         """Host metadata -> device tensors in the dtypes the operators require (int32 / int64 / int32)."""
-        return (torch.from_numpy(tables).to(self.device, non_blocking=True),
-                torch.from_numpy(slots).to(self.device, non_blocking=True),
-                torch.from_numpy(lens).to(self.device, non_blocking=True))
+        return (torch.from_numpy(np.ascontiguousarray(tables)).to(self.device, non_blocking=True),
+                torch.from_numpy(np.ascontiguousarray(slots)).to(self.device, non_blocking=True),
+                torch.from_numpy(np.ascontiguousarray(lens)).to(self.device, non_blocking=True))
