@@ -542,7 +542,8 @@ def test_gpt2_harness_batched_equals_single_and_graph_replay(golden_dir):
         eager = dec.decode(ids, toks).float().cpu().numpy()
         for i, sid in enumerate(ids):
             one = solo.decode([sid], [toks[i]])[0].float().cpu().numpy()
-            assert np.abs(eager[i] - one).max() <= 2e-2      # GEMM tiling differs with batch size
+            # fp16 GEMMs pick different tilings for M=4 and M=1: a few fp16 ulps at the logits' magnitude
+            assert np.abs(eager[i] - one).max() <= 1e-2 + 4e-3 * np.abs(one).max()
     # graph replay vs eager on identical state: clone the pools by re-running two fresh decoders
     _, _, a = _tiny_gpt2(golden_dir, dev, off_by_one=False)
     _, _, b = _tiny_gpt2(golden_dir, dev, off_by_one=False)

@@ -116,14 +116,14 @@ class PagedKVPool:
         self.allocated_blocks[seq_id] = list(allocated)
         row = self._new_row(seq_id)
         # layer l gets blocks [l, L + l, 2L + l, ...]: the first L are the reference's one-per-layer
-        blocks = np.asarray(allocated, dtype=np.int32).reshape(per_layer, L).T        # [L, per_layer]
+        blocks = np.ascontiguousarray(np.asarray(allocated, dtype=np.int32).reshape(per_layer, L).T)  # [L, per_layer]
         self._tables[:, row, :] = -1
         self._tables[:, row, :per_layer] = blocks                       # kv_cache.py:31
         self._nblocks[:, row] = per_layer
         self._filled[:, row] = seq_len - (per_layer - 1) * bs           # kv_cache.py:30 (min(seq_len, bs))
         self._seq_len[row] = seq_len
         pos = np.arange(seq_len, dtype=np.int64)
-        slots = blocks.astype(np.int64)[:, pos // bs] * bs + pos % bs   # kv_cache.py:35
+        slots = np.ascontiguousarray(blocks.astype(np.int64)[:, pos // bs] * bs + pos % bs)   # kv_cache.py:35
         return list(allocated), slots, self._tables[:, row, :].copy()
 
     def decode_step(self, seq_id: int, input_len: int = 1) -> Tuple[np.ndarray, np.ndarray]:
