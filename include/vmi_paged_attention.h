@@ -118,6 +118,32 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
                                         int32_t max_seq_len);
 
 /*
+ * paged_attention_v2 (split-KV), fp16 — the operator the reference exports next to v1
+ * (paged_attention_cuda.cpp:27-47, :53; host entry attention_kernels.cu:966-990, launcher :845-928).
+ * The context is cut into 512-token partitions (PARTITION_SIZE, :847); every (seq, head, partition)
+ * is attended independently and a second kernel merges the partitions (:564-669).
+ *
+ *   exp_sums, max_logits [num_seqs, num_heads, P] fp32   P = ceil(max_seq_len / 512)   (written)
+ *   tmp_out              [num_seqs, num_heads, P, head_size] fp16                       (written)
+ *   out                  [num_seqs, num_heads, head_size] fp16                          (written)
+ * Partitions at or past a sequence's context are left untouched, as in the reference (:116-119).
+ * variant: 0 = heuristic, 1..vmi_paged_attention_v2_variant_count() forces a decomposition.
+ * All other arguments as vmi_paged_attention_v1_f16.  Limits: num_seqs, num_heads, P <= 65535.
+ */
+int vmi_paged_attention_v2_f16(
+    void* out, void* exp_sums, void* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream, int32_t variant);
+int vmi_paged_attention_v2_variant_count(void);
+const char* vmi_paged_attention_v2_variant_name(int32_t variant);
+
+/*
  * cache_ops.reshape_and_cache, fp16 key/value into fp16 ("auto") caches.
  *
  * Replaces: reshape_and_cache(key, value, key_cache, value_cache, slot_mapping,

@@ -18,6 +18,7 @@ from .kernel_model import (  # noqa: F401
     f2h,
     h2f,
     paged_attention_v1,
+    paged_attention_v2,
     reshape_and_cache,
 )
 from .eager import (  # noqa: F401

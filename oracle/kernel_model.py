@@ -36,6 +36,9 @@ def _load() -> ctypes.CDLL:
         lib.vmi_oracle_paged_attention_v1_f16.restype = ctypes.c_int
         lib.vmi_oracle_paged_attention_v1_f16.argtypes = [
             vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, vp, i64, i64, i64, i32, i32]
+        lib.vmi_oracle_paged_attention_v2_f16.restype = ctypes.c_int
+        lib.vmi_oracle_paged_attention_v2_f16.argtypes = [
+            vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, i32, vp, i64, i64, i64]
         lib.vmi_oracle_reshape_and_cache_f16.restype = ctypes.c_int
         lib.vmi_oracle_reshape_and_cache_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64]
         lib.vmi_oracle_f2h.restype = ctypes.c_uint16
@@ -112,6 +115,39 @@ def paged_attention_v1(query: np.ndarray, key_cache: np.ndarray, value_cache: np
         if rc != 0:
             raise MemoryError("oracle allocation failed")
     return out
+
+
+def paged_attention_v2(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
+                       num_kv_heads: int, scale: float, block_tables: np.ndarray, seq_lens: np.ndarray,
+                       block_size: int, max_seq_len: int, alibi_slopes: np.ndarray | None = None):
+    """Kernel model of the split-KV operator (attention_kernels.cu:966-990): returns
+    (out [S,H,D] f16, exp_sums [S,H,P] f32, max_logits [S,H,P] f32, tmp_out [S,H,P,D] f16) with
+    P = ceil(max_seq_len / 512).  Partitions past a sequence's context keep their fill value (NaN)."""
+    assert query.dtype == np.float16 and query.ndim == 3
+    S, H, D = query.shape
+    qs = _elem_strides(query)
+    assert qs[2] == 1 and qs[1] == D
+    key_cache = np.ascontiguousarray(key_cache)
+    value_cache = np.ascontiguousarray(value_cache)
+    block_tables = np.ascontiguousarray(block_tables, dtype=np.int32)
+    seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    kb, kh = _elem_strides(key_cache)[:2]
+    P = (int(max_seq_len) + 511) // 512
+    out = np.zeros((S, H, D), dtype=np.float16)
+    exp_sums = np.full((S, H, P), np.nan, dtype=np.float32)
+    max_logits = np.full((S, H, P), np.nan, dtype=np.float32)
+    tmp_out = np.full((S, H, P, D), np.nan, dtype=np.float16)
+    alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
+    rc = _load().vmi_oracle_paged_attention_v2_f16(
+        _base_ptr(out), _base_ptr(exp_sums), _base_ptr(max_logits), _base_ptr(tmp_out), _base_ptr(query),
+        _base_ptr(key_cache), _base_ptr(value_cache), S, H, D, int(num_kv_heads), float(scale),
+        _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size), int(max_seq_len),
+        int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh))
+    if rc == 1:
+        raise RuntimeError(f"Unsupported head size / block size: {D} / {block_size}")
+    if rc != 0:
+        raise MemoryError("oracle allocation failed")
+    return out, exp_sums, max_logits, tmp_out
 
 
 def reshape_and_cache(key: np.ndarray, value: np.ndarray, key_cache: np.ndarray,

@@ -79,8 +79,9 @@ def test_python_surface_matches_reference_signatures():
     assert rc == ["key", "value", "key_cache", "value_cache", "slot_mapping", "kv_cache_dtype", "kv_scale"]
     for name in ("swap_blocks", "copy_blocks", "reshape_and_cache_flash", "convert_fp8"):          # .cpp:56-61
         assert hasattr(ext.cache_ops, name)
-    with pytest.raises(NotImplementedError):
-        ext.paged_attention_v2()
+    v2 = [p.name for p in inspect.signature(ext.paged_attention_v2).parameters.values()
+          if p.kind is not inspect.Parameter.KEYWORD_ONLY]
+    assert v2 == ["out", "exp_sums", "max_logits", "tmp_out"] + pa[1:]                      # .cpp:27-47
 
 
 def _cpu_args(D=64, dtype=torch.float16):

@@ -557,3 +557,81 @@ def test_gpt2_harness_batched_equals_single_and_graph_replay(golden_dir):
         torch.cuda.synchronize()
         assert torch.equal(la, lb), step
     assert torch.equal(a.pool.key_cache, b.pool.key_cache) and torch.equal(a.pool.value_cache, b.pool.value_cache)
+
+
+# ------------------------------------------------------------------------------------------------
+# paged_attention_v2 (split-KV, 512-token partitions + reduce) vs the kernel model of the reference's v2
+# ------------------------------------------------------------------------------------------------
+def run_hip_v2(case, max_seq_len, variant=0, alibi=None):
+    ext = _ext()
+    from vllmini_amd import ops
+
+    dev = _dev()
+    S, H, D = case["q"].shape
+    P = (max_seq_len + 511) // 512
+    qbuf = torch.from_numpy(case["qbuf"]).to(dev)
+    q = qbuf[:, : H * D].view(S, H, D)
+    out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=dev)
+    es = torch.full((S, H, P), float("nan"), dtype=torch.float32, device=dev)
+    ml = torch.full((S, H, P), float("nan"), dtype=torch.float32, device=dev)
+    tmp = torch.full((S, H, P, D), float("nan"), dtype=torch.float16, device=dev)
+    al = None if alibi is None else torch.from_numpy(alibi).to(dev)
+    fn = ops.paged_attention_v2 if variant else ext.paged_attention_v2
+    kw = {"_variant": variant} if variant else {}
+    fn(out, es, ml, tmp, q, torch.from_numpy(case["kc"]).to(dev), torch.from_numpy(case["vc"]).to(dev),
+       case["num_kv_heads"], case["scale"], torch.from_numpy(case["tables"]).to(dev),
+       torch.from_numpy(case["lens"]).to(dev), BS, max_seq_len, al, "auto", 1.0, 0, 0, 1, 1, 0, **kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), es.cpu().numpy(), ml.cpu().numpy(), tmp.cpu().numpy()
+
+
+def _check_v2(case, max_seq_len, variant=0, alibi=None, what=""):
+    got, es, ml, tmp = run_hip_v2(case, max_seq_len, variant, alibi)
+    r_out, r_es, r_ml, r_tmp = oracle.paged_attention_v2(case["q"], case["kc"], case["vc"], case["num_kv_heads"],
+                                                         case["scale"], case["tables"], case["lens"], BS, max_seq_len,
+                                                         alibi_slopes=alibi)
+    assert_close(got, r_out, what + " out")
+    for s, L in enumerate(case["lens"]):
+        used = (int(L) + 511) // 512
+        assert np.allclose(ml[s, :, :used], r_ml[s, :, :used], rtol=1e-5, atol=1e-5), what
+        assert np.allclose(es[s, :, :used], r_es[s, :, :used], rtol=2e-5, atol=1e-6), what
+        assert_close(tmp[s, :, :used], r_tmp[s, :, :used], what + " tmp_out")
+        # partitions past the context are left untouched (attention_kernels.cu:116-119)
+        assert np.isnan(es[s, :, used:]).all() and np.isnan(tmp[s, :, used:]).all(), what
+    return got
+
+
+def test_pa_v2_matches_kernel_model():
+    rng = np.random.default_rng(21)
+    lens = [0, 3, 511, 512, 513, 1024, 1100, 2047]
+    case = make_case(rng, len(lens), 12, 64, lens, q_row_pad=2, poison_tail=True, max_blocks=130)
+    _check_v2(case, 2048, what="v2 d64")
+    case = make_case(rng, 3, 8, 128, [700, 5, 1500], num_kv_heads=4)
+    _check_v2(case, 1536, alibi=(2.0 ** -np.arange(1, 9)).astype(np.float32), what="v2 d128 gqa alibi")
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_pa_v2_every_variant(D):
+    from vllmini_amd import ops
+
+    rng = np.random.default_rng(22 + D)
+    lens = [1, 600, 2000, 1025, 16]
+    case = make_case(rng, len(lens), 4, D, lens, poison_tail=True)
+    for vid, name in enumerate(ops.variant_names_v2(), start=1):
+        if name.startswith(f"v2_d{D}_"):
+            _check_v2(case, 2048, variant=vid, what=name)
+
+
+def test_pa_v2_agrees_with_v1_and_exact():
+    """v1 and v2 are different roundings of the same quantity: both within the reference's tolerances
+    of the exact answer, and identical bit for bit when a sequence has a single partition (the reduce
+    kernel then only copies, attention_kernels.cu:582-594)."""
+    rng = np.random.default_rng(23)
+    lens = [400, 512, 3000, 77]
+    case = make_case(rng, len(lens), 12, 64, lens, kv="normal")
+    v2 = run_hip_v2(case, 3008)[0]
+    v1 = run_hip(case)
+    exact = oracle.eager_paged_attention(case["q"], case["kc"], case["vc"], 12, case["scale"], case["tables"], case["lens"])
+    assert np.array_equal(v1[[0, 1, 3]].view(np.uint16), v2[[0, 1, 3]].view(np.uint16))
+    assert np.abs(v2.astype(np.float64) - exact).max() <= 2e-3
+    assert np.abs(v1.astype(np.float64) - v2.astype(np.float64)).max() <= 2e-3

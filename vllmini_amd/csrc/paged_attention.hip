@@ -107,6 +107,10 @@ struct PAParams {
   int64_t kv_block_stride;
   int64_t kv_head_stride;
   int32_t lpad;  // logits floats reserved per head in LDS (max_seq_len padded to 16)
+  // split-KV (paged_attention_v2) only: per-partition softmax statistics, `out` is tmp_out
+  float* exp_sums;             // [num_seqs, num_heads, max_num_partitions]
+  float* max_logits;           // [num_seqs, num_heads, max_num_partitions]
+  int32_t max_num_partitions;  // ceil(max_seq_len / 512)
 };
 
 // ----------------------------------------------------------------------------------------
@@ -121,10 +125,15 @@ struct PAParams {
 // grid = (ceil(num_heads / HPW), num_seqs), block = HPW*WPH*64.
 // LDS  = HPW*lpad*4 (logits)  +  HPW*2*WPH*4 (max/sum exchange)  +  HPW*WPH*D*4 (partial out)
 // ----------------------------------------------------------------------------------------
-template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false>
+//
+// PART = true is the split-KV form behind paged_attention_v2 (reference attention_kernels.cu:529-562:
+// the same kernel body with PARTITION_SIZE = 512): blockIdx.z selects a 512-token partition, the
+// partition's normalised output goes to tmp_out and its (max, exp_sum) to max_logits / exp_sums.
+template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false>
 __global__ void __launch_bounds__(HPW* WPH * 64)
     pa_v1_kernel(const PAParams p) {
   constexpr int BS = 16;
+  constexpr int PBLK = 512 / BS;  // blocks per partition (PARTITION_SIZE = 512, :847)
   constexpr int NL = D / 32;  // 1-KiB loads per K tile == per V tile
   static_assert(D % 32 == 0, "head size must be a multiple of 32");
   static_assert(64 % U == 0, "U must divide 64");
@@ -144,21 +153,29 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   // inside the row is readable; entries past the context are simply never used), so the table,
   // seq_len and q loads overlap instead of forming a chain in front of the first page load.
   const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
+  const int part = PART ? blockIdx.z : 0;
+  const int blk_lo = PART ? part * PBLK : 0;  // first block of my range (:126-127)
   int bt_sg = 0;  // which 64-entry slice of my blocks is in bt_reg
-  int32_t bt_reg = (sub + lane * WPH < p.max_blocks_per_seq) ? bt[sub + lane * WPH] : 0;
+  int32_t bt_reg = (blk_lo + sub + lane * WPH < p.max_blocks_per_seq) ? bt[blk_lo + sub + lane * WPH] : 0;
 
   // seq_len > max_seq_len overflows the logits buffer in the reference (undefined behaviour,
   // attention_kernels.cu:725-732); here the context is truncated to the LDS that was reserved.
   int L = p.seq_lens[seq];
-  L = L > p.lpad ? p.lpad : L;
-  const int nblk = (L + BS - 1) / BS;
+  if constexpr (!PART) L = L > p.lpad ? p.lpad : L;
+  const int nblk_seq = (L + BS - 1) / BS;                                     // :121
+  const int blk_hi = PART ? (blk_lo + PBLK < nblk_seq ? blk_lo + PBLK : nblk_seq) : nblk_seq;  // :128-129
+  if (PART && blk_lo * BS >= L) return;  // nothing in this partition (:116-119); uniform per workgroup
+  const int nblk = blk_hi - blk_lo;      // blocks in my range
+  const int tok_lo = blk_lo * BS;        // logits in LDS are indexed relative to the range start (:133)
+  const int Lloc = (L < blk_hi * BS ? L : blk_hi * BS) - tok_lo;              // tokens in range (:134-136)
 
   float* logits = reinterpret_cast<float*>(smem) + (size_t)hl * p.lpad;
   float* red = reinterpret_cast<float*>(smem) + (size_t)HPW * p.lpad + hl * 2 * WPH;
   float* osm = reinterpret_cast<float*>(smem) + (size_t)HPW * p.lpad + HPW * 2 * WPH +
                (size_t)hl * WPH * D;
 
-  h16* outp = p.out + ((int64_t)seq * p.num_heads + head) * D;
+  h16* outp = PART ? p.out + (((int64_t)seq * p.num_heads + head) * p.max_num_partitions + part) * D
+                   : p.out + ((int64_t)seq * p.num_heads + head) * D;
 
   if (L <= 0) {  // uniform over the workgroup (same seq): reference yields exp_sum = 0 -> out = 0
     if (sub == 0) {
@@ -187,7 +204,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   auto table_for = [&](int g) {  // lane j: physical id of my block (bt_sg*64 + j)
     const int sg = (g * U) >> 6;
     if (sg != bt_sg) {
-      const int b = sub + (sg * 64 + lane) * WPH;
+      const int b = blk_lo + sub + (sg * 64 + lane) * WPH;
       bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
       bt_sg = sg;
     }
@@ -226,7 +243,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     for (int j = 0; j < U; ++j) {
       const int idx = g * U + j;
       if (idx < nmy) {  // wave-uniform
-        const int b = sub + idx * WPH;
+        const int b = blk_lo + sub + idx * WPH;
         // q.k over this lane's 8*NL dims: fp16 operands converted to fp32, fp32 FMA chain
         // (v_fma_mix_f32) — the reference's arithmetic (dtype_float16.cuh:292-298, 399-404).
         // One accumulator per load keeps NL independent dependency chains in flight.
@@ -249,7 +266,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         float qk = p.scale * acc;
         qk += (slope != 0.f) ? slope * (float)(token - L + 1) : 0.f;
         const bool masked = token >= L;
-        if (lane < 16) logits[token] = masked ? 0.f : qk;
+        if (lane < 16) logits[token - tok_lo] = masked ? 0.f : qk;
         qk_max = masked ? qk_max : fmaxf(qk_max, qk);
       }
     }
@@ -283,7 +300,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   }
 
   float exp_sum = 0.f;
-  for (int i = sub * 64 + lane; i < L; i += WPH * 64) {
+  for (int i = sub * 64 + lane; i < Lloc; i += WPH * 64) {
     const float e = __expf(logits[i] - qk_max);
     logits[i] = e;
     exp_sum += e;
@@ -298,6 +315,13 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     exp_sum = s;
   }
   const float inv_sum = __builtin_amdgcn_rcpf(exp_sum + 1e-6f);
+  if constexpr (PART) {  // partition statistics for the reduce kernel (:349-357)
+    if (sub == 0 && lane == 0) {
+      const int64_t o = ((int64_t)seq * p.num_heads + head) * p.max_num_partitions + part;
+      p.max_logits[o] = qk_max;
+      p.exp_sums[o] = exp_sum;
+    }
+  }
 
   // =========================== V pass ====================================================
   float acc[NL];
@@ -317,10 +341,10 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     for (int j = 0; j < U; ++j) {
       const int idx = g * U + j;
       if (idx < nmy) {  // wave-uniform
-        const int b = sub + idx * WPH;
+        const int b = blk_lo + sub + idx * WPH;
         const int token0 = b * BS + hf * 8;
-        const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(logits + token0);
-        const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(logits + token0 + 4);
+        const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(logits + token0 - tok_lo);
+        const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(logits + token0 - tok_lo + 4);
         h16x8 pv;
         pv[0] = (h16)(e0[0] * inv_sum);
         pv[1] = (h16)(e0[1] * inv_sum);
@@ -330,7 +354,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         pv[5] = (h16)(e1[1] * inv_sum);
         pv[6] = (h16)(e1[2] * inv_sum);
         pv[7] = (h16)(e1[3] * inv_sum);
-        const bool last = (b == nblk - 1);  // wave-uniform
+        const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
           h16x8 v = __builtin_bit_cast(h16x8, r[j][i]);
@@ -388,6 +412,70 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
 #pragma unroll
       for (int i = 0; i < NL; ++i) outp[32 * i + (lane >> 1)] = (h16)acc[i];
     }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// paged_attention_v2 reduce: merge the partitions of one (seq, head) — reference
+// attention_kernels.cu:564-669.  grid = (num_heads, num_seqs), block = 128.
+//   1 partition  -> copy tmp_out to out (:582-594)
+//   otherwise    -> m = max_j max_logits[j]; s_j = exp_sums[j]*exp(max_logits[j]-m);
+//                   out[d] = sum_j float(tmp_out[j][d]) * s_j * 1/(sum_j s_j + 1e-6)   (fp32, j ascending)
+// LDS: 2*max_num_partitions floats + 2 reduction slots per wave.
+// ----------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(128)
+    pa_v2_reduce_kernel(h16* __restrict__ out, const float* __restrict__ exp_sums,
+                        const float* __restrict__ max_logits, const h16* __restrict__ tmp_out,
+                        const int32_t* __restrict__ seq_lens, int max_num_partitions) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int num_heads = gridDim.x;
+  const int head = blockIdx.x;
+  const int seq = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int L = seq_lens[seq];
+  const int np = (L + 511) / 512;  // :581
+  const int64_t sh = ((int64_t)seq * num_heads + head) * max_num_partitions;
+  h16* outp = out + ((int64_t)seq * num_heads + head) * D;
+  const h16* tmp = tmp_out + sh * D;
+  if (np == 1) {  // :582-594
+    for (int i = tid; i < D; i += 128) outp[i] = tmp[i];
+    return;
+  }
+  float* smax = reinterpret_cast<float*>(smem);
+  float* ssum = smax + max_num_partitions;
+  float* red = ssum + max_num_partitions;  // [4]
+
+  float m = -FLT_MAX;
+  for (int i = tid; i < np; i += 128) {  // :611-615
+    const float l = max_logits[sh + i];
+    smax[i] = l;
+    m = fmaxf(m, l);
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(red[0], red[1]);
+
+  float g = 0.f;
+  for (int i = tid; i < np; i += 128) {  // :644-649
+    const float r = exp_sums[sh + i] * __expf(smax[i] - m);
+    g += r;
+    ssum[i] = r;
+  }
+  g = wave_sum(g);
+  if (lane == 0) red[2 + wave] = g;
+  __syncthreads();
+  g = red[2] + red[3];
+  const float inv = __builtin_amdgcn_rcpf(g + 1e-6f);  // :652
+
+  for (int i = tid; i < D; i += 128) {  // :661-668
+    float acc = 0.f;
+    for (int j = 0; j < np; ++j)
+      acc = __builtin_fmaf((float)tmp[(int64_t)j * D + i] * ssum[j], inv, acc);
+    outp[i] = (h16)acc;
   }
 }
 
@@ -624,6 +712,9 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   p.kv_block_stride = kv_block_stride;
   p.kv_head_stride = kv_head_stride;
   p.lpad = lpad;
+  p.exp_sums = nullptr;
+  p.max_logits = nullptr;
+  p.max_num_partitions = 1;
 
   dim3 block(v.HPW * v.WPH * 64);
   // gridDim.y is limited to 65535: longer batches go out as consecutive launches over slices
@@ -639,6 +730,125 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 launch");
   }
+  return VMI_OK;
+}
+
+// ---- split-KV (paged_attention_v2) variants: same kernel body, PART = true -----------------
+#define VMI_VARIANT_V2(D, HPW, WPH, U, NT)                                          \
+  {                                                                                 \
+    "v2_d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, HPW, WPH, U, (bool)NT,      \
+        (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)NT, false, true>, 0         \
+  }
+static Variant g_variants_v2[] = {
+    VMI_VARIANT_V2(64, 4, 1, 4, 1),   // 1
+    VMI_VARIANT_V2(64, 1, 1, 4, 1),   // 2
+    VMI_VARIANT_V2(64, 1, 2, 4, 1),   // 3
+    VMI_VARIANT_V2(64, 1, 4, 4, 1),   // 4
+    VMI_VARIANT_V2(64, 1, 8, 2, 1),   // 5
+    VMI_VARIANT_V2(128, 4, 1, 2, 1),  // 6
+    VMI_VARIANT_V2(128, 1, 1, 2, 1),  // 7
+    VMI_VARIANT_V2(128, 1, 2, 2, 1),  // 8
+    VMI_VARIANT_V2(128, 1, 4, 2, 1),  // 9
+    VMI_VARIANT_V2(128, 1, 8, 2, 1),  // 10
+};
+static const int g_nvariants_v2 = (int)(sizeof(g_variants_v2) / sizeof(g_variants_v2[0]));
+
+static int find_variant_v2(int D, int HPW, int WPH) {
+  for (int i = 0; i < g_nvariants_v2; ++i) {
+    const Variant& v = g_variants_v2[i];
+    if (v.D == D && v.HPW == HPW && v.WPH == WPH) return i + 1;
+  }
+  return 0;
+}
+
+// a partition holds at most 32 blocks; give each (seq, head, partition) 1..8 waves so that the
+// launch has >= ~2048 waves when the batch allows it
+static int pick_variant_v2(int num_seqs, int num_heads, int head_size, int max_seq_len) {
+  const int parts = (max_seq_len + 511) / 512;
+  const long units = (long)num_seqs * num_heads * (parts > 0 ? parts : 1);
+  int wph = 1;
+  while (wph < 8 && units * wph < 2048) wph *= 2;
+  int v = (wph == 1) ? find_variant_v2(head_size, (num_heads % 4 == 0) ? 4 : 1, 1)
+                     : find_variant_v2(head_size, 1, wph);
+  return v ? v : find_variant_v2(head_size, 1, 1);
+}
+
+static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+                        const void* key_cache, const void* value_cache, int32_t num_seqs,
+                        int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
+                        const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
+                        int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                        int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                        int32_t device, void* stream, int32_t variant) {
+  if (!out || !exp_sums || !max_logits || !tmp_out || !query || !key_cache || !value_cache ||
+      !block_tables || !seq_lens)
+    return fail(VMI_E_NULL_POINTER, "paged_attention_v2: NULL tensor pointer");
+  if (head_size != 64 && head_size != 128)
+    return fail(VMI_E_HEAD_SIZE, "Unsupported head size: %d", head_size);
+  if (block_size != 16) return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: %d", block_size);
+  if (num_seqs < 0 || num_heads <= 0 || max_seq_len < 0 || max_num_blocks_per_seq < 0)
+    return fail(VMI_E_SHAPE, "paged_attention_v2: negative size");
+  if (num_seqs > 65535 || num_heads > 65535)
+    return fail(VMI_E_SHAPE, "paged_attention_v2: num_seqs/num_heads above the 65535 grid limit");
+  if (num_kv_heads <= 0 || num_heads % num_kv_heads != 0)
+    return fail(VMI_E_KV_HEADS, "paged_attention_v2: num_heads=%d not divisible by num_kv_heads=%d",
+                num_heads, num_kv_heads);
+  if (!aligned16(query) || !aligned16(key_cache) || !aligned16(value_cache) || (q_stride & 7) ||
+      (kv_block_stride & 7) || (kv_head_stride & 7))
+    return fail(VMI_E_ALIGNMENT, "paged_attention_v2: pointers/strides must be 16-byte aligned");
+  const int parts = (max_seq_len + 511) / 512;  // attention_kernels.cu:885
+  if (num_seqs == 0 || parts == 0) return VMI_OK;
+  if (parts > 65535) return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v2: too many partitions");
+  if (variant == 0) variant = pick_variant_v2(num_seqs, num_heads, head_size, max_seq_len);
+  if (variant < 1 || variant > g_nvariants_v2)
+    return fail(VMI_E_VARIANT, "paged_attention_v2: unknown variant %d", variant);
+  Variant& v = g_variants_v2[variant - 1];
+  if (v.D != head_size)
+    return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s is for head size %d", v.name, v.D);
+  if (v.WPH > 1 && num_heads % v.HPW != 0)
+    return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s needs num_heads %% %d == 0", v.name, v.HPW);
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+
+  const int lpad = 512;  // one partition of logits (:886)
+  const size_t lds = (size_t)v.HPW * lpad * 4 + (size_t)v.HPW * 2 * v.WPH * 4 +
+                     (size_t)v.HPW * v.WPH * v.D * 4;
+  PAParams p;
+  p.out = static_cast<h16*>(tmp_out);
+  p.q = static_cast<const h16*>(query);
+  p.kc = static_cast<const h16*>(key_cache);
+  p.vc = static_cast<const h16*>(value_cache);
+  p.block_tables = block_tables;
+  p.seq_lens = seq_lens;
+  p.alibi = alibi_slopes;
+  p.num_heads = num_heads;
+  p.num_kv_heads = num_kv_heads;
+  p.scale = scale;
+  p.max_blocks_per_seq = max_num_blocks_per_seq;
+  p.q_stride = q_stride;
+  p.kv_block_stride = kv_block_stride;
+  p.kv_head_stride = kv_head_stride;
+  p.lpad = lpad;
+  p.exp_sums = exp_sums;
+  p.max_logits = max_logits;
+  p.max_num_partitions = parts;
+  dim3 grid((num_heads + v.HPW - 1) / v.HPW, num_seqs, parts);  // :890
+  hipLaunchKernelGGL(v.fn, grid, dim3(v.HPW * v.WPH * 64), lds, static_cast<hipStream_t>(stream), p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "paged_attention_v2 launch");
+
+  const size_t rlds = (size_t)(2 * parts + 4) * sizeof(float);  // :894
+  dim3 rgrid(num_heads, num_seqs);                               // :893
+  if (head_size == 64)
+    hipLaunchKernelGGL(pa_v2_reduce_kernel<64>, rgrid, dim3(128), rlds, static_cast<hipStream_t>(stream),
+                       static_cast<h16*>(out), exp_sums, max_logits, static_cast<const h16*>(tmp_out),
+                       seq_lens, parts);
+  else
+    hipLaunchKernelGGL(pa_v2_reduce_kernel<128>, rgrid, dim3(128), rlds, static_cast<hipStream_t>(stream),
+                       static_cast<h16*>(out), exp_sums, max_logits, static_cast<const h16*>(tmp_out),
+                       seq_lens, parts);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "paged_attention_v2 reduce launch");
   return VMI_OK;
 }
 
@@ -735,6 +945,28 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "reshape_and_cache launch");
   return VMI_OK;
+}
+
+int vmi_paged_attention_v2_f16(void* out, void* exp_sums, void* max_logits, void* tmp_out,
+                               const void* query, const void* key_cache, const void* value_cache,
+                               int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                               int32_t num_kv_heads, float scale, const int32_t* block_tables,
+                               const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
+                               int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                               int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                               int32_t device, void* stream, int32_t variant) {
+  return vmi::launch_pa_v2(out, static_cast<float*>(exp_sums), static_cast<float*>(max_logits), tmp_out,
+                           query, key_cache, value_cache, num_seqs, num_heads, head_size, num_kv_heads,
+                           scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant);
+}
+
+int vmi_paged_attention_v2_variant_count(void) { return vmi::g_nvariants_v2; }
+
+const char* vmi_paged_attention_v2_variant_name(int32_t variant) {
+  if (variant < 1 || variant > vmi::g_nvariants_v2) return "";
+  return vmi::g_variants_v2[variant - 1].name;
 }
 
 int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blocks, int32_t nt,

@@ -185,12 +185,56 @@ def paged_attention_v1(
     return None
 
 
-def paged_attention_v2(*args, **kwargs) -> None:
-    """Exported by the reference (paged_attention_cuda.cpp:53) but never called from its Python
-    (SURVEY.md §2 #7).  The split-KV variant is a 'next' row, not built yet."""
-    raise NotImplementedError(
-        "paged_attention_v2 (split-KV) is not implemented in this build; the reference stack only "
-        "calls paged_attention_v1 (vllmini/model/gpt2.py:94)")
+def paged_attention_v2(
+    out: torch.Tensor,
+    exp_sums: torch.Tensor,
+    max_logits: torch.Tensor,
+    tmp_out: torch.Tensor,
+    query: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    num_kv_heads: int,
+    scale: float,
+    block_tables: torch.Tensor,
+    seq_lens: torch.Tensor,
+    block_size: int,
+    max_seq_len: int,
+    alibi_slopes: Optional[torch.Tensor],
+    kv_cache_dtype: str,
+    kv_scale: float,
+    tp_rank: int = 0,
+    blocksparse_local_blocks: int = 0,
+    blocksparse_vert_stride: int = 1,
+    blocksparse_block_size: int = 1,
+    blocksparse_head_sliding_step: int = 0,
+    *,
+    _variant: int = 0,
+) -> None:
+    """Split-KV decode attention (512-token partitions + merge); writes out/exp_sums/max_logits/tmp_out.
+
+    Reference: paged_attention_cuda.cpp:27-47 (signature), attention_kernels.cu:966-990 (host),
+    :529-562 + :564-669 (kernels).  The reference exports it but no Python caller exists
+    (SURVEY.md §2 #7); it is the right operator when num_seqs*num_heads is far below the CU count.
+    """
+    args = _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                      seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale,
+                      tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
+                      blocksparse_block_size, blocksparse_head_sliding_step)
+    num_seqs, num_heads, head_size = (int(x) for x in query.shape)
+    parts = (int(max_seq_len) + 511) // 512                       # attention_kernels.cu:885
+    dev = query.device
+    for name, t, dt, shape in (("exp_sums", exp_sums, torch.float32, (num_seqs, num_heads, parts)),
+                               ("max_logits", max_logits, torch.float32, (num_seqs, num_heads, parts)),
+                               ("tmp_out", tmp_out, torch.float16, (num_seqs, num_heads, parts, head_size))):
+        _check_device(name, t, dev)
+        if t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
+            raise RuntimeError(f"{name} must be a contiguous {dt} tensor of shape {shape} "
+                               f"(max_num_partitions = ceil(max_seq_len/512) = {parts})")
+    rc = _lib.load().vmi_paged_attention_v2_f16(args[0], exp_sums.data_ptr(), max_logits.data_ptr(),
+                                                tmp_out.data_ptr(), *args[1:], int(_variant))
+    if rc != 0:
+        _raise_native(rc)
+    return None
 
 
 def reshape_and_cache(
@@ -253,6 +297,12 @@ def variant_names() -> list[str]:
     lib = _lib.load()
     n = lib.vmi_paged_attention_v1_variant_count()
     return [lib.vmi_paged_attention_v1_variant_name(i + 1).decode() for i in range(n)]
+
+
+def variant_names_v2() -> list[str]:
+    lib = _lib.load()
+    n = lib.vmi_paged_attention_v2_variant_count()
+    return [lib.vmi_paged_attention_v2_variant_name(i + 1).decode() for i in range(n)]
 
 
 def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int) -> int:
