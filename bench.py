@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--op", default="v1", choices=["v1", "v2"],
+                    help="attention operator in the step: paged_attention_v1 (headline) or the split-KV paged_attention_v2")
     ap.add_argument("--variant", type=int, default=0, help="force a kernel work decomposition (0 = heuristic)")
     ap.add_argument("--sweep", action="store_true", help="time every kernel variant, write gpurun_out/sweep.json")
     ap.add_argument("--diag", action="store_true",
@@ -86,17 +88,36 @@ def init_dist(n_gpus: int):
     return None, 0, 1, 0
 
 
-def one_step(wl, out, i, variant):
-    """The reference's per-layer decode call pair, in its call order (gpt2.py:44, :62)."""
-    t = i % len(wl.tables)
+_V2_SCRATCH = {}
+
+
+def attend(wl, out, t, variant, op="v1"):
     c = wl.cfg
-    cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
-    ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
+    if op == "v1":
+        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
+                               wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0,
+                               0, 0, 1, 1, 0, _variant=variant)
+        return
+    key = (c.name, out.device)
+    if key not in _V2_SCRATCH:      # caller-owned scratch, as in the reference's v2 signature
+        P = (c.seq_len + 511) // 512
+        _V2_SCRATCH[key] = (torch.empty((c.batch, c.num_heads, P), dtype=torch.float32, device=out.device),
+                            torch.empty((c.batch, c.num_heads, P), dtype=torch.float32, device=out.device),
+                            torch.empty((c.batch, c.num_heads, P, c.head_size), dtype=torch.float16, device=out.device))
+    es, ml, tmp = _V2_SCRATCH[key]
+    ops.paged_attention_v2(out, es, ml, tmp, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
                            wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0,
                            0, 0, 1, 1, 0, _variant=variant)
 
 
-def time_steps(wl, out, steps, warmup, variant, dist, dev):
+def one_step(wl, out, i, variant, op="v1"):
+    """The reference's per-layer decode call pair, in its call order (gpt2.py:44, :62)."""
+    t = i % len(wl.tables)
+    cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
+    attend(wl, out, t, variant, op)
+
+
+def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
     """W untimed steps, then EXACTLY K timed steps between barrier+synchronize pairs
     (vllmini_amd/shard.py:timed_steps — the same code the 2-rank gloo test exercises)."""
     c = wl.cfg
@@ -106,15 +127,29 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev):
         t = i % len(wl.tables)
         cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
         ev[i][0].record()  # HIP events on the launch stream (torch's current stream)
-        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
-                               wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0,
-                               0, 0, 1, 1, 0, _variant=variant)
+        attend(wl, out, t, variant, op)
         ev[i][1].record()
 
-    elapsed = shard.timed_steps(lambda i: one_step(wl, out, i, variant), steps, warmup, dist,
+    elapsed = shard.timed_steps(lambda i: one_step(wl, out, i, variant, op), steps, warmup, dist,
                                 sync=lambda: torch.cuda.synchronize(dev), timed_step=timed)
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     return elapsed, kern_ms
+
+
+def pmc_traffic(cfg_name: str, kernel_variant: str):
+    """HBM bytes per launch of the attention kernel from the rocprofv3 PMC passes committed under
+    profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE x1024 x2 per the
+    gfx950 correction in MI355X_MICROARCH.md §HBM).  bench.py cannot run a profiler around itself, so
+    the figure comes from the latest recorded pass for this workload and kernel variant, else None."""
+    path = os.path.join(REPO, "profiles", f"pmc_{cfg_name}_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("kernel_variant") and d["kernel_variant"] != kernel_variant:
+            return None, None
+        return d["traffic_bytes_corrected"]["total"], os.path.relpath(path, REPO)
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def cpu_baseline(wl, steps):
@@ -268,7 +303,7 @@ def main():
                                                                            cfg.seq_len), "results": res}, f, indent=1)
         return
 
-    elapsed, kern_ms = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev)
+    elapsed, kern_ms = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op)
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     kern_mean_ms = shard.max_over_ranks(statistics.mean(kern_ms), dist, dev)
 
@@ -276,6 +311,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     achieved = cfg.algorithmic_bytes() / (kern_mean_ms * 1e-3) / 1e9
     vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len)
+    vname = ops.variant_names()[vid - 1] if args.op == "v1" else f"paged_attention_v2 variant {args.variant or 'auto'}"
+    traffic, traffic_src = pmc_traffic(cfg.name, vname) if args.op == "v1" else (None, None)
     line = {
         "metric": "decode_tokens_per_sec_paged_attention_v1_per_layer",
         "value": tokens / elapsed,
@@ -298,7 +335,7 @@ def main():
             "global_batch": cfg.batch * world,
             "seq_len": cfg.seq_len,
             "parallelism": f"dp{world} (independent KV pools, no data-path collective)",
-            "kernel_variant": ops.variant_names()[vid - 1],
+            "kernel_variant": vname, "op": args.op,
         },
         "paged_attention_v1_us_per_step": kern_mean_ms * 1e3,
         "paged_attention_v1_us_median": statistics.median(kern_ms) * 1e3,
@@ -309,7 +346,8 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "kernel": "pa_v1_kernel",
             "algorithmic_bytes_per_launch": cfg.algorithmic_bytes(),
         },

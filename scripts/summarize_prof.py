@@ -35,4 +35,18 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             tail = vals[10:] if len(vals) > 20 else vals
             res[name] = {"n": len(vals), "mean_raw_KiB_units": statistics.mean(tail),
                          "mean_bytes_uncorrected": statistics.mean(tail) * 1024}
+if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+    f = res["FETCH_SIZE"]["mean_bytes_uncorrected"] * 2      # gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream
+    w = res["WRITE_SIZE"]["mean_bytes_uncorrected"]
+    res["traffic_bytes_corrected"] = {"read": f, "write": w, "total": f + w}
+try:
+    b = json.load(open(os.path.join(out, "bench_under_trace.json")))
+    res["kernel_variant"] = b["config"]["kernel_variant"]
+    res["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_launch"]
+    res["bench_event_us_under_trace"] = b["paged_attention_v1_us_per_step"]
+except Exception as e:  # noqa: BLE001
+    res["bench_json_error"] = str(e)
+for k in res.get("kernel_stats", []):
+    if len(k["Name"]) > 120:
+        k["Name"] = k["Name"][:117] + "..."
 print(json.dumps(res, indent=1))

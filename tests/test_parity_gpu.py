@@ -595,7 +595,8 @@ def _check_v2(case, max_seq_len, variant=0, alibi=None, what=""):
         used = (int(L) + 511) // 512
         assert np.allclose(ml[s, :, :used], r_ml[s, :, :used], rtol=1e-5, atol=1e-5), what
         assert np.allclose(es[s, :, :used], r_es[s, :, :used], rtol=2e-5, atol=1e-6), what
-        assert_close(tmp[s, :, :used], r_tmp[s, :, :used], what + " tmp_out")
+        if used:
+            assert_close(tmp[s, :, :used], r_tmp[s, :, :used], what + " tmp_out")
         # partitions past the context are left untouched (attention_kernels.cu:116-119)
         assert np.isnan(es[s, :, used:]).all() and np.isnan(tmp[s, :, used:]).all(), what
     return got

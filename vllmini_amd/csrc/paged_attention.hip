@@ -597,11 +597,16 @@ static Variant g_variants[] = {
     VMI_VARIANT(128, 1, 8, 2, 0),  // 22
     VMI_VARIANT(128, 1, 16, 1, 0), // 23
     VMI_VARIANT(128, 4, 1, 4, 1),  // 24
+    // ---- many waves per head, non-temporal (appended: earlier ids stay stable) ----
+    VMI_VARIANT(64, 1, 8, 2, 1),    // 25
+    VMI_VARIANT(64, 1, 16, 1, 1),   // 26
+    VMI_VARIANT(128, 1, 8, 2, 1),   // 27
+    VMI_VARIANT(128, 1, 16, 1, 1),  // 28
     // ---- diagnostics: same gather pattern, no math ("loads only"); wrong results by design ----
     {"d64_h4_w1_u4_nt1_LOADSONLY", 64, 4, 1, 4, true,
-     (pa_kernel_t)pa_v1_kernel<64, 4, 1, 4, true, true>, 0},   // 25
+     (pa_kernel_t)pa_v1_kernel<64, 4, 1, 4, true, true>, 0},   // 29
     {"d64_h1_w1_u4_nt1_LOADSONLY", 64, 1, 1, 4, true,
-     (pa_kernel_t)pa_v1_kernel<64, 1, 1, 4, true, true>, 0},   // 26
+     (pa_kernel_t)pa_v1_kernel<64, 1, 1, 4, true, true>, 0},   // 30
 };
 static const int g_nvariants = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
@@ -617,26 +622,20 @@ static int find_variant(int D, int HPW, int WPH, int U, bool NT) {
 
 // Heuristic: with >= ~2 waves per SIMD worth of (seq, head) units one wave per head keeps
 // every CU streaming with no barriers; below that, deal each head's blocks to more waves.
+// Non-temporal page loads pay once the KV working set no longer fits the 256 MiB Infinity
+// Cache (cfg3 146 -> 133 us, "long" 195 -> 186 us) and are neutral below it.
 static int pick_variant(int num_seqs, int num_heads, int head_size, int max_seq_len) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + 15) / 16;
   int wph = 1;
   while (wph < 16 && units * wph < 2048 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
-  int v = 0;
-  if (head_size == 64) {
-    if (wph == 1) v = find_variant(64, (num_heads % 4 == 0) ? 4 : 1, 1, 4, true);
-    else if (wph == 2) v = find_variant(64, 1, 2, 4, true);
-    else if (wph == 4) v = find_variant(64, 1, 4, 4, true);
-    else if (wph == 8) v = find_variant(64, 1, 8, 2, false);
-    else v = find_variant(64, 1, 16, 1, false);
-    if (!v) v = find_variant(64, 1, 1, 4, false);
-  } else {
-    if (wph == 1) v = find_variant(128, (num_heads % 4 == 0) ? 4 : 1, 1, 2, true);
-    else if (wph <= 4) v = find_variant(128, 1, 4, 2, true);
-    else if (wph == 8) v = find_variant(128, 1, 8, 2, false);
-    else v = find_variant(128, 1, 16, 1, false);
-    if (!v) v = find_variant(128, 1, 1, 2, false);
-  }
+  const double kv_bytes = 4.0 * (double)units * (double)max_seq_len * head_size;
+  const bool nt = kv_bytes > 128e6;
+  const int hpw = (wph == 1 && num_heads % 4 == 0) ? 4 : 1;
+  const int u = (head_size == 64) ? (wph <= 4 ? 4 : (wph == 8 ? 2 : 1)) : (wph <= 8 ? 2 : 1);
+  int v = find_variant(head_size, hpw, wph, u, nt);
+  if (!v) v = find_variant(head_size, hpw, wph, u, !nt);
+  if (!v) v = find_variant(head_size, 1, 1, head_size == 64 ? 4 : 2, true);
   return v;
 }
 

@@ -48,6 +48,9 @@ CONFIGS = {
     "cfg3": DecodeConfig("cfg3", 256, 12, 64, 1024, 32768),
     "cfg4": DecodeConfig("cfg4", 128, 32, 128, 2048, 32768),   # 2 disjoint table sets of 16384 blocks
     "cfg5": DecodeConfig("cfg5", 256, 12, 64, 1024, 65536),
+    # not in BASELINE.json: long context, small batch — the shape split-KV (paged_attention_v2) exists for
+    "long": DecodeConfig("long", 4, 32, 128, 16384, 8192),
+    "b1": DecodeConfig("b1", 1, 12, 64, 1024, 256),
 }
 
 
