@@ -164,6 +164,26 @@ int vmi_reshape_and_cache_f16(
     int32_t device, void* stream);
 
 /*
+ * cache_ops.copy_blocks — cache_kernels.cu:96-148 (kernel :68-94).  For every layer l and pair p:
+ * K_l[dst_p] = K_l[src_p], V_l[dst_p] = V_l[src_p].
+ *   key_cache_ptrs / value_cache_ptrs   HOST arrays of num_layers DEVICE pointers (one cache per layer)
+ *   block_mapping                        DEVICE int64 [num_pairs, 2] = (src block, dst block)
+ *   block_bytes                          bytes of one block of one cache (element_size * cache[0].numel())
+ * Unlike the reference (blocking pointer-table upload, :119-126) the call does not synchronise.
+ */
+int vmi_copy_blocks(void* const* key_cache_ptrs, void* const* value_cache_ptrs, int32_t num_layers,
+                    const int64_t* block_mapping, int32_t num_pairs, int64_t block_bytes,
+                    int32_t device, void* stream);
+
+/*
+ * cache_ops.swap_blocks — cache_kernels.cu:24-63: one async memcpy per (src, dst) pair on `stream`.
+ *   block_mapping_host   HOST int64 [num_pairs, 2] (the reference requires a CPU tensor, :45)
+ *   kind                 0 = device->device (same GPU), 1 = device->host, 2 = host->device
+ */
+int vmi_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_host, int32_t num_pairs,
+                    int64_t block_bytes, int32_t kind, int32_t device, void* stream);
+
+/*
  * Diagnostic (no reference counterpart): plain coalesced 16-B/lane read of `bytes` from `src`
  * with `blocks` workgroups of 256 threads; nt != 0 uses non-temporal loads.  `sink` is a 4-byte
  * device word that is (practically) never written.  bench.py --diag uses it to report the read

@@ -79,6 +79,10 @@ def test_python_surface_matches_reference_signatures():
     assert rc == ["key", "value", "key_cache", "value_cache", "slot_mapping", "kv_cache_dtype", "kv_scale"]
     for name in ("swap_blocks", "copy_blocks", "reshape_and_cache_flash", "convert_fp8"):          # .cpp:56-61
         assert hasattr(ext.cache_ops, name)
+    assert list(inspect.signature(ext.cache_ops.swap_blocks).parameters) == ["src", "dst", "block_mapping"]
+    assert list(inspect.signature(ext.cache_ops.copy_blocks).parameters) == ["key_caches", "value_caches", "block_mapping"]
+    with pytest.raises(NotImplementedError):
+        ext.cache_ops.convert_fp8()
     v2 = [p.name for p in inspect.signature(ext.paged_attention_v2).parameters.values()
           if p.kind is not inspect.Parameter.KEYWORD_ONLY]
     assert v2 == ["out", "exp_sums", "max_logits", "tmp_out"] + pa[1:]                      # .cpp:27-47

@@ -636,3 +636,53 @@ def test_pa_v2_agrees_with_v1_and_exact():
     assert np.array_equal(v1[[0, 1, 3]].view(np.uint16), v2[[0, 1, 3]].view(np.uint16))
     assert np.abs(v2.astype(np.float64) - exact).max() <= 2e-3
     assert np.abs(v1.astype(np.float64) - v2.astype(np.float64)).max() <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# cache_ops.copy_blocks / swap_blocks: pure byte moves -> bit-exact vs numpy
+# ------------------------------------------------------------------------------------------------
+def test_copy_blocks_bit_exact_many_layers():
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(31)
+    layers, NB, H, D = 70, 12, 2, 64                      # > 64 layers: two launches
+    ks = [rng.standard_normal((NB, H, D // 8, BS, 8)).astype(np.float16) for _ in range(layers)]
+    vs = [rng.standard_normal((NB, H, D, BS)).astype(np.float16) for _ in range(layers)]
+    pairs = np.array([[0, 5], [3, 7], [3, 8], [11, 1]], dtype=np.int64)   # one source may fan out
+    tk = [torch.from_numpy(k).to(dev) for k in ks]
+    tv = [torch.from_numpy(v).to(dev) for v in vs]
+    ext.cache_ops.copy_blocks(tk, tv, torch.from_numpy(pairs).to(dev))
+    torch.cuda.synchronize()
+    for l in range(layers):
+        for s, d in pairs:
+            ks[l][d] = ks[l][s]
+            vs[l][d] = vs[l][s]
+        assert np.array_equal(tk[l].cpu().numpy().view(np.uint16), ks[l].view(np.uint16))
+        assert np.array_equal(tv[l].cpu().numpy().view(np.uint16), vs[l].view(np.uint16))
+    ext.cache_ops.copy_blocks([], [], torch.zeros((0, 2), dtype=torch.int64, device=dev))   # cache_kernels.cu:101-103
+
+
+def test_swap_blocks_device_host_roundtrip_and_errors():
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(32)
+    NB, H, D = 10, 12, 64
+    gpu = torch.from_numpy(rng.standard_normal((NB, H, D, BS)).astype(np.float16)).to(dev)
+    orig = gpu.clone()
+    host = torch.zeros((6, H, D, BS), dtype=torch.float16).pin_memory()
+    out_map = torch.tensor([[1, 0], [4, 1], [9, 5]], dtype=torch.int64)
+    ext.cache_ops.swap_blocks(gpu, host, out_map)                     # device -> host (block_manager.py:70-73 intent)
+    torch.cuda.synchronize()
+    for s, d in out_map.tolist():
+        assert torch.equal(host[d], orig[s].cpu())
+    gpu.zero_()
+    ext.cache_ops.swap_blocks(host, gpu, torch.tensor([[0, 2], [1, 3], [5, 7]], dtype=torch.int64))   # host -> device
+    dst2 = torch.zeros_like(gpu)
+    ext.cache_ops.swap_blocks(gpu, dst2, torch.tensor([[2, 9], [7, 0]], dtype=torch.int64))           # device -> device
+    torch.cuda.synchronize()
+    assert torch.equal(gpu[2], orig[1]) and torch.equal(gpu[3], orig[4]) and torch.equal(gpu[7], orig[9])
+    assert torch.equal(dst2[9], orig[1]) and torch.equal(dst2[0], orig[9]) and not dst2[1:9].any()
+    with pytest.raises(RuntimeError, match="block_mapping must be on CPU"):
+        ext.cache_ops.swap_blocks(gpu, dst2, out_map.to(dev))                                          # cache_kernels.cu:45
+    with pytest.raises(RuntimeError, match="Invalid device combination"):
+        ext.cache_ops.swap_blocks(host, host.clone(), out_map)                                         # :39

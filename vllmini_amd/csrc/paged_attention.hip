@@ -524,6 +524,34 @@ __global__ void __launch_bounds__(256)
 
 
 // ----------------------------------------------------------------------------------------
+// copy_blocks: for every layer and every (src, dst) pair copy one K block and one V block
+// inside that layer's caches — reference cache_kernels.cu:68-94 (kernel), :96-148 (host).
+// The reference uploads two pointer tables with a blocking .to(device) (:119-126); here up to
+// 64 layers' pointers ride in the kernel arguments, so the call never synchronises.
+// grid = (layers, pairs), 256 threads, 16-B moves.
+// ----------------------------------------------------------------------------------------
+struct CopyBlocksArgs {
+  uint8_t* key[64];
+  uint8_t* value[64];
+};
+
+__global__ void __launch_bounds__(256)
+    copy_blocks_kernel(const CopyBlocksArgs a, const int64_t* __restrict__ block_mapping,
+                       int64_t block_bytes) {
+  const int layer = blockIdx.x;
+  const int pair = blockIdx.y;
+  const int64_t src = block_mapping[2 * pair] * block_bytes;      // :77-78
+  const int64_t dst = block_mapping[2 * pair + 1] * block_bytes;
+  const int64_t n16 = block_bytes >> 4;
+  const u32x4* ks = reinterpret_cast<const u32x4*>(a.key[layer] + src);
+  u32x4* kd = reinterpret_cast<u32x4*>(a.key[layer] + dst);
+  const u32x4* vs = reinterpret_cast<const u32x4*>(a.value[layer] + src);
+  u32x4* vd = reinterpret_cast<u32x4*>(a.value[layer] + dst);
+  for (int64_t i = threadIdx.x; i < n16; i += 256) kd[i] = ks[i];  // :82-86
+  for (int64_t i = threadIdx.x; i < n16; i += 256) vd[i] = vs[i];  // :87-91
+}
+
+// ----------------------------------------------------------------------------------------
 // diagnostics (not part of the reference surface): what read bandwidth does this box give a
 // plain coalesced 16-B/lane stream?  Used by bench.py --diag to state the achievable ceiling
 // next to the attention kernel's number.
@@ -966,6 +994,64 @@ int vmi_paged_attention_v2_variant_count(void) { return vmi::g_nvariants_v2; }
 const char* vmi_paged_attention_v2_variant_name(int32_t variant) {
   if (variant < 1 || variant > vmi::g_nvariants_v2) return "";
   return vmi::g_variants_v2[variant - 1].name;
+}
+
+int vmi_copy_blocks(void* const* key_cache_ptrs, void* const* value_cache_ptrs, int32_t num_layers,
+                    const int64_t* block_mapping, int32_t num_pairs, int64_t block_bytes,
+                    int32_t device, void* stream) {
+  using namespace vmi;
+  if (num_layers < 0 || num_pairs < 0 || block_bytes <= 0 || (block_bytes & 15))
+    return fail(VMI_E_SHAPE, "copy_blocks: bad sizes (layers=%d pairs=%d block_bytes=%lld)", num_layers,
+                num_pairs, (long long)block_bytes);
+  if (num_layers == 0 || num_pairs == 0) return VMI_OK;   // cache_kernels.cu:101-103
+  if (!key_cache_ptrs || !value_cache_ptrs || !block_mapping)
+    return fail(VMI_E_NULL_POINTER, "copy_blocks: NULL pointer");
+  if (num_pairs > 65535) return fail(VMI_E_SHAPE, "copy_blocks: more than 65535 pairs in one call");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  for (int l0 = 0; l0 < num_layers; l0 += 64) {
+    const int nl = (num_layers - l0) < 64 ? (num_layers - l0) : 64;
+    CopyBlocksArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l < nl; ++l) {
+      if (!key_cache_ptrs[l0 + l] || !value_cache_ptrs[l0 + l] || !aligned16(key_cache_ptrs[l0 + l]) ||
+          !aligned16(value_cache_ptrs[l0 + l]))
+        return fail(VMI_E_ALIGNMENT, "copy_blocks: layer %d cache pointer NULL or not 16-byte aligned", l0 + l);
+      a.key[l] = static_cast<uint8_t*>(key_cache_ptrs[l0 + l]);
+      a.value[l] = static_cast<uint8_t*>(value_cache_ptrs[l0 + l]);
+    }
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3(nl, num_pairs), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a, block_mapping, block_bytes);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "copy_blocks launch");
+  }
+  return VMI_OK;
+}
+
+int vmi_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_host, int32_t num_pairs,
+                    int64_t block_bytes, int32_t kind, int32_t device, void* stream) {
+  using namespace vmi;
+  if (num_pairs < 0 || block_bytes <= 0) return fail(VMI_E_SHAPE, "swap_blocks: bad sizes");
+  if (num_pairs == 0) return VMI_OK;
+  if (!src || !dst || !block_mapping_host) return fail(VMI_E_NULL_POINTER, "swap_blocks: NULL pointer");
+  hipMemcpyKind k;
+  switch (kind) {  // cache_kernels.cu:28-40
+    case 0: k = hipMemcpyDeviceToDevice; break;
+    case 1: k = hipMemcpyDeviceToHost; break;
+    case 2: k = hipMemcpyHostToDevice; break;
+    default: return fail(VMI_E_SHAPE, "Invalid device combination");
+  }
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  const char* s = static_cast<const char*>(src);
+  char* d = static_cast<char*>(dst);
+  for (int i = 0; i < num_pairs; ++i) {  // :56-62
+    const int64_t so = block_mapping_host[2 * i] * block_bytes;
+    const int64_t doff = block_mapping_host[2 * i + 1] * block_bytes;
+    e = hipMemcpyAsync(d + doff, s + so, (size_t)block_bytes, k, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "swap_blocks hipMemcpyAsync");
+  }
+  return VMI_OK;
 }
 
 int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blocks, int32_t nt,
