@@ -686,3 +686,36 @@ def test_swap_blocks_device_host_roundtrip_and_errors():
         ext.cache_ops.swap_blocks(gpu, dst2, out_map.to(dev))                                          # cache_kernels.cu:45
     with pytest.raises(RuntimeError, match="Invalid device combination"):
         ext.cache_ops.swap_blocks(host, host.clone(), out_map)                                         # :39
+
+
+def test_batch_scheduler_on_gpu_equals_per_sequence_greedy(golden_dir):
+    """BatchScheduler (all sequences advanced per step through the ops) vs the same model decoding each
+    prompt alone: greedy tokens must agree wherever the top-2 logit gap is not an fp16-GEMM coin flip."""
+    from vllmini_amd.scheduler import BatchScheduler, sample_greedy
+
+    dev = _dev()
+    _, meta, dec = _tiny_gpt2(golden_dir, dev, off_by_one=False)
+    prompts = [[3, 1, 4], [15, 9, 2, 6, 5, 3, 5], [100], list(range(200, 214))]
+    sch = BatchScheduler(dec, max_length=40, eos_token_id=meta["vocab_size"] - 1, sampler=sample_greedy)
+    ids = [sch.add_sequence(p) for p in prompts]
+    steps = sch.run()
+    assert steps <= 40 and not sch.active
+    assert sorted(dec.pool.free_blocks) == list(range(dec.pool.num_blocks))
+    for sid, p in zip(ids, prompts):
+        _, _, solo = _tiny_gpt2(golden_dir, dev, off_by_one=False)
+        logits = solo.prefill(0, p)
+        seq = list(p)
+        agree = True
+        while len(seq) < 40:
+            top2 = torch.topk(logits.float(), 2).values
+            tok = int(logits.argmax())
+            if len(seq) < len(sch.sequences[sid]) and tok != sch.sequences[sid][len(seq)]:
+                assert float(top2[0] - top2[1]) < 3e-2, (sid, len(seq))   # only near-ties may differ
+                agree = False
+                break
+            seq.append(tok)
+            if tok == meta["vocab_size"] - 1:
+                break
+            logits = solo.decode([0], [tok])[0]
+        if agree:
+            assert seq == sch.sequences[sid]

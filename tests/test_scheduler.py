@@ -1,0 +1,169 @@
+"""Host logic of the batching scheduler (counterpart of vllmini/scheduler.py) with a stand-in decoder
+on CPU: the real PagedKVPool bookkeeping (no tensors) + deterministic fake logits."""
+from __future__ import annotations
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from vllmini_amd.kv_pool import PagedKVPool
+from vllmini_amd.scheduler import BatchScheduler, deal_requests, sample_greedy, sample_top_k
+
+V, EOS = 97, 96
+
+
+class FakeDecoder:
+    """next-token logits are a pure function of (last token, position): one-hot at (7*tok + pos) % 97."""
+
+    def __init__(self, num_blocks=64, layers=2, max_blocks_per_seq=8):
+        self.pool = PagedKVPool(num_blocks, 2, 64, 16, max_blocks_per_seq, layers, device="cpu", allocate_tensors=False)
+        self.decode_calls = []
+
+    @staticmethod
+    def _logits(tok, pos):
+        out = torch.zeros(V)
+        out[(7 * tok + pos) % V] = 5.0
+        return out
+
+    def prefill(self, seq_id, ids):
+        self.pool.allocate_for_prefill(seq_id, len(ids))
+        return self._logits(ids[-1], len(ids) - 1)
+
+    def decode(self, seq_ids, tokens):
+        pos = [self.pool.seq_len(s) for s in seq_ids]
+        self.pool.decode_step_batch(seq_ids)
+        self.decode_calls.append(list(seq_ids))
+        return torch.stack([self._logits(int(t), p) for t, p in zip(tokens, pos)])
+
+
+def _expected(prompt, max_length):
+    seq, tok, pos = list(prompt), prompt[-1], len(prompt) - 1
+    while len(seq) < max_length:
+        nxt = (7 * tok + pos) % V
+        seq.append(nxt)
+        if nxt == EOS:
+            break
+        tok, pos = nxt, len(seq) - 1
+    return seq
+
+
+def test_batched_schedule_equals_one_sequence_at_a_time():
+    prompts = [[1, 2, 3], [5], [9, 9, 9, 9, 9, 9], [40, 41]]
+    dec = FakeDecoder()
+    sch = BatchScheduler(dec, max_length=40, eos_token_id=EOS, sampler=sample_greedy)
+    ids = [sch.add_sequence(p) for p in prompts]
+    assert sch.run() > 0
+    for sid, p in zip(ids, prompts):
+        assert sch.sequences[sid] == _expected(p, 40)
+    assert not sch.active and not sch.last_logits and not sch.sequence_lengths
+    assert sorted(dec.pool.free_blocks) == list(range(dec.pool.num_blocks))      # every block returned (kv_cache.py:81-86)
+    assert len(dec.decode_calls[0]) == 4                                          # one call advances the whole batch
+
+
+def test_oldest_first_and_max_batch():
+    dec = FakeDecoder()
+    sch = BatchScheduler(dec, max_length=12, eos_token_id=EOS, max_batch=2, sampler=sample_greedy)
+    ids = [sch.add_sequence([i + 1]) for i in range(5)]
+    stepped = sch.step()
+    assert stepped == ids[:2]                                                     # arrival order (PriorityQueue, scheduler.py:16,60)
+    sch.run()
+    for sid in ids:
+        assert sch.sequences[sid] == _expected([sid + 1], 12)
+
+
+def test_max_length_and_eos_end_sequences():
+    dec = FakeDecoder()
+    sch = BatchScheduler(dec, max_length=6, eos_token_id=EOS, sampler=sample_greedy)
+    a = sch.add_sequence([1, 2, 3, 4, 5, 6])          # already at max_length: ends without sampling (scheduler.py:71-74)
+    tok = next(t for t in range(V) for p in [0] if (7 * t + p) % V == EOS)
+    b = sch.add_sequence([tok])                       # next token is EOS
+    sch.run()
+    assert sch.sequences[a] == [1, 2, 3, 4, 5, 6]
+    assert sch.sequences[b] == [tok, EOS]
+    assert not sch.active
+
+
+def test_out_of_blocks_evicts_youngest_other_sequence():
+    # 2 layers, 16-token blocks: each sequence needs 2 blocks at prefill and 2 more at token 17
+    dec = FakeDecoder(num_blocks=10, layers=2)
+    sch = BatchScheduler(dec, max_length=40, eos_token_id=EOS, sampler=sample_greedy)
+    ids = [sch.add_sequence([3 + i] * 15) for i in range(4)]      # 8 blocks used, 2 free
+    sch.run()
+    assert sch.evicted, "pool of 10 blocks cannot hold four sequences past 16 tokens"
+    assert sch.evicted[0] == ids[-1]                              # youngest goes first (scheduler.py:117-130)
+    done = [s for s in ids if s not in sch.evicted]
+    assert done and all(sch.sequences[s] == _expected([3 + s] * 15, 40) for s in done)
+    assert sorted(dec.pool.free_blocks) == list(range(10))
+    with pytest.raises(RuntimeError):
+        BatchScheduler(FakeDecoder(num_blocks=1), 8, EOS).add_sequence([1])   # cannot even prefill (kv_cache.py:22-23)
+
+
+def test_top_k_sampler_matches_reference_procedure():
+    """Same steps as Scheduler.sample_next_token (scheduler.py:144-153) but batched."""
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(3, 500, generator=g)
+    got = sample_top_k(logits, generator=torch.Generator().manual_seed(7))
+    gen = torch.Generator().manual_seed(7)
+    vals, idx = torch.topk(logits, 50)
+    probs = torch.softmax(vals, dim=-1)
+    choice = torch.multinomial(probs, 1, generator=gen)
+    assert torch.equal(got, idx.gather(-1, choice).squeeze(-1))
+    assert all(int(t) in set(torch.topk(logits[i], 50).indices.tolist()) for i, t in enumerate(got))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, tmpdir):
+    import torch.distributed as dist
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_scheduler import FakeDecoder, _expected
+        from vllmini_amd import shard
+
+        prompts = [[i + 1, i + 2] for i in range(5)]               # 5 requests over 2 ranks: 3 + 2
+        mine = deal_requests(len(prompts), rank, world)
+        sch = BatchScheduler(FakeDecoder(), max_length=10, eos_token_id=EOS, sampler=sample_greedy)
+        local = {sch.add_sequence(prompts[i]): i for i in mine}
+        width = -(-len(prompts) // world)
+        for _ in range(8):
+            sch.step()
+            # per-step hand-back of the newest token of every request to every rank (8 B/sequence)
+            newest = torch.full((width,), -1, dtype=torch.int64)
+            for sid, gi in local.items():
+                newest[mine.index(gi)] = sch.sequences[sid][-1]
+            gathered = [torch.empty_like(newest) for _ in range(world)]
+            dist.all_gather(gathered, newest)
+            merged = {}
+            for r in range(world):
+                for j, gi in enumerate(deal_requests(len(prompts), r, world)):
+                    merged[gi] = int(gathered[r][j])
+            assert sorted(merged) == list(range(len(prompts)))
+        for sid, gi in local.items():
+            assert sch.sequences[sid] == _expected(prompts[gi], 10)
+        assert merged == {gi: _expected(prompts[gi], 10)[-1] for gi in range(len(prompts))}
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_scheduling_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
+    assert deal_requests(5, 0, 2) == [0, 2, 4] and deal_requests(5, 1, 2) == [1, 3]
