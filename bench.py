@@ -72,7 +72,7 @@ def init_dist(n_gpus: int):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if n_gpus > 1 or world > 1:
+    if n_gpus > 1 or world > 1 or os.environ.get("VMI_FORCE_DIST") == "1":   # VMI_FORCE_DIST: 1-GPU smoke of the RCCL path
         import torch.distributed as dist
 
         if world != n_gpus:
@@ -81,8 +81,21 @@ def init_dist(n_gpus: int):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,  # "nccl" IS RCCL on ROCm
-                                device_id=torch.device("cuda", local_rank))
+        # RCCL prints a banner on STDOUT when the communicator is created; stdout must carry exactly one
+        # JSON line, so fd 1 points at stderr until the first collective has run.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world,  # "nccl" IS RCCL on ROCm
+                                    device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         return dist, rank, world, local_rank
     torch.cuda.set_device(0)
     return None, 0, 1, 0
