@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 1
+#define VMI_ABI_VERSION 2
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -82,7 +82,8 @@ const char* vmi_target_arch(void);
  *                  like the reference's dynamic shared memory, attention_kernels.cu:725-732)
  *   alibi_slopes   [num_heads] fp32 or NULL
  *
- * Supported: head_size in {64, 128}, block_size == 16, x == 8.
+ * Supported: the reference's dispatch set — head_size in {64, 80, 96, 112, 128, 192, 256}
+ * (attention_kernels.cu:738-766) x block_size in {8, 16, 32} (:789-803); x == 8.
  */
 int vmi_paged_attention_v1_f16(
     void* out, const void* query, const void* key_cache, const void* value_cache,
@@ -113,9 +114,9 @@ int vmi_paged_attention_v1_f16_variant(
 /* Number of tuning variants (valid ids are 1..count) and a short name for each. */
 int vmi_paged_attention_v1_variant_count(void);
 const char* vmi_paged_attention_v1_variant_name(int32_t variant);
-/* Variant id the heuristic would choose for this shape (>=1). */
+/* Variant id the heuristic would choose for this shape (>=1), 0 for an unsupported head/block size. */
 int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int32_t head_size,
-                                        int32_t max_seq_len);
+                                        int32_t block_size, int32_t max_seq_len);
 
 /*
  * paged_attention_v2 (split-KV), fp16 — the operator the reference exports next to v1

@@ -7,7 +7,7 @@ BS = 16
 
 
 def make_case(rng, num_seqs, num_heads, head_size, lens, num_blocks=None, max_blocks=None,
-              num_kv_heads=None, kv="uniform", poison_tail=False, q_row_pad=0):
+              num_kv_heads=None, kv="uniform", poison_tail=False, q_row_pad=0, block_size=BS):
     """Random paged-KV decode case in the reference layout.
 
     lens: list of per-sequence context lengths.  Every sequence gets distinct physical blocks in a
@@ -16,6 +16,7 @@ def make_case(rng, num_seqs, num_heads, head_size, lens, num_blocks=None, max_bl
     (attention_kernels.cu:302-303, 420-430).  q_row_pad > 0 makes `query` a strided view
     (row stride = (1+q_row_pad)*H*D, like the fused-qkv view at gpt2.py:35-39).
     """
+    BS = block_size  # noqa: N806 (shadows the module default on purpose)
     lens = np.asarray(lens, dtype=np.int32)
     assert lens.shape == (num_seqs,)
     num_kv_heads = num_kv_heads or num_heads
@@ -51,7 +52,7 @@ def make_case(rng, num_seqs, num_heads, head_size, lens, num_blocks=None, max_bl
     qbuf = rng.standard_normal((num_seqs, width)).astype(np.float16)
     q = qbuf[:, : num_heads * head_size].reshape(num_seqs, num_heads, head_size)  # strided view if padded
     return dict(q=q, qbuf=qbuf, kc=kc, vc=vc, tables=tables, lens=lens, num_kv_heads=num_kv_heads,
-                scale=float(head_size) ** -0.5, num_heads=num_heads, head_size=head_size)
+                scale=float(head_size) ** -0.5, num_heads=num_heads, head_size=head_size, bs=BS)
 
 
 def ulp16(x):

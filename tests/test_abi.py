@@ -40,7 +40,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 1
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 2
     assert typed.vmi_target_arch() == b"gfx950"
 
 
@@ -144,8 +144,8 @@ def test_c_abi_validation_codes_without_gpu():
     p16 = (p + 15) & ~15
     args = lambda hs=64, bs=16, nkv=4, ptr=p16, qs=256: (  # noqa: E731
         p16, ptr, p16, p16, 1, 4, hs, nkv, 0.125, p16, p16, bs, 16, 1, None, qs, 4096, 1024, 0, None)
-    assert lib.vmi_paged_attention_v1_f16(*args(hs=80)) == 2
-    assert b"Unsupported head size: 80" in lib.vmi_last_error_string()
+    assert lib.vmi_paged_attention_v1_f16(*args(hs=72)) == 2
+    assert b"Unsupported head size: 72" in lib.vmi_last_error_string()
     assert lib.vmi_paged_attention_v1_f16(*args(bs=64)) == 3
     assert b"Unsupported block size: 64" in lib.vmi_last_error_string()
     assert lib.vmi_paged_attention_v1_f16(*args(nkv=3)) == 4
@@ -158,11 +158,17 @@ def test_c_abi_validation_codes_without_gpu():
     assert lib.vmi_paged_attention_v1_f16_variant(*args(), 9999) == 8
     assert lib.vmi_reshape_and_cache_f16(p16, p16, p16, p16, p16, 1, 4, 64, 16, 4, 256, 256, 0, None) == 9
     assert lib.vmi_reshape_and_cache_f16(p16, p16, p16, p16, p16, 0, 4, 64, 16, 8, 256, 256, 0, None) == 0
-    assert lib.vmi_paged_attention_v1_pick_variant(256, 12, 64, 1024) >= 1
-    assert lib.vmi_paged_attention_v1_pick_variant(1, 12, 80, 64) == 0
+    assert lib.vmi_paged_attention_v1_pick_variant(256, 12, 64, 16, 1024) >= 1
+    assert lib.vmi_paged_attention_v1_pick_variant(1, 12, 80, 8, 64) >= 1
+    assert lib.vmi_paged_attention_v1_pick_variant(1, 12, 72, 16, 64) == 0
+    assert lib.vmi_paged_attention_v1_pick_variant(1, 12, 64, 64, 64) == 0
     n = lib.vmi_paged_attention_v1_variant_count()
     names = [lib.vmi_paged_attention_v1_variant_name(i + 1).decode() for i in range(n)]
-    assert len(set(names)) == n and all(nm.startswith(("d64_", "d128_")) for nm in names)
+    assert len(set(names)) == n and all(nm.startswith("d") for nm in names)
+    # every (head size, block size) of the reference's dispatch set has a kernel
+    for d in (64, 80, 96, 112, 128, 192, 256):
+        for bs in (8, 16, 32):
+            assert lib.vmi_paged_attention_v1_pick_variant(4, 8, d, bs, 2048) >= 1, (d, bs)
 
 
 def test_workload_builder_matches_survey_byte_counts():

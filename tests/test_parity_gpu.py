@@ -55,11 +55,12 @@ def run_hip(case, variant=0, out_shape=None, max_seq_len=None, alibi=None):
     out = torch.full(out_shape or (S, H, D), float("nan"), dtype=torch.float16, device=dev)
     msl = int(max_seq_len if max_seq_len is not None else max(int(case["lens"].max()), 1))
     al = None if alibi is None else torch.from_numpy(alibi).to(dev)
+    bs = case.get("bs", BS)
     if variant:
-        ops.paged_attention_v1(out, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, BS, msl, al,
+        ops.paged_attention_v1(out, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, bs, msl, al,
                                "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
     else:
-        ext.paged_attention_v1(out, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, BS, msl, al,
+        ext.paged_attention_v1(out, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, bs, msl, al,
                                "auto", 1.0, 0, 0, 1, 1, 0)
     torch.cuda.synchronize()
     return out.cpu().numpy().reshape(S, H, D)
@@ -67,7 +68,7 @@ def run_hip(case, variant=0, out_shape=None, max_seq_len=None, alibi=None):
 
 def run_model(case, alibi=None):
     return oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], case["num_kv_heads"], case["scale"],
-                                     case["tables"], case["lens"], BS, alibi_slopes=alibi, threads=8)
+                                     case["tables"], case["lens"], case.get("bs", BS), alibi_slopes=alibi, threads=8)
 
 
 def assert_close(got, ref, what=""):
@@ -110,8 +111,9 @@ def test_pa_v1_matches_kernel_model_default_variant(shape):
 def _variants_for(D):
     from vllmini_amd import ops
 
+    # block-16 table of this head size; LOADSONLY = bandwidth diagnostics, wrong by design; _bs = other block sizes
     return [(i + 1, n) for i, n in enumerate(ops.variant_names())
-            if n.startswith(f"d{D}_") and "LOADSONLY" not in n]  # LOADSONLY = bandwidth diagnostics, wrong by design
+            if n.startswith(f"d{D}_") and "LOADSONLY" not in n and "_bs" not in n]
 
 
 @pytest.mark.parametrize("D", [64, 128])
@@ -162,12 +164,12 @@ def test_pa_v1_more_sequences_than_grid_y_limit():
 
 def test_pa_v1_seq_len_beyond_max_seq_len_is_truncated_not_overflowing():
     """The reference overflows its logits buffer when seq_len > max_seq_len (UB). Here the context is
-    truncated to pad16(max_seq_len): same result as passing the truncated length."""
+    truncated to the reserved logits (max_seq_len rounded up to 32): same result as passing that length."""
     rng = np.random.default_rng(13)
     case = make_case(rng, 2, 4, 64, [100, 20], max_blocks=8)
-    got = run_hip(case, max_seq_len=40)          # LDS reserved for 48 tokens
+    got = run_hip(case, max_seq_len=40)          # LDS reserved for 64 tokens
     trunc = dict(case)
-    trunc["lens"] = np.array([48, 20], dtype=np.int32)
+    trunc["lens"] = np.array([64, 20], dtype=np.int32)
     ref = run_model(trunc)
     assert_close(got, ref, "truncated context")
 
@@ -468,7 +470,7 @@ def test_errors_raise_runtimeerror():
     good = make_case(rng, 2, 4, 64, [5, 40], max_blocks=4)
     call(good)  # sanity: valid call passes
     with pytest.raises(RuntimeError, match="Unsupported head size"):
-        call(make_case(rng, 1, 4, 80, [5], max_blocks=4))            # attention_kernels.cu:763-765
+        call(make_case(rng, 1, 4, 72, [5], max_blocks=4))            # attention_kernels.cu:763-765
     with pytest.raises(RuntimeError, match="kv cache"):
         call(good, kvd="fp8")                                        # quant_utils.cuh:538
     with pytest.raises(RuntimeError, match="kv cache"):
@@ -580,7 +582,7 @@ def run_hip_v2(case, max_seq_len, variant=0, alibi=None):
     kw = {"_variant": variant} if variant else {}
     fn(out, es, ml, tmp, q, torch.from_numpy(case["kc"]).to(dev), torch.from_numpy(case["vc"]).to(dev),
        case["num_kv_heads"], case["scale"], torch.from_numpy(case["tables"]).to(dev),
-       torch.from_numpy(case["lens"]).to(dev), BS, max_seq_len, al, "auto", 1.0, 0, 0, 1, 1, 0, **kw)
+       torch.from_numpy(case["lens"]).to(dev), case.get("bs", BS), max_seq_len, al, "auto", 1.0, 0, 0, 1, 1, 0, **kw)
     torch.cuda.synchronize()
     return out.cpu().numpy(), es.cpu().numpy(), ml.cpu().numpy(), tmp.cpu().numpy()
 
@@ -588,8 +590,8 @@ def run_hip_v2(case, max_seq_len, variant=0, alibi=None):
 def _check_v2(case, max_seq_len, variant=0, alibi=None, what=""):
     got, es, ml, tmp = run_hip_v2(case, max_seq_len, variant, alibi)
     r_out, r_es, r_ml, r_tmp = oracle.paged_attention_v2(case["q"], case["kc"], case["vc"], case["num_kv_heads"],
-                                                         case["scale"], case["tables"], case["lens"], BS, max_seq_len,
-                                                         alibi_slopes=alibi)
+                                                         case["scale"], case["tables"], case["lens"], case.get("bs", BS),
+                                                         max_seq_len, alibi_slopes=alibi)
     assert_close(got, r_out, what + " out")
     for s, L in enumerate(case["lens"]):
         used = (int(L) + 511) // 512
@@ -619,7 +621,7 @@ def test_pa_v2_every_variant(D):
     lens = [1, 600, 2000, 1025, 16]
     case = make_case(rng, len(lens), 4, D, lens, poison_tail=True)
     for vid, name in enumerate(ops.variant_names_v2(), start=1):
-        if name.startswith(f"v2_d{D}_"):
+        if name.startswith(f"v2_d{D}_") and "_bs" not in name:
             _check_v2(case, 2048, variant=vid, what=name)
 
 
@@ -719,3 +721,59 @@ def test_batch_scheduler_on_gpu_equals_per_sequence_greedy(golden_dir):
             logits = solo.decode([0], [tok])[0]
         if agree:
             assert seq == sch.sequences[sid]
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's whole dispatch set: head sizes (attention_kernels.cu:738-766) x block sizes (:789-803)
+# ------------------------------------------------------------------------------------------------
+ALL_HEADS = (64, 80, 96, 112, 128, 192, 256)
+ALL_BLOCKS = (8, 16, 32)
+
+
+@pytest.mark.parametrize("bs", ALL_BLOCKS)
+@pytest.mark.parametrize("D", ALL_HEADS)
+def test_every_head_and_block_size_v1_and_v2(D, bs):
+    from vllmini_amd import ops
+
+    rng = np.random.default_rng(D * 100 + bs)
+    lens = [1, bs - 1, bs, bs + 1, 5 * bs + 3, 520, 700]
+    case = make_case(rng, len(lens), 4, D, lens, q_row_pad=2, poison_tail=True, block_size=bs, num_kv_heads=2)
+    ref = run_model(case)
+    assert_close(run_hip(case), ref, f"v1 D{D} bs{bs} default")
+    tag = f"d{D}_bs{bs}_" if not (bs == 16 and D in (64, 128)) else f"d{D}_"
+    for vid, name in enumerate(ops.variant_names(), start=1):
+        if name.startswith(tag) and "LOADSONLY" not in name and (("_bs" in name) == ("_bs" in tag)):
+            assert_close(run_hip(case, variant=vid), ref, name)
+    _check_v2(case, 1024, what=f"v2 D{D} bs{bs} default")
+    tag2 = "v2_" + tag
+    for vid, name in enumerate(ops.variant_names_v2(), start=1):
+        if name.startswith(tag2) and (("_bs" in name) == ("_bs" in tag2)):
+            _check_v2(case, 1024, variant=vid, what=name)
+
+
+@pytest.mark.parametrize("D,bs", [(80, 16), (96, 8), (256, 32), (112, 32)])
+def test_reshape_and_cache_then_attend_other_layouts(D, bs):
+    """Both ops together in a non-default layout: rows written by reshape_and_cache are what
+    paged_attention_v1 reads back (eager attention over the original rows as the yardstick)."""
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(D + bs)
+    H, L, NB = 3, 3 * bs + 2, 9
+    key = rng.standard_normal((L, H, D)).astype(np.float16)
+    val = rng.standard_normal((L, H, D)).astype(np.float16)
+    q = rng.standard_normal((1, H, D)).astype(np.float16)
+    table = rng.permutation(NB)[:4].astype(np.int32).reshape(1, 4)
+    slots = table[0, np.arange(L) // bs].astype(np.int64) * bs + np.arange(L) % bs
+    kc = torch.full((NB, H, D // 8, bs, 8), float("nan"), dtype=torch.float16, device=dev)
+    vc = torch.full((NB, H, D, bs), float("nan"), dtype=torch.float16, device=dev)
+    ext.cache_ops.reshape_and_cache(torch.from_numpy(key).to(dev), torch.from_numpy(val).to(dev), kc, vc,
+                                    torch.from_numpy(slots).to(dev), "auto", 1.0)
+    out = torch.empty((1, H, D), dtype=torch.float16, device=dev)
+    ext.paged_attention_v1(out, torch.from_numpy(q).to(dev), kc, vc, H, D ** -0.5, torch.from_numpy(table).to(dev),
+                           torch.tensor([L], dtype=torch.int32, device=dev), bs, L, None, "auto", 1.0, 0, 0, 1, 1, 0)
+    torch.cuda.synchronize()
+    w = np.einsum("hd,lhd->hl", q[0].astype(np.float64), key.astype(np.float64)) * D ** -0.5
+    p = np.exp(w - w.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    exact = np.einsum("hl,lhd->hd", p, val.astype(np.float64))
+    assert np.abs(out.cpu().numpy()[0].astype(np.float64) - exact).max() <= 3e-3

@@ -2,8 +2,8 @@
 
 The reference builds its kernels as a torch CUDAExtension for sm_70..sm_89
 (paged_attention_ext/setup.py:21-46, build.sh:3-5).  Here there is no torch/pybind in the
-native code at all: one `hipcc --offload-arch=gfx950 -shared -fPIC` producing
-vllmini_amd/_C/libvmi_paged_attention.so, loaded through ctypes (vllmini_amd/_lib.py).
+native code at all: two hipcc translation units (core kernels + C-ABI; extra head/block-size instantiations)
+compiled concurrently and linked into vllmini_amd/_C/libvmi_paged_attention.so, loaded through ctypes (vllmini_amd/_lib.py).
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so is
 git-ignored but travels to the GPU box with the repo snapshot.
@@ -17,7 +17,10 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
-SRC = os.path.join(PKG_DIR, "csrc", "paged_attention.hip")
+CSRC = os.path.join(PKG_DIR, "csrc")
+SRC = os.path.join(CSRC, "paged_attention.hip")              # core kernels + host code + C-ABI
+SRC_EXTRA = os.path.join(CSRC, "pa_variants_extra.hip")       # remaining head/block-size instantiations
+HDR = os.path.join(CSRC, "pa_kernel.hpp")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 OUT_DIR = os.path.join(PKG_DIR, "_C")
 LIB_NAME = "libvmi_paged_attention.so"
@@ -32,7 +35,6 @@ HIPCC_FLAGS = [
     "-std=c++17",
     "-ffp-contract=off",
     "-fPIC",
-    "-shared",
     "-fno-gpu-rdc",
     f"-I{INCLUDE}",
 ]
@@ -46,7 +48,7 @@ def _hipcc() -> str:
 
 
 def _deps() -> list[str]:
-    return [SRC, os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.abspath(__file__)]
+    return [SRC, SRC_EXTRA, HDR, os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.abspath(__file__)]
 
 
 def is_stale() -> bool:
@@ -62,12 +64,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(OUT_DIR, exist_ok=True)
     tmp = LIB_PATH + ".tmp"
-    cmd = [_hipcc(), *HIPCC_FLAGS, SRC, "-o", tmp]
+    objs = []
+    procs = []
+    for src in (SRC, SRC_EXTRA):                      # the two units compile concurrently
+        obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        objs.append(obj)
+    for cmd, proc in procs:
+        out, err = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({proc.returncode}): {' '.join(cmd)}\n{out}\n{err}")
+    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", tmp]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    proc = subprocess.run(cmd, capture_output=True, text=True)
+        print(" ".join(link), file=sys.stderr)
+    proc = subprocess.run(link, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+        raise RuntimeError(f"link failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

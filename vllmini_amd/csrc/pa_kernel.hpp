@@ -1,0 +1,479 @@
+// pa_kernel.hpp — kernel templates of the MI355X paged-attention decode path (gfx950 only).
+// Included by paged_attention.hip (core instantiations + host code + C-ABI) and by
+// pa_variants_extra.hip (the remaining head-size / block-size combinations).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+namespace vmi {
+
+typedef _Float16 h16;
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// LDS logits are written as float and re-read 4 at a time: the vector view must alias float
+typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));
+
+// ----------------------------------------------------------------------------------------
+// device helpers
+// ----------------------------------------------------------------------------------------
+
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const h16* p) {
+  if constexpr (NT) {
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  } else {
+    return *reinterpret_cast<const u32x4*>(p);
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+struct PAParams {
+  h16* out;
+  const h16* q;
+  const h16* kc;
+  const h16* vc;
+  const int32_t* block_tables;
+  const int32_t* seq_lens;
+  const float* alibi;
+  int32_t num_heads;
+  int32_t num_kv_heads;
+  float scale;
+  int32_t max_blocks_per_seq;
+  int64_t q_stride;
+  int64_t kv_block_stride;
+  int64_t kv_head_stride;
+  int32_t lpad;  // logits floats reserved per head in LDS (max_seq_len padded to 16)
+  // split-KV (paged_attention_v2) only: per-partition softmax statistics, `out` is tmp_out
+  float* exp_sums;             // [num_seqs, num_heads, max_num_partitions]
+  float* max_logits;           // [num_seqs, num_heads, max_num_partitions]
+  int32_t max_num_partitions;  // ceil(max_seq_len / 512)
+};
+
+// ----------------------------------------------------------------------------------------
+// paged_attention_v1
+//
+//   D    head size (64 | 128)
+//   HPW  heads per workgroup   (each head owns WPH waves)
+//   WPH  waves per head        (blocks of one (seq, head) are dealt round-robin to them)
+//   U    blocks per register group (software-pipeline depth = 2 groups)
+//   NT   non-temporal page loads
+//
+// grid = (ceil(num_heads / HPW), num_seqs), block = HPW*WPH*64.
+// LDS  = HPW*lpad*4 (logits)  +  HPW*2*WPH*4 (max/sum exchange)  +  HPW*WPH*D*4 (partial out)
+// ----------------------------------------------------------------------------------------
+//
+// PART = true is the split-KV form behind paged_attention_v2 (reference attention_kernels.cu:529-562:
+// the same kernel body with PARTITION_SIZE = 512): blockIdx.z selects a 512-token partition, the
+// partition's normalised output goes to tmp_out and its (max, exp_sum) to max_logits / exp_sums.
+//
+// BS (block size 8 | 16 | 32) and D (any multiple of 8) generalise the lane maps:
+//   K tile = D/8 chunks x BS tokens of 16 B; a load covers 64/BS chunks; lane = chunk*BS + token
+//   V tile = D rows x BS/8 units of 16 B;   a load covers 512/BS rows;  lane = row*(BS/8) + unit
+// When D*BS/8 is not a multiple of 64 (head 80/112, ...) the last load of a tile is predicated.
+template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16>
+__global__ void __launch_bounds__(HPW* WPH * 64)
+    pa_v1_kernel(const PAParams p) {
+  constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
+  constexpr int UNITS = D * BS / 8;       // 16-B units in one (block, head) tile of K — and of V
+  constexpr int NL = (UNITS + 63) / 64;   // 1-KiB loads per tile
+  constexpr int TAIL = UNITS - 64 * (NL - 1);  // active lanes of the last load (64 = full)
+  constexpr int CPL = 64 / BS;            // K: chunks per load
+  constexpr int UPR = BS / 8;             // V: 16-B units per dim row
+  constexpr int RPL = 64 / UPR;           // V: rows per load
+  static_assert(D % 8 == 0, "head size must be a multiple of 8");
+  static_assert(BS == 8 || BS == 16 || BS == 32, "block size 8, 16 or 32");
+  static_assert(64 % U == 0, "U must divide 64");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = wave / WPH;
+  const int sub = wave % WPH;
+  const int seq = blockIdx.y;
+  const int head = blockIdx.x * HPW + hl;
+  if (WPH == 1 && head >= p.num_heads) return;  // host guarantees H % HPW == 0 when WPH > 1
+
+  // The first 64 block-table entries of this wave are requested BEFORE seq_len is known (any entry
+  // inside the row is readable; entries past the context are simply never used), so the table,
+  // seq_len and q loads overlap instead of forming a chain in front of the first page load.
+  const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
+  const int part = PART ? blockIdx.z : 0;
+  const int blk_lo = PART ? part * PBLK : 0;  // first block of my range (:126-127)
+  int bt_sg = 0;  // which 64-entry slice of my blocks is in bt_reg
+  int32_t bt_reg = (blk_lo + sub + lane * WPH < p.max_blocks_per_seq) ? bt[blk_lo + sub + lane * WPH] : 0;
+
+  // seq_len > max_seq_len overflows the logits buffer in the reference (undefined behaviour,
+  // attention_kernels.cu:725-732); here the context is truncated to the LDS that was reserved.
+  int L = p.seq_lens[seq];
+  if constexpr (!PART) L = L > p.lpad ? p.lpad : L;
+  const int nblk_seq = (L + BS - 1) / BS;                                     // :121
+  const int blk_hi = PART ? (blk_lo + PBLK < nblk_seq ? blk_lo + PBLK : nblk_seq) : nblk_seq;  // :128-129
+  if (PART && blk_lo * BS >= L) return;  // nothing in this partition (:116-119); uniform per workgroup
+  const int nblk = blk_hi - blk_lo;      // blocks in my range
+  const int tok_lo = blk_lo * BS;        // logits in LDS are indexed relative to the range start (:133)
+  const int Lloc = (L < blk_hi * BS ? L : blk_hi * BS) - tok_lo;              // tokens in range (:134-136)
+
+  float* logits = reinterpret_cast<float*>(smem) + (size_t)hl * p.lpad;
+  float* red = reinterpret_cast<float*>(smem) + (size_t)HPW * p.lpad + hl * 2 * WPH;
+  float* osm = reinterpret_cast<float*>(smem) + (size_t)HPW * p.lpad + HPW * 2 * WPH +
+               (size_t)hl * WPH * D;
+
+  h16* outp = PART ? p.out + (((int64_t)seq * p.num_heads + head) * p.max_num_partitions + part) * D
+                   : p.out + ((int64_t)seq * p.num_heads + head) * D;
+
+  if (L <= 0) {  // uniform over the workgroup (same seq): reference yields exp_sum = 0 -> out = 0
+    if (sub == 0) {
+      for (int d = lane; d < D; d += 64) outp[d] = (h16)0.f;
+    }
+    return;
+  }
+
+  const int kvh = head / (p.num_heads / p.num_kv_heads);
+  const float slope = p.alibi ? p.alibi[head] : 0.f;
+
+  // ---- q: this lane's 8-dim chunks, one per K load -------------------------------------
+  const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
+  const int c4 = lane / BS;  // chunk-within-load
+  const int tk = lane % BS;  // token-within-block
+  const bool tail_ok = (TAIL == 64) || lane < TAIL;  // this lane takes part in the last load of a tile
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 qreg[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    qreg[i] = (i < NL - 1 || tail_ok) ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8) : zero4;
+
+  const h16* kbase = p.kc + (int64_t)kvh * p.kv_head_stride + lane * 8;
+  const h16* vbase = p.vc + (int64_t)kvh * p.kv_head_stride + lane * 8;
+
+  // ---- my share of the blocks: b = sub + idx*WPH, idx in [0, nmy) -----------------------
+  const int nmy = nblk > sub ? (nblk - sub + WPH - 1) / WPH : 0;
+  const int ngroups = (nmy + U - 1) / U;
+  auto table_for = [&](int g) {  // lane j: physical id of my block (bt_sg*64 + j)
+    const int sg = (g * U) >> 6;
+    if (sg != bt_sg) {
+      const int b = blk_lo + sub + (sg * 64 + lane) * WPH;
+      bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
+      bt_sg = sg;
+    }
+  };
+
+  auto load_group = [&](u32x4(&r)[U][NL], const h16* base, int g) {
+    table_for(g);
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      int idx = g * U + j;
+      idx = idx < nmy ? idx : nmy - 1;  // padding slots re-read my last block (never OOB)
+      const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
+      // (sc0/sc1 cache-policy bits and buffer- vs flat-addressed loads were measured neutral on
+      //  this stream; only `nt` pays: profiles/r01_cfg3_sweep_cache_policy_bits.json)
+      {
+        const h16* ptr = base + phys * p.kv_block_stride;
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+          r[j][i] = (i < NL - 1 || tail_ok) ? ld16<NT>(ptr + i * 512) : zero4;  // masked lanes add 0
+      }
+    }
+  };
+
+  // =========================== K pass: logits -> LDS, running max ========================
+  float qk_max = -FLT_MAX;
+
+  uint32_t fold = 0;  // LOADS_ONLY diagnostic: xor of everything loaded
+  auto compute_k = [&](u32x4(&r)[U][NL], int g) {
+    if constexpr (LOADS_ONLY) {
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) fold ^= r[j][i][0] ^ r[j][i][1] ^ r[j][i][2] ^ r[j][i][3];
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int idx = g * U + j;
+      if (idx < nmy) {  // wave-uniform
+        const int b = blk_lo + sub + idx * WPH;
+        // q.k over this lane's 8*NL dims: fp16 operands converted to fp32, fp32 FMA chain
+        // (v_fma_mix_f32) — the reference's arithmetic (dtype_float16.cuh:292-298, 399-404).
+        // One accumulator per load keeps NL independent dependency chains in flight.
+        float accv[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const h16x8 qh = __builtin_bit_cast(h16x8, qreg[i]);
+          const h16x8 kh = __builtin_bit_cast(h16x8, r[j][i]);
+          float a = (float)qh[0] * (float)kh[0];
+#pragma unroll
+          for (int e = 1; e < 8; ++e) a = __builtin_fmaf((float)qh[e], (float)kh[e], a);
+          accv[i] = a;
+        }
+        float acc = accv[0];
+#pragma unroll
+        for (int i = 1; i < NL; ++i) acc += accv[i];
+#pragma unroll
+        for (int m = BS; m < 64; m <<= 1) acc += __shfl_xor(acc, m);  // lanes holding the same token
+        const int token = b * BS + tk;
+        float qk = p.scale * acc;
+        qk += (slope != 0.f) ? slope * (float)(token - L + 1) : 0.f;
+        const bool masked = token >= L;
+        if (lane < BS) logits[token - tok_lo] = masked ? 0.f : qk;
+        qk_max = masked ? qk_max : fmaxf(qk_max, qk);
+      }
+    }
+  };
+
+  u32x4 ra[U][NL], rb[U][NL];
+  {
+    if (ngroups > 0) load_group(ra, kbase, 0);
+    int g = 0;
+    for (; g + 2 <= ngroups; g += 2) {
+      load_group(rb, kbase, g + 1);
+      compute_k(ra, g);
+      if (g + 2 < ngroups) load_group(ra, kbase, g + 2);
+      compute_k(rb, g + 1);
+    }
+    if (g < ngroups) compute_k(ra, g);
+  }
+
+  // first V group goes out now: HBM stays busy while the softmax runs
+  if (ngroups > 0) load_group(ra, vbase, 0);
+
+  // =========================== softmax over the logits in LDS ============================
+  qk_max = wave_max(qk_max);
+  if constexpr (WPH > 1) {
+    if (lane == 0) red[sub] = qk_max;
+    __syncthreads();
+    float m = -FLT_MAX;
+#pragma unroll
+    for (int w = 0; w < WPH; ++w) m = fmaxf(m, red[w]);
+    qk_max = m;
+  }
+
+  float exp_sum = 0.f;
+  for (int i = sub * 64 + lane; i < Lloc; i += WPH * 64) {
+    const float e = __expf(logits[i] - qk_max);
+    logits[i] = e;
+    exp_sum += e;
+  }
+  exp_sum = wave_sum(exp_sum);
+  if constexpr (WPH > 1) {
+    if (lane == 0) red[WPH + sub] = exp_sum;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPH; ++w) s += red[WPH + w];
+    exp_sum = s;
+  }
+  const float inv_sum = __builtin_amdgcn_rcpf(exp_sum + 1e-6f);
+  if constexpr (PART) {  // partition statistics for the reduce kernel (:349-357)
+    if (sub == 0 && lane == 0) {
+      const int64_t o = ((int64_t)seq * p.num_heads + head) * p.max_num_partitions + part;
+      p.max_logits[o] = qk_max;
+      p.exp_sums[o] = exp_sum;
+    }
+  }
+
+  // =========================== V pass ====================================================
+  float acc[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc[i] = 0.f;
+  const int hf = lane % UPR;   // which 8-token group of the block this lane owns
+  const int rowl = lane / UPR;  // dim row within a load
+
+  auto compute_v = [&](u32x4(&r)[U][NL], int g) {
+    if constexpr (LOADS_ONLY) {
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) fold ^= r[j][i][0] ^ r[j][i][1] ^ r[j][i][2] ^ r[j][i][3];
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int idx = g * U + j;
+      if (idx < nmy) {  // wave-uniform
+        const int b = blk_lo + sub + idx * WPH;
+        const int token0 = b * BS + hf * 8;
+        const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(logits + token0 - tok_lo);
+        const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(logits + token0 - tok_lo + 4);
+        h16x8 pv;
+        pv[0] = (h16)(e0[0] * inv_sum);
+        pv[1] = (h16)(e0[1] * inv_sum);
+        pv[2] = (h16)(e0[2] * inv_sum);
+        pv[3] = (h16)(e0[3] * inv_sum);
+        pv[4] = (h16)(e1[0] * inv_sum);
+        pv[5] = (h16)(e1[1] * inv_sum);
+        pv[6] = (h16)(e1[2] * inv_sum);
+        pv[7] = (h16)(e1[3] * inv_sum);
+        const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          h16x8 v = __builtin_bit_cast(h16x8, r[j][i]);
+          if (last) {
+            // tokens past the context may hold stale/NaN bytes: zero them (ref :420-430)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (token0 + e < L) ? v[e] : (h16)0.f;
+          }
+          const h16x8 pr = pv * v;  // 4 x v_pk_mul_f16, each product rounded to fp16
+          h16x2 c = h16x2{pr[0], pr[1]} + h16x2{pr[2], pr[3]};
+          c = c + h16x2{pr[4], pr[5]};
+          c = c + h16x2{pr[6], pr[7]};
+          acc[i] += ((float)c[0] + (float)c[1]);
+        }
+      }
+    }
+  };
+
+  {
+    int g = 0;
+    for (; g + 2 <= ngroups; g += 2) {
+      load_group(rb, vbase, g + 1);
+      compute_v(ra, g);
+      if (g + 2 < ngroups) load_group(ra, vbase, g + 2);
+      compute_v(rb, g + 1);
+    }
+    if (g < ngroups) compute_v(ra, g);
+  }
+
+  if constexpr (LOADS_ONLY) {
+    if (fold == 0x9e3779b9u) outp[lane] = (h16)1.f;  // practically never; keeps the loads live
+    return;
+  }
+
+  // the UPR lanes of a row hold its 8-token groups
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+#pragma unroll
+    for (int m = 1; m < UPR; m <<= 1) acc[i] += __shfl_xor(acc[i], m);
+  }
+
+  if constexpr (WPH > 1) {
+    if (hf == 0) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int row = RPL * i + rowl;
+        if (row < D) osm[sub * D + row] = acc[i];
+      }
+    }
+    __syncthreads();
+    if (sub == 0) {
+      for (int d = lane; d < D; d += 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) s += osm[w * D + d];
+        outp[d] = (h16)s;
+      }
+    }
+  } else {
+    if (hf == 0) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int row = RPL * i + rowl;
+        if (row < D) outp[row] = (h16)acc[i];
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// paged_attention_v2 reduce: merge the partitions of one (seq, head) — reference
+// attention_kernels.cu:564-669.  grid = (num_heads, num_seqs), block = 128.
+//   1 partition  -> copy tmp_out to out (:582-594)
+//   otherwise    -> m = max_j max_logits[j]; s_j = exp_sums[j]*exp(max_logits[j]-m);
+//                   out[d] = sum_j float(tmp_out[j][d]) * s_j * 1/(sum_j s_j + 1e-6)   (fp32, j ascending)
+// LDS: 2*max_num_partitions floats + 2 reduction slots per wave.
+// ----------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(128)
+    pa_v2_reduce_kernel(h16* __restrict__ out, const float* __restrict__ exp_sums,
+                        const float* __restrict__ max_logits, const h16* __restrict__ tmp_out,
+                        const int32_t* __restrict__ seq_lens, int max_num_partitions) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int num_heads = gridDim.x;
+  const int head = blockIdx.x;
+  const int seq = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int L = seq_lens[seq];
+  const int np = (L + 511) / 512;  // :581
+  const int64_t sh = ((int64_t)seq * num_heads + head) * max_num_partitions;
+  h16* outp = out + ((int64_t)seq * num_heads + head) * D;
+  const h16* tmp = tmp_out + sh * D;
+  if (np == 1) {  // :582-594
+    for (int i = tid; i < D; i += 128) outp[i] = tmp[i];
+    return;
+  }
+  float* smax = reinterpret_cast<float*>(smem);
+  float* ssum = smax + max_num_partitions;
+  float* red = ssum + max_num_partitions;  // [4]
+
+  float m = -FLT_MAX;
+  for (int i = tid; i < np; i += 128) {  // :611-615
+    const float l = max_logits[sh + i];
+    smax[i] = l;
+    m = fmaxf(m, l);
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(red[0], red[1]);
+
+  float g = 0.f;
+  for (int i = tid; i < np; i += 128) {  // :644-649
+    const float r = exp_sums[sh + i] * __expf(smax[i] - m);
+    g += r;
+    ssum[i] = r;
+  }
+  g = wave_sum(g);
+  if (lane == 0) red[2 + wave] = g;
+  __syncthreads();
+  g = red[2] + red[3];
+  const float inv = __builtin_amdgcn_rcpf(g + 1e-6f);  // :652
+
+  for (int i = tid; i < D; i += 128) {  // :661-668
+    float acc = 0.f;
+    for (int j = 0; j < np; ++j)
+      acc = __builtin_fmaf((float)tmp[(int64_t)j * D + i] * ssum[j], inv, acc);
+    outp[i] = (h16)acc;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// host-side variant descriptor (shared by the translation units that instantiate kernels)
+// ----------------------------------------------------------------------------------------
+typedef void (*pa_kernel_t)(const PAParams);
+
+struct Variant {
+  const char* name;
+  int D, BS, HPW, WPH, U;
+  bool NT;
+  pa_kernel_t fn;
+  int lds_attr_set;  // largest dynamic-LDS size already granted through hipFuncSetAttribute
+};
+
+typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
+
+// kernels for the non-core (head size, block size) combinations live in pa_variants_extra.hip
+extern Variant g_extra_variants_v1[];
+extern const int g_extra_nvariants_v1;
+extern Variant g_extra_variants_v2[];
+extern const int g_extra_nvariants_v2;
+pa_reduce_t extra_reduce_kernel(int head_size);  // nullptr if that head size is not built there
+
+}  // namespace vmi

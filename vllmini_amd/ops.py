@@ -305,6 +305,6 @@ def variant_names_v2() -> list[str]:
     return [lib.vmi_paged_attention_v2_variant_name(i + 1).decode() for i in range(n)]
 
 
-def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int) -> int:
-    return int(_lib.load().vmi_paged_attention_v1_pick_variant(num_seqs, num_heads, head_size,
+def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16) -> int:
+    return int(_lib.load().vmi_paged_attention_v1_pick_variant(num_seqs, num_heads, head_size, block_size,
                                                                 max_seq_len))
