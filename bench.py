@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="override the config's batch (diagnostic sweeps)")
+    ap.add_argument("--seq-len", type=int, default=0, help="override the config's seq_len (diagnostic sweeps)")
     ap.add_argument("--op", default="v1", choices=["v1", "v2"],
                     help="attention operator in the step: paged_attention_v1 (headline) or the split-KV paged_attention_v2")
     ap.add_argument("--variant", type=int, default=0, help="force a kernel work decomposition (0 = heuristic)")
@@ -251,6 +253,13 @@ def main():
     dist, rank, world, local_rank = init_dist(args.gpus)
     dev = torch.device("cuda", local_rank)
     cfg = CONFIGS[args.config]
+    if args.batch or args.seq_len:
+        import dataclasses
+        b_ = args.batch or cfg.batch
+        l_ = args.seq_len or cfg.seq_len
+        per = -(-l_ // cfg.block_size)
+        cfg = dataclasses.replace(cfg, name=f"{cfg.name}_b{b_}_l{l_}", batch=b_, seq_len=l_,
+                                  num_blocks=max(2 * b_ * per, 64))
     if args.e2e:
         run_e2e(args, dist, rank, world, local_rank, dev)
         if dist is not None:
@@ -288,6 +297,24 @@ def main():
                 ms = statistics.median(a.elapsed_time(b) for a, b in evs)
                 res.append({"nt": nt, "blocks": blocks, "bytes": nbytes, "us": ms * 1e3, "gbps": nbytes / (ms * 1e-3) / 1e9})
                 print(json.dumps(res[-1]), file=sys.stderr, flush=True)
+        # gather reads: contiguous chunk size as the variable (3072 waves = 768 blocks of 256, like cfg3)
+        for nt in (1,):
+            for blocks in (768, 1536):
+                for kb in (1, 2, 4, 8, 16, 32, 64):
+                    evs = []
+                    for i in range(24):
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        s_ = wl.value_cache if i % 2 else wl.key_cache
+                        a.record()
+                        rc = lib.vmi_diag_gather_read(s_.data_ptr(), nbytes, sink.data_ptr(), kb, blocks, nt, local_rank, stream)
+                        b.record()
+                        assert rc == 0, _lib.last_error()
+                        evs.append((a, b))
+                    torch.cuda.synchronize(dev)
+                    ms = statistics.median(a.elapsed_time(b) for a, b in evs[4:])
+                    res.append({"kind": "gather", "chunk_kb": kb, "nt": nt, "blocks": blocks, "bytes": nbytes,
+                                "us": ms * 1e3, "gbps": nbytes / (ms * 1e-3) / 1e9})
+                    print(json.dumps(res[-1]), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
         with open(os.path.join(REPO, "gpurun_out", "diag.json"), "w") as f:
             json.dump(res, f, indent=1)
@@ -361,7 +388,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "kernel": "pa_v1_kernel",
+            "kernel": "pa_v1_mh_kernel" if "_mh" in vname else "pa_v1_kernel",
             "algorithmic_bytes_per_launch": cfg.algorithmic_bytes(),
         },
     }

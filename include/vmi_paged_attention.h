@@ -193,6 +193,14 @@ int vmi_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_hos
 int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blocks, int32_t nt,
                          int32_t device, void* stream);
 
+/*
+ * Diagnostic: read `bytes` from `src` as pseudo-randomly ordered contiguous chunks of chunk_kb KiB
+ * (1..64, power of two), one chunk stream per wave, 8 KiB in flight per wave — the attention kernel's
+ * access pattern without the math, with the contiguous-chunk size as the variable.
+ */
+int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chunk_kb, int32_t blocks,
+                         int32_t nt, int32_t device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ for f in find("trace/**/*kernel_stats.csv"):
         for r in rows[:8]]
 # per-dispatch durations of the attention kernel (skip warm-up dispatches)
 for f in find("trace/**/*kernel_trace.csv"):
-    rows = [r for r in csv.DictReader(open(f)) if "pa_v1_kernel" in r.get("Kernel_Name", "")]
+    rows = [r for r in csv.DictReader(open(f)) if "pa_v1_" in r.get("Kernel_Name", "")]
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     if d:
         tail = d[10:] if len(d) > 20 else d
@@ -30,7 +30,7 @@ for f in find("trace/**/*kernel_trace.csv"):
 for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     for f in find(f"{sub}/**/*counter_collection.csv"):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                if "pa_v1_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == name]
+                if "pa_v1_" in r.get("Kernel_Name", "") and r.get("Counter_Name") == name]
         if vals:
             tail = vals[10:] if len(vals) > 20 else vals
             res[name] = {"n": len(vals), "mean_raw_KiB_units": statistics.mean(tail),

@@ -85,7 +85,8 @@ struct PAParams {
 //   K tile = D/8 chunks x BS tokens of 16 B; a load covers 64/BS chunks; lane = chunk*BS + token
 //   V tile = D rows x BS/8 units of 16 B;   a load covers 512/BS rows;  lane = row*(BS/8) + unit
 // When D*BS/8 is not a multiple of 64 (head 80/112, ...) the last load of a tile is predicated.
-template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16>
+template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
+          bool LOCK = false, int DEPTH = 2>
 __global__ void __launch_bounds__(HPW* WPH * 64)
     pa_v1_kernel(const PAParams p) {
   constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
@@ -175,6 +176,12 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   };
 
   auto load_group = [&](u32x4(&r)[U][NL], const h16* base, int g) {
+    // LOCK: the waves of this workgroup own ADJACENT heads of one sequence, whose tiles are contiguous
+    // in the cache (HPW * tile bytes per block).  Issuing their page loads in lockstep turns HPW
+    // separate 2-KiB reads into one HPW*2-KiB burst per block, which HBM serves measurably faster
+    // (gather microbenchmark: 2 KiB chunks 6.36 TB/s, 8 KiB 6.67, 16 KiB 6.8).  All waves of the
+    // workgroup run the same number of groups (same sequence), so the barrier count matches.
+    if constexpr (LOCK) __builtin_amdgcn_s_barrier();
     table_for(g);
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -237,8 +244,12 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     }
   };
 
-  u32x4 ra[U][NL], rb[U][NL];
-  {
+  // Register pipeline over page groups: DEPTH buffers rotate statically; DEPTH-1 groups are in
+  // flight while one is consumed (DEPTH = 2: classic double buffer; 3: one more group of queue depth
+  // for the lockstep variants, whose groups are small).
+  static_assert(DEPTH == 2 || DEPTH == 3, "pipeline depth 2 or 3");
+  u32x4 ra[U][NL], rb[U][NL], rc[DEPTH == 3 ? U : 1][NL];
+  if constexpr (DEPTH == 2) {
     if (ngroups > 0) load_group(ra, kbase, 0);
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
@@ -248,10 +259,27 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       compute_k(rb, g + 1);
     }
     if (g < ngroups) compute_k(ra, g);
+  } else {
+    if (ngroups > 0) load_group(ra, kbase, 0);
+    if (ngroups > 1) load_group(rb, kbase, 1);
+    int g = 0;
+    for (; g + 3 <= ngroups; g += 3) {
+      load_group(rc, kbase, g + 2);
+      compute_k(ra, g);
+      if (g + 3 < ngroups) load_group(ra, kbase, g + 3);
+      compute_k(rb, g + 1);
+      if (g + 4 < ngroups) load_group(rb, kbase, g + 4);
+      compute_k(rc, g + 2);
+    }
+    if (g < ngroups) compute_k(ra, g);
+    if (g + 1 < ngroups) compute_k(rb, g + 1);
   }
 
-  // first V group goes out now: HBM stays busy while the softmax runs
+  // first V group(s) go out now: HBM stays busy while the softmax runs
   if (ngroups > 0) load_group(ra, vbase, 0);
+  if constexpr (DEPTH == 3) {
+    if (ngroups > 1) load_group(rb, vbase, 1);
+  }
 
   // =========================== softmax over the logits in LDS ============================
   qk_max = wave_max(qk_max);
@@ -339,7 +367,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     }
   };
 
-  {
+  if constexpr (DEPTH == 2) {
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
       load_group(rb, vbase, g + 1);
@@ -348,6 +376,18 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       compute_v(rb, g + 1);
     }
     if (g < ngroups) compute_v(ra, g);
+  } else {
+    int g = 0;
+    for (; g + 3 <= ngroups; g += 3) {
+      load_group(rc, vbase, g + 2);
+      compute_v(ra, g);
+      if (g + 3 < ngroups) load_group(ra, vbase, g + 3);
+      compute_v(rb, g + 1);
+      if (g + 4 < ngroups) load_group(rb, vbase, g + 4);
+      compute_v(rc, g + 2);
+    }
+    if (g < ngroups) compute_v(ra, g);
+    if (g + 1 < ngroups) compute_v(rb, g + 1);
   }
 
   if constexpr (LOADS_ONLY) {
@@ -385,6 +425,233 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       for (int i = 0; i < NL; ++i) {
         const int row = RPL * i + rowl;
         if (row < D) outp[row] = (h16)acc[i];
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// paged_attention_v1, "multi-head wave" form for large batches (block size 16, D % 32 == 0):
+// ONE wavefront owns HPT ADJACENT heads of one sequence.  In the reference layout the tiles of
+// adjacent heads of a block are contiguous, so the wave's page reads become HPT*D*32-byte
+// contiguous chunks (8 KiB at D=64, HPT=4) instead of 2-KiB ones; HBM serves bigger chunks
+// faster (profiles/: gather microbenchmark 2 KiB 6.36 TB/s, 8 KiB 6.67, 16 KiB 6.8).  With LOCK
+// the HPW waves of a workgroup (HPW*HPT adjacent heads) additionally issue in lockstep.
+// Arithmetic per head is exactly that of pa_v1_kernel (same rounding points).
+// grid = (ceil(H / (HPW*HPT)), num_seqs), block = HPW*64, LDS = HPW*HPT*lpad*4.
+// ----------------------------------------------------------------------------------------
+template <int D, int HPW, int HPT, int U, bool NT, bool LOCK>
+__global__ void __launch_bounds__(HPW * 64)
+    pa_v1_mh_kernel(const PAParams p) {
+  constexpr int BS = 16;
+  constexpr int NL = D / 32;
+  static_assert(D % 32 == 0 && 64 % U == 0, "multi-head kernel: D multiple of 32, U divides 64");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int hl = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int seq = blockIdx.y;
+  const int head0 = (blockIdx.x * HPW + hl) * HPT;
+  const int nh = (p.num_heads - head0) < HPT ? (p.num_heads - head0) : HPT;  // wave-uniform
+  if (nh <= 0) return;  // a terminated wave does not take part in s_barrier
+
+  const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
+  int bt_sg = 0;
+  int32_t bt_reg = (lane < p.max_blocks_per_seq) ? bt[lane] : 0;
+
+  int L = p.seq_lens[seq];
+  L = L > p.lpad ? p.lpad : L;
+  const int nblk = (L + BS - 1) / BS;
+  const int ngroups = (nblk + U - 1) / U;
+  float* logits0 = reinterpret_cast<float*>(smem) + (size_t)hl * HPT * p.lpad;
+  h16* out0 = p.out + ((int64_t)seq * p.num_heads + head0) * D;
+
+  if (L <= 0) {
+    for (int hh = 0; hh < nh; ++hh)
+      for (int d = lane; d < D; d += 64) out0[hh * D + d] = (h16)0.f;
+    return;
+  }
+
+  const int c4 = lane >> 4;
+  const int tk = lane & 15;
+  const int qpk = p.num_heads / p.num_kv_heads;
+  int64_t hoff[HPT];  // element offset of each head's tile inside a block
+  float slope[HPT];
+  u32x4 qreg[HPT][NL];
+#pragma unroll
+  for (int hh = 0; hh < HPT; ++hh) {
+    const int head = head0 + (hh < nh ? hh : 0);
+    hoff[hh] = (int64_t)(head / qpk) * p.kv_head_stride + lane * 8;
+    slope[hh] = p.alibi ? p.alibi[head] : 0.f;
+    const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) qreg[hh][i] = *reinterpret_cast<const u32x4*>(qp + (4 * i + c4) * 8);
+  }
+
+  auto table_for = [&](int g) {
+    const int sg = (g * U) >> 6;
+    if (sg != bt_sg) {
+      const int b = sg * 64 + lane;
+      bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
+      bt_sg = sg;
+    }
+  };
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_group = [&](u32x4(&r)[U][HPT][NL], const h16* cache, int g) {
+    if constexpr (LOCK) __builtin_amdgcn_s_barrier();
+    table_for(g);
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      int idx = g * U + j;
+      idx = idx < nblk ? idx : nblk - 1;
+      const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
+      const h16* blk = cache + phys * p.kv_block_stride;
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+          r[j][hh][i] = (hh < nh) ? ld16<NT>(blk + hoff[hh] + i * 512) : zero4;
+      }
+    }
+  };
+
+  float qk_max[HPT];
+#pragma unroll
+  for (int hh = 0; hh < HPT; ++hh) qk_max[hh] = -FLT_MAX;
+
+  auto compute_k = [&](u32x4(&r)[U][HPT][NL], int g) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int b = g * U + j;
+      if (b < nblk) {
+        const int token = b * BS + tk;
+        const bool masked = token >= L;
+#pragma unroll
+        for (int hh = 0; hh < HPT; ++hh) {
+          if (hh < nh) {
+            float accv[NL];
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+              const h16x8 qh = __builtin_bit_cast(h16x8, qreg[hh][i]);
+              const h16x8 kh = __builtin_bit_cast(h16x8, r[j][hh][i]);
+              float a = (float)qh[0] * (float)kh[0];
+#pragma unroll
+              for (int e = 1; e < 8; ++e) a = __builtin_fmaf((float)qh[e], (float)kh[e], a);
+              accv[i] = a;
+            }
+            float acc = accv[0];
+#pragma unroll
+            for (int i = 1; i < NL; ++i) acc += accv[i];
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            float qk = p.scale * acc;
+            qk += (slope[hh] != 0.f) ? slope[hh] * (float)(token - L + 1) : 0.f;
+            if (lane < 16) logits0[hh * p.lpad + token] = masked ? 0.f : qk;
+            qk_max[hh] = masked ? qk_max[hh] : fmaxf(qk_max[hh], qk);
+          }
+        }
+      }
+    }
+  };
+
+  u32x4 ra[U][HPT][NL], rb[U][HPT][NL];
+  {
+    if (ngroups > 0) load_group(ra, p.kc, 0);
+    int g = 0;
+    for (; g + 2 <= ngroups; g += 2) {
+      load_group(rb, p.kc, g + 1);
+      compute_k(ra, g);
+      if (g + 2 < ngroups) load_group(ra, p.kc, g + 2);
+      compute_k(rb, g + 1);
+    }
+    if (g < ngroups) compute_k(ra, g);
+  }
+  if (ngroups > 0) load_group(ra, p.vc, 0);
+
+  float inv_sum[HPT];
+#pragma unroll
+  for (int hh = 0; hh < HPT; ++hh) {
+    inv_sum[hh] = 0.f;
+    if (hh < nh) {
+      const float m = wave_max(qk_max[hh]);
+      float* lg = logits0 + hh * p.lpad;
+      float es = 0.f;
+      for (int i = lane; i < L; i += 64) {
+        const float e = __expf(lg[i] - m);
+        lg[i] = e;
+        es += e;
+      }
+      inv_sum[hh] = __builtin_amdgcn_rcpf(wave_sum(es) + 1e-6f);
+    }
+  }
+
+  float acc[HPT][NL];
+#pragma unroll
+  for (int hh = 0; hh < HPT; ++hh)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc[hh][i] = 0.f;
+  const int hf = lane & 1;
+
+  auto compute_v = [&](u32x4(&r)[U][HPT][NL], int g) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int b = g * U + j;
+      if (b < nblk) {
+        const int token0 = b * BS + hf * 8;
+        const bool last = (b == nblk - 1);
+#pragma unroll
+        for (int hh = 0; hh < HPT; ++hh) {
+          if (hh < nh) {
+            const float* lg = logits0 + hh * p.lpad + token0;
+            const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(lg);
+            const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(lg + 4);
+            const float is = inv_sum[hh];
+            h16x8 pv;
+            pv[0] = (h16)(e0[0] * is);
+            pv[1] = (h16)(e0[1] * is);
+            pv[2] = (h16)(e0[2] * is);
+            pv[3] = (h16)(e0[3] * is);
+            pv[4] = (h16)(e1[0] * is);
+            pv[5] = (h16)(e1[1] * is);
+            pv[6] = (h16)(e1[2] * is);
+            pv[7] = (h16)(e1[3] * is);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+              h16x8 v = __builtin_bit_cast(h16x8, r[j][hh][i]);
+              if (last) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (token0 + e < L) ? v[e] : (h16)0.f;
+              }
+              const h16x8 pr = pv * v;
+              h16x2 c = h16x2{pr[0], pr[1]} + h16x2{pr[2], pr[3]};
+              c = c + h16x2{pr[4], pr[5]};
+              c = c + h16x2{pr[6], pr[7]};
+              acc[hh][i] += ((float)c[0] + (float)c[1]);
+            }
+          }
+        }
+      }
+    }
+  };
+  {
+    int g = 0;
+    for (; g + 2 <= ngroups; g += 2) {
+      load_group(rb, p.vc, g + 1);
+      compute_v(ra, g);
+      if (g + 2 < ngroups) load_group(ra, p.vc, g + 2);
+      compute_v(rb, g + 1);
+    }
+    if (g < ngroups) compute_v(ra, g);
+  }
+
+#pragma unroll
+  for (int hh = 0; hh < HPT; ++hh) {
+    if (hh < nh) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const float a = acc[hh][i] + __shfl_xor(acc[hh][i], 1);
+        if (hf == 0) out0[hh * D + 32 * i + (lane >> 1)] = (h16)a;
       }
     }
   }
@@ -463,6 +730,7 @@ struct Variant {
   const char* name;
   int D, BS, HPW, WPH, U;
   bool NT;
+  int HPT;  // heads per wave (1 except for the multi-head kernel)
   pa_kernel_t fn;
   int lds_attr_set;  // largest dynamic-LDS size already granted through hipFuncSetAttribute
 };

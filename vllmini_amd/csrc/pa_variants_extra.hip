@@ -7,10 +7,10 @@
 namespace vmi {
 
 #define VMI_X1(D, BS, WPH, U) \
-  {"d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, \
+  {"d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, 1, \
    (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, false, BS>, 0}
 #define VMI_X2(D, BS, WPH, U) \
-  {"v2_d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, \
+  {"v2_d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, 1, \
    (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, true, BS>, 0}
 
 Variant g_extra_variants_v1[] = {

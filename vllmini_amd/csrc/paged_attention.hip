@@ -159,12 +159,59 @@ __global__ void __launch_bounds__(256) stream_read_kernel(const u32x4* __restric
   if (x == 0x9e3779b9u) sink[0] = x;  // practically never: keeps the loads live
 }
 
+// diagnostic: read the buffer as pseudo-randomly ordered contiguous chunks of CHUNK_KB KiB, one
+// chunk stream per wave, 8 KiB in flight per wave (the attention kernel's pattern with the math
+// removed and the chunk size made a parameter).
+template <int CHUNK_KB, bool NT>
+__global__ void __launch_bounds__(256) gather_read_kernel(const u32x4* __restrict__ src, uint32_t nchunks,
+                                                          uint32_t stride, uint32_t* __restrict__ sink) {
+  constexpr int G = CHUNK_KB >= 8 ? 1 : 8 / CHUNK_KB;  // chunks per group -> 8 loads per group
+  constexpr int LPC = CHUNK_KB;                         // 1-KiB loads per chunk
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (uint32_t i = wave * G; i < nchunks; i += nwaves * G) {
+    u32x4 r[G][LPC > 8 ? 8 : LPC];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const uint32_t c = (uint32_t)(((uint64_t)(i + g) * stride) % nchunks);  // stride coprime with nchunks
+      const u32x4* base = src + (size_t)c * (CHUNK_KB * 64) + lane;
+#pragma unroll
+      for (int l = 0; l < (LPC > 8 ? 8 : LPC); ++l) {
+        if constexpr (NT) r[g][l] = __builtin_nontemporal_load(base + l * 64);
+        else r[g][l] = base[l * 64];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int l = 0; l < (LPC > 8 ? 8 : LPC); ++l) acc ^= r[g][l];
+    if constexpr (LPC > 8) {  // chunks above 8 KiB: remaining loads in 8-load batches
+      const uint32_t c = (uint32_t)(((uint64_t)i * stride) % nchunks);
+      const u32x4* base = src + (size_t)c * (CHUNK_KB * 64) + lane;
+      for (int l0 = 8; l0 < LPC; l0 += 8) {
+        u32x4 q[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+          if constexpr (NT) q[l] = __builtin_nontemporal_load(base + (l0 + l) * 64);
+          else q[l] = base[(l0 + l) * 64];
+        }
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc ^= q[l];
+      }
+    }
+  }
+  const uint32_t x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+  if (x == 0x9e3779b9u) sink[0] = x;
+}
+
 // ----------------------------------------------------------------------------------------
 // host side: variant table, validation, launch
 // ----------------------------------------------------------------------------------------
 #define VMI_VARIANT(D, HPW, WPH, U, NT)                                          \
   {                                                                              \
-    "d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, 16, HPW, WPH, U, (bool)NT,  \
+    "d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, 16, HPW, WPH, U, (bool)NT, 1, \
         (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)NT>, 0                   \
   }
 
@@ -202,11 +249,50 @@ static Variant g_variants[] = {
     VMI_VARIANT(64, 1, 16, 1, 1),   // 26
     VMI_VARIANT(128, 1, 8, 2, 1),   // 27
     VMI_VARIANT(128, 1, 16, 1, 1),  // 28
+    // ---- shallower page groups (fewer bytes in flight per CU turned out faster on cfg3) ----
+    VMI_VARIANT(64, 4, 1, 2, 1), VMI_VARIANT(64, 4, 1, 1, 1), VMI_VARIANT(64, 6, 1, 2, 1), VMI_VARIANT(64, 6, 1, 1, 1),
+    VMI_VARIANT(64, 12, 1, 2, 1), VMI_VARIANT(64, 12, 1, 1, 1), VMI_VARIANT(64, 1, 1, 2, 1), VMI_VARIANT(64, 1, 1, 1, 1),
+    VMI_VARIANT(64, 2, 1, 2, 1), VMI_VARIANT(64, 3, 1, 2, 1), VMI_VARIANT(128, 4, 1, 1, 1), VMI_VARIANT(128, 8, 1, 1, 1),
+    VMI_VARIANT(128, 16, 1, 1, 1), VMI_VARIANT(128, 1, 1, 1, 1), VMI_VARIANT(128, 2, 1, 1, 1),
+    VMI_VARIANT(64, 1, 2, 1, 1), VMI_VARIANT(64, 1, 2, 2, 1), VMI_VARIANT(64, 1, 4, 1, 1), VMI_VARIANT(64, 1, 4, 2, 1),
+    VMI_VARIANT(64, 1, 8, 1, 1), VMI_VARIANT(128, 1, 2, 1, 1), VMI_VARIANT(128, 1, 4, 1, 1), VMI_VARIANT(128, 1, 8, 1, 1),
+    // ---- lockstep workgroups: adjacent heads issue their page loads together (bigger HBM bursts) ----
+#define VMI_LOCK(D, HPW, U) {"d" #D "_h" #HPW "_w1_u" #U "_nt1_lock", D, 16, HPW, 1, U, true, 1, \
+     (pa_kernel_t)pa_v1_kernel<D, HPW, 1, U, true, false, false, 16, true>, 0}
+    VMI_LOCK(64, 4, 4), VMI_LOCK(64, 4, 2), VMI_LOCK(64, 2, 4), VMI_LOCK(64, 6, 2), VMI_LOCK(64, 12, 2),
+    VMI_LOCK(64, 12, 1), VMI_LOCK(64, 6, 4), VMI_LOCK(128, 4, 2), VMI_LOCK(128, 8, 1), VMI_LOCK(128, 4, 1),
+    VMI_LOCK(64, 3, 2), VMI_LOCK(64, 3, 4), VMI_LOCK(64, 6, 1), VMI_LOCK(64, 4, 1), VMI_LOCK(64, 12, 4),
+    VMI_LOCK(128, 2, 2), VMI_LOCK(128, 8, 2), VMI_LOCK(128, 2, 1), VMI_LOCK(128, 16, 1),
+#define VMI_LOCK3(D, HPW, U) {"d" #D "_h" #HPW "_w1_u" #U "_nt1_lock_p3", D, 16, HPW, 1, U, true, 1, \
+     (pa_kernel_t)pa_v1_kernel<D, HPW, 1, U, true, false, false, 16, true, 3>, 0}
+    VMI_LOCK3(64, 6, 2), VMI_LOCK3(64, 6, 1), VMI_LOCK3(64, 4, 1), VMI_LOCK3(64, 4, 2), VMI_LOCK3(64, 12, 2),
+    VMI_LOCK3(64, 12, 1), VMI_LOCK3(64, 6, 4), VMI_LOCK3(128, 16, 1), VMI_LOCK3(128, 8, 1), VMI_LOCK3(128, 8, 2),
+    VMI_LOCK3(128, 16, 2),
+#undef VMI_LOCK3
+#undef VMI_LOCK
+    // ---- multi-head waves: one wave reads HPT adjacent heads' tiles as one contiguous chunk ----
+#define VMI_MH(D, HPW, HPT, U, LOCK, SUF) {"d" #D "_mh" #HPT "_h" #HPW "_u" #U "_nt1" SUF, D, 16, HPW, 1, U, true, HPT, \
+     (pa_kernel_t)pa_v1_mh_kernel<D, HPW, HPT, U, true, LOCK>, 0}
+    VMI_MH(64, 1, 2, 2, false, ""), VMI_MH(64, 1, 2, 4, false, ""), VMI_MH(64, 1, 4, 1, false, ""),
+    VMI_MH(64, 1, 4, 2, false, ""), VMI_MH(64, 2, 2, 2, false, ""), VMI_MH(64, 3, 2, 2, true, "_lock"),
+    VMI_MH(64, 6, 2, 2, true, "_lock"), VMI_MH(64, 6, 2, 1, true, "_lock"), VMI_MH(64, 3, 4, 1, true, "_lock"),
+    VMI_MH(64, 3, 4, 2, true, "_lock"), VMI_MH(64, 3, 2, 4, true, "_lock"), VMI_MH(64, 2, 2, 2, true, "_lock"),
+    VMI_MH(128, 1, 2, 1, false, ""), VMI_MH(128, 1, 2, 2, false, ""), VMI_MH(128, 4, 2, 1, true, "_lock"),
+    VMI_MH(128, 8, 2, 1, true, "_lock"), VMI_MH(128, 4, 4, 1, true, "_lock"),
+#undef VMI_MH
     // ---- diagnostics: same gather pattern, no math ("loads only"); wrong results by design ----
-    {"d64_h4_w1_u4_nt1_LOADSONLY", 64, 16, 4, 1, 4, true,
+    {"d64_h4_w1_u4_nt1_LOADSONLY", 64, 16, 4, 1, 4, true, 1,
      (pa_kernel_t)pa_v1_kernel<64, 4, 1, 4, true, true>, 0},   // 29
-    {"d64_h1_w1_u4_nt1_LOADSONLY", 64, 16, 1, 1, 4, true,
+    {"d64_h1_w1_u4_nt1_LOADSONLY", 64, 16, 1, 1, 4, true, 1,
      (pa_kernel_t)pa_v1_kernel<64, 1, 1, 4, true, true>, 0},   // 30
+    {"d64_h6_w1_u2_nt1_lock_LOADSONLY", 64, 16, 6, 1, 2, true, 1,
+     (pa_kernel_t)pa_v1_kernel<64, 6, 1, 2, true, true, false, 16, true>, 0},
+    {"d64_h6_w1_u4_nt1_lock_LOADSONLY", 64, 16, 6, 1, 4, true, 1,
+     (pa_kernel_t)pa_v1_kernel<64, 6, 1, 4, true, true, false, 16, true>, 0},
+    {"d64_h12_w1_u2_nt1_lock_LOADSONLY", 64, 16, 12, 1, 2, true, 1,
+     (pa_kernel_t)pa_v1_kernel<64, 12, 1, 2, true, true, false, 16, true>, 0},
+    {"d64_h6_w1_u2_nt1_LOADSONLY", 64, 16, 6, 1, 2, true, 1,
+     (pa_kernel_t)pa_v1_kernel<64, 6, 1, 2, true, true, false, 16, false>, 0},
 };
 static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
@@ -216,12 +302,13 @@ static Variant& variant_v1(int id) {  // 1-based
 }
 
 static bool is_diag(const Variant& v) { return strstr(v.name, "LOADSONLY") != nullptr; }
+static bool is_lock(const Variant& v) { return strstr(v.name, "_lock") != nullptr || v.HPT > 1; }
 
 static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = any */) {
   for (int id = 1; id <= nvariants_v1(); ++id) {
     const Variant& v = variant_v1(id);
     if (v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
-        (NT < 0 || v.NT == (bool)NT) && !is_diag(v))
+        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v))
       return id;
   }
   return 0;
@@ -232,22 +319,37 @@ static bool head_size_supported(int d) {  // the reference's switch, attention_k
 }
 static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }  // :789-803
 
-// Heuristic: with >= ~2 waves per SIMD worth of (seq, head) units one wave per head keeps
-// every CU streaming with no barriers; below that, deal each head's blocks to more waves.
-// Non-temporal page loads pay once the KV working set no longer fits the 256 MiB Infinity
-// Cache (cfg3 146 -> 133 us, "long" 195 -> 186 us) and are neutral below it.
+// Heuristic (measured on MI355X, profiles/r01c_*):
+//  * waves: one wave per (seq, head) once that gives >= 3072 waves (12 per CU); otherwise deal each
+//    head's blocks to 2..16 waves so the launch still has ~3072 waves;
+//  * queue depth: what matters is BYTES IN FLIGHT PER CU, and more is not better — deeper register
+//    rings congest the memory path (cfg3: U=4 133 us, U=2 127 us, U=1 124 us at 12 waves/CU) while too
+//    few bytes leave the launch latency-bound (U=1 at 6 waves/CU: 90 us vs 63 us).  U is the smallest
+//    of {1,2,4} that keeps >= 24 KiB in flight per CU;
+//  * non-temporal page loads once the KV working set exceeds the 256 MiB Infinity Cache;
+//  * D = 128 with a full chip: multi-head waves in lockstep give HBM 16-64 KiB bursts (cfg4 660 -> 616 us).
 static int pick_variant(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
-  while (wph < 16 && units * wph < 2048 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  while (wph < 16 && units * wph < 3072 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   const double kv_bytes = 4.0 * (double)units * (double)max_seq_len * head_size;
   const int nt = kv_bytes > 128e6 ? 1 : 0;
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {  // core table: full menu
+    const double waves_per_cu = (double)units * wph / 256.0;
+    const double tile_kib = head_size * 16 * 2 / 1024.0;
+    int u = 1;
+    while (u < 4 && waves_per_cu * u * tile_kib < 24.0) u *= 2;
+    if (wph == 1 && head_size == 128 && nt && num_heads % 16 == 0 && waves_per_cu >= 12.0) {
+      for (int id = 1; id <= nvariants_v1(); ++id) {  // d128_mh4_h4_u1_nt1_lock
+        const Variant& c = variant_v1(id);
+        if (c.D == 128 && c.HPT == 4 && c.HPW == 4 && c.U == 1) return id;
+      }
+    }
     const int hpw = (wph == 1 && num_heads % 4 == 0) ? 4 : 1;
-    const int u = (head_size == 64) ? (wph <= 4 ? 4 : (wph == 8 ? 2 : 1)) : (wph <= 8 ? 2 : 1);
     int v = find_variant(head_size, 16, hpw, wph, u, nt);
     if (!v) v = find_variant(head_size, 16, hpw, wph, u, -1);
+    for (int uu = 1; uu <= 8 && !v; uu *= 2) v = find_variant(head_size, 16, hpw, wph, uu, -1);
     if (!v) v = find_variant(head_size, 16, 1, 1, -1, 1);
     return v;
   }
@@ -299,7 +401,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                 v.HPW);
 
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
-  const size_t lds = (size_t)v.HPW * lpad * 4 + (size_t)v.HPW * 2 * v.WPH * 4 +
+  const size_t lds = (size_t)v.HPW * v.HPT * lpad * 4 + (size_t)v.HPW * 2 * v.WPH * 4 +
                      (size_t)v.HPW * v.WPH * v.D * 4;
   if (lds > 160 * 1024)
     return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v1: max_seq_len=%d needs %zu B of LDS per "
@@ -343,7 +445,8 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     ps.q = p.q + (int64_t)s0 * q_stride;
     ps.block_tables = p.block_tables + (int64_t)s0 * max_num_blocks_per_seq;
     ps.seq_lens = p.seq_lens + s0;
-    dim3 grid((num_heads + v.HPW - 1) / v.HPW, ns, 1);
+    const int hpg = v.HPW * v.HPT;  // heads per workgroup
+    dim3 grid((num_heads + hpg - 1) / hpg, ns, 1);
     hipLaunchKernelGGL(v.fn, grid, block, lds, static_cast<hipStream_t>(stream), ps);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 launch");
@@ -354,7 +457,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
 // ---- split-KV (paged_attention_v2) variants: same kernel body, PART = true -----------------
 #define VMI_VARIANT_V2(D, HPW, WPH, U, NT)                                          \
   {                                                                                 \
-    "v2_d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, 16, HPW, WPH, U, (bool)NT,  \
+    "v2_d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, 16, HPW, WPH, U, (bool)NT, 1, \
         (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)NT, false, true>, 0         \
   }
 static Variant g_variants_v2[] = {
@@ -675,6 +778,35 @@ int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blo
                        static_cast<const u32x4*>(src), n16, static_cast<uint32_t*>(sink));
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "diag_stream_read launch");
+  return VMI_OK;
+}
+
+int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chunk_kb, int32_t blocks,
+                         int32_t nt, int32_t device, void* stream) {
+  using namespace vmi;
+  if (!src || !sink || bytes < 65536 || blocks <= 0) return fail(VMI_E_SHAPE, "diag_gather_read: bad args");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  const uint32_t nchunks = (uint32_t)(bytes / ((int64_t)chunk_kb * 1024));
+  uint32_t stride = 2654435761u % nchunks;  // Knuth multiplicative hash, made coprime below
+  if (stride < 2) stride = 7;
+  auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
+  while (gcd(stride, nchunks) != 1) ++stride;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const u32x4* p = static_cast<const u32x4*>(src);
+  uint32_t* sk = static_cast<uint32_t*>(sink);
+#define VMI_GR(KB)                                                                                   \
+  case KB:                                                                                           \
+    if (nt) hipLaunchKernelGGL((gather_read_kernel<KB, true>), dim3(blocks), dim3(256), 0, st, p, nchunks, stride, sk); \
+    else hipLaunchKernelGGL((gather_read_kernel<KB, false>), dim3(blocks), dim3(256), 0, st, p, nchunks, stride, sk);   \
+    break;
+  switch (chunk_kb) {
+    VMI_GR(1) VMI_GR(2) VMI_GR(4) VMI_GR(8) VMI_GR(16) VMI_GR(32) VMI_GR(64)
+    default: return fail(VMI_E_SHAPE, "diag_gather_read: chunk_kb must be 1,2,4,8,16,32,64");
+  }
+#undef VMI_GR
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "diag_gather_read launch");
   return VMI_OK;
 }
 
