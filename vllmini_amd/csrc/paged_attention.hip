@@ -72,19 +72,39 @@ __global__ void __launch_bounds__(256)
                              const int64_t* __restrict__ slot_mapping, int64_t key_stride,
                              int64_t value_stride, int H, int D, int BS) {
   const int64_t token = blockIdx.x;
+  const int n8 = (H * D) >> 3;
+  const h16* ksrc = key + token * key_stride;
+  const h16* vsrc = value + token * value_stride;
+  // The row loads do not depend on the slot: the first chunk of every lane is requested BEFORE the
+  // slot lookup is consumed, so the two memory round trips overlap (rows of skipped tokens are valid
+  // memory too; they are simply not stored).
+  h16x8 kv0, vv0;
+  const int c0 = threadIdx.x;
+  if (c0 < n8) {
+    if constexpr (VEC) {
+      kv0 = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(ksrc + (c0 << 3)));
+      vv0 = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(vsrc + (c0 << 3)));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        kv0[e] = ksrc[(c0 << 3) + e];
+        vv0[e] = vsrc[(c0 << 3) + e];
+      }
+    }
+  }
   const int64_t slot = slot_mapping[token];
   if (slot < 0) return;  // padding token (ref cache_kernels.cu:165-169)
   const int64_t blk = slot / BS;
   const int64_t off = slot % BS;
-  const int n8 = (H * D) >> 3;
-  const h16* ksrc = key + token * key_stride;
-  const h16* vsrc = value + token * value_stride;
-  for (int c = threadIdx.x; c < n8; c += blockDim.x) {
+  for (int c = c0; c < n8; c += blockDim.x) {
     const int i = c << 3;
     const int h = i / D;
     const int d = i - h * D;
     h16x8 kv, vv;
-    if constexpr (VEC) {
+    if (c == c0) {
+      kv = kv0;
+      vv = vv0;
+    } else if constexpr (VEC) {
       kv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(ksrc + i));
       vv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(vsrc + i));
     } else {
