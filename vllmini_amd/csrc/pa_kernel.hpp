@@ -86,7 +86,7 @@ struct PAParams {
 //   V tile = D rows x BS/8 units of 16 B;   a load covers 512/BS rows;  lane = row*(BS/8) + unit
 // When D*BS/8 is not a multiple of 64 (head 80/112, ...) the last load of a tile is predicated.
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
-          bool LOCK = false, int DEPTH = 2>
+          bool LOCK = false>
 __global__ void __launch_bounds__(HPW* WPH * 64)
     pa_v1_kernel(const PAParams p) {
   constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
@@ -244,12 +244,10 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     }
   };
 
-  // Register pipeline over page groups: DEPTH buffers rotate statically; DEPTH-1 groups are in
-  // flight while one is consumed (DEPTH = 2: classic double buffer; 3: one more group of queue depth
-  // for the lockstep variants, whose groups are small).
-  static_assert(DEPTH == 2 || DEPTH == 3, "pipeline depth 2 or 3");
-  u32x4 ra[U][NL], rb[U][NL], rc[DEPTH == 3 ? U : 1][NL];
-  if constexpr (DEPTH == 2) {
+  // Register double buffer over page groups: group g+1 is in flight while group g is consumed.
+  // (A third stage was measured and changed nothing; profiles/r01c_cfg3_variant_sweep.json.)
+  u32x4 ra[U][NL], rb[U][NL];
+  {
     if (ngroups > 0) load_group(ra, kbase, 0);
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
@@ -259,27 +257,10 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       compute_k(rb, g + 1);
     }
     if (g < ngroups) compute_k(ra, g);
-  } else {
-    if (ngroups > 0) load_group(ra, kbase, 0);
-    if (ngroups > 1) load_group(rb, kbase, 1);
-    int g = 0;
-    for (; g + 3 <= ngroups; g += 3) {
-      load_group(rc, kbase, g + 2);
-      compute_k(ra, g);
-      if (g + 3 < ngroups) load_group(ra, kbase, g + 3);
-      compute_k(rb, g + 1);
-      if (g + 4 < ngroups) load_group(rb, kbase, g + 4);
-      compute_k(rc, g + 2);
-    }
-    if (g < ngroups) compute_k(ra, g);
-    if (g + 1 < ngroups) compute_k(rb, g + 1);
   }
 
-  // first V group(s) go out now: HBM stays busy while the softmax runs
+  // first V group goes out now: HBM stays busy while the softmax runs
   if (ngroups > 0) load_group(ra, vbase, 0);
-  if constexpr (DEPTH == 3) {
-    if (ngroups > 1) load_group(rb, vbase, 1);
-  }
 
   // =========================== softmax over the logits in LDS ============================
   qk_max = wave_max(qk_max);
@@ -367,7 +348,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     }
   };
 
-  if constexpr (DEPTH == 2) {
+  {
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
       load_group(rb, vbase, g + 1);
@@ -376,18 +357,6 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       compute_v(rb, g + 1);
     }
     if (g < ngroups) compute_v(ra, g);
-  } else {
-    int g = 0;
-    for (; g + 3 <= ngroups; g += 3) {
-      load_group(rc, vbase, g + 2);
-      compute_v(ra, g);
-      if (g + 3 < ngroups) load_group(ra, vbase, g + 3);
-      compute_v(rb, g + 1);
-      if (g + 4 < ngroups) load_group(rb, vbase, g + 4);
-      compute_v(rc, g + 2);
-    }
-    if (g < ngroups) compute_v(ra, g);
-    if (g + 1 < ngroups) compute_v(rb, g + 1);
   }
 
   if constexpr (LOADS_ONLY) {

@@ -237,82 +237,50 @@ __global__ void __launch_bounds__(256) gather_read_kernel(const u32x4* __restric
 
 // Core table: block size 16, head sizes 64 / 128 (what the reference's callers use).  Ids are
 // 1-based positions in [core..., extra...]; names are what profiles/ and tests refer to.
+// The menu is what survived this round's sweeps (profiles/r01*_variant_sweep*.json hold the
+// measurements of everything that was tried, including variants since removed: 3-deep register
+// pipelines, lockstep / multi-head waves at D = 64, 6- and 12-head workgroups).
 static Variant g_variants[] = {
-    // ---- head size 64 ----
-    VMI_VARIANT(64, 1, 1, 4, 0),   // 1
-    VMI_VARIANT(64, 4, 1, 4, 0),   // 2
-    VMI_VARIANT(64, 1, 4, 4, 0),   // 3
-    VMI_VARIANT(64, 2, 2, 4, 0),   // 4
-    VMI_VARIANT(64, 4, 1, 8, 0),   // 5
-    VMI_VARIANT(64, 4, 1, 2, 0),   // 6
-    VMI_VARIANT(64, 1, 1, 4, 1),   // 7
-    VMI_VARIANT(64, 4, 1, 4, 1),   // 8
-    VMI_VARIANT(64, 1, 4, 4, 1),   // 9
-    VMI_VARIANT(64, 1, 8, 2, 0),   // 10
-    VMI_VARIANT(64, 1, 16, 1, 0),  // 11
-    VMI_VARIANT(64, 4, 1, 8, 1),   // 12
-    VMI_VARIANT(64, 2, 1, 4, 1),   // 13
-    VMI_VARIANT(64, 1, 2, 4, 1),   // 14
+    // ---- head size 64: one wave per (seq, head); U = blocks in flight per wave ----
+    VMI_VARIANT(64, 4, 1, 1, 1),   // full chip (>= 12 waves/CU): the cfg3 kernel
+    VMI_VARIANT(64, 1, 1, 1, 1),   // same, num_heads not a multiple of 4
+    VMI_VARIANT(64, 4, 1, 2, 1),
+    VMI_VARIANT(64, 1, 1, 2, 1),
+    VMI_VARIANT(64, 4, 1, 4, 1),   // the first kernel of round 1 (reference point, 133 us at cfg3)
+    VMI_VARIANT(64, 1, 1, 4, 1),
+    VMI_VARIANT(64, 4, 1, 4, 0),   // temporal loads: KV working set inside the Infinity Cache
+    VMI_VARIANT(64, 1, 1, 4, 0),
+    // ---- head size 64: 2..16 waves per head (small batches), nt and temporal ----
+    VMI_VARIANT(64, 1, 2, 1, 1), VMI_VARIANT(64, 1, 2, 2, 1), VMI_VARIANT(64, 1, 2, 4, 1),
+    VMI_VARIANT(64, 1, 4, 1, 1), VMI_VARIANT(64, 1, 4, 2, 1), VMI_VARIANT(64, 1, 4, 4, 1),
+    VMI_VARIANT(64, 1, 8, 1, 1), VMI_VARIANT(64, 1, 8, 2, 1), VMI_VARIANT(64, 1, 16, 1, 1),
+    VMI_VARIANT(64, 1, 4, 4, 0), VMI_VARIANT(64, 1, 8, 2, 0), VMI_VARIANT(64, 1, 16, 1, 0),
+    VMI_VARIANT(64, 2, 2, 4, 0),   // two heads x two waves: exercises HPW > 1 with WPH > 1
     // ---- head size 128 ----
-    VMI_VARIANT(128, 1, 1, 2, 0),  // 15
-    VMI_VARIANT(128, 4, 1, 2, 0),  // 16
-    VMI_VARIANT(128, 1, 4, 2, 0),  // 17
-    VMI_VARIANT(128, 4, 1, 4, 0),  // 18
-    VMI_VARIANT(128, 1, 1, 2, 1),  // 19
-    VMI_VARIANT(128, 4, 1, 2, 1),  // 20
-    VMI_VARIANT(128, 1, 4, 2, 1),  // 21
-    VMI_VARIANT(128, 1, 8, 2, 0),  // 22
-    VMI_VARIANT(128, 1, 16, 1, 0), // 23
-    VMI_VARIANT(128, 4, 1, 4, 1),  // 24
-    // ---- many waves per head, non-temporal (appended: earlier ids stay stable) ----
-    VMI_VARIANT(64, 1, 8, 2, 1),    // 25
-    VMI_VARIANT(64, 1, 16, 1, 1),   // 26
-    VMI_VARIANT(128, 1, 8, 2, 1),   // 27
-    VMI_VARIANT(128, 1, 16, 1, 1),  // 28
-    // ---- shallower page groups (fewer bytes in flight per CU turned out faster on cfg3) ----
-    VMI_VARIANT(64, 4, 1, 2, 1), VMI_VARIANT(64, 4, 1, 1, 1), VMI_VARIANT(64, 6, 1, 2, 1), VMI_VARIANT(64, 6, 1, 1, 1),
-    VMI_VARIANT(64, 12, 1, 2, 1), VMI_VARIANT(64, 12, 1, 1, 1), VMI_VARIANT(64, 1, 1, 2, 1), VMI_VARIANT(64, 1, 1, 1, 1),
-    VMI_VARIANT(64, 2, 1, 2, 1), VMI_VARIANT(64, 3, 1, 2, 1), VMI_VARIANT(128, 4, 1, 1, 1), VMI_VARIANT(128, 8, 1, 1, 1),
-    VMI_VARIANT(128, 16, 1, 1, 1), VMI_VARIANT(128, 1, 1, 1, 1), VMI_VARIANT(128, 2, 1, 1, 1),
-    VMI_VARIANT(64, 1, 2, 1, 1), VMI_VARIANT(64, 1, 2, 2, 1), VMI_VARIANT(64, 1, 4, 1, 1), VMI_VARIANT(64, 1, 4, 2, 1),
-    VMI_VARIANT(64, 1, 8, 1, 1), VMI_VARIANT(128, 1, 2, 1, 1), VMI_VARIANT(128, 1, 4, 1, 1), VMI_VARIANT(128, 1, 8, 1, 1),
-    // ---- lockstep workgroups: adjacent heads issue their page loads together (bigger HBM bursts) ----
+    VMI_VARIANT(128, 4, 1, 1, 1), VMI_VARIANT(128, 1, 1, 1, 1), VMI_VARIANT(128, 4, 1, 2, 1),
+    VMI_VARIANT(128, 1, 1, 2, 1), VMI_VARIANT(128, 4, 1, 2, 0), VMI_VARIANT(128, 1, 1, 2, 0),
+    VMI_VARIANT(128, 1, 2, 1, 1), VMI_VARIANT(128, 1, 4, 1, 1), VMI_VARIANT(128, 1, 4, 2, 1),
+    VMI_VARIANT(128, 1, 8, 1, 1), VMI_VARIANT(128, 1, 8, 2, 1), VMI_VARIANT(128, 1, 16, 1, 1),
+    VMI_VARIANT(128, 1, 4, 2, 0), VMI_VARIANT(128, 1, 8, 2, 0), VMI_VARIANT(128, 1, 16, 1, 0),
+    // ---- head size 128, full chip: adjacent heads read together (HBM sees 16-64 KiB bursts) ----
 #define VMI_LOCK(D, HPW, U) {"d" #D "_h" #HPW "_w1_u" #U "_nt1_lock", D, 16, HPW, 1, U, true, 1, \
      (pa_kernel_t)pa_v1_kernel<D, HPW, 1, U, true, false, false, 16, true>, 0}
-    VMI_LOCK(64, 4, 4), VMI_LOCK(64, 4, 2), VMI_LOCK(64, 2, 4), VMI_LOCK(64, 6, 2), VMI_LOCK(64, 12, 2),
-    VMI_LOCK(64, 12, 1), VMI_LOCK(64, 6, 4), VMI_LOCK(128, 4, 2), VMI_LOCK(128, 8, 1), VMI_LOCK(128, 4, 1),
-    VMI_LOCK(64, 3, 2), VMI_LOCK(64, 3, 4), VMI_LOCK(64, 6, 1), VMI_LOCK(64, 4, 1), VMI_LOCK(64, 12, 4),
-    VMI_LOCK(128, 2, 2), VMI_LOCK(128, 8, 2), VMI_LOCK(128, 2, 1), VMI_LOCK(128, 16, 1),
-#define VMI_LOCK3(D, HPW, U) {"d" #D "_h" #HPW "_w1_u" #U "_nt1_lock_p3", D, 16, HPW, 1, U, true, 1, \
-     (pa_kernel_t)pa_v1_kernel<D, HPW, 1, U, true, false, false, 16, true, 3>, 0}
-    VMI_LOCK3(64, 6, 2), VMI_LOCK3(64, 6, 1), VMI_LOCK3(64, 4, 1), VMI_LOCK3(64, 4, 2), VMI_LOCK3(64, 12, 2),
-    VMI_LOCK3(64, 12, 1), VMI_LOCK3(64, 6, 4), VMI_LOCK3(128, 16, 1), VMI_LOCK3(128, 8, 1), VMI_LOCK3(128, 8, 2),
-    VMI_LOCK3(128, 16, 2),
-#undef VMI_LOCK3
-#undef VMI_LOCK
-    // ---- multi-head waves: one wave reads HPT adjacent heads' tiles as one contiguous chunk ----
 #define VMI_MH(D, HPW, HPT, U, LOCK, SUF) {"d" #D "_mh" #HPT "_h" #HPW "_u" #U "_nt1" SUF, D, 16, HPW, 1, U, true, HPT, \
      (pa_kernel_t)pa_v1_mh_kernel<D, HPW, HPT, U, true, LOCK>, 0}
-    VMI_MH(64, 1, 2, 2, false, ""), VMI_MH(64, 1, 2, 4, false, ""), VMI_MH(64, 1, 4, 1, false, ""),
-    VMI_MH(64, 1, 4, 2, false, ""), VMI_MH(64, 2, 2, 2, false, ""), VMI_MH(64, 3, 2, 2, true, "_lock"),
-    VMI_MH(64, 6, 2, 2, true, "_lock"), VMI_MH(64, 6, 2, 1, true, "_lock"), VMI_MH(64, 3, 4, 1, true, "_lock"),
-    VMI_MH(64, 3, 4, 2, true, "_lock"), VMI_MH(64, 3, 2, 4, true, "_lock"), VMI_MH(64, 2, 2, 2, true, "_lock"),
-    VMI_MH(128, 1, 2, 1, false, ""), VMI_MH(128, 1, 2, 2, false, ""), VMI_MH(128, 4, 2, 1, true, "_lock"),
-    VMI_MH(128, 8, 2, 1, true, "_lock"), VMI_MH(128, 4, 4, 1, true, "_lock"),
+    VMI_LOCK(128, 8, 1), VMI_LOCK(128, 16, 1),
+    VMI_MH(128, 4, 4, 1, true, "_lock"),    // the cfg4 kernel (16 | num_heads)
+    VMI_MH(128, 8, 2, 1, true, "_lock"),
+    VMI_MH(128, 1, 2, 1, false, ""),
+    VMI_MH(64, 1, 2, 2, false, ""),         // D = 64 reference points (neutral there)
+    VMI_MH(64, 3, 2, 2, true, "_lock"),
+    VMI_LOCK(64, 6, 2),
 #undef VMI_MH
+#undef VMI_LOCK
     // ---- diagnostics: same gather pattern, no math ("loads only"); wrong results by design ----
     {"d64_h4_w1_u4_nt1_LOADSONLY", 64, 16, 4, 1, 4, true, 1,
-     (pa_kernel_t)pa_v1_kernel<64, 4, 1, 4, true, true>, 0},   // 29
-    {"d64_h1_w1_u4_nt1_LOADSONLY", 64, 16, 1, 1, 4, true, 1,
-     (pa_kernel_t)pa_v1_kernel<64, 1, 1, 4, true, true>, 0},   // 30
-    {"d64_h6_w1_u2_nt1_lock_LOADSONLY", 64, 16, 6, 1, 2, true, 1,
-     (pa_kernel_t)pa_v1_kernel<64, 6, 1, 2, true, true, false, 16, true>, 0},
-    {"d64_h6_w1_u4_nt1_lock_LOADSONLY", 64, 16, 6, 1, 4, true, 1,
-     (pa_kernel_t)pa_v1_kernel<64, 6, 1, 4, true, true, false, 16, true>, 0},
-    {"d64_h12_w1_u2_nt1_lock_LOADSONLY", 64, 16, 12, 1, 2, true, 1,
-     (pa_kernel_t)pa_v1_kernel<64, 12, 1, 2, true, true, false, 16, true>, 0},
-    {"d64_h6_w1_u2_nt1_LOADSONLY", 64, 16, 6, 1, 2, true, 1,
-     (pa_kernel_t)pa_v1_kernel<64, 6, 1, 2, true, true, false, 16, false>, 0},
+     (pa_kernel_t)pa_v1_kernel<64, 4, 1, 4, true, true>, 0},
+    {"d64_h4_w1_u1_nt1_LOADSONLY", 64, 16, 4, 1, 1, true, 1,
+     (pa_kernel_t)pa_v1_kernel<64, 4, 1, 1, true, true>, 0},
 };
 static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
@@ -367,9 +335,12 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
       }
     }
     const int hpw = (wph == 1 && num_heads % 4 == 0) ? 4 : 1;
-    int v = find_variant(head_size, 16, hpw, wph, u, nt);
-    if (!v) v = find_variant(head_size, 16, hpw, wph, u, -1);
-    for (int uu = 1; uu <= 8 && !v; uu *= 2) v = find_variant(head_size, 16, hpw, wph, uu, -1);
+    int v = 0;
+    for (int uu = u; uu >= 1 && !v; uu /= 2) {  // nearest available depth at or below the target
+      v = find_variant(head_size, 16, hpw, wph, uu, nt);
+      if (!v) v = find_variant(head_size, 16, hpw, wph, uu, -1);
+    }
+    for (int uu = u * 2; uu <= 8 && !v; uu *= 2) v = find_variant(head_size, 16, hpw, wph, uu, -1);
     if (!v) v = find_variant(head_size, 16, 1, 1, -1, 1);
     return v;
   }
