@@ -253,6 +253,10 @@ def main():
     dist, rank, world, local_rank = init_dist(args.gpus)
     dev = torch.device("cuda", local_rank)
     cfg = CONFIGS[args.config]
+    if world > 1 and args.config == "cfg3":
+        # BASELINE.json configs[4]: batch 2048 over 8 GPUs = 256 sequences per GPU (the cfg3 shape) with a
+        # per-GPU KV pool of 65536 blocks.  Same kernel work per GPU as N=1; only the pool is larger.
+        cfg = CONFIGS["cfg5"]
     if args.batch or args.seq_len:
         import dataclasses
         b_ = args.batch or cfg.batch
