@@ -165,6 +165,16 @@ int vmi_reshape_and_cache_f16(
     int32_t device, void* stream);
 
 /*
+ * cache_ops.reshape_and_cache_flash — cache_kernels.cu:283-317 (kernel :209-240): scatter rows into the
+ * flash layout k_cache / v_cache [num_blocks, block_size, num_heads, head_size]; any 2-byte element type.
+ * block_stride = k_cache.stride(0) (must equal v_cache.stride(0), :302).
+ */
+int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_cache, void* v_cache,
+                                   const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
+                                   int32_t head_size, int32_t block_size, int64_t block_stride,
+                                   int64_t key_stride, int64_t value_stride, int32_t device, void* stream);
+
+/*
  * cache_ops.copy_blocks — cache_kernels.cu:96-148 (kernel :68-94).  For every layer l and pair p:
  * K_l[dst_p] = K_l[src_p], V_l[dst_p] = V_l[src_p].
  *   key_cache_ptrs / value_cache_ptrs   HOST arrays of num_layers DEVICE pointers (one cache per layer)

@@ -777,3 +777,31 @@ def test_reshape_and_cache_then_attend_other_layouts(D, bs):
     p /= p.sum(-1, keepdims=True)
     exact = np.einsum("hl,lhd->hd", p, val.astype(np.float64))
     assert np.abs(out.cpu().numpy()[0].astype(np.float64) - exact).max() <= 3e-3
+
+
+def test_reshape_and_cache_flash_bit_exact():
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(41)
+    for T, H, D, bs, strided in ((9, 12, 64, 16, True), (33, 4, 80, 32, False), (5, 3, 20, 8, False)):
+        NB = T // bs + 3
+        kc = rng.standard_normal((NB, bs, H, D)).astype(np.float16)
+        vc = rng.standard_normal((NB, bs, H, D)).astype(np.float16)
+        width = 3 * H * D if strided else H * D
+        buf = rng.standard_normal((2, T, width)).astype(np.float16)
+        key, val = buf[0][:, : H * D].reshape(T, H, D), buf[1][:, : H * D].reshape(T, H, D)
+        slots = rng.permutation(NB * bs)[:T].astype(np.int64)
+        slots[1] = -1
+        tb = torch.from_numpy(buf).to(dev)
+        tk, tv = tb[0][:, : H * D].view(T, H, D), tb[1][:, : H * D].view(T, H, D)
+        t_kc, t_vc = torch.from_numpy(kc).to(dev), torch.from_numpy(vc).to(dev)
+        ext.cache_ops.reshape_and_cache_flash(tk, tv, t_kc, t_vc, torch.from_numpy(slots).to(dev), "auto")
+        torch.cuda.synchronize()
+        for t in range(T):                                   # cache_kernels.cu:226-231 index math, in numpy
+            if slots[t] >= 0:
+                kc[slots[t] // bs, slots[t] % bs] = key[t]
+                vc[slots[t] // bs, slots[t] % bs] = val[t]
+        assert np.array_equal(t_kc.cpu().numpy().view(np.uint16), kc.view(np.uint16))
+        assert np.array_equal(t_vc.cpu().numpy().view(np.uint16), vc.view(np.uint16))
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
+        ext.cache_ops.reshape_and_cache_flash(tk, tv, t_kc, t_vc, torch.from_numpy(slots).to(dev), "fp8")

@@ -40,6 +40,8 @@ SIGNATURES = {
     "vmi_paged_attention_v2_f16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32]),
     "vmi_paged_attention_v2_variant_count": (ctypes.c_int, []),
     "vmi_paged_attention_v2_variant_name": (ctypes.c_char_p, [_i32]),
+    "vmi_reshape_and_cache_flash_16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                                      _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _c_void_p]),
     "vmi_copy_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _i32, _c_void_p, _i32, _i64, _i32, _c_void_p]),
     "vmi_swap_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i32, _i64, _i32, _i32, _c_void_p]),
     "vmi_diag_gather_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),

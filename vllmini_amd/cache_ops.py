@@ -3,7 +3,8 @@
   reshape_and_cache   the one op the reference's Python calls (vllmini/model/gpt2.py:81)   -> ops.py
   copy_blocks         cache_kernels.cu:96-148    multi-layer block copy (copy-on-write / forking)
   swap_blocks         cache_kernels.cu:24-63     block moves device<->device / device<->host (preemption)
-  reshape_and_cache_flash, convert_fp8           exported by the reference, no caller, not built
+  reshape_and_cache_flash  cache_kernels.cu:283-317  scatter into the flash layout [NB, block_size, H, D]
+  convert_fp8              exported by the reference, compiled to assert(false) there (ENABLE_FP8 undefined), not built
 """
 from __future__ import annotations
 
@@ -86,6 +87,40 @@ def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tenso
     return None
 
 
+def reshape_and_cache_flash(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                            slot_mapping: torch.Tensor, kv_cache_dtype: str) -> None:
+    """Scatter rows into flash-layout caches [num_blocks, block_size, num_heads, head_size].
+    Reference: cache_kernels.cu:283-317.  Pure copy; fp16 or bf16."""
+    if kv_cache_dtype != "auto":
+        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")          # :291-293
+    if key.dim() != 3 or key.shape != value.shape or key.dtype != value.dtype or key.element_size() != 2:
+        raise RuntimeError("key/value must be [num_tokens, num_heads, head_size] tensors of one 2-byte dtype")
+    dev = key.device
+    for name, t in (("key", key), ("value", value), ("k_cache", k_cache), ("v_cache", v_cache),
+                    ("slot_mapping", slot_mapping)):
+        _check_device(name, t, dev)
+    num_tokens, num_heads, head_size = (int(s) for s in key.shape)
+    if k_cache.dim() != 4 or tuple(k_cache.shape[2:]) != (num_heads, head_size) or k_cache.shape != v_cache.shape \
+            or k_cache.dtype != key.dtype or v_cache.dtype != key.dtype:
+        raise RuntimeError("k_cache/v_cache must be [num_blocks, block_size, num_heads, head_size] of key's dtype")
+    if k_cache.stride(0) != v_cache.stride(0):
+        raise RuntimeError("k_cache and v_cache must have the same block stride")           # :302
+    if not k_cache[0].is_contiguous() or not v_cache[0].is_contiguous():
+        raise RuntimeError("cache blocks must be dense")
+    if key.stride(2) != 1 or key.stride(1) != head_size or value.stride(2) != 1 or value.stride(1) != head_size:
+        raise RuntimeError("key/value must be contiguous in their last two dimensions")
+    if slot_mapping.dtype != torch.int64 or slot_mapping.numel() != num_tokens or not slot_mapping.is_contiguous():
+        raise RuntimeError("slot_mapping must be a contiguous int64 [num_tokens] tensor")
+    rc = _lib.load().vmi_reshape_and_cache_flash_16(
+        key.data_ptr(), value.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr(),
+        num_tokens, num_heads, head_size, int(k_cache.shape[1]), int(k_cache.stride(0)), int(key.stride(0)),
+        int(value.stride(0)), dev.index if dev.index is not None else torch.cuda.current_device(),
+        torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        _raise_native(rc)
+    return None
+
+
 def _not_built(name: str, where: str):
     def fn(*args, **kwargs):
         raise NotImplementedError(
@@ -95,5 +130,4 @@ def _not_built(name: str, where: str):
     return fn
 
 
-reshape_and_cache_flash = _not_built("reshape_and_cache_flash", "cache_kernels.cu:283-317")
 convert_fp8 = _not_built("convert_fp8", "cache_kernels.cu:335-392")

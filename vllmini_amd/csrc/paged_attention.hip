@@ -124,6 +124,37 @@ __global__ void __launch_bounds__(256)
 
 
 // ----------------------------------------------------------------------------------------
+// reshape_and_cache_flash: scatter new-token rows into the flash layout
+// [num_blocks, block_size, num_heads, head_size] — reference cache_kernels.cu:209-240 (kernel),
+// :283-317 (host).  A token's H*D row stays contiguous, so this is one 16-B copy per lane per chunk.
+// Works for any 2-byte element type (pure copy).
+// ----------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+    reshape_and_cache_flash_kernel(const h16* __restrict__ key, const h16* __restrict__ value,
+                                   h16* __restrict__ kc, h16* __restrict__ vc,
+                                   const int64_t* __restrict__ slot_mapping, int64_t block_stride,
+                                   int64_t key_stride, int64_t value_stride, int n, int BS) {
+  const int64_t token = blockIdx.x;
+  const int64_t slot = slot_mapping[token];
+  if (slot < 0) return;  // :218-221
+  const int64_t dst = (slot / BS) * block_stride + (slot % BS) * (int64_t)n;  // :226-228
+  const h16* ks = key + token * key_stride;
+  const h16* vs = value + token * value_stride;
+  if constexpr (VEC) {
+    for (int c = threadIdx.x; c < (n >> 3); c += blockDim.x) {
+      *reinterpret_cast<u32x4*>(kc + dst + (c << 3)) = *reinterpret_cast<const u32x4*>(ks + (c << 3));
+      *reinterpret_cast<u32x4*>(vc + dst + (c << 3)) = *reinterpret_cast<const u32x4*>(vs + (c << 3));
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      kc[dst + i] = ks[i];
+      vc[dst + i] = vs[i];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // copy_blocks: for every layer and every (src, dst) pair copy one K block and one V block
 // inside that layer's caches — reference cache_kernels.cu:68-94 (kernel), :96-148 (host).
 // The reference uploads two pointer tables with a blocking .to(device) (:119-126); here up to
@@ -671,6 +702,39 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
   }
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "reshape_and_cache launch");
+  return VMI_OK;
+}
+
+int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_cache, void* v_cache,
+                                   const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
+                                   int32_t head_size, int32_t block_size, int64_t block_stride,
+                                   int64_t key_stride, int64_t value_stride, int32_t device, void* stream) {
+  using namespace vmi;
+  if (!key || !value || !k_cache || !v_cache || !slot_mapping)
+    return fail(VMI_E_NULL_POINTER, "reshape_and_cache_flash: NULL tensor pointer");
+  if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || block_size <= 0)
+    return fail(VMI_E_SHAPE, "reshape_and_cache_flash: bad sizes");
+  if (num_tokens == 0) return VMI_OK;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  const int n = num_heads * head_size;
+  const bool vec = aligned16(key) && aligned16(value) && aligned16(k_cache) && aligned16(v_cache) &&
+                   !(key_stride & 7) && !(value_stride & 7) && !(block_stride & 7) && !(n & 7);
+  int threads = (((vec ? n >> 3 : n) + 63) / 64) * 64;
+  threads = threads > 256 ? 256 : threads;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec)
+    hipLaunchKernelGGL(reshape_and_cache_flash_kernel<true>, dim3(num_tokens), dim3(threads), 0, st,
+                       static_cast<const h16*>(key), static_cast<const h16*>(value), static_cast<h16*>(k_cache),
+                       static_cast<h16*>(v_cache), slot_mapping, block_stride, key_stride, value_stride, n,
+                       block_size);
+  else
+    hipLaunchKernelGGL(reshape_and_cache_flash_kernel<false>, dim3(num_tokens), dim3(threads), 0, st,
+                       static_cast<const h16*>(key), static_cast<const h16*>(value), static_cast<h16*>(k_cache),
+                       static_cast<h16*>(v_cache), slot_mapping, block_stride, key_stride, value_stride, n,
+                       block_size);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "reshape_and_cache_flash launch");
   return VMI_OK;
 }
 
