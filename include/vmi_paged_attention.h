@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 2
+#define VMI_ABI_VERSION 3
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -103,6 +103,32 @@ int vmi_paged_attention_v1_f16(
  */
 int vmi_paged_attention_v1_f16_variant(
     void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream, int32_t variant);
+
+/*
+ * bfloat16 forms of the two attention operators (the reference dispatches on the element type,
+ * quant_utils.cuh:529-566; arithmetic dtype_bfloat16.cuh).  Same arguments as the _f16 entries plus an
+ * explicit variant (0 = heuristic; bf16 variant names start with "bf16_").  query/out/caches hold bfloat16.
+ * reshape_and_cache / reshape_and_cache_flash / copy_blocks / swap_blocks are byte copies and serve both types.
+ */
+int vmi_paged_attention_v1_bf16(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream, int32_t variant);
+int vmi_paged_attention_v2_bf16(
+    void* out, void* exp_sums, void* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
     int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
     float scale,
     const int32_t* block_tables, const int32_t* seq_lens,

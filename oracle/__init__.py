@@ -14,7 +14,9 @@ kernel's own outputs (cannot be produced here), pinned against the reference's P
 path via tests/golden/.
 """
 from .kernel_model import (  # noqa: F401
+    bf16_bits_to_f32,
     build,
+    f32_to_bf16_bits,
     f2h,
     h2f,
     paged_attention_v1,

@@ -36,6 +36,15 @@ def _load() -> ctypes.CDLL:
         lib.vmi_oracle_paged_attention_v1_f16.restype = ctypes.c_int
         lib.vmi_oracle_paged_attention_v1_f16.argtypes = [
             vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, vp, i64, i64, i64, i32, i32]
+        lib.vmi_oracle_paged_attention_v1.restype = ctypes.c_int
+        lib.vmi_oracle_paged_attention_v1.argtypes = lib.vmi_oracle_paged_attention_v1_f16.argtypes + [i32]
+        lib.vmi_oracle_paged_attention_v2.restype = ctypes.c_int
+        lib.vmi_oracle_paged_attention_v2.argtypes = [
+            vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, i32, vp, i64, i64, i64, i32]
+        lib.vmi_oracle_f2b.restype = ctypes.c_uint16
+        lib.vmi_oracle_f2b.argtypes = [f32]
+        lib.vmi_oracle_b2f.restype = f32
+        lib.vmi_oracle_b2f.argtypes = [ctypes.c_uint16]
         lib.vmi_oracle_paged_attention_v2_f16.restype = ctypes.c_int
         lib.vmi_oracle_paged_attention_v2_f16.argtypes = [
             vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, i32, vp, i64, i64, i64]
@@ -72,13 +81,15 @@ def _base_ptr(a: np.ndarray) -> int:
 def paged_attention_v1(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
                        num_kv_heads: int, scale: float, block_tables: np.ndarray,
                        seq_lens: np.ndarray, block_size: int,
-                       alibi_slopes: np.ndarray | None = None, threads: int = 1) -> np.ndarray:
-    """Kernel-model output [num_seqs, num_heads, head_size] float16.
+                       alibi_slopes: np.ndarray | None = None, threads: int = 1, bf16: bool = False) -> np.ndarray:
+    """Kernel-model output [num_seqs, num_heads, head_size] float16 (uint16 bit patterns when bf16=True).
 
     `query` may be a strided view (row stride = query.strides[0]); caches are float16 arrays in
-    the reference layout; block_tables int32 [S, MB]; seq_lens int32 [S].
+    the reference layout (uint16 arrays holding bfloat16 bit patterns when bf16=True);
+    block_tables int32 [S, MB]; seq_lens int32 [S].
     """
-    assert query.dtype == np.float16 and key_cache.dtype == np.float16 and value_cache.dtype == np.float16
+    et = np.uint16 if bf16 else np.float16
+    assert query.dtype == et and key_cache.dtype == et and value_cache.dtype == et
     assert query.ndim == 3 and key_cache.ndim == 5 and value_cache.ndim == 4
     S, H, D = query.shape
     qs = _elem_strides(query)
@@ -89,18 +100,18 @@ def paged_attention_v1(query: np.ndarray, key_cache: np.ndarray, value_cache: np
     seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
     assert block_tables.shape[0] == S and seq_lens.shape[0] == S
     kb, kh = _elem_strides(key_cache)[:2]
-    out = np.zeros((S, H, D), dtype=np.float16)
+    out = np.zeros((S, H, D), dtype=et)
     alibi = None
     if alibi_slopes is not None:
         alibi = np.ascontiguousarray(alibi_slopes, dtype=np.float32)
     lib = _load()
 
     def run(lo: int, hi: int) -> int:
-        return lib.vmi_oracle_paged_attention_v1_f16(
+        return lib.vmi_oracle_paged_attention_v1(
             _base_ptr(out), _base_ptr(query), _base_ptr(key_cache), _base_ptr(value_cache),
             S, H, D, int(num_kv_heads), float(scale), _base_ptr(block_tables), _base_ptr(seq_lens),
             int(block_size), int(block_tables.shape[1]),
-            None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh), lo, hi)
+            None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh), lo, hi, 1 if bf16 else 0)
 
     threads = max(1, min(int(threads), S))
     if threads == 1:
@@ -119,11 +130,13 @@ def paged_attention_v1(query: np.ndarray, key_cache: np.ndarray, value_cache: np
 
 def paged_attention_v2(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
                        num_kv_heads: int, scale: float, block_tables: np.ndarray, seq_lens: np.ndarray,
-                       block_size: int, max_seq_len: int, alibi_slopes: np.ndarray | None = None):
+                       block_size: int, max_seq_len: int, alibi_slopes: np.ndarray | None = None,
+                       bf16: bool = False):
     """Kernel model of the split-KV operator (attention_kernels.cu:966-990): returns
     (out [S,H,D] f16, exp_sums [S,H,P] f32, max_logits [S,H,P] f32, tmp_out [S,H,P,D] f16) with
     P = ceil(max_seq_len / 512).  Partitions past a sequence's context keep their fill value (NaN)."""
-    assert query.dtype == np.float16 and query.ndim == 3
+    et = np.uint16 if bf16 else np.float16
+    assert query.dtype == et and query.ndim == 3
     S, H, D = query.shape
     qs = _elem_strides(query)
     assert qs[2] == 1 and qs[1] == D
@@ -133,16 +146,17 @@ def paged_attention_v2(query: np.ndarray, key_cache: np.ndarray, value_cache: np
     seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
     kb, kh = _elem_strides(key_cache)[:2]
     P = (int(max_seq_len) + 511) // 512
-    out = np.zeros((S, H, D), dtype=np.float16)
+    out = np.zeros((S, H, D), dtype=et)
     exp_sums = np.full((S, H, P), np.nan, dtype=np.float32)
     max_logits = np.full((S, H, P), np.nan, dtype=np.float32)
-    tmp_out = np.full((S, H, P, D), np.nan, dtype=np.float16)
+    tmp_out = np.full((S, H, P, D), 0x7FC0 if bf16 else np.nan, dtype=et)   # NaN fill in either encoding
     alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
-    rc = _load().vmi_oracle_paged_attention_v2_f16(
+    rc = _load().vmi_oracle_paged_attention_v2(
         _base_ptr(out), _base_ptr(exp_sums), _base_ptr(max_logits), _base_ptr(tmp_out), _base_ptr(query),
         _base_ptr(key_cache), _base_ptr(value_cache), S, H, D, int(num_kv_heads), float(scale),
         _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size), int(max_seq_len),
-        int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh))
+        int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
+        1 if bf16 else 0)
     if rc == 1:
         raise RuntimeError(f"Unsupported head size / block size: {D} / {block_size}")
     if rc != 0:
@@ -150,11 +164,22 @@ def paged_attention_v2(query: np.ndarray, key_cache: np.ndarray, value_cache: np
     return out, exp_sums, max_logits, tmp_out
 
 
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> bfloat16 bit patterns (uint16), round-to-nearest-even (numpy side of f2b)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    return r.reshape(np.shape(x))
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(np.shape(b))
+
+
 def reshape_and_cache(key: np.ndarray, value: np.ndarray, key_cache: np.ndarray,
                       value_cache: np.ndarray, slot_mapping: np.ndarray) -> None:
-    """In-place scatter into contiguous float16 caches (reference layout)."""
-    assert key.dtype == np.float16 and value.dtype == np.float16
-    assert key_cache.dtype == np.float16 and value_cache.dtype == np.float16
+    """In-place scatter into contiguous 2-byte-element caches (reference layout); float16, or uint16
+    arrays holding bfloat16 bit patterns (the op is a pure copy)."""
+    assert key.dtype == value.dtype == key_cache.dtype == value_cache.dtype and key.itemsize == 2
     assert key_cache.flags.c_contiguous and value_cache.flags.c_contiguous
     T, H, D = key.shape
     ks, vs = _elem_strides(key), _elem_strides(value)

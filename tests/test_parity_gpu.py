@@ -805,3 +805,116 @@ def test_reshape_and_cache_flash_bit_exact():
         assert np.array_equal(t_vc.cpu().numpy().view(np.uint16), vc.view(np.uint16))
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
         ext.cache_ops.reshape_and_cache_flash(tk, tv, t_kc, t_vc, torch.from_numpy(slots).to(dev), "fp8")
+
+
+# ------------------------------------------------------------------------------------------------
+# bfloat16 (the reference dispatches on the element type; arithmetic: dtype_bfloat16.cuh)
+# ------------------------------------------------------------------------------------------------
+def _to_bf16_case(case):
+    """Same values rounded to bfloat16; numpy side holds uint16 bit patterns."""
+    c = dict(case)
+    for k in ("qbuf", "kc", "vc"):
+        c[k] = oracle.f32_to_bf16_bits(np.nan_to_num(case[k].astype(np.float32), nan=0.0)
+                                       if k == "qbuf" else case[k].astype(np.float32))
+    S, H, D = case["q"].shape
+    c["q"] = c["qbuf"][:, : H * D].reshape(S, H, D)
+    return c
+
+
+def _bf16_tensor(bits, dev):
+    return torch.from_numpy(bits.view(np.int16)).to(dev).view(torch.bfloat16)
+
+
+def run_hip_bf16(case, variant=0, max_seq_len=None, v2=False):
+    ext = _ext()
+    from vllmini_amd import ops
+
+    dev = _dev()
+    S, H, D = case["q"].shape
+    bs = case.get("bs", BS)
+    q = _bf16_tensor(case["qbuf"], dev)[:, : H * D].view(S, H, D)
+    kc, vc = _bf16_tensor(case["kc"], dev), _bf16_tensor(case["vc"], dev)
+    tab, lens = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
+    msl = int(max_seq_len if max_seq_len is not None else max(int(case["lens"].max()), 1))
+    out = torch.full((S, H, D), float("nan"), dtype=torch.bfloat16, device=dev)
+    if v2:
+        P = (msl + 511) // 512
+        es = torch.empty((S, H, P), dtype=torch.float32, device=dev)
+        ml = torch.empty((S, H, P), dtype=torch.float32, device=dev)
+        tmp = torch.empty((S, H, P, D), dtype=torch.bfloat16, device=dev)
+        ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, bs, msl, None,
+                               "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+    else:
+        ops.paged_attention_v1(out, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, bs, msl, None,
+                               "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+    torch.cuda.synchronize()
+    return out.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def assert_close_bf16(got_bits, ref_bits, what=""):
+    got, ref = oracle.bf16_bits_to_f32(got_bits).astype(np.float64), oracle.bf16_bits_to_f32(ref_bits).astype(np.float64)
+    assert np.isfinite(got).all(), f"{what}: non-finite"
+    d = np.abs(got - ref)
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -126))) - 7)   # bf16: 8 significand bits
+    bad = d > np.maximum(2 * ulp, 2e-4)
+    assert not bad.any(), f"{what}: {bad.sum()} outputs off by more than 2 bf16 ulp (max {d.max():.3e})"
+
+
+@pytest.mark.parametrize("bs", ALL_BLOCKS)
+@pytest.mark.parametrize("D", ALL_HEADS)
+def test_bf16_every_head_and_block_size_v1_and_v2(D, bs):
+    from vllmini_amd import ops
+
+    rng = np.random.default_rng(7 * D + bs)
+    lens = [1, bs + 1, 5 * bs + 3, 520, 700]
+    case = _to_bf16_case(make_case(rng, len(lens), 4, D, lens, q_row_pad=2, block_size=bs, num_kv_heads=2))
+    ref = oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], 2, case["scale"], case["tables"], case["lens"],
+                                    bs, threads=8, bf16=True)
+    assert_close_bf16(run_hip_bf16(case), ref, f"bf16 v1 D{D} bs{bs}")
+    tag = f"bf16_d{D}_bs{bs}_"
+    for vid, name in enumerate(ops.variant_names(), start=1):
+        if name.startswith(tag) or (D == 128 and bs == 16 and name.startswith("bf16_d128_mh")):
+            assert_close_bf16(run_hip_bf16(case, variant=vid), ref, name)
+    ref2 = oracle.paged_attention_v2(case["q"], case["kc"], case["vc"], 2, case["scale"], case["tables"], case["lens"],
+                                     bs, 1024, bf16=True)[0]
+    assert_close_bf16(run_hip_bf16(case, max_seq_len=1024, v2=True), ref2, f"bf16 v2 D{D} bs{bs}")
+    for vid, name in enumerate(ops.variant_names_v2(), start=1):
+        if name.startswith("bf16_v2_d%d_bs%d_" % (D, bs)):
+            assert_close_bf16(run_hip_bf16(case, variant=vid, max_seq_len=1024, v2=True), ref2, name)
+
+
+def test_bf16_vs_exact_and_mixed_dtype_errors():
+    rng = np.random.default_rng(51)
+    lens = [3, 64, 1000]
+    case = _to_bf16_case(make_case(rng, 3, 12, 64, lens, kv="normal"))
+    got = oracle.bf16_bits_to_f32(run_hip_bf16(case)).astype(np.float64)
+    exact = oracle.eager_paged_attention(oracle.bf16_bits_to_f32(case["q"]), oracle.bf16_bits_to_f32(case["kc"]),
+                                         oracle.bf16_bits_to_f32(case["vc"]), 12, case["scale"], case["tables"], case["lens"])
+    assert np.abs(got - exact).max() <= 2e-2            # bf16 keeps 8 significand bits
+    ext = _ext()
+    dev = _dev()
+    q = torch.zeros((1, 4, 64), dtype=torch.bfloat16, device=dev)
+    kc = torch.zeros((4, 4, 8, 16, 8), dtype=torch.float16, device=dev)
+    vc = torch.zeros((4, 4, 64, 16), dtype=torch.float16, device=dev)
+    with pytest.raises(RuntimeError, match="key_cache/value_cache must be torch.bfloat16"):
+        ext.paged_attention_v1(torch.empty_like(q), q, kc, vc, 4, 0.125, torch.zeros((1, 2), dtype=torch.int32, device=dev),
+                               torch.ones(1, dtype=torch.int32, device=dev), 16, 16, None, "auto", 1.0, 0, 0, 1, 1, 0)
+
+
+def test_bf16_reshape_and_cache_bit_exact():
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(52)
+    T, H, D, NB = 21, 12, 64, 6
+    kc = oracle.f32_to_bf16_bits(rng.standard_normal((NB, H, D // 8, BS, 8)).astype(np.float32))
+    vc = oracle.f32_to_bf16_bits(rng.standard_normal((NB, H, D, BS)).astype(np.float32))
+    key = oracle.f32_to_bf16_bits(rng.standard_normal((T, H, D)).astype(np.float32))
+    val = oracle.f32_to_bf16_bits(rng.standard_normal((T, H, D)).astype(np.float32))
+    slots = rng.permutation(NB * BS)[:T].astype(np.int64)
+    t_kc, t_vc = _bf16_tensor(kc, dev), _bf16_tensor(vc, dev)
+    ext.cache_ops.reshape_and_cache(_bf16_tensor(key, dev), _bf16_tensor(val, dev), t_kc, t_vc,
+                                    torch.from_numpy(slots).to(dev), "auto", 1.0)
+    torch.cuda.synchronize()
+    oracle.reshape_and_cache(key, val, kc, vc, slots)
+    assert np.array_equal(t_kc.view(torch.int16).cpu().numpy().view(np.uint16), kc)
+    assert np.array_equal(t_vc.view(torch.int16).cpu().numpy().view(np.uint16), vc)

@@ -2,7 +2,7 @@
 
 The reference builds its kernels as a torch CUDAExtension for sm_70..sm_89
 (paged_attention_ext/setup.py:21-46, build.sh:3-5).  Here there is no torch/pybind in the
-native code at all: two hipcc translation units (core kernels + C-ABI; extra head/block-size instantiations)
+native code at all: three hipcc translation units (core kernels + C-ABI; extra head/block-size instantiations; bfloat16)
 compiled concurrently and linked into vllmini_amd/_C/libvmi_paged_attention.so, loaded through ctypes (vllmini_amd/_lib.py).
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so is
@@ -20,6 +20,7 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 SRC = os.path.join(CSRC, "paged_attention.hip")              # core kernels + host code + C-ABI
 SRC_EXTRA = os.path.join(CSRC, "pa_variants_extra.hip")       # remaining head/block-size instantiations
+SRC_BF16 = os.path.join(CSRC, "pa_variants_bf16.hip")         # bfloat16 instantiations
 HDR = os.path.join(CSRC, "pa_kernel.hpp")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 OUT_DIR = os.path.join(PKG_DIR, "_C")
@@ -48,7 +49,7 @@ def _hipcc() -> str:
 
 
 def _deps() -> list[str]:
-    return [SRC, SRC_EXTRA, HDR, os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.abspath(__file__)]
+    return [SRC, SRC_EXTRA, SRC_BF16, HDR, os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.abspath(__file__)]
 
 
 def is_stale() -> bool:
@@ -66,7 +67,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     tmp = LIB_PATH + ".tmp"
     objs = []
     procs = []
-    for src in (SRC, SRC_EXTRA):                      # the two units compile concurrently
+    for src in (SRC, SRC_EXTRA, SRC_BF16):            # the units compile concurrently
         obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
         cmd = [_hipcc(), *HIPCC_FLAGS, "-c", src, "-o", obj]
         if verbose:

@@ -30,6 +30,101 @@ __device__ __forceinline__ u32x4 ld16(const h16* p) {
   }
 }
 
+// ---- bfloat16 helpers (element type selected by the BF template flag) ---------------------------
+// Reference arithmetic (dtype_bfloat16.cuh): operands widen to fp32 by a 16-bit shift, __hmul2 rounds each
+// product to bf16 (RNE), sums are fp32, stores round to bf16 (RNE).  fp32 holds bf16 products exactly, so
+// "fp32 multiply, then round the upper 16 bits" reproduces __hmul2.
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ float bf_round(float x) {  // x rounded to bf16 precision, kept in an fp32
+  uint32_t u = __builtin_bit_cast(uint32_t, x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __builtin_bit_cast(float, u & 0xffff0000u);
+}
+template <bool BF>
+__device__ __forceinline__ uint16_t to_elem(float x) {  // fp32 -> fp16 / bf16 bit pattern, RNE
+  if constexpr (BF) return (uint16_t)(__builtin_bit_cast(uint32_t, bf_round(x)) >> 16);
+  else return __builtin_bit_cast(uint16_t, (h16)x);
+}
+template <bool BF>
+__device__ __forceinline__ float from_elem(uint16_t b) {
+  if constexpr (BF) return __builtin_bit_cast(float, (uint32_t)b << 16);
+  else return (float)__builtin_bit_cast(h16, b);
+}
+
+// q.k over one 16-byte chunk pair (8 dims): fp32 FMA chain on widened operands
+template <bool BF>
+__device__ __forceinline__ float dot8(const u32x4 q, const u32x4 k) {
+  if constexpr (BF) {
+    float a = bf_lo(q[0]) * bf_lo(k[0]);
+    a = __builtin_fmaf(bf_hi(q[0]), bf_hi(k[0]), a);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      a = __builtin_fmaf(bf_lo(q[w]), bf_lo(k[w]), a);
+      a = __builtin_fmaf(bf_hi(q[w]), bf_hi(k[w]), a);
+    }
+    return a;
+  } else {
+    const h16x8 qh = __builtin_bit_cast(h16x8, q);
+    const h16x8 kh = __builtin_bit_cast(h16x8, k);
+    float a = (float)qh[0] * (float)kh[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) a = __builtin_fmaf((float)qh[e], (float)kh[e], a);
+    return a;
+  }
+}
+
+// p.v over 8 tokens of one dim row.  e0/e1: the 8 exp values, is: 1/(sum+1e-6); `keep` = bit mask of the
+// tokens inside the context (only consulted when `last`).
+//   fp16: p -> fp16, 4 packed fp16 products, packed fp16 adds ((p0v0+p2v2)+p4v4)+p6v6 / odd, fp32 add of halves
+//   bf16: p -> bf16, products rounded to bf16, fp32 sums ((s01+s23)+s45)+s67
+template <bool BF>
+struct PV8 {
+  h16x8 ph;     // fp16 probabilities
+  float pf[8];  // bf16-rounded probabilities held in fp32
+  __device__ __forceinline__ void set(const f32x4 e0, const f32x4 e1, float is) {
+    if constexpr (BF) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pf[k] = bf_round(e0[k] * is);
+        pf[4 + k] = bf_round(e1[k] * is);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ph[k] = (h16)(e0[k] * is);
+        ph[4 + k] = (h16)(e1[k] * is);
+      }
+    }
+  }
+  __device__ __forceinline__ float dot(const u32x4 vraw, bool last, int token0, int L) const {
+    if constexpr (BF) {
+      float s[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float v0 = bf_lo(vraw[w]), v1 = bf_hi(vraw[w]);
+        if (last) {  // tokens past the context may hold stale/NaN bytes: zero them (ref :420-430)
+          v0 = (token0 + 2 * w < L) ? v0 : 0.f;
+          v1 = (token0 + 2 * w + 1 < L) ? v1 : 0.f;
+        }
+        s[w] = bf_round(pf[2 * w] * v0) + bf_round(pf[2 * w + 1] * v1);
+      }
+      return ((s[0] + s[1]) + s[2]) + s[3];
+    } else {
+      h16x8 v = __builtin_bit_cast(h16x8, vraw);
+      if (last) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (token0 + e < L) ? v[e] : (h16)0.f;
+      }
+      const h16x8 pr = ph * v;  // 4 x v_pk_mul_f16, each product rounded to fp16
+      h16x2 c = h16x2{pr[0], pr[1]} + h16x2{pr[2], pr[3]};
+      c = c + h16x2{pr[4], pr[5]};
+      c = c + h16x2{pr[6], pr[7]};
+      return (float)c[0] + (float)c[1];
+    }
+  }
+};
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
@@ -86,7 +181,7 @@ struct PAParams {
 //   V tile = D rows x BS/8 units of 16 B;   a load covers 512/BS rows;  lane = row*(BS/8) + unit
 // When D*BS/8 is not a multiple of 64 (head 80/112, ...) the last load of a tile is predicated.
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
-          bool LOCK = false>
+          bool LOCK = false, bool BF = false>
 __global__ void __launch_bounds__(HPW* WPH * 64)
     pa_v1_kernel(const PAParams p) {
   constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
@@ -136,12 +231,13 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   float* osm = reinterpret_cast<float*>(smem) + (size_t)HPW * p.lpad + HPW * 2 * WPH +
                (size_t)hl * WPH * D;
 
-  h16* outp = PART ? p.out + (((int64_t)seq * p.num_heads + head) * p.max_num_partitions + part) * D
-                   : p.out + ((int64_t)seq * p.num_heads + head) * D;
+  uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) +
+                   (PART ? (((int64_t)seq * p.num_heads + head) * p.max_num_partitions + part) * D
+                         : ((int64_t)seq * p.num_heads + head) * D);
 
   if (L <= 0) {  // uniform over the workgroup (same seq): reference yields exp_sum = 0 -> out = 0
     if (sub == 0) {
-      for (int d = lane; d < D; d += 64) outp[d] = (h16)0.f;
+      for (int d = lane; d < D; d += 64) outp[d] = 0;  // +0.0 in fp16 and in bf16
     }
     return;
   }
@@ -221,14 +317,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         // One accumulator per load keeps NL independent dependency chains in flight.
         float accv[NL];
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-          const h16x8 qh = __builtin_bit_cast(h16x8, qreg[i]);
-          const h16x8 kh = __builtin_bit_cast(h16x8, r[j][i]);
-          float a = (float)qh[0] * (float)kh[0];
-#pragma unroll
-          for (int e = 1; e < 8; ++e) a = __builtin_fmaf((float)qh[e], (float)kh[e], a);
-          accv[i] = a;
-        }
+        for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[i], r[j][i]);
         float acc = accv[0];
 #pragma unroll
         for (int i = 1; i < NL; ++i) acc += accv[i];
@@ -320,30 +409,11 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         const int token0 = b * BS + hf * 8;
         const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(logits + token0 - tok_lo);
         const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(logits + token0 - tok_lo + 4);
-        h16x8 pv;
-        pv[0] = (h16)(e0[0] * inv_sum);
-        pv[1] = (h16)(e0[1] * inv_sum);
-        pv[2] = (h16)(e0[2] * inv_sum);
-        pv[3] = (h16)(e0[3] * inv_sum);
-        pv[4] = (h16)(e1[0] * inv_sum);
-        pv[5] = (h16)(e1[1] * inv_sum);
-        pv[6] = (h16)(e1[2] * inv_sum);
-        pv[7] = (h16)(e1[3] * inv_sum);
+        PV8<BF> pv;
+        pv.set(e0, e1, inv_sum);
         const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-          h16x8 v = __builtin_bit_cast(h16x8, r[j][i]);
-          if (last) {
-            // tokens past the context may hold stale/NaN bytes: zero them (ref :420-430)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (token0 + e < L) ? v[e] : (h16)0.f;
-          }
-          const h16x8 pr = pv * v;  // 4 x v_pk_mul_f16, each product rounded to fp16
-          h16x2 c = h16x2{pr[0], pr[1]} + h16x2{pr[2], pr[3]};
-          c = c + h16x2{pr[4], pr[5]};
-          c = c + h16x2{pr[6], pr[7]};
-          acc[i] += ((float)c[0] + (float)c[1]);
-        }
+        for (int i = 0; i < NL; ++i) acc[i] += pv.dot(r[j][i], last, token0, L);
       }
     }
   };
@@ -360,7 +430,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   }
 
   if constexpr (LOADS_ONLY) {
-    if (fold == 0x9e3779b9u) outp[lane] = (h16)1.f;  // practically never; keeps the loads live
+    if (fold == 0x9e3779b9u) outp[lane] = 1;  // practically never; keeps the loads live
     return;
   }
 
@@ -385,7 +455,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WPH; ++w) s += osm[w * D + d];
-        outp[d] = (h16)s;
+        outp[d] = to_elem<BF>(s);
       }
     }
   } else {
@@ -393,7 +463,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const int row = RPL * i + rowl;
-        if (row < D) outp[row] = (h16)acc[i];
+        if (row < D) outp[row] = to_elem<BF>(acc[i]);
       }
     }
   }
@@ -409,7 +479,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
 // Arithmetic per head is exactly that of pa_v1_kernel (same rounding points).
 // grid = (ceil(H / (HPW*HPT)), num_seqs), block = HPW*64, LDS = HPW*HPT*lpad*4.
 // ----------------------------------------------------------------------------------------
-template <int D, int HPW, int HPT, int U, bool NT, bool LOCK>
+template <int D, int HPW, int HPT, int U, bool NT, bool LOCK, bool BF = false>
 __global__ void __launch_bounds__(HPW * 64)
     pa_v1_mh_kernel(const PAParams p) {
   constexpr int BS = 16;
@@ -434,11 +504,11 @@ __global__ void __launch_bounds__(HPW * 64)
   const int nblk = (L + BS - 1) / BS;
   const int ngroups = (nblk + U - 1) / U;
   float* logits0 = reinterpret_cast<float*>(smem) + (size_t)hl * HPT * p.lpad;
-  h16* out0 = p.out + ((int64_t)seq * p.num_heads + head0) * D;
+  uint16_t* out0 = reinterpret_cast<uint16_t*>(p.out) + ((int64_t)seq * p.num_heads + head0) * D;
 
   if (L <= 0) {
     for (int hh = 0; hh < nh; ++hh)
-      for (int d = lane; d < D; d += 64) out0[hh * D + d] = (h16)0.f;
+      for (int d = lane; d < D; d += 64) out0[hh * D + d] = 0;
     return;
   }
 
@@ -501,14 +571,7 @@ __global__ void __launch_bounds__(HPW * 64)
           if (hh < nh) {
             float accv[NL];
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-              const h16x8 qh = __builtin_bit_cast(h16x8, qreg[hh][i]);
-              const h16x8 kh = __builtin_bit_cast(h16x8, r[j][hh][i]);
-              float a = (float)qh[0] * (float)kh[0];
-#pragma unroll
-              for (int e = 1; e < 8; ++e) a = __builtin_fmaf((float)qh[e], (float)kh[e], a);
-              accv[i] = a;
-            }
+            for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[hh][i], r[j][hh][i]);
             float acc = accv[0];
 #pragma unroll
             for (int i = 1; i < NL; ++i) acc += accv[i];
@@ -576,28 +639,10 @@ __global__ void __launch_bounds__(HPW * 64)
             const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(lg);
             const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(lg + 4);
             const float is = inv_sum[hh];
-            h16x8 pv;
-            pv[0] = (h16)(e0[0] * is);
-            pv[1] = (h16)(e0[1] * is);
-            pv[2] = (h16)(e0[2] * is);
-            pv[3] = (h16)(e0[3] * is);
-            pv[4] = (h16)(e1[0] * is);
-            pv[5] = (h16)(e1[1] * is);
-            pv[6] = (h16)(e1[2] * is);
-            pv[7] = (h16)(e1[3] * is);
+            PV8<BF> pv;
+            pv.set(e0, e1, is);
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-              h16x8 v = __builtin_bit_cast(h16x8, r[j][hh][i]);
-              if (last) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (token0 + e < L) ? v[e] : (h16)0.f;
-              }
-              const h16x8 pr = pv * v;
-              h16x2 c = h16x2{pr[0], pr[1]} + h16x2{pr[2], pr[3]};
-              c = c + h16x2{pr[4], pr[5]};
-              c = c + h16x2{pr[6], pr[7]};
-              acc[hh][i] += ((float)c[0] + (float)c[1]);
-            }
+            for (int i = 0; i < NL; ++i) acc[hh][i] += pv.dot(r[j][hh][i], last, token0, L);
           }
         }
       }
@@ -620,7 +665,7 @@ __global__ void __launch_bounds__(HPW * 64)
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const float a = acc[hh][i] + __shfl_xor(acc[hh][i], 1);
-        if (hf == 0) out0[hh * D + 32 * i + (lane >> 1)] = (h16)a;
+        if (hf == 0) out0[hh * D + 32 * i + (lane >> 1)] = to_elem<BF>(a);
       }
     }
   }
@@ -634,10 +679,10 @@ __global__ void __launch_bounds__(HPW * 64)
 //                   out[d] = sum_j float(tmp_out[j][d]) * s_j * 1/(sum_j s_j + 1e-6)   (fp32, j ascending)
 // LDS: 2*max_num_partitions floats + 2 reduction slots per wave.
 // ----------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool BF = false>
 __global__ void __launch_bounds__(128)
-    pa_v2_reduce_kernel(h16* __restrict__ out, const float* __restrict__ exp_sums,
-                        const float* __restrict__ max_logits, const h16* __restrict__ tmp_out,
+    pa_v2_reduce_kernel(h16* __restrict__ out_, const float* __restrict__ exp_sums,
+                        const float* __restrict__ max_logits, const h16* __restrict__ tmp_out_,
                         const int32_t* __restrict__ seq_lens, int max_num_partitions) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int num_heads = gridDim.x;
@@ -649,8 +694,8 @@ __global__ void __launch_bounds__(128)
   const int L = seq_lens[seq];
   const int np = (L + 511) / 512;  // :581
   const int64_t sh = ((int64_t)seq * num_heads + head) * max_num_partitions;
-  h16* outp = out + ((int64_t)seq * num_heads + head) * D;
-  const h16* tmp = tmp_out + sh * D;
+  uint16_t* outp = reinterpret_cast<uint16_t*>(out_) + ((int64_t)seq * num_heads + head) * D;
+  const uint16_t* tmp = reinterpret_cast<const uint16_t*>(tmp_out_) + sh * D;
   if (np == 1) {  // :582-594
     for (int i = tid; i < D; i += 128) outp[i] = tmp[i];
     return;
@@ -685,8 +730,8 @@ __global__ void __launch_bounds__(128)
   for (int i = tid; i < D; i += 128) {  // :661-668
     float acc = 0.f;
     for (int j = 0; j < np; ++j)
-      acc = __builtin_fmaf((float)tmp[(int64_t)j * D + i] * ssum[j], inv, acc);
-    outp[i] = (h16)acc;
+      acc = __builtin_fmaf(from_elem<BF>(tmp[(int64_t)j * D + i]) * ssum[j], inv, acc);
+    outp[i] = to_elem<BF>(acc);
   }
 }
 
@@ -700,6 +745,7 @@ struct Variant {
   int D, BS, HPW, WPH, U;
   bool NT;
   int HPT;  // heads per wave (1 except for the multi-head kernel)
+  bool BF;  // element type: false = fp16, true = bfloat16
   pa_kernel_t fn;
   int lds_attr_set;  // largest dynamic-LDS size already granted through hipFuncSetAttribute
 };
@@ -711,6 +757,12 @@ extern Variant g_extra_variants_v1[];
 extern const int g_extra_nvariants_v1;
 extern Variant g_extra_variants_v2[];
 extern const int g_extra_nvariants_v2;
-pa_reduce_t extra_reduce_kernel(int head_size);  // nullptr if that head size is not built there
+pa_reduce_t extra_reduce_kernel(int head_size, bool bf16);  // nullptr if that head size is not built there
+// bfloat16 instantiations of the same (head size, block size) set live in pa_variants_bf16.hip
+extern Variant g_bf16_variants_v1[];
+extern const int g_bf16_nvariants_v1;
+extern Variant g_bf16_variants_v2[];
+extern const int g_bf16_nvariants_v2;
+pa_reduce_t bf16_reduce_kernel(int head_size);
 
 }  // namespace vmi

@@ -7,10 +7,10 @@
 namespace vmi {
 
 #define VMI_X1(D, BS, WPH, U) \
-  {"d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, 1, \
+  {"d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, 1, false, \
    (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, false, BS>, 0}
 #define VMI_X2(D, BS, WPH, U) \
-  {"v2_d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, 1, \
+  {"v2_d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, 1, false, \
    (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, true, BS>, 0}
 
 Variant g_extra_variants_v1[] = {
@@ -59,7 +59,8 @@ Variant g_extra_variants_v2[] = {
 };
 const int g_extra_nvariants_v2 = (int)(sizeof(g_extra_variants_v2) / sizeof(g_extra_variants_v2[0]));
 
-pa_reduce_t extra_reduce_kernel(int head_size) {
+pa_reduce_t extra_reduce_kernel(int head_size, bool bf16) {
+  if (bf16) return nullptr;
   switch (head_size) {
     case 80: return (pa_reduce_t)pa_v2_reduce_kernel<80>;
     case 96: return (pa_reduce_t)pa_v2_reduce_kernel<96>;

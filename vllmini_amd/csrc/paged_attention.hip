@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) gather_read_kernel(const u32x4* __restric
 // ----------------------------------------------------------------------------------------
 #define VMI_VARIANT(D, HPW, WPH, U, NT)                                          \
   {                                                                              \
-    "d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, 16, HPW, WPH, U, (bool)NT, 1, \
+    "d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, 16, HPW, WPH, U, (bool)NT, 1, false, \
         (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)NT>, 0                   \
   }
 
@@ -294,9 +294,9 @@ static Variant g_variants[] = {
     VMI_VARIANT(128, 1, 8, 1, 1), VMI_VARIANT(128, 1, 8, 2, 1), VMI_VARIANT(128, 1, 16, 1, 1),
     VMI_VARIANT(128, 1, 4, 2, 0), VMI_VARIANT(128, 1, 8, 2, 0), VMI_VARIANT(128, 1, 16, 1, 0),
     // ---- head size 128, full chip: adjacent heads read together (HBM sees 16-64 KiB bursts) ----
-#define VMI_LOCK(D, HPW, U) {"d" #D "_h" #HPW "_w1_u" #U "_nt1_lock", D, 16, HPW, 1, U, true, 1, \
+#define VMI_LOCK(D, HPW, U) {"d" #D "_h" #HPW "_w1_u" #U "_nt1_lock", D, 16, HPW, 1, U, true, 1, false, \
      (pa_kernel_t)pa_v1_kernel<D, HPW, 1, U, true, false, false, 16, true>, 0}
-#define VMI_MH(D, HPW, HPT, U, LOCK, SUF) {"d" #D "_mh" #HPT "_h" #HPW "_u" #U "_nt1" SUF, D, 16, HPW, 1, U, true, HPT, \
+#define VMI_MH(D, HPW, HPT, U, LOCK, SUF) {"d" #D "_mh" #HPT "_h" #HPW "_u" #U "_nt1" SUF, D, 16, HPW, 1, U, true, HPT, false, \
      (pa_kernel_t)pa_v1_mh_kernel<D, HPW, HPT, U, true, LOCK>, 0}
     VMI_LOCK(128, 8, 1), VMI_LOCK(128, 16, 1),
     VMI_MH(128, 4, 4, 1, true, "_lock"),    // the cfg4 kernel (16 | num_heads)
@@ -308,25 +308,27 @@ static Variant g_variants[] = {
 #undef VMI_MH
 #undef VMI_LOCK
     // ---- diagnostics: same gather pattern, no math ("loads only"); wrong results by design ----
-    {"d64_h4_w1_u4_nt1_LOADSONLY", 64, 16, 4, 1, 4, true, 1,
+    {"d64_h4_w1_u4_nt1_LOADSONLY", 64, 16, 4, 1, 4, true, 1, false,
      (pa_kernel_t)pa_v1_kernel<64, 4, 1, 4, true, true>, 0},
-    {"d64_h4_w1_u1_nt1_LOADSONLY", 64, 16, 4, 1, 1, true, 1,
+    {"d64_h4_w1_u1_nt1_LOADSONLY", 64, 16, 4, 1, 1, true, 1, false,
      (pa_kernel_t)pa_v1_kernel<64, 4, 1, 1, true, true>, 0},
 };
 static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
-static int nvariants_v1() { return g_ncore + g_extra_nvariants_v1; }
-static Variant& variant_v1(int id) {  // 1-based
-  return id <= g_ncore ? g_variants[id - 1] : g_extra_variants_v1[id - 1 - g_ncore];
+static int nvariants_v1() { return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1; }
+static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf16]
+  if (id <= g_ncore) return g_variants[id - 1];
+  if (id <= g_ncore + g_extra_nvariants_v1) return g_extra_variants_v1[id - 1 - g_ncore];
+  return g_bf16_variants_v1[id - 1 - g_ncore - g_extra_nvariants_v1];
 }
 
 static bool is_diag(const Variant& v) { return strstr(v.name, "LOADSONLY") != nullptr; }
 static bool is_lock(const Variant& v) { return strstr(v.name, "_lock") != nullptr || v.HPT > 1; }
 
-static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = any */) {
+static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = any */, bool bf = false) {
   for (int id = 1; id <= nvariants_v1(); ++id) {
     const Variant& v = variant_v1(id);
-    if (v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
+    if (v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
         (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v))
       return id;
   }
@@ -347,7 +349,8 @@ static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }
 //    of {1,2,4} that keeps >= 24 KiB in flight per CU;
 //  * non-temporal page loads once the KV working set exceeds the 256 MiB Infinity Cache;
 //  * D = 128 with a full chip: multi-head waves in lockstep give HBM 16-64 KiB bursts (cfg4 660 -> 616 us).
-static int pick_variant(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len) {
+static int pick_variant(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
+                        bool bf = false) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
@@ -362,22 +365,25 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
     if (wph == 1 && head_size == 128 && nt && num_heads % 16 == 0 && waves_per_cu >= 12.0) {
       for (int id = 1; id <= nvariants_v1(); ++id) {  // d128_mh4_h4_u1_nt1_lock
         const Variant& c = variant_v1(id);
-        if (c.D == 128 && c.HPT == 4 && c.HPW == 4 && c.U == 1) return id;
+        if (c.BF == bf && c.D == 128 && c.HPT == 4 && c.HPW == 4 && c.U == 1) return id;
       }
     }
     const int hpw = (wph == 1 && num_heads % 4 == 0) ? 4 : 1;
     int v = 0;
     for (int uu = u; uu >= 1 && !v; uu /= 2) {  // nearest available depth at or below the target
-      v = find_variant(head_size, 16, hpw, wph, uu, nt);
-      if (!v) v = find_variant(head_size, 16, hpw, wph, uu, -1);
+      v = find_variant(head_size, 16, hpw, wph, uu, nt, bf);
+      if (!v) v = find_variant(head_size, 16, hpw, wph, uu, -1, bf);
     }
-    for (int uu = u * 2; uu <= 8 && !v; uu *= 2) v = find_variant(head_size, 16, hpw, wph, uu, -1);
-    if (!v) v = find_variant(head_size, 16, 1, 1, -1, 1);
+    for (int uu = u * 2; uu <= 8 && !v; uu *= 2) v = find_variant(head_size, 16, hpw, wph, uu, -1, bf);
+    if (!v && wph > 1) {  // smaller menus (bf16): nearest available waves-per-head
+      for (int ww = wph / 2; ww >= 1 && !v; ww /= 2) v = find_variant(head_size, 16, 1, ww, -1, -1, bf);
+    }
+    if (!v) v = find_variant(head_size, 16, 1, 1, -1, -1, bf);
     return v;
   }
   // extra table: one wave or four waves per head
-  int v = find_variant(head_size, block_size, 1, wph == 1 ? 1 : 4, -1, -1);
-  if (!v) v = find_variant(head_size, block_size, 1, 1, -1, -1);
+  int v = find_variant(head_size, block_size, 1, wph == 1 ? 1 : 4, -1, -1, bf);
+  if (!v) v = find_variant(head_size, block_size, 1, 1, -1, -1, bf);
   return v;
 }
 
@@ -389,7 +395,8 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
                         int32_t max_seq_len, int32_t max_num_blocks_per_seq,
                         const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
-                        int64_t kv_head_stride, int32_t device, void* stream, int32_t variant) {
+                        int64_t kv_head_stride, int32_t device, void* stream, int32_t variant,
+                        bool bf = false) {
   if (!out || !query || !key_cache || !value_cache || !block_tables || !seq_lens)
     return fail(VMI_E_NULL_POINTER, "paged_attention_v1: NULL tensor pointer");
   if (!head_size_supported(head_size))
@@ -411,10 +418,13 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                 (long long)kv_head_stride);
   if (num_seqs == 0) return VMI_OK;
 
-  if (variant == 0) variant = pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len);
+  if (variant == 0) variant = pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
   if (variant < 1 || variant > nvariants_v1())
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
   Variant& v = variant_v1(variant);
+  if (v.BF != bf)
+    return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s is for %s elements", v.name,
+                v.BF ? "bfloat16" : "float16");
   if (v.D != head_size || v.BS != block_size)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s is for head size %d / block size %d, "
                 "got %d / %d", v.name, v.D, v.BS, head_size, block_size);
@@ -479,7 +489,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
 // ---- split-KV (paged_attention_v2) variants: same kernel body, PART = true -----------------
 #define VMI_VARIANT_V2(D, HPW, WPH, U, NT)                                          \
   {                                                                                 \
-    "v2_d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, 16, HPW, WPH, U, (bool)NT, 1, \
+    "v2_d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, 16, HPW, WPH, U, (bool)NT, 1, false, \
         (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)NT, false, true>, 0         \
   }
 static Variant g_variants_v2[] = {
@@ -496,40 +506,43 @@ static Variant g_variants_v2[] = {
 };
 static const int g_ncore_v2 = (int)(sizeof(g_variants_v2) / sizeof(g_variants_v2[0]));
 
-static int nvariants_v2() { return g_ncore_v2 + g_extra_nvariants_v2; }
+static int nvariants_v2() { return g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2; }
 static Variant& variant_v2(int id) {
-  return id <= g_ncore_v2 ? g_variants_v2[id - 1] : g_extra_variants_v2[id - 1 - g_ncore_v2];
+  if (id <= g_ncore_v2) return g_variants_v2[id - 1];
+  if (id <= g_ncore_v2 + g_extra_nvariants_v2) return g_extra_variants_v2[id - 1 - g_ncore_v2];
+  return g_bf16_variants_v2[id - 1 - g_ncore_v2 - g_extra_nvariants_v2];
 }
 
-static int find_variant_v2(int D, int BS, int HPW, int WPH) {
+static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false) {
   for (int id = 1; id <= nvariants_v2(); ++id) {
     const Variant& v = variant_v2(id);
-    if (v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH) return id;
+    if (v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH) return id;
   }
   return 0;
 }
 
 // a partition holds 512 / block_size blocks; give each (seq, head, partition) 1..8 waves so that the
 // launch has >= ~2048 waves when the batch allows it
-static int pick_variant_v2(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len) {
+static int pick_variant_v2(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
+                           bool bf = false) {
   const int parts = (max_seq_len + 511) / 512;
   const long units = (long)num_seqs * num_heads * (parts > 0 ? parts : 1);
   int wph = 1;
   while (wph < 8 && units * wph < 2048) wph *= 2;
   int v = 0;
-  if (block_size == 16 && (head_size == 64 || head_size == 128)) {
+  if (!bf && block_size == 16 && (head_size == 64 || head_size == 128)) {
     v = (wph == 1) ? find_variant_v2(head_size, 16, (num_heads % 4 == 0) ? 4 : 1, 1)
                    : find_variant_v2(head_size, 16, 1, wph);
-  } else {
-    v = find_variant_v2(head_size, block_size, 1, wph == 1 ? 1 : 4);
   }
-  return v ? v : find_variant_v2(head_size, block_size, 1, 1);
+  if (!v) v = find_variant_v2(head_size, block_size, 1, wph == 1 ? 1 : 4, bf);
+  return v ? v : find_variant_v2(head_size, block_size, 1, 1, bf);
 }
 
-static pa_reduce_t reduce_kernel_for(int head_size) {
+static pa_reduce_t reduce_kernel_for(int head_size, bool bf) {
+  if (bf) return bf16_reduce_kernel(head_size);
   if (head_size == 64) return (pa_reduce_t)pa_v2_reduce_kernel<64>;
   if (head_size == 128) return (pa_reduce_t)pa_v2_reduce_kernel<128>;
-  return extra_reduce_kernel(head_size);
+  return extra_reduce_kernel(head_size, false);
 }
 
 static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
@@ -538,7 +551,7 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
                         const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
                         int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
                         int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                        int32_t device, void* stream, int32_t variant) {
+                        int32_t device, void* stream, int32_t variant, bool bf = false) {
   if (!out || !exp_sums || !max_logits || !tmp_out || !query || !key_cache || !value_cache ||
       !block_tables || !seq_lens)
     return fail(VMI_E_NULL_POINTER, "paged_attention_v2: NULL tensor pointer");
@@ -559,10 +572,13 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   const int parts = (max_seq_len + 511) / 512;  // attention_kernels.cu:885
   if (num_seqs == 0 || parts == 0) return VMI_OK;
   if (parts > 65535) return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v2: too many partitions");
-  if (variant == 0) variant = pick_variant_v2(num_seqs, num_heads, head_size, block_size, max_seq_len);
+  if (variant == 0) variant = pick_variant_v2(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
   if (variant < 1 || variant > nvariants_v2())
     return fail(VMI_E_VARIANT, "paged_attention_v2: unknown variant %d", variant);
   Variant& v = variant_v2(variant);
+  if (v.BF != bf)
+    return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s is for %s elements", v.name,
+                v.BF ? "bfloat16" : "float16");
   if (v.D != head_size || v.BS != block_size)
     return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s is for head size %d / block size %d", v.name,
                 v.D, v.BS);
@@ -600,7 +616,7 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
 
   const size_t rlds = (size_t)(2 * parts + 4) * sizeof(float);  // :894
   dim3 rgrid(num_heads, num_seqs);                               // :893
-  pa_reduce_t red = reduce_kernel_for(head_size);
+  pa_reduce_t red = reduce_kernel_for(head_size, bf);
   if (!red) return fail(VMI_E_HEAD_SIZE, "Unsupported head size: %d", head_size);
   hipLaunchKernelGGL(red, rgrid, dim3(128), rlds, static_cast<hipStream_t>(stream), static_cast<h16*>(out),
                      static_cast<const float*>(exp_sums), static_cast<const float*>(max_logits),
@@ -648,6 +664,34 @@ int vmi_paged_attention_v1_f16_variant(void* out, const void* query, const void*
                            num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
                            max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
                            kv_head_stride, device, stream, variant);
+}
+
+int vmi_paged_attention_v1_bf16(void* out, const void* query, const void* key_cache,
+                                const void* value_cache, int32_t num_seqs, int32_t num_heads,
+                                int32_t head_size, int32_t num_kv_heads, float scale,
+                                const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
+                                int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+                                const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                                int64_t kv_head_stride, int32_t device, void* stream, int32_t variant) {
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, true);
+}
+
+int vmi_paged_attention_v2_bf16(void* out, void* exp_sums, void* max_logits, void* tmp_out,
+                                const void* query, const void* key_cache, const void* value_cache,
+                                int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                int32_t num_kv_heads, float scale, const int32_t* block_tables,
+                                const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
+                                int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                                int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                int32_t device, void* stream, int32_t variant) {
+  return vmi::launch_pa_v2(out, static_cast<float*>(exp_sums), static_cast<float*>(max_logits), tmp_out,
+                           query, key_cache, value_cache, num_seqs, num_heads, head_size, num_kv_heads,
+                           scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, true);
 }
 
 int vmi_paged_attention_v1_variant_count(void) { return vmi::nvariants_v1(); }

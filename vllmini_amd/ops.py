@@ -74,9 +74,9 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
     """Validate and flatten the 18 reference arguments into the C-ABI argument tuple."""
     if query.dim() != 3:
         raise RuntimeError(f"query must be [num_seqs, num_heads, head_size], got {tuple(query.shape)}")
-    if query.dtype != torch.float16:
-        # reference dispatches float/half/bf16 (quant_utils.cuh:529-566); only fp16 is built here,
-        # which is the only dtype its callers use (gpt2.py, scheduler.py:13)
+    if query.dtype not in (torch.float16, torch.bfloat16):
+        # reference dispatches float/half/bf16 (quant_utils.cuh:529-566); half and bf16 are built here
+        # (its callers only use half: gpt2.py, scheduler.py:13); fp32 has a different cache layout (x = 4)
         raise RuntimeError(f"Unsupported input type of paged attention: {query.dtype}")
     _check_kv_cache_dtype(kv_cache_dtype)
     if int(blocksparse_vert_stride) > 1:
@@ -87,10 +87,10 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
     for name, t in (("out", out), ("key_cache", key_cache), ("value_cache", value_cache),
                     ("block_tables", block_tables), ("seq_lens", seq_lens)):
         _check_device(name, t, dev)
-    if key_cache.dtype != torch.float16 or value_cache.dtype != torch.float16:
-        raise RuntimeError("key_cache/value_cache must be float16 for kv_cache_dtype='auto'")
-    if out.dtype != torch.float16:
-        raise RuntimeError(f"out must be float16, got {out.dtype}")
+    if key_cache.dtype != query.dtype or value_cache.dtype != query.dtype:
+        raise RuntimeError(f"key_cache/value_cache must be {query.dtype} for kv_cache_dtype='auto'")
+    if out.dtype != query.dtype:
+        raise RuntimeError(f"out must be {query.dtype}, got {out.dtype}")
     if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
         raise RuntimeError("block_tables and seq_lens must be int32")
 
@@ -176,7 +176,9 @@ def paged_attention_v1(
                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
                       blocksparse_block_size, blocksparse_head_sliding_step)
     lib = _lib.load()
-    if _variant:
+    if query.dtype == torch.bfloat16:
+        rc = lib.vmi_paged_attention_v1_bf16(*args, int(_variant))
+    elif _variant:
         rc = lib.vmi_paged_attention_v1_f16_variant(*args, int(_variant))
     else:
         rc = lib.vmi_paged_attention_v1_f16(*args)
@@ -225,13 +227,14 @@ def paged_attention_v2(
     dev = query.device
     for name, t, dt, shape in (("exp_sums", exp_sums, torch.float32, (num_seqs, num_heads, parts)),
                                ("max_logits", max_logits, torch.float32, (num_seqs, num_heads, parts)),
-                               ("tmp_out", tmp_out, torch.float16, (num_seqs, num_heads, parts, head_size))):
+                               ("tmp_out", tmp_out, query.dtype, (num_seqs, num_heads, parts, head_size))):
         _check_device(name, t, dev)
         if t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
             raise RuntimeError(f"{name} must be a contiguous {dt} tensor of shape {shape} "
                                f"(max_num_partitions = ceil(max_seq_len/512) = {parts})")
-    rc = _lib.load().vmi_paged_attention_v2_f16(args[0], exp_sums.data_ptr(), max_logits.data_ptr(),
-                                                tmp_out.data_ptr(), *args[1:], int(_variant))
+    fn = _lib.load().vmi_paged_attention_v2_bf16 if query.dtype == torch.bfloat16 else \
+        _lib.load().vmi_paged_attention_v2_f16
+    rc = fn(args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:], int(_variant))
     if rc != 0:
         _raise_native(rc)
     return None
@@ -253,14 +256,14 @@ def reshape_and_cache(
     _check_kv_cache_dtype(kv_cache_dtype)
     if key.dim() != 3 or value.dim() != 3 or key.shape != value.shape:
         raise RuntimeError("key and value must both be [num_tokens, num_heads, head_size]")
-    if key.dtype != torch.float16 or value.dtype != torch.float16:
+    if key.dtype not in (torch.float16, torch.bfloat16) or value.dtype != key.dtype:
         raise RuntimeError(f"Unsupported input type of reshape_and_cache: {key.dtype}")
     dev = key.device
     for name, t in (("key", key), ("value", value), ("key_cache", key_cache),
                     ("value_cache", value_cache), ("slot_mapping", slot_mapping)):
         _check_device(name, t, dev)
-    if key_cache.dtype != torch.float16 or value_cache.dtype != torch.float16:
-        raise RuntimeError("key_cache/value_cache must be float16 for kv_cache_dtype='auto'")
+    if key_cache.dtype != key.dtype or value_cache.dtype != key.dtype:
+        raise RuntimeError(f"key_cache/value_cache must be {key.dtype} for kv_cache_dtype='auto'")
     if slot_mapping.dtype != torch.int64:
         raise RuntimeError("slot_mapping must be int64")
     num_tokens, num_heads, head_size = (int(s) for s in key.shape)       # cache_kernels.cu:265-267
