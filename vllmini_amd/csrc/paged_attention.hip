@@ -54,6 +54,24 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// Make `device` current for the duration of a call and restore the caller's device afterwards
+// (the reference wraps its launches in at::cuda::OptionalCUDAGuard, attention_kernels.cu:736).
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  hipError_t err;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      changed = (err == hipSuccess);
+    }
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
 static int hip_fail(hipError_t e, const char* what) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
   return -(int)e;
@@ -439,7 +457,8 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v1: max_seq_len=%d needs %zu B of LDS per "
                 "workgroup (variant %s), limit 163840", max_seq_len, lds, v.name);
 
-  hipError_t e = hipSetDevice(device);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   if (lds > 48 * 1024 && (int)lds > v.lds_attr_set) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn),
@@ -584,7 +603,8 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
                 v.D, v.BS);
   if (v.WPH > 1 && num_heads % v.HPW != 0)
     return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s needs num_heads %% %d == 0", v.name, v.HPW);
-  hipError_t e = hipSetDevice(device);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
 
   const int lpad = 512;  // one partition of logits (:886)
@@ -724,7 +744,8 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
   if (!aligned16(key_cache))
     return fail(VMI_E_ALIGNMENT, "reshape_and_cache: key_cache must be 16-byte aligned");
   if (num_tokens == 0) return VMI_OK;
-  hipError_t e = hipSetDevice(device);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   const bool vec = aligned16(key) && aligned16(value) && !(key_stride & 7) && !(value_stride & 7);
   const int n8 = (num_heads * head_size) >> 3;
@@ -759,7 +780,8 @@ int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_c
   if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || block_size <= 0)
     return fail(VMI_E_SHAPE, "reshape_and_cache_flash: bad sizes");
   if (num_tokens == 0) return VMI_OK;
-  hipError_t e = hipSetDevice(device);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   const int n = num_heads * head_size;
   const bool vec = aligned16(key) && aligned16(value) && aligned16(k_cache) && aligned16(v_cache) &&
@@ -815,7 +837,8 @@ int vmi_copy_blocks(void* const* key_cache_ptrs, void* const* value_cache_ptrs, 
   if (!key_cache_ptrs || !value_cache_ptrs || !block_mapping)
     return fail(VMI_E_NULL_POINTER, "copy_blocks: NULL pointer");
   if (num_pairs > 65535) return fail(VMI_E_SHAPE, "copy_blocks: more than 65535 pairs in one call");
-  hipError_t e = hipSetDevice(device);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   for (int l0 = 0; l0 < num_layers; l0 += 64) {
     const int nl = (num_layers - l0) < 64 ? (num_layers - l0) : 64;
@@ -849,7 +872,8 @@ int vmi_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_hos
     case 2: k = hipMemcpyHostToDevice; break;
     default: return fail(VMI_E_SHAPE, "Invalid device combination");
   }
-  hipError_t e = hipSetDevice(device);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   const char* s = static_cast<const char*>(src);
   char* d = static_cast<char*>(dst);
@@ -866,7 +890,8 @@ int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blo
                          int32_t device, void* stream) {
   using namespace vmi;
   if (!src || !sink || bytes < 16 || blocks <= 0) return fail(VMI_E_SHAPE, "diag_stream_read: bad args");
-  hipError_t e = hipSetDevice(device);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   const size_t n16 = (size_t)bytes / 16;
   if (nt)
@@ -884,7 +909,8 @@ int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chu
                          int32_t nt, int32_t device, void* stream) {
   using namespace vmi;
   if (!src || !sink || bytes < 65536 || blocks <= 0) return fail(VMI_E_SHAPE, "diag_gather_read: bad args");
-  hipError_t e = hipSetDevice(device);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   const uint32_t nchunks = (uint32_t)(bytes / ((int64_t)chunk_kb * 1024));
   uint32_t stride = 2654435761u % nchunks;  // Knuth multiplicative hash, made coprime below
