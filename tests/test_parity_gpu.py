@@ -918,3 +918,25 @@ def test_bf16_reshape_and_cache_bit_exact():
     oracle.reshape_and_cache(key, val, kc, vc, slots)
     assert np.array_equal(t_kc.view(torch.int16).cpu().numpy().view(np.uint16), kc)
     assert np.array_equal(t_vc.view(torch.int16).cpu().numpy().view(np.uint16), vc)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a plain C ABI: a C program (no Python, no torch) built with gcc links the library and
+    the oracle's C restatement, runs both ops on hipMalloc'd buffers and compares."""
+    import shutil
+    import subprocess
+
+    from vllmini_amd import build
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.dirname(build.build())
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", os.path.join(repo, "tests", "c_abi", "c_abi_smoke.c"), os.path.join(repo, "oracle", "pa_kernel_model.c"),
+           "-std=c11", "-ffp-contract=off", "-O1", "-D__HIP_PLATFORM_AMD__", f"-I{os.path.join(repo, 'include')}",
+           f"-I{rocm}/include", f"-L{libdir}", "-lvmi_paged_attention", f"-L{rocm}/lib", "-lamdhip64",
+           f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rocm}/lib", "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
