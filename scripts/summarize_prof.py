@@ -35,6 +35,20 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             tail = vals[10:] if len(vals) > 20 else vals
             res[name] = {"n": len(vals), "mean_raw_KiB_units": statistics.mean(tail),
                          "mean_bytes_uncorrected": statistics.mean(tail) * 1024}
+# SQ / MFMA passes: mean per dispatch of every counter collected for the attention kernel
+for sub in ("pmc_sq", "pmc_mfma"):
+    for f in find(f"{sub}/**/*counter_collection.csv"):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if "pa_v1_" in r.get("Kernel_Name", ""):
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            tail = v[10:] if len(v) > 20 else v
+            res.setdefault("sq_counters_mean_per_dispatch", {})[k] = statistics.mean(tail)
+c = res.get("sq_counters_mean_per_dispatch", {})
+if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
+    res["sq_fractions_of_wave_cycles"] = {k: c[k] / c["SQ_WAVE_CYCLES"] for k in
+                                          ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in c}
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     f = res["FETCH_SIZE"]["mean_bytes_uncorrected"] * 2      # gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream
     w = res["WRITE_SIZE"]["mean_bytes_uncorrected"]

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <type_traits>
 
 namespace vmi {
 
@@ -97,24 +98,31 @@ struct PV8 {
       }
     }
   }
+  // MASK = false is the steady state: no tail handling is compiled in at all (the compiler would
+  // otherwise if-convert the wave-uniform `last` test into v_cndmask on every block).
+  template <bool MASK>
   __device__ __forceinline__ float dot(const u32x4 vraw, bool last, int token0, int L) const {
     if constexpr (BF) {
       float s[4];
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         float v0 = bf_lo(vraw[w]), v1 = bf_hi(vraw[w]);
-        if (last) {  // tokens past the context may hold stale/NaN bytes: zero them (ref :420-430)
-          v0 = (token0 + 2 * w < L) ? v0 : 0.f;
-          v1 = (token0 + 2 * w + 1 < L) ? v1 : 0.f;
+        if constexpr (MASK) {
+          if (last) {  // tokens past the context may hold stale/NaN bytes: zero them (ref :420-430)
+            v0 = (token0 + 2 * w < L) ? v0 : 0.f;
+            v1 = (token0 + 2 * w + 1 < L) ? v1 : 0.f;
+          }
         }
         s[w] = bf_round(pf[2 * w] * v0) + bf_round(pf[2 * w + 1] * v1);
       }
       return ((s[0] + s[1]) + s[2]) + s[3];
     } else {
       h16x8 v = __builtin_bit_cast(h16x8, vraw);
-      if (last) {
+      if constexpr (MASK) {
+        if (last) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (token0 + e < L) ? v[e] : (h16)0.f;
+          for (int e = 0; e < 8; ++e) v[e] = (token0 + e < L) ? v[e] : (h16)0.f;
+        }
       }
       const h16x8 pr = ph * v;  // 4 x v_pk_mul_f16, each product rounded to fp16
       h16x2 c = h16x2{pr[0], pr[1]} + h16x2{pr[2], pr[3]};
@@ -393,7 +401,10 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   const int hf = lane % UPR;   // which 8-token group of the block this lane owns
   const int rowl = lane / UPR;  // dim row within a load
 
-  auto compute_v = [&](u32x4(&r)[U][NL], int g) {
+  // `masked` is a compile-time tag: only the LAST page group of a wave can contain the sequence's last
+  // block, so only that call site compiles the tail masking in.
+  auto compute_v = [&](auto masked, u32x4(&r)[U][NL], int g) {
+    constexpr bool MASK = decltype(masked)::value;
     if constexpr (LOADS_ONLY) {
 #pragma unroll
       for (int j = 0; j < U; ++j)
@@ -413,7 +424,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         pv.set(e0, e1, inv_sum);
         const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
 #pragma unroll
-        for (int i = 0; i < NL; ++i) acc[i] += pv.dot(r[j][i], last, token0, L);
+        for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
       }
     }
   };
@@ -422,11 +433,15 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
       load_group(rb, vbase, g + 1);
-      compute_v(ra, g);
-      if (g + 2 < ngroups) load_group(ra, vbase, g + 2);
-      compute_v(rb, g + 1);
+      compute_v(std::false_type{}, ra, g);
+      if (g + 2 < ngroups) {
+        load_group(ra, vbase, g + 2);
+        compute_v(std::false_type{}, rb, g + 1);
+      } else {
+        compute_v(std::true_type{}, rb, g + 1);  // final group of an even count
+      }
     }
-    if (g < ngroups) compute_v(ra, g);
+    if (g < ngroups) compute_v(std::true_type{}, ra, g);  // final group of an odd count
   }
 
   if constexpr (LOADS_ONLY) {
@@ -625,7 +640,8 @@ __global__ void __launch_bounds__(HPW * 64)
     for (int i = 0; i < NL; ++i) acc[hh][i] = 0.f;
   const int hf = lane & 1;
 
-  auto compute_v = [&](u32x4(&r)[U][HPT][NL], int g) {
+  auto compute_v = [&](auto masked, u32x4(&r)[U][HPT][NL], int g) {
+    constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const int b = g * U + j;
@@ -642,7 +658,7 @@ __global__ void __launch_bounds__(HPW * 64)
             PV8<BF> pv;
             pv.set(e0, e1, is);
 #pragma unroll
-            for (int i = 0; i < NL; ++i) acc[hh][i] += pv.dot(r[j][hh][i], last, token0, L);
+            for (int i = 0; i < NL; ++i) acc[hh][i] += pv.template dot<MASK>(r[j][hh][i], last, token0, L);
           }
         }
       }
@@ -652,11 +668,15 @@ __global__ void __launch_bounds__(HPW * 64)
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
       load_group(rb, p.vc, g + 1);
-      compute_v(ra, g);
-      if (g + 2 < ngroups) load_group(ra, p.vc, g + 2);
-      compute_v(rb, g + 1);
+      compute_v(std::false_type{}, ra, g);
+      if (g + 2 < ngroups) {
+        load_group(ra, p.vc, g + 2);
+        compute_v(std::false_type{}, rb, g + 1);
+      } else {
+        compute_v(std::true_type{}, rb, g + 1);
+      }
     }
-    if (g < ngroups) compute_v(ra, g);
+    if (g < ngroups) compute_v(std::true_type{}, ra, g);
   }
 
 #pragma unroll
