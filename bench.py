@@ -301,22 +301,23 @@ def main():
                 ms = statistics.median(a.elapsed_time(b) for a, b in evs)
                 res.append({"nt": nt, "blocks": blocks, "bytes": nbytes, "us": ms * 1e3, "gbps": nbytes / (ms * 1e-3) / 1e9})
                 print(json.dumps(res[-1]), file=sys.stderr, flush=True)
-        # gather reads: contiguous chunk size as the variable (3072 waves = 768 blocks of 256, like cfg3)
-        for nt in (1,):
-            for blocks in (768, 1536):
-                for kb in (1, 2, 4, 8, 16, 32, 64):
+        # gather reads: contiguous chunk size x KiB in flight per wave x waves (768 blocks of 256 = 3072 waves = cfg3)
+        for blocks in (768, 384, 192):
+            for kb in (2, 4, 8, 16):
+                for infl in (1, 2, 4, 8, 16):
                     evs = []
-                    for i in range(24):
+                    for i in range(16):
                         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         s_ = wl.value_cache if i % 2 else wl.key_cache
                         a.record()
-                        rc = lib.vmi_diag_gather_read(s_.data_ptr(), nbytes, sink.data_ptr(), kb, blocks, nt, local_rank, stream)
+                        rc = lib.vmi_diag_gather_read(s_.data_ptr(), nbytes, sink.data_ptr(), kb, infl, blocks, 1, local_rank, stream)
                         b.record()
                         assert rc == 0, _lib.last_error()
                         evs.append((a, b))
                     torch.cuda.synchronize(dev)
                     ms = statistics.median(a.elapsed_time(b) for a, b in evs[4:])
-                    res.append({"kind": "gather", "chunk_kb": kb, "nt": nt, "blocks": blocks, "bytes": nbytes,
+                    res.append({"kind": "gather", "chunk_kb": kb, "inflight_kb_per_wave": infl, "waves": blocks * 4,
+                                "inflight_kb_per_cu": infl * blocks * 4 / 256, "bytes": nbytes,
                                 "us": ms * 1e3, "gbps": nbytes / (ms * 1e-3) / 1e9})
                     print(json.dumps(res[-1]), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
@@ -392,7 +393,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "kernel": "pa_v1_mh_kernel" if "_mh" in vname else "pa_v1_kernel",
+            "kernel": "pa_v1_kernel",
             "algorithmic_bytes_per_launch": cfg.algorithmic_bytes(),
         },
     }

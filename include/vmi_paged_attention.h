@@ -231,11 +231,12 @@ int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blo
 
 /*
  * Diagnostic: read `bytes` from `src` as pseudo-randomly ordered contiguous chunks of chunk_kb KiB
- * (1..64, power of two), one chunk stream per wave, 8 KiB in flight per wave — the attention kernel's
- * access pattern without the math, with the contiguous-chunk size as the variable.
+ * (1..64, power of two), one chunk stream per wave, inflight_kb KiB (1,2,4,8,16) requested per wave before
+ * anything is consumed — the attention kernel's access pattern without the math, with the contiguous-chunk
+ * size and the queue depth as the variables.
  */
-int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chunk_kb, int32_t blocks,
-                         int32_t nt, int32_t device, void* stream);
+int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chunk_kb, int32_t inflight_kb,
+                         int32_t blocks, int32_t nt, int32_t device, void* stream);
 
 #ifdef __cplusplus
 }

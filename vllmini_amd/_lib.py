@@ -46,7 +46,7 @@ SIGNATURES = {
                                                       _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _c_void_p]),
     "vmi_copy_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _i32, _c_void_p, _i32, _i64, _i32, _c_void_p]),
     "vmi_swap_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i32, _i64, _i32, _i32, _c_void_p]),
-    "vmi_diag_gather_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "vmi_diag_gather_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _i32, _i32, _c_void_p]),
     "vmi_diag_stream_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "vmi_reshape_and_cache_f16": (ctypes.c_int, [
         _c_void_p, _c_void_p, _c_void_p, _c_void_p,  # key, value, key_cache, value_cache

@@ -168,28 +168,32 @@ struct PAParams {
 };
 
 // ----------------------------------------------------------------------------------------
-// paged_attention_v1
+// paged_attention_v1 / the partition kernel of paged_attention_v2
 //
-//   D    head size (64 | 128)
-//   HPW  heads per workgroup   (each head owns WPH waves)
-//   WPH  waves per head        (blocks of one (seq, head) are dealt round-robin to them)
-//   U    blocks per register group (software-pipeline depth = 2 groups)
-//   NT   non-temporal page loads
+//   D     head size (any multiple of 8; the reference set is 64..256)
+//   HPW   head SLOTS per workgroup        (each slot owns WPH waves)
+//   WPH   waves per slot                  (the blocks of a slot are dealt round-robin to them)
+//   HPT   ADJACENT heads per slot/wave    (a wave reads the HPT tiles of a block as one contiguous
+//                                          HPT*D*BS*2-byte chunk: bigger chunks are served faster by HBM)
+//   U     blocks per register group       (group g+1 is in flight while group g is consumed)
+//   NT    non-temporal page loads
+//   PART  split-KV form behind paged_attention_v2 (reference attention_kernels.cu:529-562: the same
+//         kernel body with PARTITION_SIZE = 512): blockIdx.z selects a 512-token partition, the
+//         partition's normalised output goes to tmp_out and its (max, exp_sum) to max_logits / exp_sums
+//   BS    block size 8 | 16 | 32;  BF  bfloat16 instead of float16 elements
+//   LOCK  the waves of a workgroup issue each page group together (one s_barrier per group): with
+//         WPH = 1 they own adjacent head slots, so HBM sees one HPW*HPT-tile burst per block
 //
-// grid = (ceil(num_heads / HPW), num_seqs), block = HPW*WPH*64.
-// LDS  = HPW*lpad*4 (logits)  +  HPW*2*WPH*4 (max/sum exchange)  +  HPW*WPH*D*4 (partial out)
-// ----------------------------------------------------------------------------------------
-//
-// PART = true is the split-KV form behind paged_attention_v2 (reference attention_kernels.cu:529-562:
-// the same kernel body with PARTITION_SIZE = 512): blockIdx.z selects a 512-token partition, the
-// partition's normalised output goes to tmp_out and its (max, exp_sum) to max_logits / exp_sums.
-//
-// BS (block size 8 | 16 | 32) and D (any multiple of 8) generalise the lane maps:
+// Lane maps (BS and D general):
 //   K tile = D/8 chunks x BS tokens of 16 B; a load covers 64/BS chunks; lane = chunk*BS + token
 //   V tile = D rows x BS/8 units of 16 B;   a load covers 512/BS rows;  lane = row*(BS/8) + unit
-// When D*BS/8 is not a multiple of 64 (head 80/112, ...) the last load of a tile is predicated.
+//   when D*BS/8 is not a multiple of 64 (head 80/112, ...) the last load of a tile is predicated.
+//
+// grid = (ceil(H / (HPW*HPT)), num_seqs[, partitions]), block = HPW*WPH*64.
+// LDS  = HPW*HPT * ( lpad*4 (logits) + 2*WPH*4 (max/sum exchange) + WPH*D*4 (partial out) ).
+// ----------------------------------------------------------------------------------------
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
-          bool LOCK = false, bool BF = false>
+          bool LOCK = false, bool BF = false, int HPT = 1>
 __global__ void __launch_bounds__(HPW* WPH * 64)
     pa_v1_kernel(const PAParams p) {
   constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
@@ -202,17 +206,22 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   static_assert(D % 8 == 0, "head size must be a multiple of 8");
   static_assert(BS == 8 || BS == 16 || BS == 32, "block size 8, 16 or 32");
   static_assert(64 % U == 0, "U must divide 64");
+  static_assert(!(LOCK && WPH > 1), "lockstep needs every wave to run the same number of page groups");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hl = wave / WPH;
-  const int sub = wave % WPH;
+  const int hl = wave / WPH;   // head slot
+  const int sub = wave % WPH;  // wave within the slot
   const int seq = blockIdx.y;
-  const int head = blockIdx.x * HPW + hl;
-  if (WPH == 1 && head >= p.num_heads) return;  // host guarantees H % HPW == 0 when WPH > 1
+  const int head0 = (blockIdx.x * HPW + hl) * HPT;
+  // valid heads of this slot (wave-uniform).  With WPH > 1 the host guarantees H % (HPW*HPT) == 0, so every
+  // wave reaches every barrier; with WPH == 1 there are no barriers except LOCK's, which ignores ended waves.
+  const int nh = (p.num_heads - head0) < HPT ? (p.num_heads - head0) : HPT;
+  if (WPH == 1 && nh <= 0) return;
+  auto valid = [&](int hh) { return HPT == 1 || hh < nh; };
 
   // The first 64 block-table entries of this wave are requested BEFORE seq_len is known (any entry
   // inside the row is readable; entries past the context are simply never used), so the table,
@@ -234,40 +243,47 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   const int tok_lo = blk_lo * BS;        // logits in LDS are indexed relative to the range start (:133)
   const int Lloc = (L < blk_hi * BS ? L : blk_hi * BS) - tok_lo;              // tokens in range (:134-136)
 
-  float* logits = reinterpret_cast<float*>(smem) + (size_t)hl * p.lpad;
-  float* red = reinterpret_cast<float*>(smem) + (size_t)HPW * p.lpad + hl * 2 * WPH;
-  float* osm = reinterpret_cast<float*>(smem) + (size_t)HPW * p.lpad + HPW * 2 * WPH +
-               (size_t)hl * WPH * D;
+  float* smem_f = reinterpret_cast<float*>(smem);
+  float* logits0 = smem_f + (size_t)(hl * HPT) * p.lpad;                                    // + hh*lpad
+  float* red0 = smem_f + (size_t)HPW * HPT * p.lpad + (hl * HPT) * 2 * WPH;                 // + hh*2*WPH
+  float* osm0 = smem_f + (size_t)HPW * HPT * p.lpad + HPW * HPT * 2 * WPH + (size_t)(hl * HPT) * WPH * D;
 
-  uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) +
-                   (PART ? (((int64_t)seq * p.num_heads + head) * p.max_num_partitions + part) * D
-                         : ((int64_t)seq * p.num_heads + head) * D);
+  const int64_t ostride = PART ? (int64_t)p.max_num_partitions * D : D;  // out elements between heads
+  uint16_t* out0 = reinterpret_cast<uint16_t*>(p.out) +
+                   (PART ? (((int64_t)seq * p.num_heads + head0) * p.max_num_partitions + part) * D
+                         : ((int64_t)seq * p.num_heads + head0) * D);
 
   if (L <= 0) {  // uniform over the workgroup (same seq): reference yields exp_sum = 0 -> out = 0
     if (sub == 0) {
-      for (int d = lane; d < D; d += 64) outp[d] = 0;  // +0.0 in fp16 and in bf16
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh)
+        if (valid(hh))
+          for (int d = lane; d < D; d += 64) out0[hh * ostride + d] = 0;  // +0.0 in fp16 and in bf16
     }
     return;
   }
 
-  const int kvh = head / (p.num_heads / p.num_kv_heads);
-  const float slope = p.alibi ? p.alibi[head] : 0.f;
-
-  // ---- q: this lane's 8-dim chunks, one per K load -------------------------------------
-  const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
+  // ---- per head: tile offset inside a block, ALiBi slope, this lane's q chunks (one per K load) ----
   const int c4 = lane / BS;  // chunk-within-load
   const int tk = lane % BS;  // token-within-block
   const bool tail_ok = (TAIL == 64) || lane < TAIL;  // this lane takes part in the last load of a tile
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  u32x4 qreg[NL];
+  const int qpk = p.num_heads / p.num_kv_heads;
+  int64_t hoff[HPT];
+  float slope[HPT];
+  u32x4 qreg[HPT][NL];
 #pragma unroll
-  for (int i = 0; i < NL; ++i)
-    qreg[i] = (i < NL - 1 || tail_ok) ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8) : zero4;
+  for (int hh = 0; hh < HPT; ++hh) {
+    const int head = head0 + (valid(hh) ? hh : 0);
+    hoff[hh] = (int64_t)(head / qpk) * p.kv_head_stride + lane * 8;
+    slope[hh] = p.alibi ? p.alibi[head] : 0.f;
+    const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      qreg[hh][i] = (i < NL - 1 || tail_ok) ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8) : zero4;
+  }
 
-  const h16* kbase = p.kc + (int64_t)kvh * p.kv_head_stride + lane * 8;
-  const h16* vbase = p.vc + (int64_t)kvh * p.kv_head_stride + lane * 8;
-
-  // ---- my share of the blocks: b = sub + idx*WPH, idx in [0, nmy) -----------------------
+  // ---- my share of the blocks: b = blk_lo + sub + idx*WPH, idx in [0, nmy) ----------------
   const int nmy = nblk > sub ? (nblk - sub + WPH - 1) / WPH : 0;
   const int ngroups = (nmy + U - 1) / U;
   auto table_for = [&](int g) {  // lane j: physical id of my block (bt_sg*64 + j)
@@ -279,12 +295,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     }
   };
 
-  auto load_group = [&](u32x4(&r)[U][NL], const h16* base, int g) {
-    // LOCK: the waves of this workgroup own ADJACENT heads of one sequence, whose tiles are contiguous
-    // in the cache (HPW * tile bytes per block).  Issuing their page loads in lockstep turns HPW
-    // separate 2-KiB reads into one HPW*2-KiB burst per block, which HBM serves measurably faster
-    // (gather microbenchmark: 2 KiB chunks 6.36 TB/s, 8 KiB 6.67, 16 KiB 6.8).  All waves of the
-    // workgroup run the same number of groups (same sequence), so the barrier count matches.
+  auto load_group = [&](u32x4(&r)[U][HPT][NL], const h16* cache, int g) {
     if constexpr (LOCK) __builtin_amdgcn_s_barrier();
     table_for(g);
 #pragma unroll
@@ -294,307 +305,59 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
       // (sc0/sc1 cache-policy bits and buffer- vs flat-addressed loads were measured neutral on
       //  this stream; only `nt` pays: profiles/r01_cfg3_sweep_cache_policy_bits.json)
-      {
-        const h16* ptr = base + phys * p.kv_block_stride;
+      const h16* blk = cache + phys * p.kv_block_stride;
 #pragma unroll
-        for (int i = 0; i < NL; ++i)
-          r[j][i] = (i < NL - 1 || tail_ok) ? ld16<NT>(ptr + i * 512) : zero4;  // masked lanes add 0
+      for (int hh = 0; hh < HPT; ++hh) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)  // masked lanes / absent heads contribute zeros
+          r[j][hh][i] = (valid(hh) && (i < NL - 1 || tail_ok)) ? ld16<NT>(blk + hoff[hh] + i * 512) : zero4;
       }
     }
   };
 
   // =========================== K pass: logits -> LDS, running max ========================
-  float qk_max = -FLT_MAX;
-
-  uint32_t fold = 0;  // LOADS_ONLY diagnostic: xor of everything loaded
-  auto compute_k = [&](u32x4(&r)[U][NL], int g) {
-    if constexpr (LOADS_ONLY) {
-#pragma unroll
-      for (int j = 0; j < U; ++j)
-#pragma unroll
-        for (int i = 0; i < NL; ++i) fold ^= r[j][i][0] ^ r[j][i][1] ^ r[j][i][2] ^ r[j][i][3];
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int idx = g * U + j;
-      if (idx < nmy) {  // wave-uniform
-        const int b = blk_lo + sub + idx * WPH;
-        // q.k over this lane's 8*NL dims: fp16 operands converted to fp32, fp32 FMA chain
-        // (v_fma_mix_f32) — the reference's arithmetic (dtype_float16.cuh:292-298, 399-404).
-        // One accumulator per load keeps NL independent dependency chains in flight.
-        float accv[NL];
-#pragma unroll
-        for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[i], r[j][i]);
-        float acc = accv[0];
-#pragma unroll
-        for (int i = 1; i < NL; ++i) acc += accv[i];
-#pragma unroll
-        for (int m = BS; m < 64; m <<= 1) acc += __shfl_xor(acc, m);  // lanes holding the same token
-        const int token = b * BS + tk;
-        float qk = p.scale * acc;
-        qk += (slope != 0.f) ? slope * (float)(token - L + 1) : 0.f;
-        const bool masked = token >= L;
-        if (lane < BS) logits[token - tok_lo] = masked ? 0.f : qk;
-        qk_max = masked ? qk_max : fmaxf(qk_max, qk);
-      }
-    }
-  };
-
-  // Register double buffer over page groups: group g+1 is in flight while group g is consumed.
-  // (A third stage was measured and changed nothing; profiles/r01c_cfg3_variant_sweep.json.)
-  u32x4 ra[U][NL], rb[U][NL];
-  {
-    if (ngroups > 0) load_group(ra, kbase, 0);
-    int g = 0;
-    for (; g + 2 <= ngroups; g += 2) {
-      load_group(rb, kbase, g + 1);
-      compute_k(ra, g);
-      if (g + 2 < ngroups) load_group(ra, kbase, g + 2);
-      compute_k(rb, g + 1);
-    }
-    if (g < ngroups) compute_k(ra, g);
-  }
-
-  // first V group goes out now: HBM stays busy while the softmax runs
-  if (ngroups > 0) load_group(ra, vbase, 0);
-
-  // =========================== softmax over the logits in LDS ============================
-  qk_max = wave_max(qk_max);
-  if constexpr (WPH > 1) {
-    if (lane == 0) red[sub] = qk_max;
-    __syncthreads();
-    float m = -FLT_MAX;
-#pragma unroll
-    for (int w = 0; w < WPH; ++w) m = fmaxf(m, red[w]);
-    qk_max = m;
-  }
-
-  float exp_sum = 0.f;
-  for (int i = sub * 64 + lane; i < Lloc; i += WPH * 64) {
-    const float e = __expf(logits[i] - qk_max);
-    logits[i] = e;
-    exp_sum += e;
-  }
-  exp_sum = wave_sum(exp_sum);
-  if constexpr (WPH > 1) {
-    if (lane == 0) red[WPH + sub] = exp_sum;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < WPH; ++w) s += red[WPH + w];
-    exp_sum = s;
-  }
-  const float inv_sum = __builtin_amdgcn_rcpf(exp_sum + 1e-6f);
-  if constexpr (PART) {  // partition statistics for the reduce kernel (:349-357)
-    if (sub == 0 && lane == 0) {
-      const int64_t o = ((int64_t)seq * p.num_heads + head) * p.max_num_partitions + part;
-      p.max_logits[o] = qk_max;
-      p.exp_sums[o] = exp_sum;
-    }
-  }
-
-  // =========================== V pass ====================================================
-  float acc[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) acc[i] = 0.f;
-  const int hf = lane % UPR;   // which 8-token group of the block this lane owns
-  const int rowl = lane / UPR;  // dim row within a load
-
-  // `masked` is a compile-time tag: only the LAST page group of a wave can contain the sequence's last
-  // block, so only that call site compiles the tail masking in.
-  auto compute_v = [&](auto masked, u32x4(&r)[U][NL], int g) {
-    constexpr bool MASK = decltype(masked)::value;
-    if constexpr (LOADS_ONLY) {
-#pragma unroll
-      for (int j = 0; j < U; ++j)
-#pragma unroll
-        for (int i = 0; i < NL; ++i) fold ^= r[j][i][0] ^ r[j][i][1] ^ r[j][i][2] ^ r[j][i][3];
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int idx = g * U + j;
-      if (idx < nmy) {  // wave-uniform
-        const int b = blk_lo + sub + idx * WPH;
-        const int token0 = b * BS + hf * 8;
-        const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(logits + token0 - tok_lo);
-        const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(logits + token0 - tok_lo + 4);
-        PV8<BF> pv;
-        pv.set(e0, e1, inv_sum);
-        const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
-#pragma unroll
-        for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
-      }
-    }
-  };
-
-  {
-    int g = 0;
-    for (; g + 2 <= ngroups; g += 2) {
-      load_group(rb, vbase, g + 1);
-      compute_v(std::false_type{}, ra, g);
-      if (g + 2 < ngroups) {
-        load_group(ra, vbase, g + 2);
-        compute_v(std::false_type{}, rb, g + 1);
-      } else {
-        compute_v(std::true_type{}, rb, g + 1);  // final group of an even count
-      }
-    }
-    if (g < ngroups) compute_v(std::true_type{}, ra, g);  // final group of an odd count
-  }
-
-  if constexpr (LOADS_ONLY) {
-    if (fold == 0x9e3779b9u) outp[lane] = 1;  // practically never; keeps the loads live
-    return;
-  }
-
-  // the UPR lanes of a row hold its 8-token groups
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-#pragma unroll
-    for (int m = 1; m < UPR; m <<= 1) acc[i] += __shfl_xor(acc[i], m);
-  }
-
-  if constexpr (WPH > 1) {
-    if (hf == 0) {
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const int row = RPL * i + rowl;
-        if (row < D) osm[sub * D + row] = acc[i];
-      }
-    }
-    __syncthreads();
-    if (sub == 0) {
-      for (int d = lane; d < D; d += 64) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < WPH; ++w) s += osm[w * D + d];
-        outp[d] = to_elem<BF>(s);
-      }
-    }
-  } else {
-    if (hf == 0) {
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const int row = RPL * i + rowl;
-        if (row < D) outp[row] = to_elem<BF>(acc[i]);
-      }
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------------------
-// paged_attention_v1, "multi-head wave" form for large batches (block size 16, D % 32 == 0):
-// ONE wavefront owns HPT ADJACENT heads of one sequence.  In the reference layout the tiles of
-// adjacent heads of a block are contiguous, so the wave's page reads become HPT*D*32-byte
-// contiguous chunks (8 KiB at D=64, HPT=4) instead of 2-KiB ones; HBM serves bigger chunks
-// faster (profiles/: gather microbenchmark 2 KiB 6.36 TB/s, 8 KiB 6.67, 16 KiB 6.8).  With LOCK
-// the HPW waves of a workgroup (HPW*HPT adjacent heads) additionally issue in lockstep.
-// Arithmetic per head is exactly that of pa_v1_kernel (same rounding points).
-// grid = (ceil(H / (HPW*HPT)), num_seqs), block = HPW*64, LDS = HPW*HPT*lpad*4.
-// ----------------------------------------------------------------------------------------
-template <int D, int HPW, int HPT, int U, bool NT, bool LOCK, bool BF = false>
-__global__ void __launch_bounds__(HPW * 64)
-    pa_v1_mh_kernel(const PAParams p) {
-  constexpr int BS = 16;
-  constexpr int NL = D / 32;
-  static_assert(D % 32 == 0 && 64 % U == 0, "multi-head kernel: D multiple of 32, U divides 64");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int hl = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int seq = blockIdx.y;
-  const int head0 = (blockIdx.x * HPW + hl) * HPT;
-  const int nh = (p.num_heads - head0) < HPT ? (p.num_heads - head0) : HPT;  // wave-uniform
-  if (nh <= 0) return;  // a terminated wave does not take part in s_barrier
-
-  const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
-  int bt_sg = 0;
-  int32_t bt_reg = (lane < p.max_blocks_per_seq) ? bt[lane] : 0;
-
-  int L = p.seq_lens[seq];
-  L = L > p.lpad ? p.lpad : L;
-  const int nblk = (L + BS - 1) / BS;
-  const int ngroups = (nblk + U - 1) / U;
-  float* logits0 = reinterpret_cast<float*>(smem) + (size_t)hl * HPT * p.lpad;
-  uint16_t* out0 = reinterpret_cast<uint16_t*>(p.out) + ((int64_t)seq * p.num_heads + head0) * D;
-
-  if (L <= 0) {
-    for (int hh = 0; hh < nh; ++hh)
-      for (int d = lane; d < D; d += 64) out0[hh * D + d] = 0;
-    return;
-  }
-
-  const int c4 = lane >> 4;
-  const int tk = lane & 15;
-  const int qpk = p.num_heads / p.num_kv_heads;
-  int64_t hoff[HPT];  // element offset of each head's tile inside a block
-  float slope[HPT];
-  u32x4 qreg[HPT][NL];
-#pragma unroll
-  for (int hh = 0; hh < HPT; ++hh) {
-    const int head = head0 + (hh < nh ? hh : 0);
-    hoff[hh] = (int64_t)(head / qpk) * p.kv_head_stride + lane * 8;
-    slope[hh] = p.alibi ? p.alibi[head] : 0.f;
-    const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) qreg[hh][i] = *reinterpret_cast<const u32x4*>(qp + (4 * i + c4) * 8);
-  }
-
-  auto table_for = [&](int g) {
-    const int sg = (g * U) >> 6;
-    if (sg != bt_sg) {
-      const int b = sg * 64 + lane;
-      bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
-      bt_sg = sg;
-    }
-  };
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  auto load_group = [&](u32x4(&r)[U][HPT][NL], const h16* cache, int g) {
-    if constexpr (LOCK) __builtin_amdgcn_s_barrier();
-    table_for(g);
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      int idx = g * U + j;
-      idx = idx < nblk ? idx : nblk - 1;
-      const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
-      const h16* blk = cache + phys * p.kv_block_stride;
-#pragma unroll
-      for (int hh = 0; hh < HPT; ++hh) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i)
-          r[j][hh][i] = (hh < nh) ? ld16<NT>(blk + hoff[hh] + i * 512) : zero4;
-      }
-    }
-  };
-
   float qk_max[HPT];
 #pragma unroll
   for (int hh = 0; hh < HPT; ++hh) qk_max[hh] = -FLT_MAX;
 
+  uint32_t fold = 0;  // LOADS_ONLY diagnostic: xor of everything loaded
+  auto fold_all = [&](u32x4(&r)[U][HPT][NL]) {
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) fold ^= r[j][hh][i][0] ^ r[j][hh][i][1] ^ r[j][hh][i][2] ^ r[j][hh][i][3];
+  };
   auto compute_k = [&](u32x4(&r)[U][HPT][NL], int g) {
+    if constexpr (LOADS_ONLY) {
+      fold_all(r);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const int b = g * U + j;
-      if (b < nblk) {
+      const int idx = g * U + j;
+      if (idx < nmy) {  // wave-uniform
+        const int b = blk_lo + sub + idx * WPH;
         const int token = b * BS + tk;
         const bool masked = token >= L;
 #pragma unroll
         for (int hh = 0; hh < HPT; ++hh) {
-          if (hh < nh) {
+          if (valid(hh)) {
+            // q.k over this lane's 8*NL dims: operands widened to fp32, fp32 FMA chain (v_fma_mix_f32 for
+            // fp16) — the reference's arithmetic (dtype_float16.cuh:292-298, 399-404).  One accumulator
+            // per load keeps NL independent dependency chains in flight.
             float accv[NL];
 #pragma unroll
             for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[hh][i], r[j][hh][i]);
             float acc = accv[0];
 #pragma unroll
             for (int i = 1; i < NL; ++i) acc += accv[i];
-            acc += __shfl_xor(acc, 16);
-            acc += __shfl_xor(acc, 32);
+#pragma unroll
+            for (int m = BS; m < 64; m <<= 1) acc += __shfl_xor(acc, m);  // lanes holding the same token
             float qk = p.scale * acc;
             qk += (slope[hh] != 0.f) ? slope[hh] * (float)(token - L + 1) : 0.f;
-            if (lane < 16) logits0[hh * p.lpad + token] = masked ? 0.f : qk;
+            if (lane < BS) logits0[hh * p.lpad + token - tok_lo] = masked ? 0.f : qk;
             qk_max[hh] = masked ? qk_max[hh] : fmaxf(qk_max[hh], qk);
           }
         }
@@ -602,6 +365,8 @@ __global__ void __launch_bounds__(HPW * 64)
     }
   };
 
+  // Register double buffer over page groups: group g+1 is in flight while group g is consumed.
+  // (A third stage was measured and changed nothing; profiles/r01c_cfg3_variant_sweep.json.)
   u32x4 ra[U][HPT][NL], rb[U][HPT][NL];
   {
     if (ngroups > 0) load_group(ra, p.kc, 0);
@@ -614,49 +379,103 @@ __global__ void __launch_bounds__(HPW * 64)
     }
     if (g < ngroups) compute_k(ra, g);
   }
+
+  // first V group goes out now: HBM stays busy while the softmax runs
   if (ngroups > 0) load_group(ra, p.vc, 0);
 
+  // =========================== softmax over the logits in LDS ============================
   float inv_sum[HPT];
+  {
+    float m[HPT], es[HPT];
 #pragma unroll
-  for (int hh = 0; hh < HPT; ++hh) {
-    inv_sum[hh] = 0.f;
-    if (hh < nh) {
-      const float m = wave_max(qk_max[hh]);
-      float* lg = logits0 + hh * p.lpad;
-      float es = 0.f;
-      for (int i = lane; i < L; i += 64) {
-        const float e = __expf(lg[i] - m);
-        lg[i] = e;
-        es += e;
+    for (int hh = 0; hh < HPT; ++hh) {
+      m[hh] = wave_max(qk_max[hh]);
+      if constexpr (WPH > 1) {
+        if (lane == 0) red0[hh * 2 * WPH + sub] = m[hh];
       }
-      inv_sum[hh] = __builtin_amdgcn_rcpf(wave_sum(es) + 1e-6f);
+    }
+    if constexpr (WPH > 1) {
+      __syncthreads();  // also: every wave's logits are in LDS
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        float mm = -FLT_MAX;
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) mm = fmaxf(mm, red0[hh * 2 * WPH + w]);
+        m[hh] = mm;
+      }
+    }
+#pragma unroll
+    for (int hh = 0; hh < HPT; ++hh) {
+      es[hh] = 0.f;
+      if (valid(hh)) {
+        float* lg = logits0 + hh * p.lpad;
+        float e_sum = 0.f;
+        for (int i = sub * 64 + lane; i < Lloc; i += WPH * 64) {
+          const float e = __expf(lg[i] - m[hh]);
+          lg[i] = e;
+          e_sum += e;
+        }
+        es[hh] = wave_sum(e_sum);
+      }
+      if constexpr (WPH > 1) {
+        if (lane == 0) red0[hh * 2 * WPH + WPH + sub] = es[hh];
+      }
+    }
+    if constexpr (WPH > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        float ssum = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPH; ++w) ssum += red0[hh * 2 * WPH + WPH + w];
+        es[hh] = ssum;
+      }
+    }
+#pragma unroll
+    for (int hh = 0; hh < HPT; ++hh) {
+      inv_sum[hh] = __builtin_amdgcn_rcpf(es[hh] + 1e-6f);
+      if constexpr (PART) {  // partition statistics for the reduce kernel (:349-357)
+        if (valid(hh) && sub == 0 && lane == 0) {
+          const int64_t o = ((int64_t)seq * p.num_heads + head0 + hh) * p.max_num_partitions + part;
+          p.max_logits[o] = m[hh];
+          p.exp_sums[o] = es[hh];
+        }
+      }
     }
   }
 
+  // =========================== V pass ====================================================
   float acc[HPT][NL];
 #pragma unroll
   for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
     for (int i = 0; i < NL; ++i) acc[hh][i] = 0.f;
-  const int hf = lane & 1;
+  const int hf = lane % UPR;   // which 8-token group of the block this lane owns
+  const int rowl = lane / UPR;  // dim row within a load
 
+  // `masked` is a compile-time tag: only the LAST page group of a wave can contain the sequence's last
+  // block, so only that call site compiles the tail masking in.
   auto compute_v = [&](auto masked, u32x4(&r)[U][HPT][NL], int g) {
     constexpr bool MASK = decltype(masked)::value;
+    if constexpr (LOADS_ONLY) {
+      fold_all(r);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const int b = g * U + j;
-      if (b < nblk) {
+      const int idx = g * U + j;
+      if (idx < nmy) {  // wave-uniform
+        const int b = blk_lo + sub + idx * WPH;
         const int token0 = b * BS + hf * 8;
-        const bool last = (b == nblk - 1);
+        const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
 #pragma unroll
         for (int hh = 0; hh < HPT; ++hh) {
-          if (hh < nh) {
-            const float* lg = logits0 + hh * p.lpad + token0;
+          if (valid(hh)) {
+            const float* lg = logits0 + hh * p.lpad + token0 - tok_lo;
             const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(lg);
             const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(lg + 4);
-            const float is = inv_sum[hh];
             PV8<BF> pv;
-            pv.set(e0, e1, is);
+            pv.set(e0, e1, inv_sum[hh]);
 #pragma unroll
             for (int i = 0; i < NL; ++i) acc[hh][i] += pv.template dot<MASK>(r[j][hh][i], last, token0, L);
           }
@@ -664,6 +483,7 @@ __global__ void __launch_bounds__(HPW * 64)
       }
     }
   };
+
   {
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
@@ -673,19 +493,63 @@ __global__ void __launch_bounds__(HPW * 64)
         load_group(ra, p.vc, g + 2);
         compute_v(std::false_type{}, rb, g + 1);
       } else {
-        compute_v(std::true_type{}, rb, g + 1);
+        compute_v(std::true_type{}, rb, g + 1);  // final group of an even count
       }
     }
-    if (g < ngroups) compute_v(std::true_type{}, ra, g);
+    if (g < ngroups) compute_v(std::true_type{}, ra, g);  // final group of an odd count
   }
 
+  if constexpr (LOADS_ONLY) {
+    if (fold == 0x9e3779b9u) out0[lane] = 1;  // practically never; keeps the loads live
+    return;
+  }
+
+  // the UPR lanes of a row hold its 8-token groups
 #pragma unroll
   for (int hh = 0; hh < HPT; ++hh) {
-    if (hh < nh) {
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const float a = acc[hh][i] + __shfl_xor(acc[hh][i], 1);
-        if (hf == 0) out0[hh * D + 32 * i + (lane >> 1)] = to_elem<BF>(a);
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int m = 1; m < UPR; m <<= 1) acc[hh][i] += __shfl_xor(acc[hh][i], m);
+    }
+  }
+
+  if constexpr (WPH > 1) {
+    if (hf == 0) {
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const int row = RPL * i + rowl;
+          if (row < D) osm0[(hh * WPH + sub) * D + row] = acc[hh][i];
+        }
+      }
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        if (valid(hh)) {
+          for (int d = lane; d < D; d += 64) {
+            float ssum = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPH; ++w) ssum += osm0[(hh * WPH + w) * D + d];
+            out0[hh * ostride + d] = to_elem<BF>(ssum);
+          }
+        }
+      }
+    }
+  } else {
+    if (hf == 0) {
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        if (valid(hh)) {
+#pragma unroll
+          for (int i = 0; i < NL; ++i) {
+            const int row = RPL * i + rowl;
+            if (row < D) out0[hh * ostride + row] = to_elem<BF>(acc[hh][i]);
+          }
+        }
       }
     }
   }

@@ -20,7 +20,7 @@ Variant g_bf16_variants_v1[] = {
     VMI_B1(128, 16, 4, 1, 1), VMI_B1(128, 16, 1, 1, 1), VMI_B1(128, 16, 1, 2, 1), VMI_B1(128, 16, 1, 4, 1),
     VMI_B1(128, 16, 1, 8, 1), VMI_B1(128, 16, 1, 16, 1), VMI_B1(128, 16, 1, 4, 2),
     {"bf16_d128_mh4_h4_u1_nt1_lock", 128, 16, 4, 1, 1, true, 4, true,
-     (pa_kernel_t)pa_v1_mh_kernel<128, 4, 4, 1, true, true, true>, 0},
+     (pa_kernel_t)pa_v1_kernel<128, 4, 1, 1, true, false, false, 16, true, true, 4>, 0},
     // the rest of the dispatch set
     VMI_B1(64, 8, 1, 1, 8), VMI_B1(64, 8, 1, 4, 8),
     VMI_B1(64, 32, 1, 1, 2), VMI_B1(64, 32, 1, 4, 2),

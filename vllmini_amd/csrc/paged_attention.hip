@@ -229,46 +229,34 @@ __global__ void __launch_bounds__(256) stream_read_kernel(const u32x4* __restric
 }
 
 // diagnostic: read the buffer as pseudo-randomly ordered contiguous chunks of CHUNK_KB KiB, one
-// chunk stream per wave, 8 KiB in flight per wave (the attention kernel's pattern with the math
-// removed and the chunk size made a parameter).
-template <int CHUNK_KB, bool NT>
+// chunk stream per wave, with INFLIGHT_KB KiB requested per wave before anything is consumed (the
+// attention kernel's pattern with the math removed; chunk size and queue depth are the variables).
+template <int CHUNK_KB, int INFLIGHT_KB, bool NT>
 __global__ void __launch_bounds__(256) gather_read_kernel(const u32x4* __restrict__ src, uint32_t nchunks,
                                                           uint32_t stride, uint32_t* __restrict__ sink) {
-  constexpr int G = CHUNK_KB >= 8 ? 1 : 8 / CHUNK_KB;  // chunks per group -> 8 loads per group
-  constexpr int LPC = CHUNK_KB;                         // 1-KiB loads per chunk
+  constexpr int LPG = INFLIGHT_KB;                                   // 1-KiB loads per group
+  constexpr int CPG = INFLIGHT_KB >= CHUNK_KB ? INFLIGHT_KB / CHUNK_KB : 1;  // chunks per group
+  constexpr int LPC = CHUNK_KB < INFLIGHT_KB ? CHUNK_KB : INFLIGHT_KB;       // loads per chunk per group
+  constexpr int GPC = CHUNK_KB > INFLIGHT_KB ? CHUNK_KB / INFLIGHT_KB : 1;   // groups per chunk
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   const int lane = threadIdx.x & 63;
   u32x4 acc = {0u, 0u, 0u, 0u};
-  for (uint32_t i = wave * G; i < nchunks; i += nwaves * G) {
-    u32x4 r[G][LPC > 8 ? 8 : LPC];
+  for (uint32_t i = wave * CPG; i < nchunks; i += nwaves * CPG) {
+    for (int part = 0; part < GPC; ++part) {
+      u32x4 r[LPG];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const uint32_t c = (uint32_t)(((uint64_t)(i + g) * stride) % nchunks);  // stride coprime with nchunks
-      const u32x4* base = src + (size_t)c * (CHUNK_KB * 64) + lane;
+      for (int g = 0; g < CPG; ++g) {
+        const uint32_t c = (uint32_t)(((uint64_t)(i + g) * stride) % nchunks);  // stride coprime with nchunks
+        const u32x4* base = src + (size_t)c * (CHUNK_KB * 64) + (size_t)part * LPC * 64 + lane;
 #pragma unroll
-      for (int l = 0; l < (LPC > 8 ? 8 : LPC); ++l) {
-        if constexpr (NT) r[g][l] = __builtin_nontemporal_load(base + l * 64);
-        else r[g][l] = base[l * 64];
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int l = 0; l < (LPC > 8 ? 8 : LPC); ++l) acc ^= r[g][l];
-    if constexpr (LPC > 8) {  // chunks above 8 KiB: remaining loads in 8-load batches
-      const uint32_t c = (uint32_t)(((uint64_t)i * stride) % nchunks);
-      const u32x4* base = src + (size_t)c * (CHUNK_KB * 64) + lane;
-      for (int l0 = 8; l0 < LPC; l0 += 8) {
-        u32x4 q[8];
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-          if constexpr (NT) q[l] = __builtin_nontemporal_load(base + (l0 + l) * 64);
-          else q[l] = base[(l0 + l) * 64];
+        for (int l = 0; l < LPC; ++l) {
+          if constexpr (NT) r[g * LPC + l] = __builtin_nontemporal_load(base + l * 64);
+          else r[g * LPC + l] = base[l * 64];
         }
-#pragma unroll
-        for (int l = 0; l < 8; ++l) acc ^= q[l];
       }
+#pragma unroll
+      for (int l = 0; l < LPG; ++l) acc ^= r[l];
     }
   }
   const uint32_t x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
@@ -315,7 +303,9 @@ static Variant g_variants[] = {
 #define VMI_LOCK(D, HPW, U) {"d" #D "_h" #HPW "_w1_u" #U "_nt1_lock", D, 16, HPW, 1, U, true, 1, false, \
      (pa_kernel_t)pa_v1_kernel<D, HPW, 1, U, true, false, false, 16, true>, 0}
 #define VMI_MH(D, HPW, HPT, U, LOCK, SUF) {"d" #D "_mh" #HPT "_h" #HPW "_u" #U "_nt1" SUF, D, 16, HPW, 1, U, true, HPT, false, \
-     (pa_kernel_t)pa_v1_mh_kernel<D, HPW, HPT, U, true, LOCK>, 0}
+     (pa_kernel_t)pa_v1_kernel<D, HPW, 1, U, true, false, false, 16, LOCK, false, HPT>, 0}
+#define VMI_MHW(D, HPW, WPH, HPT, U) {"d" #D "_mh" #HPT "_h" #HPW "_w" #WPH "_u" #U "_nt1", D, 16, HPW, WPH, U, true, HPT, false, \
+     (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, 16, false, false, HPT>, 0}
     VMI_LOCK(128, 8, 1), VMI_LOCK(128, 16, 1),
     VMI_MH(128, 4, 4, 1, true, "_lock"),    // the cfg4 kernel (16 | num_heads)
     VMI_MH(128, 8, 2, 1, true, "_lock"),
@@ -323,6 +313,10 @@ static Variant g_variants[] = {
     VMI_MH(64, 1, 2, 2, false, ""),         // D = 64 reference points (neutral there)
     VMI_MH(64, 3, 2, 2, true, "_lock"),
     VMI_LOCK(64, 6, 2),
+    // ---- D = 64: adjacent heads per wave AND several waves per slot (4-8 KiB chunks at 3072 waves).  Measured no
+    //      better than one head per wave, as were fat waves with deep groups: profiles/r01e_cfg3_multihead_sweep.json ----
+    VMI_MHW(64, 2, 2, 2, 1), VMI_MHW(64, 1, 2, 4, 1),
+#undef VMI_MHW
 #undef VMI_MH
 #undef VMI_LOCK
     // ---- diagnostics: same gather pattern, no math ("loads only"); wrong results by design ----
@@ -446,13 +440,12 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (v.D != head_size || v.BS != block_size)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s is for head size %d / block size %d, "
                 "got %d / %d", v.name, v.D, v.BS, head_size, block_size);
-  if (v.WPH > 1 && num_heads % v.HPW != 0)
+  if (v.WPH > 1 && num_heads % (v.HPW * v.HPT) != 0)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s needs num_heads %% %d == 0", v.name,
-                v.HPW);
+                v.HPW * v.HPT);
 
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
-  const size_t lds = (size_t)v.HPW * v.HPT * lpad * 4 + (size_t)v.HPW * 2 * v.WPH * 4 +
-                     (size_t)v.HPW * v.WPH * v.D * 4;
+  const size_t lds = (size_t)v.HPW * v.HPT * ((size_t)lpad * 4 + 2 * v.WPH * 4 + (size_t)v.WPH * v.D * 4);
   if (lds > 160 * 1024)
     return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v1: max_seq_len=%d needs %zu B of LDS per "
                 "workgroup (variant %s), limit 163840", max_seq_len, lds, v.name);
@@ -905,8 +898,8 @@ int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blo
   return VMI_OK;
 }
 
-int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chunk_kb, int32_t blocks,
-                         int32_t nt, int32_t device, void* stream) {
+int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chunk_kb, int32_t inflight_kb,
+                         int32_t blocks, int32_t nt, int32_t device, void* stream) {
   using namespace vmi;
   if (!src || !sink || bytes < 65536 || blocks <= 0) return fail(VMI_E_SHAPE, "diag_gather_read: bad args");
   DeviceGuard guard(device);
@@ -920,16 +913,18 @@ int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chu
   hipStream_t st = static_cast<hipStream_t>(stream);
   const u32x4* p = static_cast<const u32x4*>(src);
   uint32_t* sk = static_cast<uint32_t*>(sink);
-#define VMI_GR(KB)                                                                                   \
-  case KB:                                                                                           \
-    if (nt) hipLaunchKernelGGL((gather_read_kernel<KB, true>), dim3(blocks), dim3(256), 0, st, p, nchunks, stride, sk); \
-    else hipLaunchKernelGGL((gather_read_kernel<KB, false>), dim3(blocks), dim3(256), 0, st, p, nchunks, stride, sk);   \
-    break;
-  switch (chunk_kb) {
-    VMI_GR(1) VMI_GR(2) VMI_GR(4) VMI_GR(8) VMI_GR(16) VMI_GR(32) VMI_GR(64)
-    default: return fail(VMI_E_SHAPE, "diag_gather_read: chunk_kb must be 1,2,4,8,16,32,64");
+  bool ok = false;
+#define VMI_GR(KB, IF)                                                                                      \
+  if (chunk_kb == KB && inflight_kb == IF) {                                                                \
+    ok = true;                                                                                              \
+    if (nt) hipLaunchKernelGGL((gather_read_kernel<KB, IF, true>), dim3(blocks), dim3(256), 0, st, p, nchunks, stride, sk); \
+    else hipLaunchKernelGGL((gather_read_kernel<KB, IF, false>), dim3(blocks), dim3(256), 0, st, p, nchunks, stride, sk);   \
   }
+#define VMI_GR_ROW(KB) VMI_GR(KB, 1) VMI_GR(KB, 2) VMI_GR(KB, 4) VMI_GR(KB, 8) VMI_GR(KB, 16)
+  VMI_GR_ROW(1) VMI_GR_ROW(2) VMI_GR_ROW(4) VMI_GR_ROW(8) VMI_GR_ROW(16) VMI_GR_ROW(32) VMI_GR_ROW(64)
+#undef VMI_GR_ROW
 #undef VMI_GR
+  if (!ok) return fail(VMI_E_SHAPE, "diag_gather_read: chunk_kb in {1..64}, inflight_kb in {1,2,4,8,16} (powers of two)");
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "diag_gather_read launch");
   return VMI_OK;
