@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="override the config's batch (diagnostic sweeps)")
     ap.add_argument("--seq-len", type=int, default=0, help="override the config's seq_len (diagnostic sweeps)")
-    ap.add_argument("--op", default="v1", choices=["v1", "v2"],
+    ap.add_argument("--op", default="v1", choices=["v1", "v2", "fused"],
                     help="attention operator in the step: paged_attention_v1 (headline) or the split-KV paged_attention_v2")
     ap.add_argument("--variant", type=int, default=0, help="force a kernel work decomposition (0 = heuristic)")
     ap.add_argument("--sweep", action="store_true", help="time every kernel variant, write gpurun_out/sweep.json")
@@ -61,8 +61,12 @@ def parse_args():
     ap.add_argument("--e2e", action="store_true",
                     help="end-to-end GPT-2 small decode (12 layers, random weights) on the batched harness: "
                          "extra JSON line on stderr + gpurun_out/e2e.json")
+    ap.add_argument("--e2e-fused", action="store_true", help="e2e with one fused append+attention launch per layer")
     ap.add_argument("--e2e-context", type=int, default=1008, help="context length the e2e sequences start at")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-step measurement")
+    ap.add_argument("--skip-reshape", action="store_true",
+                    help="DIAGNOSTIC (invalid as a bench line): attention launches back to back, no reshape_and_cache")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--sequential-tables", action="store_true",
                     help="physically sequential pages instead of a random permutation (diagnostic)")
@@ -104,10 +108,15 @@ def init_dist(n_gpus: int):
 
 
 _V2_SCRATCH = {}
+SKIP_RESHAPE = False
 
 
 def attend(wl, out, t, variant, op="v1"):
     c = wl.cfg
+    if op == "fused":   # reshape_and_cache + paged_attention_v1 in one launch (extension, include/vmi_paged_attention.h)
+        ops.paged_attention_v1_append(out, wl.query, wl.key, wl.value, wl.key_cache, wl.value_cache, c.num_heads,
+                                      wl.scale, wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, _variant=variant)
+        return
     if op == "v1":
         ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
                                wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0,
@@ -128,7 +137,8 @@ def attend(wl, out, t, variant, op="v1"):
 def one_step(wl, out, i, variant, op="v1"):
     """The reference's per-layer decode call pair, in its call order (gpt2.py:44, :62)."""
     t = i % len(wl.tables)
-    cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
+    if op != "fused" and not SKIP_RESHAPE:
+        cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
     attend(wl, out, t, variant, op)
 
 
@@ -140,7 +150,8 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
 
     def timed(i):
         t = i % len(wl.tables)
-        cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
+        if op != "fused" and not SKIP_RESHAPE:
+            cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
         ev[i][0].record()  # HIP events on the launch stream (torch's current stream)
         attend(wl, out, t, variant, op)
         ev[i][1].record()
@@ -223,7 +234,7 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
     pool.free_blocks = perm.tolist()
     for s in range(cfg.batch):
         pool.allocate_for_prefill(s, ctx0)           # bookkeeping only: the pages already hold synthetic KV
-    dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool)
+    dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, fused_append=args.e2e_fused)
     ids = list(range(cfg.batch))
     tok = torch.randint(0, dims.vocab_size, (cfg.batch,), device=dev, generator=g)
 
@@ -238,11 +249,13 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "context": ctx0, "batch_per_gpu": cfg.batch,
            "data": "synthetic KV + random-init GPT-2 small weights", "dtype": "f16",
-           "note": "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy"}
+           "note": ("12 x (c_attn, paged_attention_v1_append [fused], c_proj, MLP) + lm_head, hipGraph replay, greedy"
+                    if args.e2e_fused else
+                    "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy")}
     if rank == 0:
         print(json.dumps(res), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(REPO, "gpurun_out", "e2e.json"), "w") as f:
+        with open(os.path.join(REPO, "gpurun_out", "e2e_fused.json" if args.e2e_fused else "e2e.json"), "w") as f:
             json.dump(res, f, indent=1)
 
 
@@ -348,6 +361,8 @@ def main():
                                                                            cfg.seq_len), "results": res}, f, indent=1)
         return
 
+    global SKIP_RESHAPE
+    SKIP_RESHAPE = args.skip_reshape
     elapsed, kern_ms = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op)
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     kern_mean_ms = shard.max_over_ranks(statistics.mean(kern_ms), dist, dev)
@@ -356,7 +371,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     achieved = cfg.algorithmic_bytes() / (kern_mean_ms * 1e-3) / 1e9
     vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len)
-    vname = ops.variant_names()[vid - 1] if args.op == "v1" else f"paged_attention_v2 variant {args.variant or 'auto'}"
+    vname = ops.variant_names()[vid - 1] if args.op in ("v1", "fused") else f"paged_attention_v2 variant {args.variant or 'auto'}"
     traffic, traffic_src = pmc_traffic(cfg.name, vname) if args.op == "v1" else (None, None)
     line = {
         "metric": "decode_tokens_per_sec_paged_attention_v1_per_layer",
@@ -376,7 +391,8 @@ def main():
                         f"seq_len {cfg.seq_len}, {cfg.num_heads} heads x {cfg.head_size}, block_size {cfg.block_size}, "
                         f"num_blocks {cfg.num_blocks}/GPU, fp16 KV, random-permutation block tables"
                         + (" (SEQUENTIAL tables)" if args.sequential_tables else "")
-                        + (" (ragged lens)" if args.ragged else ""),
+                        + (" (ragged lens)" if args.ragged else "")
+                        + (" (DIAGNOSTIC: reshape_and_cache skipped)" if args.skip_reshape else ""),
             "global_batch": cfg.batch * world,
             "seq_len": cfg.seq_len,
             "parallelism": f"dp{world} (independent KV pools, no data-path collective)",
@@ -397,6 +413,15 @@ def main():
             "algorithmic_bytes_per_launch": cfg.algorithmic_bytes(),
         },
     }
+    if args.op == "v1" and not args.no_fused:
+        # the same step as ONE launch (vmi_paged_attention_v1_append_f16: bit-identical caches and out,
+        # tests/test_parity_gpu.py); reported beside `value`, which stays the reference's two-op call pair
+        f_elapsed, f_kern = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op="fused")
+        f_elapsed = shard.max_over_ranks(f_elapsed, dist, dev)
+        line["fused_step"] = {"op": "paged_attention_v1_append (reshape_and_cache + paged_attention_v1, one launch)",
+                              "value": tokens / f_elapsed, "unit": "tokens/s",
+                              "ms_per_step": f_elapsed / args.steps * 1e3,
+                              "kernel_us_mean": statistics.mean(f_kern) * 1e3}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps)
     elif rank == 0:

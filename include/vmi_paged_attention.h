@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 3
+#define VMI_ABI_VERSION 4
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -136,6 +136,44 @@ int vmi_paged_attention_v2_bf16(
     const float* alibi_slopes,
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     int32_t device, void* stream, int32_t variant);
+
+/*
+ * Fused decode step: cache_ops.reshape_and_cache + paged_attention_v1 in ONE launch (extension; the reference
+ * issues the two ops back to back for every layer, vllmini/model/gpt2.py:87-112).
+ *
+ * key/value [num_seqs, num_kv_heads, head_size] (row strides key_stride/value_stride, elements) hold this step's
+ * token of every sequence.  Row i is stored at position seq_lens[i]-1 of sequence i, i.e. into slot
+ *   block_tables[i][(seq_lens[i]-1)/block_size]*block_size + (seq_lens[i]-1)%block_size
+ * — the slot the reference's block manager hands to reshape_and_cache for a decode step
+ * (vllmini/block_manager.py decode_step) — and the attention over positions 0..seq_lens[i]-1 takes that token
+ * from the rows themselves.  Caches and `out` end up bit-identical to
+ *   vmi_reshape_and_cache_f16(key, value, ..., slot_mapping = those slots) ; vmi_paged_attention_v1_f16(...)
+ * A sequence must own its last block (no two sequences append into one block; the reference never shares blocks).
+ * Rows with seq_lens[i] <= 0 append nothing.  key rows must be 16-byte aligned.  variant: 0 = heuristic.
+ * The first 20 arguments are those of vmi_paged_attention_v1_f16 (caches mutable here).
+ */
+int vmi_paged_attention_v1_append_f16(
+    void* out, const void* query, void* key_cache, void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream,
+    const void* key, const void* value, int64_t key_stride, int64_t value_stride,
+    int32_t variant);
+int vmi_paged_attention_v1_append_bf16(
+    void* out, const void* query, void* key_cache, void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream,
+    const void* key, const void* value, int64_t key_stride, int64_t value_stride,
+    int32_t variant);
 
 /* Number of tuning variants (valid ids are 1..count) and a short name for each. */
 int vmi_paged_attention_v1_variant_count(void);

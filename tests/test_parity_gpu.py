@@ -489,7 +489,7 @@ def test_errors_raise_runtimeerror():
 # ------------------------------------------------------------------------------------------------
 # the ops under their real caller: batched GPT-2 decode harness vs the REFERENCE model's logits
 # ------------------------------------------------------------------------------------------------
-def _tiny_gpt2(golden_dir, dev, max_seqs=8, off_by_one=True):
+def _tiny_gpt2(golden_dir, dev, max_seqs=8, off_by_one=True, fused=False):
     from vllmini_amd.gpt2_decode import GPT2Dims, GPT2PagedDecoder
     from vllmini_amd.kv_pool import PagedKVPool
 
@@ -500,7 +500,7 @@ def _tiny_gpt2(golden_dir, dev, max_seqs=8, off_by_one=True):
     sd = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("sd/")}
     pool = PagedKVPool(meta["num_blocks"] * 8, dims.n_head, dims.head_size, meta["block_size"],
                        meta["max_blocks_per_seq"], dims.n_layer, device=dev, max_seqs=max_seqs)
-    return z, meta, GPT2PagedDecoder(dims, sd, pool, reference_off_by_one=off_by_one)
+    return z, meta, GPT2PagedDecoder(dims, sd, pool, reference_off_by_one=off_by_one, fused_append=fused)
 
 
 def test_gpt2_harness_reproduces_reference_model_logits(golden_dir):
@@ -559,6 +559,29 @@ def test_gpt2_harness_batched_equals_single_and_graph_replay(golden_dir):
         torch.cuda.synchronize()
         assert torch.equal(la, lb), step
     assert torch.equal(a.pool.key_cache, b.pool.key_cache) and torch.equal(a.pool.value_cache, b.pool.value_cache)
+
+
+def test_gpt2_harness_fused_append_is_bit_identical_to_the_call_pair(golden_dir):
+    """The decode harness with one fused launch per layer (paged_attention_v1_append) against the reference's
+    call pair (reshape_and_cache + paged_attention_v1): same logits bit for bit, same caches, eager and graph."""
+    dev = _dev()
+    _, meta, a = _tiny_gpt2(golden_dir, dev, off_by_one=False)
+    _, _, b = _tiny_gpt2(golden_dir, dev, off_by_one=False, fused=True)
+    rng = np.random.default_rng(3)
+    prompts = {1: [5, 6, 7], 2: list(range(30, 45)), 3: [9], 4: list(range(60, 76)), 5: list(range(8))}
+    for sid, pr in prompts.items():
+        a.prefill(sid, pr)
+        b.prefill(sid, pr)
+    ids = list(prompts)
+    for step in range(24):                       # crosses block boundaries for every sequence
+        toks = rng.integers(0, meta["vocab_size"], len(ids)).tolist()
+        la = a.decode(ids, toks, use_graph=False)
+        lb = b.decode(ids, toks, use_graph=(step % 2 == 1))
+        torch.cuda.synchronize()
+        assert torch.equal(la, lb), step
+    assert torch.equal(a.pool.key_cache, b.pool.key_cache) and torch.equal(a.pool.value_cache, b.pool.value_cache)
+    with pytest.raises(ValueError):
+        _tiny_gpt2(golden_dir, dev, off_by_one=True, fused=True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -940,3 +963,104 @@ def test_c_abi_from_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------------------------------------
+# fused decode step (vmi_paged_attention_v1_append_*): must be BIT-identical — caches and out — to
+# cache_ops.reshape_and_cache followed by paged_attention_v1 with the same work decomposition
+# ------------------------------------------------------------------------------------------------
+def _append_vs_two_ops(case, variant, dtype=torch.float16, seed=0, what=""):
+    from vllmini_amd import cache_ops, ops
+
+    dev = _dev()
+    S, H, D = case["q"].shape
+    Hkv, bs = case["num_kv_heads"], case.get("bs", BS)
+    rng = np.random.default_rng(seed)
+
+    def up(a):
+        t = torch.from_numpy(np.nan_to_num(a.astype(np.float32), nan=7.0)).to(dev).to(dtype)
+        return t
+
+    qbuf = up(case["qbuf"])
+    q = qbuf[:, : H * D].view(S, H, D)
+    # this step's rows as a fused [S, 3*Hkv*D] buffer: key/value are strided views (gpt2.py:35-39)
+    kvbuf = torch.from_numpy(rng.standard_normal((S, 3 * Hkv * D)).astype(np.float32)).to(dev).to(dtype)
+    key = kvbuf[:, Hkv * D: 2 * Hkv * D].view(S, Hkv, D)
+    value = kvbuf[:, 2 * Hkv * D:].view(S, Hkv, D)
+    tab = torch.from_numpy(case["tables"]).to(dev)
+    lens_np = case["lens"]
+    lens = torch.from_numpy(lens_np).to(dev)
+    pos = np.maximum(lens_np.astype(np.int64) - 1, 0)
+    slots_np = case["tables"][np.arange(S), pos // bs].astype(np.int64) * bs + pos % bs
+    slots_np[lens_np <= 0] = -1                                     # padding rows are skipped (cache_kernels.cu:232-235)
+    slots = torch.from_numpy(slots_np).to(dev)
+    msl = max(int(lens_np.max()), 1)
+
+    kc_a, vc_a = up(case["kc"]), up(case["vc"])
+    kc_b, vc_b = kc_a.clone(), vc_a.clone()
+    out_a = torch.full((S, H, D), float("nan"), dtype=dtype, device=dev)
+    out_b = torch.full((S, H, D), float("nan"), dtype=dtype, device=dev)
+    cache_ops.reshape_and_cache(key, value, kc_a, vc_a, slots, "auto", 1.0)
+    ops.paged_attention_v1(out_a, q, kc_a, vc_a, Hkv, case["scale"], tab, lens, bs, msl, None, "auto", 1.0,
+                           _variant=variant)
+    ops.paged_attention_v1_append(out_b, q, key, value, kc_b, vc_b, Hkv, case["scale"], tab, lens, bs, msl,
+                                  _variant=variant)
+    torch.cuda.synchronize()
+    i16 = torch.int16
+    assert torch.equal(kc_a.view(i16), kc_b.view(i16)), f"{what}: key cache differs"
+    assert torch.equal(vc_a.view(i16), vc_b.view(i16)), f"{what}: value cache differs"
+    assert torch.isfinite(out_b.float()).all(), f"{what}: non-finite"
+    assert torch.equal(out_a.view(i16), out_b.view(i16)), \
+        f"{what}: out differs, max {float((out_a.float() - out_b.float()).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_append_every_variant_bit_identical_to_two_ops(D):
+    H = 8
+    lens = [1, 16, 17, 100, 333, 1024, 47, 2, 0, 512]     # block starts, block ends, empty row
+    rng = np.random.default_rng(300 + D)
+    case = make_case(rng, len(lens), H, D, lens, q_row_pad=2, poison_tail=True)
+    for vid, name in [(0, "heuristic")] + _variants_for(D):
+        _append_vs_two_ops(case, vid, seed=vid, what=name)
+
+
+@pytest.mark.parametrize("D", [64, 80, 96, 112, 128, 192, 256])
+@pytest.mark.parametrize("bs", [8, 16, 32])
+def test_append_every_head_and_block_size_gqa_fp16_bf16(D, bs):
+    from vllmini_amd import ops
+
+    rng = np.random.default_rng(400 + D + bs)
+    lens = [1, bs, bs + 1, 5 * bs - 1, 300, 2]
+    case = make_case(rng, len(lens), 4, D, lens, q_row_pad=1, block_size=bs, num_kv_heads=2)
+    _append_vs_two_ops(case, 0, what=f"fp16 D{D} bs{bs}")
+    _append_vs_two_ops(case, 0, dtype=torch.bfloat16, what=f"bf16 D{D} bs{bs}")
+    tag16, tagbf = (f"d{D}_" if bs == 16 else f"d{D}_bs{bs}_"), f"bf16_d{D}_bs{bs}_"
+    for vid, name in enumerate(ops.variant_names(), start=1):
+        if "LOADSONLY" in name:
+            continue
+        if name.startswith(tag16) and (bs != 16 or "_bs" not in name):
+            _append_vs_two_ops(case, vid, what=name)
+        elif name.startswith(tagbf):
+            _append_vs_two_ops(case, vid, dtype=torch.bfloat16, what=name)
+
+
+def test_append_full_size_cfg3_step_equals_two_ops():
+    """BASELINE configs[1] at full size: one fused launch == reshape_and_cache + paged_attention_v1."""
+    from vllmini_amd import cache_ops, ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    cfg = CONFIGS["cfg3"]
+    wl = make_workload(cfg, torch.device("cuda:0"), seed=9, table_sets=1)
+    kc2, vc2 = wl.key_cache.clone(), wl.value_cache.clone()
+    tab, lens = wl.tables[0], wl.seq_lens
+    out_a = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device="cuda:0")
+    out_b = torch.empty_like(out_a)
+    cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[0], "auto", 1.0)
+    ops.paged_attention_v1(out_a, wl.query, wl.key_cache, wl.value_cache, cfg.num_heads, wl.scale, tab, lens,
+                           cfg.block_size, cfg.seq_len, None, "auto", 1.0)
+    ops.paged_attention_v1_append(out_b, wl.query, wl.key, wl.value, kc2, vc2, cfg.num_heads, wl.scale, tab, lens,
+                                  cfg.block_size, cfg.seq_len)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16))
+    assert torch.equal(wl.key_cache.view(torch.int16), kc2.view(torch.int16))
+    assert torch.equal(wl.value_cache.view(torch.int16), vc2.view(torch.int16))

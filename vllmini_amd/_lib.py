@@ -36,6 +36,8 @@ SIGNATURES = {
     "vmi_paged_attention_v1_f16_variant": (ctypes.c_int, list(_PA_ARGS) + [_i32]),
     "vmi_paged_attention_v1_bf16": (ctypes.c_int, list(_PA_ARGS) + [_i32]),
     "vmi_paged_attention_v2_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32]),
+    "vmi_paged_attention_v1_append_f16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
+    "vmi_paged_attention_v1_append_bf16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
     "vmi_paged_attention_v1_variant_count": (ctypes.c_int, []),
     "vmi_paged_attention_v1_variant_name": (ctypes.c_char_p, [_i32]),
     "vmi_paged_attention_v1_pick_variant": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
@@ -57,7 +59,7 @@ SIGNATURES = {
     ]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lock = threading.Lock()
 _lib = None

@@ -2,7 +2,8 @@
 
 The reference builds its kernels as a torch CUDAExtension for sm_70..sm_89
 (paged_attention_ext/setup.py:21-46, build.sh:3-5).  Here there is no torch/pybind in the
-native code at all: three hipcc translation units (core kernels + C-ABI; extra head/block-size instantiations; bfloat16)
+native code at all: six hipcc translation units (core kernels + C-ABI; extra head/block-size instantiations; bfloat16;
+and the fused-append twin of each of the three kernel menus)
 compiled concurrently and linked into vllmini_amd/_C/libvmi_paged_attention.so, loaded through ctypes (vllmini_amd/_lib.py).
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so is
@@ -21,6 +22,9 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 SRC = os.path.join(CSRC, "paged_attention.hip")              # core kernels + host code + C-ABI
 SRC_EXTRA = os.path.join(CSRC, "pa_variants_extra.hip")       # remaining head/block-size instantiations
 SRC_BF16 = os.path.join(CSRC, "pa_variants_bf16.hip")         # bfloat16 instantiations
+SRC_APPEND = [os.path.join(CSRC, f"pa_append_{t}.hip") for t in ("core", "extra", "bf16")]   # fused-append twins
+TABLES = [os.path.join(CSRC, f"pa_table_{t}.inc") for t in ("core", "extra", "bf16")]         # shared kernel menus
+SOURCES = [SRC, SRC_EXTRA, SRC_BF16, *SRC_APPEND]
 HDR = os.path.join(CSRC, "pa_kernel.hpp")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 OUT_DIR = os.path.join(PKG_DIR, "_C")
@@ -36,7 +40,7 @@ HIPCC_FLAGS = [
     "-std=c++17",
     "-ffp-contract=off",
     "-fPIC",
-    "-fno-gpu-rdc",
+    "-fno-gpu-rdc", *os.environ.get("VMI_EXTRA_FLAGS", "").split(),
     f"-I{INCLUDE}",
 ]
 
@@ -49,7 +53,7 @@ def _hipcc() -> str:
 
 
 def _deps() -> list[str]:
-    return [SRC, SRC_EXTRA, SRC_BF16, HDR, os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.abspath(__file__)]
+    return [*SOURCES, *TABLES, HDR, os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.abspath(__file__)]
 
 
 def is_stale() -> bool:
@@ -67,7 +71,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     tmp = LIB_PATH + ".tmp"
     objs = []
     procs = []
-    for src in (SRC, SRC_EXTRA, SRC_BF16):            # the units compile concurrently
+    for src in SOURCES:                               # the units compile concurrently
         obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
         cmd = [_hipcc(), *HIPCC_FLAGS, "-c", src, "-o", obj]
         if verbose:
@@ -78,7 +82,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         out, err = proc.communicate()
         if proc.returncode != 0:
             raise RuntimeError(f"hipcc failed ({proc.returncode}): {' '.join(cmd)}\n{out}\n{err}")
-    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", tmp]
+    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *os.environ.get("VMI_EXTRA_FLAGS", "").split(), *objs, "-o", tmp]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     proc = subprocess.run(link, capture_output=True, text=True)

@@ -1,0 +1,15 @@
+// pa_append_core.hip — fused-append (APP = true) instantiations of the paged_attention_v1 menu for block 16 x head 64 / 128 (fp16):
+// row i here is row i of the plain table built from the same pa_table_core.inc, so a variant id means the same work
+// decomposition for vmi_paged_attention_v1_* and vmi_paged_attention_v1_append_*.  A translation unit of its own
+// only so that the six units compile concurrently.
+#define VMI_APP true
+#include "pa_kernel.hpp"
+
+namespace vmi {
+
+Variant g_app_core_variants[] = {
+#include "pa_table_core.inc"
+};
+const int g_app_core_nvariants = (int)(sizeof(g_app_core_variants) / sizeof(g_app_core_variants[0]));
+
+}  // namespace vmi

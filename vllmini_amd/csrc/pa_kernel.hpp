@@ -165,6 +165,14 @@ struct PAParams {
   float* exp_sums;             // [num_seqs, num_heads, max_num_partitions]
   float* max_logits;           // [num_seqs, num_heads, max_num_partitions]
   int32_t max_num_partitions;  // ceil(max_seq_len / 512)
+  // fused append (vmi_paged_attention_v1_append_*), v1 only; key == nullptr -> plain paged_attention_v1.
+  // This step's rows [num_seqs, num_kv_heads, D] are stored into slot seq_len-1 of each sequence's last block
+  // (what cache_ops.reshape_and_cache does with slot = table[(L-1)/BS]*BS + (L-1)%BS, cache_kernels.cu:219-260)
+  // and the attention takes that token from the rows themselves, so the two ops need no launch boundary.
+  const h16* key;
+  const h16* value;
+  int64_t key_stride;
+  int64_t value_stride;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -193,7 +201,7 @@ struct PAParams {
 // LDS  = HPW*HPT * ( lpad*4 (logits) + 2*WPH*4 (max/sum exchange) + WPH*D*4 (partial out) ).
 // ----------------------------------------------------------------------------------------
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
-          bool LOCK = false, bool BF = false, int HPT = 1>
+          bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false>
 __global__ void __launch_bounds__(HPW* WPH * 64)
     pa_v1_kernel(const PAParams p) {
   constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
@@ -207,6 +215,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   static_assert(BS == 8 || BS == 16 || BS == 32, "block size 8, 16 or 32");
   static_assert(64 % U == 0, "U must divide 64");
   static_assert(!(LOCK && WPH > 1), "lockstep needs every wave to run the same number of page groups");
+  static_assert(!(APP && (PART || LOADS_ONLY)), "the fused append exists for paged_attention_v1 only");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -216,6 +225,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   const int hl = wave / WPH;   // head slot
   const int sub = wave % WPH;  // wave within the slot
   const int seq = blockIdx.y;
+
   const int head0 = (blockIdx.x * HPW + hl) * HPT;
   // valid heads of this slot (wave-uniform).  With WPH > 1 the host guarantees H % (HPW*HPT) == 0, so every
   // wave reaches every barrier; with WPH == 1 there are no barriers except LOCK's, which ignores ended waves.
@@ -235,6 +245,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   // seq_len > max_seq_len overflows the logits buffer in the reference (undefined behaviour,
   // attention_kernels.cu:725-732); here the context is truncated to the LDS that was reserved.
   int L = p.seq_lens[seq];
+  const int Lfull = L;
   if constexpr (!PART) L = L > p.lpad ? p.lpad : L;
   const int nblk_seq = (L + BS - 1) / BS;                                     // :121
   const int blk_hi = PART ? (blk_lo + PBLK < nblk_seq ? blk_lo + PBLK : nblk_seq) : nblk_seq;  // :128-129
@@ -283,6 +294,33 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       qreg[hh][i] = (i < NL - 1 || tail_ok) ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8) : zero4;
   }
 
+  // ---- fused append (APP): this step's key/value rows, in the lane map of the K / V tiles.  They are patched
+  //      into the page registers where the attention meets position Lfull-1; whatever bytes the cache holds there
+  //      at that moment (old, or already the writer workgroup's) are never used. ----
+  // APP_TILE: write the patched last-block tiles back whole (full 128-B lines, non-temporal) instead of the
+  // token's 16-B / 2-B pieces; costs NL*4 registers per head to hold the K tile until the end, so only for HPT = 1.
+  constexpr bool APP_TILE = APP && HPT == 1;
+  u32x4 klast[APP_TILE ? NL : 1];
+  bool own_last = false;              // wave-uniform: this wave met block lbA
+  const int lbA = (Lfull - 1) / BS;   // block and in-block offset of the appended token
+  const int offA = (Lfull - 1) % BS;
+  u32x4 knew[APP ? HPT : 1][APP ? NL : 1];
+  uint32_t vnew[APP ? HPT : 1][APP ? NL : 1];
+  if constexpr (APP) {
+#pragma unroll
+    for (int hh = 0; hh < HPT; ++hh) {
+      const int kvh = (head0 + (valid(hh) ? hh : 0)) / qpk;
+      const h16* kr = p.key + (int64_t)seq * p.key_stride + (int64_t)kvh * D;
+      const h16* vr = p.value + (int64_t)seq * p.value_stride + (int64_t)kvh * D;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        knew[hh][i] = (i < NL - 1 || tail_ok) ? *reinterpret_cast<const u32x4*>(kr + (CPL * i + c4) * 8) : zero4;
+        const int row = (64 / (BS / 8)) * i + lane / (BS / 8);
+        vnew[hh][i] = row < D ? (uint32_t)__builtin_bit_cast(uint16_t, vr[row]) : 0u;
+      }
+    }
+  }
+
   // ---- my share of the blocks: b = blk_lo + sub + idx*WPH, idx in [0, nmy) ----------------
   const int nmy = nblk > sub ? (nblk - sub + WPH - 1) / WPH : 0;
   const int ngroups = (nmy + U - 1) / U;
@@ -315,6 +353,16 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     }
   };
 
+  auto store_tile = [&](h16* cache, u32x4(&t)[NL], int idx) {  // APP_TILE (HPT = 1)
+    if ((head0 % qpk) == 0) {  // one writer per KV head
+      const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);  // bt_reg still holds this group's slice
+      h16* dst = cache + phys * p.kv_block_stride + hoff[0];
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        if (i < NL - 1 || tail_ok) __builtin_nontemporal_store(t[i], reinterpret_cast<u32x4*>(dst + i * 512));
+    }
+  };
+
   // =========================== K pass: logits -> LDS, running max ========================
   float qk_max[HPT];
 #pragma unroll
@@ -329,7 +377,10 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
 #pragma unroll
         for (int i = 0; i < NL; ++i) fold ^= r[j][hh][i][0] ^ r[j][hh][i][1] ^ r[j][hh][i][2] ^ r[j][hh][i][3];
   };
-  auto compute_k = [&](u32x4(&r)[U][HPT][NL], int g) {
+  // `final_tag` is a compile-time tag: true only at the call sites that handle a wave's LAST page group — the
+  // only place the appended token can be met — so the steady-state loop body carries no append code.
+  auto compute_k = [&](auto final_tag, u32x4(&r)[U][HPT][NL], int g) {
+    constexpr bool FINAL = decltype(final_tag)::value;
     if constexpr (LOADS_ONLY) {
       fold_all(r);
       return;
@@ -347,6 +398,16 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
             // q.k over this lane's 8*NL dims: operands widened to fp32, fp32 FMA chain (v_fma_mix_f32 for
             // fp16) — the reference's arithmetic (dtype_float16.cuh:292-298, 399-404).  One accumulator
             // per load keeps NL independent dependency chains in flight.
+            if constexpr (APP && FINAL) {
+              if (b == lbA) {  // wave-uniform, once per wave at most
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                  r[j][hh][i] = (tk == offA) ? knew[hh][i] : r[j][hh][i];
+                  if constexpr (APP_TILE) klast[i] = r[j][hh][i];
+                }
+                own_last = true;
+              }
+            }
             float accv[NL];
 #pragma unroll
             for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[hh][i], r[j][hh][i]);
@@ -373,11 +434,15 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
       load_group(rb, p.kc, g + 1);
-      compute_k(ra, g);
-      if (g + 2 < ngroups) load_group(ra, p.kc, g + 2);
-      compute_k(rb, g + 1);
+      compute_k(std::false_type{}, ra, g);
+      if (g + 2 < ngroups) {
+        load_group(ra, p.kc, g + 2);
+        compute_k(std::false_type{}, rb, g + 1);
+      } else {
+        compute_k(std::integral_constant<bool, APP>{}, rb, g + 1);  // final group of an even count
+      }
     }
-    if (g < ngroups) compute_k(ra, g);
+    if (g < ngroups) compute_k(std::integral_constant<bool, APP>{}, ra, g);  // final group of an odd count
   }
 
   // first V group goes out now: HBM stays busy while the softmax runs
@@ -474,6 +539,25 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
             const float* lg = logits0 + hh * p.lpad + token0 - tok_lo;
             const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(lg);
             const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(lg + 4);
+            if constexpr (APP && MASK) {  // the appended token lives in the sequence's last block -> final group only
+              if (b == lbA && hf == (offA >> 3)) {
+                const int e = offA & 7;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+#pragma unroll
+                  for (int w = 0; w < 4; ++w) {
+                    const uint32_t old = r[j][hh][i][w];
+                    const uint32_t vb = vnew[hh][i];
+                    const uint32_t patched = (e & 1) ? ((old & 0x0000ffffu) | (vb << 16)) : ((old & 0xffff0000u) | vb);
+                    r[j][hh][i][w] = ((e >> 1) == w) ? patched : old;
+                  }
+                }
+              }
+              // the wave's last page group: no load is waited on after this point (see the epilogue)
+              if constexpr (APP_TILE) {
+                if (b == lbA) store_tile(const_cast<h16*>(p.vc), r[j][hh], idx);
+              }
+            }
             PV8<BF> pv;
             pv.set(e0, e1, inv_sum[hh]);
 #pragma unroll
@@ -548,6 +632,36 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
           for (int i = 0; i < NL; ++i) {
             const int row = RPL * i + rowl;
             if (row < D) out0[hh * ostride + row] = to_elem<BF>(acc[hh][i]);
+          }
+        }
+      }
+    }
+  }
+
+  // APP: the cache write — what cache_ops.reshape_and_cache does for slot (table[lbA], offA),
+  // cache_kernels.cu:219-260 — is the wave's LAST act.  Measured on the 124-us cfg3 launch
+  // (profiles/r01f_fused_append_experiments.md): the same stores issued between the K and V passes +14 us (loads
+  // and stores share vmcnt on gfx9-family ISAs, so the next wait on a page load also waits for the write
+  // acknowledgement); a writer wave per workgroup +18 us and writer workgroups +10 us (writes into the middle of
+  // the read stream); here +5 us (pieces) / +3 us (whole tiles, non-temporal).
+  if constexpr (APP_TILE) {
+    if (own_last) store_tile(const_cast<h16*>(p.kc), klast, nmy - 1);
+  } else if constexpr (APP) {
+    if (sub == 0 && lbA < p.max_blocks_per_seq) {
+      const int64_t phys = bt[lbA];
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        if (valid(hh) && (head0 + hh) % qpk == 0) {  // one writer per KV head
+          h16* kdst = const_cast<h16*>(p.kc) + phys * p.kv_block_stride + hoff[hh];
+          h16* vtile = const_cast<h16*>(p.vc) + phys * p.kv_block_stride + hoff[hh] - lane * 8;
+#pragma unroll
+          for (int i = 0; i < NL; ++i) {
+            // K: the lane holding (chunk, token offA) of load i owns exactly those 16 bytes of the tile
+            if (tk == offA && (i < NL - 1 || tail_ok)) *reinterpret_cast<u32x4*>(kdst + i * 512) = knew[hh][i];
+            // V: element offA of dim row `row`
+            const int row = RPL * i + rowl;
+            if (hf == (offA >> 3) && row < D)
+              reinterpret_cast<uint16_t*>(vtile)[row * BS + offA] = (uint16_t)vnew[hh][i];
           }
         }
       }
@@ -636,6 +750,12 @@ struct Variant {
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
 
+// One row of a paged_attention_v1 menu (pa_table_*.inc).  The including unit defines VMI_APP: false for the plain
+// kernels, true for the fused-append kernels ("loads only" diagnostics stay plain).
+#define VMI_ROW(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT)                                           \
+  {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, BF,                                                          \
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), LO, false, BS, LOCK, BF, HPT, (VMI_APP) && !(LO)>, 0},
+
 // kernels for the non-core (head size, block size) combinations live in pa_variants_extra.hip
 extern Variant g_extra_variants_v1[];
 extern const int g_extra_nvariants_v1;
@@ -647,6 +767,13 @@ extern Variant g_bf16_variants_v1[];
 extern const int g_bf16_nvariants_v1;
 extern Variant g_bf16_variants_v2[];
 extern const int g_bf16_nvariants_v2;
+// fused-append twins of the three v1 menus (pa_append_*.hip), row for row
+extern Variant g_app_core_variants[];
+extern const int g_app_core_nvariants;
+extern Variant g_app_extra_variants[];
+extern const int g_app_extra_nvariants;
+extern Variant g_app_bf16_variants[];
+extern const int g_app_bf16_nvariants;
 pa_reduce_t bf16_reduce_kernel(int head_size);
 
 }  // namespace vmi

@@ -6,41 +6,13 @@
 
 namespace vmi {
 
-#define VMI_B1(D, BS, HPW, WPH, U) \
-  {"bf16_d" #D "_bs" #BS "_h" #HPW "_w" #WPH "_u" #U "_nt1", D, BS, HPW, WPH, U, true, 1, true, \
-   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, BS, false, true>, 0}
 #define VMI_B2(D, BS, WPH, U) \
   {"bf16_v2_d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, 1, true, \
    (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, true, BS, false, true>, 0}
 
+#define VMI_APP false
 Variant g_bf16_variants_v1[] = {
-    // block 16 x head 64 / 128: the heuristic's menu
-    VMI_B1(64, 16, 4, 1, 1), VMI_B1(64, 16, 1, 1, 1), VMI_B1(64, 16, 1, 2, 1), VMI_B1(64, 16, 1, 4, 1),
-    VMI_B1(64, 16, 1, 8, 1), VMI_B1(64, 16, 1, 16, 1), VMI_B1(64, 16, 1, 4, 4),
-    VMI_B1(128, 16, 4, 1, 1), VMI_B1(128, 16, 1, 1, 1), VMI_B1(128, 16, 1, 2, 1), VMI_B1(128, 16, 1, 4, 1),
-    VMI_B1(128, 16, 1, 8, 1), VMI_B1(128, 16, 1, 16, 1), VMI_B1(128, 16, 1, 4, 2),
-    {"bf16_d128_mh4_h4_u1_nt1_lock", 128, 16, 4, 1, 1, true, 4, true,
-     (pa_kernel_t)pa_v1_kernel<128, 4, 1, 1, true, false, false, 16, true, true, 4>, 0},
-    // the rest of the dispatch set
-    VMI_B1(64, 8, 1, 1, 8), VMI_B1(64, 8, 1, 4, 8),
-    VMI_B1(64, 32, 1, 1, 2), VMI_B1(64, 32, 1, 4, 2),
-    VMI_B1(80, 8, 1, 1, 4), VMI_B1(80, 8, 1, 4, 4),
-    VMI_B1(80, 16, 1, 1, 2), VMI_B1(80, 16, 1, 4, 2),
-    VMI_B1(80, 32, 1, 1, 1), VMI_B1(80, 32, 1, 4, 1),
-    VMI_B1(96, 8, 1, 1, 4), VMI_B1(96, 8, 1, 4, 4),
-    VMI_B1(96, 16, 1, 1, 2), VMI_B1(96, 16, 1, 4, 2),
-    VMI_B1(96, 32, 1, 1, 1), VMI_B1(96, 32, 1, 4, 1),
-    VMI_B1(112, 8, 1, 1, 4), VMI_B1(112, 8, 1, 4, 4),
-    VMI_B1(112, 16, 1, 1, 2), VMI_B1(112, 16, 1, 4, 2),
-    VMI_B1(112, 32, 1, 1, 1), VMI_B1(112, 32, 1, 4, 1),
-    VMI_B1(128, 8, 1, 1, 4), VMI_B1(128, 8, 1, 4, 4),
-    VMI_B1(128, 32, 1, 1, 1), VMI_B1(128, 32, 1, 4, 1),
-    VMI_B1(192, 8, 1, 1, 2), VMI_B1(192, 8, 1, 4, 2),
-    VMI_B1(192, 16, 1, 1, 1), VMI_B1(192, 16, 1, 4, 1),
-    VMI_B1(192, 32, 1, 1, 1), VMI_B1(192, 32, 1, 4, 1),
-    VMI_B1(256, 8, 1, 1, 2), VMI_B1(256, 8, 1, 4, 2),
-    VMI_B1(256, 16, 1, 1, 1), VMI_B1(256, 16, 1, 4, 1),
-    VMI_B1(256, 32, 1, 1, 1), VMI_B1(256, 32, 1, 4, 1),
+#include "pa_table_bf16.inc"
 };
 const int g_bf16_nvariants_v1 = (int)(sizeof(g_bf16_variants_v1) / sizeof(g_bf16_variants_v1[0]));
 

@@ -6,33 +6,13 @@
 
 namespace vmi {
 
-#define VMI_X1(D, BS, WPH, U) \
-  {"d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, 1, false, \
-   (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, false, BS>, 0}
 #define VMI_X2(D, BS, WPH, U) \
   {"v2_d" #D "_bs" #BS "_h1_w" #WPH "_u" #U "_nt1", D, BS, 1, WPH, U, true, 1, false, \
    (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, true, BS>, 0}
 
+#define VMI_APP false
 Variant g_extra_variants_v1[] = {
-    VMI_X1(64, 8, 1, 8), VMI_X1(64, 8, 4, 8),
-    VMI_X1(64, 32, 1, 2), VMI_X1(64, 32, 4, 2),
-    VMI_X1(80, 8, 1, 4), VMI_X1(80, 8, 4, 4),
-    VMI_X1(80, 16, 1, 2), VMI_X1(80, 16, 4, 2),
-    VMI_X1(80, 32, 1, 1), VMI_X1(80, 32, 4, 1),
-    VMI_X1(96, 8, 1, 4), VMI_X1(96, 8, 4, 4),
-    VMI_X1(96, 16, 1, 2), VMI_X1(96, 16, 4, 2),
-    VMI_X1(96, 32, 1, 1), VMI_X1(96, 32, 4, 1),
-    VMI_X1(112, 8, 1, 4), VMI_X1(112, 8, 4, 4),
-    VMI_X1(112, 16, 1, 2), VMI_X1(112, 16, 4, 2),
-    VMI_X1(112, 32, 1, 1), VMI_X1(112, 32, 4, 1),
-    VMI_X1(128, 8, 1, 4), VMI_X1(128, 8, 4, 4),
-    VMI_X1(128, 32, 1, 1), VMI_X1(128, 32, 4, 1),
-    VMI_X1(192, 8, 1, 2), VMI_X1(192, 8, 4, 2),
-    VMI_X1(192, 16, 1, 1), VMI_X1(192, 16, 4, 1),
-    VMI_X1(192, 32, 1, 1), VMI_X1(192, 32, 4, 1),
-    VMI_X1(256, 8, 1, 2), VMI_X1(256, 8, 4, 2),
-    VMI_X1(256, 16, 1, 1), VMI_X1(256, 16, 4, 1),
-    VMI_X1(256, 32, 1, 1), VMI_X1(256, 32, 4, 1),
+#include "pa_table_extra.inc"
 };
 const int g_extra_nvariants_v1 = (int)(sizeof(g_extra_variants_v1) / sizeof(g_extra_variants_v1[0]));
 

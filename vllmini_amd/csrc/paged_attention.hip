@@ -266,64 +266,10 @@ __global__ void __launch_bounds__(256) gather_read_kernel(const u32x4* __restric
 // ----------------------------------------------------------------------------------------
 // host side: variant table, validation, launch
 // ----------------------------------------------------------------------------------------
-#define VMI_VARIANT(D, HPW, WPH, U, NT)                                          \
-  {                                                                              \
-    "d" #D "_h" #HPW "_w" #WPH "_u" #U "_nt" #NT, D, 16, HPW, WPH, U, (bool)NT, 1, false, \
-        (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)NT>, 0                   \
-  }
-
-// Core table: block size 16, head sizes 64 / 128 (what the reference's callers use).  Ids are
-// 1-based positions in [core..., extra...]; names are what profiles/ and tests refer to.
-// The menu is what survived this round's sweeps (profiles/r01*_variant_sweep*.json hold the
-// measurements of everything that was tried, including variants since removed: 3-deep register
-// pipelines, lockstep / multi-head waves at D = 64, 6- and 12-head workgroups).
+// Core menu: pa_table_core.inc (shared with pa_append_core.hip).
+#define VMI_APP false
 static Variant g_variants[] = {
-    // ---- head size 64: one wave per (seq, head); U = blocks in flight per wave ----
-    VMI_VARIANT(64, 4, 1, 1, 1),   // full chip (>= 12 waves/CU): the cfg3 kernel
-    VMI_VARIANT(64, 1, 1, 1, 1),   // same, num_heads not a multiple of 4
-    VMI_VARIANT(64, 4, 1, 2, 1),
-    VMI_VARIANT(64, 1, 1, 2, 1),
-    VMI_VARIANT(64, 4, 1, 4, 1),   // the first kernel of round 1 (reference point, 133 us at cfg3)
-    VMI_VARIANT(64, 1, 1, 4, 1),
-    VMI_VARIANT(64, 4, 1, 4, 0),   // temporal loads: KV working set inside the Infinity Cache
-    VMI_VARIANT(64, 1, 1, 4, 0),
-    // ---- head size 64: 2..16 waves per head (small batches), nt and temporal ----
-    VMI_VARIANT(64, 1, 2, 1, 1), VMI_VARIANT(64, 1, 2, 2, 1), VMI_VARIANT(64, 1, 2, 4, 1),
-    VMI_VARIANT(64, 1, 4, 1, 1), VMI_VARIANT(64, 1, 4, 2, 1), VMI_VARIANT(64, 1, 4, 4, 1),
-    VMI_VARIANT(64, 1, 8, 1, 1), VMI_VARIANT(64, 1, 8, 2, 1), VMI_VARIANT(64, 1, 16, 1, 1),
-    VMI_VARIANT(64, 1, 4, 4, 0), VMI_VARIANT(64, 1, 8, 2, 0), VMI_VARIANT(64, 1, 16, 1, 0),
-    VMI_VARIANT(64, 2, 2, 4, 0),   // two heads x two waves: exercises HPW > 1 with WPH > 1
-    // ---- head size 128 ----
-    VMI_VARIANT(128, 4, 1, 1, 1), VMI_VARIANT(128, 1, 1, 1, 1), VMI_VARIANT(128, 4, 1, 2, 1),
-    VMI_VARIANT(128, 1, 1, 2, 1), VMI_VARIANT(128, 4, 1, 2, 0), VMI_VARIANT(128, 1, 1, 2, 0),
-    VMI_VARIANT(128, 1, 2, 1, 1), VMI_VARIANT(128, 1, 4, 1, 1), VMI_VARIANT(128, 1, 4, 2, 1),
-    VMI_VARIANT(128, 1, 8, 1, 1), VMI_VARIANT(128, 1, 8, 2, 1), VMI_VARIANT(128, 1, 16, 1, 1),
-    VMI_VARIANT(128, 1, 4, 2, 0), VMI_VARIANT(128, 1, 8, 2, 0), VMI_VARIANT(128, 1, 16, 1, 0),
-    // ---- head size 128, full chip: adjacent heads read together (HBM sees 16-64 KiB bursts) ----
-#define VMI_LOCK(D, HPW, U) {"d" #D "_h" #HPW "_w1_u" #U "_nt1_lock", D, 16, HPW, 1, U, true, 1, false, \
-     (pa_kernel_t)pa_v1_kernel<D, HPW, 1, U, true, false, false, 16, true>, 0}
-#define VMI_MH(D, HPW, HPT, U, LOCK, SUF) {"d" #D "_mh" #HPT "_h" #HPW "_u" #U "_nt1" SUF, D, 16, HPW, 1, U, true, HPT, false, \
-     (pa_kernel_t)pa_v1_kernel<D, HPW, 1, U, true, false, false, 16, LOCK, false, HPT>, 0}
-#define VMI_MHW(D, HPW, WPH, HPT, U) {"d" #D "_mh" #HPT "_h" #HPW "_w" #WPH "_u" #U "_nt1", D, 16, HPW, WPH, U, true, HPT, false, \
-     (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, 16, false, false, HPT>, 0}
-    VMI_LOCK(128, 8, 1), VMI_LOCK(128, 16, 1),
-    VMI_MH(128, 4, 4, 1, true, "_lock"),    // the cfg4 kernel (16 | num_heads)
-    VMI_MH(128, 8, 2, 1, true, "_lock"),
-    VMI_MH(128, 1, 2, 1, false, ""),
-    VMI_MH(64, 1, 2, 2, false, ""),         // D = 64 reference points (neutral there)
-    VMI_MH(64, 3, 2, 2, true, "_lock"),
-    VMI_LOCK(64, 6, 2),
-    // ---- D = 64: adjacent heads per wave AND several waves per slot (4-8 KiB chunks at 3072 waves).  Measured no
-    //      better than one head per wave, as were fat waves with deep groups: profiles/r01e_cfg3_multihead_sweep.json ----
-    VMI_MHW(64, 2, 2, 2, 1), VMI_MHW(64, 1, 2, 4, 1),
-#undef VMI_MHW
-#undef VMI_MH
-#undef VMI_LOCK
-    // ---- diagnostics: same gather pattern, no math ("loads only"); wrong results by design ----
-    {"d64_h4_w1_u4_nt1_LOADSONLY", 64, 16, 4, 1, 4, true, 1, false,
-     (pa_kernel_t)pa_v1_kernel<64, 4, 1, 4, true, true>, 0},
-    {"d64_h4_w1_u1_nt1_LOADSONLY", 64, 16, 4, 1, 1, true, 1, false,
-     (pa_kernel_t)pa_v1_kernel<64, 4, 1, 1, true, true>, 0},
+#include "pa_table_core.inc"
 };
 static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
@@ -401,6 +347,16 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// fused-append twin of a v1 variant id (same row of the same menu, pa_append_*.hip)
+static Variant* app_variant_v1(int id) {
+  if (g_app_core_nvariants != g_ncore || g_app_extra_nvariants != g_extra_nvariants_v1 ||
+      g_app_bf16_nvariants != g_bf16_nvariants_v1)
+    return nullptr;
+  if (id <= g_ncore) return &g_app_core_variants[id - 1];
+  if (id <= g_ncore + g_extra_nvariants_v1) return &g_app_extra_variants[id - 1 - g_ncore];
+  return &g_app_bf16_variants[id - 1 - g_ncore - g_extra_nvariants_v1];
+}
+
 static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         const void* value_cache, int32_t num_seqs, int32_t num_heads,
                         int32_t head_size, int32_t num_kv_heads, float scale,
@@ -408,9 +364,17 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         int32_t max_seq_len, int32_t max_num_blocks_per_seq,
                         const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
                         int64_t kv_head_stride, int32_t device, void* stream, int32_t variant,
-                        bool bf = false) {
+                        bool bf = false, bool append = false, const void* key = nullptr,
+                        const void* value = nullptr, int64_t key_stride = 0, int64_t value_stride = 0) {
   if (!out || !query || !key_cache || !value_cache || !block_tables || !seq_lens)
     return fail(VMI_E_NULL_POINTER, "paged_attention_v1: NULL tensor pointer");
+  if (append) {
+    if (!key || !value) return fail(VMI_E_NULL_POINTER, "paged_attention_v1_append: NULL key/value pointer");
+    // the fused kernel moves a key row as 16-B chunks (the stand-alone reshape_and_cache has a scalar path)
+    if (!aligned16(key) || (key_stride & 7))
+      return fail(VMI_E_ALIGNMENT, "paged_attention_v1_append: key rows must be 16-byte aligned "
+                  "(key_stride=%lld)", (long long)key_stride);
+  }
   if (!head_size_supported(head_size))
     return fail(VMI_E_HEAD_SIZE, "Unsupported head size: %d", head_size);
   if (!block_size_supported(block_size))
@@ -433,7 +397,11 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (variant == 0) variant = pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
   if (variant < 1 || variant > nvariants_v1())
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
-  Variant& v = variant_v1(variant);
+  Variant* vp = append ? app_variant_v1(variant) : &variant_v1(variant);
+  if (!vp) return fail(VMI_E_VARIANT, "paged_attention_v1_append: kernel menus out of step (build error)");
+  Variant& v = *vp;
+  if (append && is_diag(v))
+    return fail(VMI_E_VARIANT, "paged_attention_v1_append: %s is a bandwidth diagnostic", v.name);
   if (v.BF != bf)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s is for %s elements", v.name,
                 v.BF ? "bfloat16" : "float16");
@@ -479,6 +447,10 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   p.exp_sums = nullptr;
   p.max_logits = nullptr;
   p.max_num_partitions = 1;
+  p.key = append ? static_cast<const h16*>(key) : nullptr;
+  p.value = append ? static_cast<const h16*>(value) : nullptr;
+  p.key_stride = key_stride;
+  p.value_stride = value_stride;
 
   dim3 block(v.HPW * v.WPH * 64);
   // gridDim.y is limited to 65535: longer batches go out as consecutive launches over slices
@@ -489,6 +461,10 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     ps.q = p.q + (int64_t)s0 * q_stride;
     ps.block_tables = p.block_tables + (int64_t)s0 * max_num_blocks_per_seq;
     ps.seq_lens = p.seq_lens + s0;
+    if (append) {
+      ps.key = p.key + (int64_t)s0 * key_stride;
+      ps.value = p.value + (int64_t)s0 * value_stride;
+    }
     const int hpg = v.HPW * v.HPT;  // heads per workgroup
     dim3 grid((num_heads + hpg - 1) / hpg, ns, 1);
     hipLaunchKernelGGL(v.fn, grid, block, lds, static_cast<hipStream_t>(stream), ps);
@@ -622,6 +598,10 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   p.exp_sums = exp_sums;
   p.max_logits = max_logits;
   p.max_num_partitions = parts;
+  p.key = nullptr;
+  p.value = nullptr;
+  p.key_stride = 0;
+  p.value_stride = 0;
   dim3 grid((num_heads + v.HPW - 1) / v.HPW, num_seqs, parts);  // :890
   hipLaunchKernelGGL(v.fn, grid, dim3(v.HPW * v.WPH * 64), lds, static_cast<hipStream_t>(stream), p);
   e = hipGetLastError();
@@ -690,6 +670,36 @@ int vmi_paged_attention_v1_bf16(void* out, const void* query, const void* key_ca
                            num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
                            max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
                            kv_head_stride, device, stream, variant, true);
+}
+
+int vmi_paged_attention_v1_append_f16(void* out, const void* query, void* key_cache, void* value_cache,
+                                      int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                      int32_t num_kv_heads, float scale, const int32_t* block_tables,
+                                      const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
+                                      int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                                      int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                      int32_t device, void* stream, const void* key, const void* value,
+                                      int64_t key_stride, int64_t value_stride, int32_t variant) {
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, false, true, key, value, key_stride,
+                           value_stride);
+}
+
+int vmi_paged_attention_v1_append_bf16(void* out, const void* query, void* key_cache, void* value_cache,
+                                       int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                       int32_t num_kv_heads, float scale, const int32_t* block_tables,
+                                       const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
+                                       int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                                       int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                       int32_t device, void* stream, const void* key, const void* value,
+                                       int64_t key_stride, int64_t value_stride, int32_t variant) {
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, true, true, key, value, key_stride,
+                           value_stride);
 }
 
 int vmi_paged_attention_v2_bf16(void* out, void* exp_sums, void* max_logits, void* tmp_out,

@@ -81,11 +81,18 @@ class GPT2PagedDecoder:
     """Prefill + batched decode of GPT-2 over a PagedKVPool, calling the two hot-path ops."""
 
     def __init__(self, dims: GPT2Dims, state_dict: Dict[str, torch.Tensor], pool: PagedKVPool,
-                 reference_off_by_one: bool = False):
+                 reference_off_by_one: bool = False, fused_append: bool = False):
         assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
         assert pool.head_size == dims.head_size
         self.dims, self.sd, self.pool = dims, state_dict, pool
         self.reference_off_by_one = reference_off_by_one
+        # fused_append: one launch per layer (ops.paged_attention_v1_append) instead of the reference's call pair
+        # reshape_and_cache + paged_attention_v1 (gpt2.py:44, :62); bit-identical caches and outputs.  It derives
+        # the slot from seq_lens-1, so it cannot reproduce the reference caller's off-by-one seq_lens.
+        if fused_append and reference_off_by_one:
+            raise ValueError("fused_append writes at position seq_lens-1; reference_off_by_one passes seq_lens-1 "
+                             "as the length, so the two cannot be combined")
+        self.fused_append = fused_append
         self.scale = dims.head_size ** -0.5                    # gpt2.py:13
         self.device = pool.device
         self.max_seq_len = pool.max_blocks_per_seq * pool.block_size   # capacity, like scheduler.py:97
@@ -142,10 +149,14 @@ class GPT2PagedDecoder:
         for i in range(d.n_layer):
             p = f"transformer.h.{i}."
             q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)
-            cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i], "auto", 1.0)  # gpt2.py:44
             out = torch.empty((B, d.n_head, d.head_size), dtype=q.dtype, device=q.device)   # empty_like(q) is contiguous, gpt2.py:93
-            ops.paged_attention_v1(out, q, pool.key_cache, pool.value_cache, d.n_head, self.scale, st["tables"][i],
-                                   st["seq_lens"], pool.block_size, self.max_seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0)
+            if self.fused_append:
+                ops.paged_attention_v1_append(out, q, k, v, pool.key_cache, pool.value_cache, d.n_head, self.scale,
+                                              st["tables"][i], st["seq_lens"], pool.block_size, self.max_seq_len)
+            else:
+                cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i], "auto", 1.0)  # gpt2.py:44
+                ops.paged_attention_v1(out, q, pool.key_cache, pool.value_cache, d.n_head, self.scale, st["tables"][i],
+                                       st["seq_lens"], pool.block_size, self.max_seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0)
             x = x + F.linear(out.view(B, d.n_embd), self.sd[p + "attn.c_proj.weight"], self.sd[p + "attn.c_proj.bias"])
             x = x + self._mlp(self._ln(x, p + "ln_2"), p)
         return F.linear(self._ln(x, "transformer.ln_f"), self.sd["lm_head.weight"])   # [B, V]

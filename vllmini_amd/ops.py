@@ -187,6 +187,53 @@ def paged_attention_v1(
     return None
 
 
+def paged_attention_v1_append(
+    out: torch.Tensor,
+    query: torch.Tensor,
+    key: torch.Tensor,
+    value: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    num_kv_heads: int,
+    scale: float,
+    block_tables: torch.Tensor,
+    seq_lens: torch.Tensor,
+    block_size: int,
+    max_seq_len: int,
+    alibi_slopes: Optional[torch.Tensor] = None,
+    kv_cache_dtype: str = "auto",
+    kv_scale: float = 1.0,
+    *,
+    _variant: int = 0,
+) -> None:
+    """Fused decode step (extension, include/vmi_paged_attention.h: vmi_paged_attention_v1_append_*):
+
+        cache_ops.reshape_and_cache(key, value, key_cache, value_cache, slot_of_position(seq_lens-1), ...)
+        paged_attention_v1(out, query, key_cache, value_cache, ...)
+
+    in one launch — the pair the reference issues per layer (gpt2.py:87-112).  `seq_lens` already counts this
+    step's token (as in gpt2.py:99-104); its slot is derived from the block table, so no slot_mapping is passed.
+    Caches and `out` are bit-identical to the two-op sequence (tests/test_parity_gpu.py).
+    """
+    args = _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                      seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, 0, 0, 1, 1, 0)
+    num_seqs, _, head_size = (int(s) for s in query.shape)
+    for name, t in (("key", key), ("value", value)):
+        _check_device(name, t, query.device)
+        if t.dtype != query.dtype:
+            raise RuntimeError(f"{name} must be {query.dtype}, got {t.dtype}")
+        if t.dim() != 3 or tuple(int(x) for x in t.shape) != (num_seqs, int(num_kv_heads), head_size):
+            raise RuntimeError(f"{name} must be [num_seqs, num_kv_heads, head_size], got {tuple(t.shape)}")
+        if t.stride(2) != 1 or t.stride(1) != head_size:
+            raise RuntimeError(f"{name} must be contiguous in its last two dimensions")
+    lib = _lib.load()
+    fn = lib.vmi_paged_attention_v1_append_bf16 if query.dtype == torch.bfloat16 else lib.vmi_paged_attention_v1_append_f16
+    rc = fn(*args, key.data_ptr(), value.data_ptr(), int(key.stride(0)), int(value.stride(0)), int(_variant))
+    if rc != 0:
+        _raise_native(rc)
+    return None
+
+
 def paged_attention_v2(
     out: torch.Tensor,
     exp_sums: torch.Tensor,
