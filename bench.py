@@ -372,7 +372,8 @@ def main():
     achieved = cfg.algorithmic_bytes() / (kern_mean_ms * 1e-3) / 1e9
     vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len)
     vname = ops.variant_names()[vid - 1] if args.op in ("v1", "fused") else f"paged_attention_v2 variant {args.variant or 'auto'}"
-    traffic, traffic_src = pmc_traffic(cfg.name, vname) if args.op == "v1" else (None, None)
+    traffic, traffic_src = (pmc_traffic(cfg.name, vname) if args.op == "v1" else
+                            pmc_traffic(cfg.name + "_fused", vname) if args.op == "fused" else (None, None))
     line = {
         "metric": "decode_tokens_per_sec_paged_attention_v1_per_layer",
         "value": tokens / elapsed,
