@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--sequential-tables", action="store_true",
                     help="physically sequential pages instead of a random permutation (diagnostic)")
     ap.add_argument("--ragged", action="store_true", help="seq_lens ~ U{1..L} (diagnostic)")
+    ap.add_argument("--hint-mean", action="store_true",
+                    help="pass the batch's mean length to the heuristic (what a host-side scheduler can do)")
     return ap.parse_args()
 
 
@@ -363,6 +365,10 @@ def main():
 
     global SKIP_RESHAPE
     SKIP_RESHAPE = args.skip_reshape
+    if args.hint_mean and not args.variant and args.op in ("v1", "fused"):
+        lens_h = wl.seq_lens.cpu()
+        args.variant = ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, int(lens_h.max()), cfg.block_size,
+                                        mean_seq_len=int(lens_h.float().mean()))
     elapsed, kern_ms = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op)
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     kern_mean_ms = shard.max_over_ranks(statistics.mean(kern_ms), dist, dev)

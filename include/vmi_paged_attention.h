@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 4
+#define VMI_ABI_VERSION 5
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -181,6 +181,14 @@ const char* vmi_paged_attention_v1_variant_name(int32_t variant);
 /* Variant id the heuristic would choose for this shape (>=1), 0 for an unsupported head/block size. */
 int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                         int32_t block_size, int32_t max_seq_len);
+/*
+ * The same heuristic with what a caller may know on the host: the batch's mean sequence length (0 = unknown) and
+ * the element type.  mean_seq_len well below max_seq_len marks a ragged batch, for which a many-waves-per-head
+ * decomposition is chosen (the hardware dispatcher then balances the chip).  Pass the result as `variant`.
+ */
+int vmi_paged_attention_v1_pick_variant_hint(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                             int32_t block_size, int32_t max_seq_len,
+                                             int32_t mean_seq_len, int32_t is_bf16);
 
 /*
  * paged_attention_v2 (split-KV), fp16 — the operator the reference exports next to v1

@@ -40,7 +40,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 4
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 5
     assert typed.vmi_target_arch() == b"gfx950"
 
 
@@ -189,3 +189,24 @@ def test_workload_builder_matches_survey_byte_counts():
     for tab, slot in zip(wl.tables, wl.slots):
         blk = tab[torch.arange(c.batch), (lens - 1) // 16].to(torch.int64)
         assert torch.equal(slot, blk * 16 + (lens - 1) % 16)
+
+
+def test_heuristic_picks_follow_the_host_hint():
+    """vmi_paged_attention_v1_pick_variant[_hint] need no GPU: full-chip uniform batches get one (adaptive-depth)
+    wave per head, a batch whose mean length is well below its longest gets eight waves per head, small batches
+    get as many waves per head as it takes to fill the chip."""
+    from vllmini_amd import ops
+
+    names = ops.variant_names()
+    pick = lambda *a, **k: names[ops.pick_variant(*a, **k) - 1]          # noqa: E731
+    assert pick(256, 12, 64, 1024) == "d64_h4_w1_u1a4_nt1"
+    assert pick(256, 12, 64, 1024, mean_seq_len=1024) == "d64_h4_w1_u1a4_nt1"
+    assert pick(256, 12, 64, 1024, mean_seq_len=900) == "d64_h4_w1_u1a4_nt1"
+    assert pick(256, 12, 64, 1024, mean_seq_len=512) == "d64_h1_w8_u1_nt1"
+    assert pick(128, 32, 128, 2048) == "d128_mh4_h4_u1_nt1_lock"
+    assert pick(128, 32, 128, 2048, mean_seq_len=1000) == "d128_h1_w8_u1_nt1"
+    assert "_w16_" in pick(1, 12, 64, 1024)
+    assert pick(256, 12, 64, 1024, bf16=True).startswith("bf16_d64_bs16_h4_w1")
+    assert pick(256, 12, 64, 1024, mean_seq_len=300, bf16=True) == "bf16_d64_bs16_h1_w8_u1_nt1"
+    assert pick(256, 5, 80, 1024, 32) == "d80_bs32_h1_w4_u1_nt1"       # 1280 (seq, head) units do not fill 256 CUs
+    assert pick(1024, 5, 80, 1024, 32) == "d80_bs32_h1_w1_u1_nt1"

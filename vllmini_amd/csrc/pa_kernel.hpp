@@ -184,6 +184,8 @@ struct PAParams {
 //   HPT   ADJACENT heads per slot/wave    (a wave reads the HPT tiles of a block as one contiguous
 //                                          HPT*D*BS*2-byte chunk: bigger chunks are served faster by HBM)
 //   U     blocks per register group       (group g+1 is in flight while group g is consumed)
+//   UMAX  adaptive queue depth: a wave whose sequence is >= 1.4x / 2.8x the launch's mean length runs the
+//         2U / 4U-deep form of the same code (0 = fixed U) — see the selection code at the end of the kernel
 //   NT    non-temporal page loads
 //   PART  split-KV form behind paged_attention_v2 (reference attention_kernels.cu:529-562: the same
 //         kernel body with PARTITION_SIZE = 512): blockIdx.z selects a 512-token partition, the
@@ -201,7 +203,7 @@ struct PAParams {
 // LDS  = HPW*HPT * ( lpad*4 (logits) + 2*WPH*4 (max/sum exchange) + WPH*D*4 (partial out) ).
 // ----------------------------------------------------------------------------------------
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
-          bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false>
+          bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0>
 __global__ void __launch_bounds__(HPW* WPH * 64)
     pa_v1_kernel(const PAParams p) {
   constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
@@ -246,6 +248,9 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   // attention_kernels.cu:725-732); here the context is truncated to the LDS that was reserved.
   int L = p.seq_lens[seq];
   const int Lfull = L;
+  // UMAX: 64 sequence lengths sampled evenly across this launch (requested now, used when the queue depth is chosen)
+  int samp = 0;
+  if constexpr (UMAX >= 2 * U && !PART) samp = p.seq_lens[(int)(((int64_t)lane * gridDim.y) >> 6)];
   if constexpr (!PART) L = L > p.lpad ? p.lpad : L;
   const int nblk_seq = (L + BS - 1) / BS;                                     // :121
   const int blk_hi = PART ? (blk_lo + PBLK < nblk_seq ? blk_lo + PBLK : nblk_seq) : nblk_seq;  // :128-129
@@ -300,7 +305,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   // APP_TILE: write the patched last-block tiles back whole (full 128-B lines, non-temporal) instead of the
   // token's 16-B / 2-B pieces; costs NL*4 registers per head to hold the K tile until the end, so only for HPT = 1.
   constexpr bool APP_TILE = APP && HPT == 1;
-  u32x4 klast[APP_TILE ? NL : 1];
+  u32x4 klast[APP_TILE ? NL : 1], vlast[APP_TILE ? NL : 1];
   bool own_last = false;              // wave-uniform: this wave met block lbA
   const int lbA = (Lfull - 1) / BS;   // block and in-block offset of the appended token
   const int offA = (Lfull - 1) % BS;
@@ -323,35 +328,19 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
 
   // ---- my share of the blocks: b = blk_lo + sub + idx*WPH, idx in [0, nmy) ----------------
   const int nmy = nblk > sub ? (nblk - sub + WPH - 1) / WPH : 0;
-  const int ngroups = (nmy + U - 1) / U;
-  auto table_for = [&](int g) {  // lane j: physical id of my block (bt_sg*64 + j)
-    const int sg = (g * U) >> 6;
-    if (sg != bt_sg) {
-      const int b = blk_lo + sub + (sg * 64 + lane) * WPH;
-      bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
-      bt_sg = sg;
-    }
-  };
 
-  auto load_group = [&](u32x4(&r)[U][HPT][NL], const h16* cache, int g) {
-    if constexpr (LOCK) __builtin_amdgcn_s_barrier();
-    table_for(g);
+  float qk_max[HPT];
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      int idx = g * U + j;
-      idx = idx < nmy ? idx : nmy - 1;  // padding slots re-read my last block (never OOB)
-      const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
-      // (sc0/sc1 cache-policy bits and buffer- vs flat-addressed loads were measured neutral on
-      //  this stream; only `nt` pays: profiles/r01_cfg3_sweep_cache_policy_bits.json)
-      const h16* blk = cache + phys * p.kv_block_stride;
+  for (int hh = 0; hh < HPT; ++hh) qk_max[hh] = -FLT_MAX;
+  uint32_t fold = 0;  // LOADS_ONLY diagnostic: xor of everything loaded
+  float inv_sum[HPT];
+  float acc[HPT][NL];
 #pragma unroll
-      for (int hh = 0; hh < HPT; ++hh) {
+  for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
-        for (int i = 0; i < NL; ++i)  // masked lanes / absent heads contribute zeros
-          r[j][hh][i] = (valid(hh) && (i < NL - 1 || tail_ok)) ? ld16<NT>(blk + hoff[hh] + i * 512) : zero4;
-      }
-    }
-  };
+    for (int i = 0; i < NL; ++i) acc[hh][i] = 0.f;
+  const int hf = lane % UPR;   // which 8-token group of the block this lane owns
+  const int rowl = lane / UPR;  // dim row within a load
 
   auto store_tile = [&](h16* cache, u32x4(&t)[NL], int idx) {  // APP_TILE (HPT = 1)
     if ((head0 % qpk) == 0) {  // one writer per KV head
@@ -363,224 +352,268 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     }
   };
 
-  // =========================== K pass: logits -> LDS, running max ========================
-  float qk_max[HPT];
-#pragma unroll
-  for (int hh = 0; hh < HPT; ++hh) qk_max[hh] = -FLT_MAX;
+  // The K pass, the softmax and the V pass for a compile-time group size UU (blocks per register group).
+  auto run = [&](auto utag) {
+    constexpr int UU = decltype(utag)::value;
+    const int ngroups = (nmy + UU - 1) / UU;
+    auto table_for = [&](int g) {  // lane j: physical id of my block (bt_sg*64 + j)
+      const int sg = (g * UU) >> 6;
+      if (sg != bt_sg) {
+        const int b = blk_lo + sub + (sg * 64 + lane) * WPH;
+        bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
+        bt_sg = sg;
+      }
+    };
 
-  uint32_t fold = 0;  // LOADS_ONLY diagnostic: xor of everything loaded
-  auto fold_all = [&](u32x4(&r)[U][HPT][NL]) {
-#pragma unroll
-    for (int j = 0; j < U; ++j)
-#pragma unroll
-      for (int hh = 0; hh < HPT; ++hh)
-#pragma unroll
-        for (int i = 0; i < NL; ++i) fold ^= r[j][hh][i][0] ^ r[j][hh][i][1] ^ r[j][hh][i][2] ^ r[j][hh][i][3];
-  };
-  // `final_tag` is a compile-time tag: true only at the call sites that handle a wave's LAST page group — the
-  // only place the appended token can be met — so the steady-state loop body carries no append code.
-  auto compute_k = [&](auto final_tag, u32x4(&r)[U][HPT][NL], int g) {
-    constexpr bool FINAL = decltype(final_tag)::value;
-    if constexpr (LOADS_ONLY) {
-      fold_all(r);
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int idx = g * U + j;
-      if (idx < nmy) {  // wave-uniform
-        const int b = blk_lo + sub + idx * WPH;
-        const int token = b * BS + tk;
-        const bool masked = token >= L;
-#pragma unroll
+    auto load_group = [&](u32x4(&r)[UU][HPT][NL], const h16* cache, int g) {
+      if constexpr (LOCK) __builtin_amdgcn_s_barrier();
+      table_for(g);
+  #pragma unroll
+      for (int j = 0; j < UU; ++j) {
+        int idx = g * UU + j;
+        idx = idx < nmy ? idx : nmy - 1;  // padding slots re-read my last block (never OOB)
+        const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
+        // (sc0/sc1 cache-policy bits and buffer- vs flat-addressed loads were measured neutral on
+        //  this stream; only `nt` pays: profiles/r01_cfg3_sweep_cache_policy_bits.json)
+        const h16* blk = cache + phys * p.kv_block_stride;
+  #pragma unroll
         for (int hh = 0; hh < HPT; ++hh) {
-          if (valid(hh)) {
-            // q.k over this lane's 8*NL dims: operands widened to fp32, fp32 FMA chain (v_fma_mix_f32 for
-            // fp16) — the reference's arithmetic (dtype_float16.cuh:292-298, 399-404).  One accumulator
-            // per load keeps NL independent dependency chains in flight.
-            if constexpr (APP && FINAL) {
-              if (b == lbA) {  // wave-uniform, once per wave at most
-#pragma unroll
-                for (int i = 0; i < NL; ++i) {
-                  r[j][hh][i] = (tk == offA) ? knew[hh][i] : r[j][hh][i];
-                  if constexpr (APP_TILE) klast[i] = r[j][hh][i];
+  #pragma unroll
+          for (int i = 0; i < NL; ++i)  // masked lanes / absent heads contribute zeros
+            r[j][hh][i] = (valid(hh) && (i < NL - 1 || tail_ok)) ? ld16<NT>(blk + hoff[hh] + i * 512) : zero4;
+        }
+      }
+    };
+
+    // =========================== K pass: logits -> LDS, running max ========================
+    auto fold_all = [&](u32x4(&r)[UU][HPT][NL]) {
+  #pragma unroll
+      for (int j = 0; j < UU; ++j)
+  #pragma unroll
+        for (int hh = 0; hh < HPT; ++hh)
+  #pragma unroll
+          for (int i = 0; i < NL; ++i) fold ^= r[j][hh][i][0] ^ r[j][hh][i][1] ^ r[j][hh][i][2] ^ r[j][hh][i][3];
+    };
+    // `final_tag` is a compile-time tag: true only at the call sites that handle a wave's LAST page group — the
+    // only place the appended token can be met — so the steady-state loop body carries no append code.
+    auto compute_k = [&](auto final_tag, u32x4(&r)[UU][HPT][NL], int g) {
+      constexpr bool FINAL = decltype(final_tag)::value;
+      if constexpr (LOADS_ONLY) {
+        fold_all(r);
+        return;
+      }
+  #pragma unroll
+      for (int j = 0; j < UU; ++j) {
+        const int idx = g * UU + j;
+        if (idx < nmy) {  // wave-uniform
+          const int b = blk_lo + sub + idx * WPH;
+          const int token = b * BS + tk;
+          const bool masked = token >= L;
+  #pragma unroll
+          for (int hh = 0; hh < HPT; ++hh) {
+            if (valid(hh)) {
+              // q.k over this lane's 8*NL dims: operands widened to fp32, fp32 FMA chain (v_fma_mix_f32 for
+              // fp16) — the reference's arithmetic (dtype_float16.cuh:292-298, 399-404).  One accumulator
+              // per load keeps NL independent dependency chains in flight.
+              if constexpr (APP && FINAL) {
+                if (b == lbA) {  // wave-uniform, once per wave at most
+  #pragma unroll
+                  for (int i = 0; i < NL; ++i) {
+                    r[j][hh][i] = (tk == offA) ? knew[hh][i] : r[j][hh][i];
+                    if constexpr (APP_TILE) klast[i] = r[j][hh][i];
+                  }
+                  own_last = true;
                 }
-                own_last = true;
               }
+              float accv[NL];
+  #pragma unroll
+              for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[hh][i], r[j][hh][i]);
+              float acc = accv[0];
+  #pragma unroll
+              for (int i = 1; i < NL; ++i) acc += accv[i];
+  #pragma unroll
+              for (int m = BS; m < 64; m <<= 1) acc += __shfl_xor(acc, m);  // lanes holding the same token
+              float qk = p.scale * acc;
+              qk += (slope[hh] != 0.f) ? slope[hh] * (float)(token - L + 1) : 0.f;
+              if (lane < BS) logits0[hh * p.lpad + token - tok_lo] = masked ? 0.f : qk;
+              qk_max[hh] = masked ? qk_max[hh] : fmaxf(qk_max[hh], qk);
             }
-            float accv[NL];
-#pragma unroll
-            for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[hh][i], r[j][hh][i]);
-            float acc = accv[0];
-#pragma unroll
-            for (int i = 1; i < NL; ++i) acc += accv[i];
-#pragma unroll
-            for (int m = BS; m < 64; m <<= 1) acc += __shfl_xor(acc, m);  // lanes holding the same token
-            float qk = p.scale * acc;
-            qk += (slope[hh] != 0.f) ? slope[hh] * (float)(token - L + 1) : 0.f;
-            if (lane < BS) logits0[hh * p.lpad + token - tok_lo] = masked ? 0.f : qk;
-            qk_max[hh] = masked ? qk_max[hh] : fmaxf(qk_max[hh], qk);
+          }
+        }
+      }
+    };
+
+    // Register double buffer over page groups: group g+1 is in flight while group g is consumed.
+    // (A third stage was measured and changed nothing; profiles/r01c_cfg3_variant_sweep.json.)
+    u32x4 ra[UU][HPT][NL], rb[UU][HPT][NL];
+    {
+      if (ngroups > 0) load_group(ra, p.kc, 0);
+      int g = 0;
+      for (; g + 2 <= ngroups; g += 2) {
+        load_group(rb, p.kc, g + 1);
+        compute_k(std::false_type{}, ra, g);
+        if (g + 2 < ngroups) {
+          load_group(ra, p.kc, g + 2);
+          compute_k(std::false_type{}, rb, g + 1);
+        } else {
+          compute_k(std::integral_constant<bool, APP>{}, rb, g + 1);  // final group of an even count
+        }
+      }
+      if (g < ngroups) compute_k(std::integral_constant<bool, APP>{}, ra, g);  // final group of an odd count
+    }
+
+    // first V group goes out now: HBM stays busy while the softmax runs
+    if (ngroups > 0) load_group(ra, p.vc, 0);
+
+    // =========================== softmax over the logits in LDS ============================
+    {
+      float m[HPT], es[HPT];
+  #pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        m[hh] = wave_max(qk_max[hh]);
+        if constexpr (WPH > 1) {
+          if (lane == 0) red0[hh * 2 * WPH + sub] = m[hh];
+        }
+      }
+      if constexpr (WPH > 1) {
+        __syncthreads();  // also: every wave's logits are in LDS
+  #pragma unroll
+        for (int hh = 0; hh < HPT; ++hh) {
+          float mm = -FLT_MAX;
+  #pragma unroll
+          for (int w = 0; w < WPH; ++w) mm = fmaxf(mm, red0[hh * 2 * WPH + w]);
+          m[hh] = mm;
+        }
+      }
+  #pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        es[hh] = 0.f;
+        if (valid(hh)) {
+          float* lg = logits0 + hh * p.lpad;
+          float e_sum = 0.f;
+          for (int i = sub * 64 + lane; i < Lloc; i += WPH * 64) {
+            const float e = __expf(lg[i] - m[hh]);
+            lg[i] = e;
+            e_sum += e;
+          }
+          es[hh] = wave_sum(e_sum);
+        }
+        if constexpr (WPH > 1) {
+          if (lane == 0) red0[hh * 2 * WPH + WPH + sub] = es[hh];
+        }
+      }
+      if constexpr (WPH > 1) {
+        __syncthreads();
+  #pragma unroll
+        for (int hh = 0; hh < HPT; ++hh) {
+          float ssum = 0.f;
+  #pragma unroll
+          for (int w = 0; w < WPH; ++w) ssum += red0[hh * 2 * WPH + WPH + w];
+          es[hh] = ssum;
+        }
+      }
+  #pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        inv_sum[hh] = __builtin_amdgcn_rcpf(es[hh] + 1e-6f);
+        if constexpr (PART) {  // partition statistics for the reduce kernel (:349-357)
+          if (valid(hh) && sub == 0 && lane == 0) {
+            const int64_t o = ((int64_t)seq * p.num_heads + head0 + hh) * p.max_num_partitions + part;
+            p.max_logits[o] = m[hh];
+            p.exp_sums[o] = es[hh];
           }
         }
       }
     }
-  };
 
-  // Register double buffer over page groups: group g+1 is in flight while group g is consumed.
-  // (A third stage was measured and changed nothing; profiles/r01c_cfg3_variant_sweep.json.)
-  u32x4 ra[U][HPT][NL], rb[U][HPT][NL];
-  {
-    if (ngroups > 0) load_group(ra, p.kc, 0);
-    int g = 0;
-    for (; g + 2 <= ngroups; g += 2) {
-      load_group(rb, p.kc, g + 1);
-      compute_k(std::false_type{}, ra, g);
-      if (g + 2 < ngroups) {
-        load_group(ra, p.kc, g + 2);
-        compute_k(std::false_type{}, rb, g + 1);
-      } else {
-        compute_k(std::integral_constant<bool, APP>{}, rb, g + 1);  // final group of an even count
+    // =========================== V pass ====================================================
+    // `masked` is a compile-time tag: only the LAST page group of a wave can contain the sequence's last
+    // block, so only that call site compiles the tail masking in.
+    auto compute_v = [&](auto masked, u32x4(&r)[UU][HPT][NL], int g) {
+      constexpr bool MASK = decltype(masked)::value;
+      if constexpr (LOADS_ONLY) {
+        fold_all(r);
+        return;
       }
-    }
-    if (g < ngroups) compute_k(std::integral_constant<bool, APP>{}, ra, g);  // final group of an odd count
-  }
-
-  // first V group goes out now: HBM stays busy while the softmax runs
-  if (ngroups > 0) load_group(ra, p.vc, 0);
-
-  // =========================== softmax over the logits in LDS ============================
-  float inv_sum[HPT];
-  {
-    float m[HPT], es[HPT];
+  #pragma unroll
+      for (int j = 0; j < UU; ++j) {
+        const int idx = g * UU + j;
+        if (idx < nmy) {  // wave-uniform
+          const int b = blk_lo + sub + idx * WPH;
+          const int token0 = b * BS + hf * 8;
+          const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
+  #pragma unroll
+          for (int hh = 0; hh < HPT; ++hh) {
+            if (valid(hh)) {
+              const float* lg = logits0 + hh * p.lpad + token0 - tok_lo;
+              const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(lg);
+              const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(lg + 4);
+              if constexpr (APP && MASK) {  // the appended token lives in the sequence's last block -> final group only
+                if (b == lbA && hf == (offA >> 3)) {
+                  const int e = offA & 7;
+  #pragma unroll
+                  for (int i = 0; i < NL; ++i) {
+  #pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                      const uint32_t old = r[j][hh][i][w];
+                      const uint32_t vb = vnew[hh][i];
+                      const uint32_t patched = (e & 1) ? ((old & 0x0000ffffu) | (vb << 16)) : ((old & 0xffff0000u) | vb);
+                      r[j][hh][i][w] = ((e >> 1) == w) ? patched : old;
+                    }
+                  }
+                }
+                // held until the epilogue: with WPH > 1 a __syncthreads follows, and its fence would wait for the store
+                if constexpr (APP_TILE) {
+                  if (b == lbA) {
 #pragma unroll
-    for (int hh = 0; hh < HPT; ++hh) {
-      m[hh] = wave_max(qk_max[hh]);
-      if constexpr (WPH > 1) {
-        if (lane == 0) red0[hh * 2 * WPH + sub] = m[hh];
-      }
-    }
-    if constexpr (WPH > 1) {
-      __syncthreads();  // also: every wave's logits are in LDS
-#pragma unroll
-      for (int hh = 0; hh < HPT; ++hh) {
-        float mm = -FLT_MAX;
-#pragma unroll
-        for (int w = 0; w < WPH; ++w) mm = fmaxf(mm, red0[hh * 2 * WPH + w]);
-        m[hh] = mm;
-      }
-    }
-#pragma unroll
-    for (int hh = 0; hh < HPT; ++hh) {
-      es[hh] = 0.f;
-      if (valid(hh)) {
-        float* lg = logits0 + hh * p.lpad;
-        float e_sum = 0.f;
-        for (int i = sub * 64 + lane; i < Lloc; i += WPH * 64) {
-          const float e = __expf(lg[i] - m[hh]);
-          lg[i] = e;
-          e_sum += e;
-        }
-        es[hh] = wave_sum(e_sum);
-      }
-      if constexpr (WPH > 1) {
-        if (lane == 0) red0[hh * 2 * WPH + WPH + sub] = es[hh];
-      }
-    }
-    if constexpr (WPH > 1) {
-      __syncthreads();
-#pragma unroll
-      for (int hh = 0; hh < HPT; ++hh) {
-        float ssum = 0.f;
-#pragma unroll
-        for (int w = 0; w < WPH; ++w) ssum += red0[hh * 2 * WPH + WPH + w];
-        es[hh] = ssum;
-      }
-    }
-#pragma unroll
-    for (int hh = 0; hh < HPT; ++hh) {
-      inv_sum[hh] = __builtin_amdgcn_rcpf(es[hh] + 1e-6f);
-      if constexpr (PART) {  // partition statistics for the reduce kernel (:349-357)
-        if (valid(hh) && sub == 0 && lane == 0) {
-          const int64_t o = ((int64_t)seq * p.num_heads + head0 + hh) * p.max_num_partitions + part;
-          p.max_logits[o] = m[hh];
-          p.exp_sums[o] = es[hh];
-        }
-      }
-    }
-  }
-
-  // =========================== V pass ====================================================
-  float acc[HPT][NL];
-#pragma unroll
-  for (int hh = 0; hh < HPT; ++hh)
-#pragma unroll
-    for (int i = 0; i < NL; ++i) acc[hh][i] = 0.f;
-  const int hf = lane % UPR;   // which 8-token group of the block this lane owns
-  const int rowl = lane / UPR;  // dim row within a load
-
-  // `masked` is a compile-time tag: only the LAST page group of a wave can contain the sequence's last
-  // block, so only that call site compiles the tail masking in.
-  auto compute_v = [&](auto masked, u32x4(&r)[U][HPT][NL], int g) {
-    constexpr bool MASK = decltype(masked)::value;
-    if constexpr (LOADS_ONLY) {
-      fold_all(r);
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int idx = g * U + j;
-      if (idx < nmy) {  // wave-uniform
-        const int b = blk_lo + sub + idx * WPH;
-        const int token0 = b * BS + hf * 8;
-        const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
-#pragma unroll
-        for (int hh = 0; hh < HPT; ++hh) {
-          if (valid(hh)) {
-            const float* lg = logits0 + hh * p.lpad + token0 - tok_lo;
-            const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(lg);
-            const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(lg + 4);
-            if constexpr (APP && MASK) {  // the appended token lives in the sequence's last block -> final group only
-              if (b == lbA && hf == (offA >> 3)) {
-                const int e = offA & 7;
-#pragma unroll
-                for (int i = 0; i < NL; ++i) {
-#pragma unroll
-                  for (int w = 0; w < 4; ++w) {
-                    const uint32_t old = r[j][hh][i][w];
-                    const uint32_t vb = vnew[hh][i];
-                    const uint32_t patched = (e & 1) ? ((old & 0x0000ffffu) | (vb << 16)) : ((old & 0xffff0000u) | vb);
-                    r[j][hh][i][w] = ((e >> 1) == w) ? patched : old;
+                    for (int i = 0; i < NL; ++i) vlast[i] = r[j][hh][i];
                   }
                 }
               }
-              // the wave's last page group: no load is waited on after this point (see the epilogue)
-              if constexpr (APP_TILE) {
-                if (b == lbA) store_tile(const_cast<h16*>(p.vc), r[j][hh], idx);
-              }
+              PV8<BF> pv;
+              pv.set(e0, e1, inv_sum[hh]);
+  #pragma unroll
+              for (int i = 0; i < NL; ++i) acc[hh][i] += pv.template dot<MASK>(r[j][hh][i], last, token0, L);
             }
-            PV8<BF> pv;
-            pv.set(e0, e1, inv_sum[hh]);
-#pragma unroll
-            for (int i = 0; i < NL; ++i) acc[hh][i] += pv.template dot<MASK>(r[j][hh][i], last, token0, L);
           }
         }
       }
+    };
+
+    {
+      int g = 0;
+      for (; g + 2 <= ngroups; g += 2) {
+        load_group(rb, p.vc, g + 1);
+        compute_v(std::false_type{}, ra, g);
+        if (g + 2 < ngroups) {
+          load_group(ra, p.vc, g + 2);
+          compute_v(std::false_type{}, rb, g + 1);
+        } else {
+          compute_v(std::true_type{}, rb, g + 1);  // final group of an even count
+        }
+      }
+      if (g < ngroups) compute_v(std::true_type{}, ra, g);  // final group of an odd count
     }
+
   };
 
-  {
-    int g = 0;
-    for (; g + 2 <= ngroups; g += 2) {
-      load_group(rb, p.vc, g + 1);
-      compute_v(std::false_type{}, ra, g);
-      if (g + 2 < ngroups) {
-        load_group(ra, p.vc, g + 2);
-        compute_v(std::false_type{}, rb, g + 1);
-      } else {
-        compute_v(std::true_type{}, rb, g + 1);  // final group of an even count
-      }
-    }
-    if (g < ngroups) compute_v(std::true_type{}, ra, g);  // final group of an odd count
+  // Queue depth per wave.  On a full chip the shallowest queue is the fastest when every sequence has the same
+  // length, but a wave moves at most its bytes in flight per memory round trip: in a RAGGED batch
+  // the long sequences are left running alone at that rate after the short ones have finished (cfg3 with
+  // seq_lens ~ U{1..1024}: 101 us for 50 % of the bytes).  Giving every wave a queue proportional to its share of
+  // the work, U_i ~ L_i / mean(L), makes them finish together while the total bytes in flight stay what the
+  // uniform case uses.  mean(L) is estimated from 64 sequence lengths sampled evenly across the launch.
+  if constexpr (UMAX >= 2 * U && !PART) {
+    const float mean_len = wave_sum((float)(samp > 0 ? samp : 0)) * (1.f / 64.f);
+    const float ratio = (float)Lfull / fmaxf(mean_len, 1.f);
+    const int level = __builtin_amdgcn_readfirstlane(ratio >= 2.8f ? 2 : (ratio >= 1.4f ? 1 : 0));
+    if (UMAX >= 4 * U && level == 2)
+      run(std::integral_constant<int, (UMAX >= 4 * U ? 4 * U : U)>{});
+    else if (level >= 1)
+      run(std::integral_constant<int, 2 * U>{});
+    else
+      run(std::integral_constant<int, U>{});
+  } else {
+    run(std::integral_constant<int, U>{});
   }
 
   if constexpr (LOADS_ONLY) {
@@ -645,7 +678,10 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   // acknowledgement); a writer wave per workgroup +18 us and writer workgroups +10 us (writes into the middle of
   // the read stream); here +5 us (pieces) / +3 us (whole tiles, non-temporal).
   if constexpr (APP_TILE) {
-    if (own_last) store_tile(const_cast<h16*>(p.kc), klast, nmy - 1);
+    if (own_last) {
+      store_tile(const_cast<h16*>(p.kc), klast, nmy - 1);
+      store_tile(const_cast<h16*>(p.vc), vlast, nmy - 1);
+    }
   } else if constexpr (APP) {
     if (sub == 0 && lbA < p.max_blocks_per_seq) {
       const int64_t phys = bt[lbA];
@@ -746,15 +782,19 @@ struct Variant {
   bool BF;  // element type: false = fp16, true = bfloat16
   pa_kernel_t fn;
   int lds_attr_set;  // largest dynamic-LDS size already granted through hipFuncSetAttribute
+  int UMAX;          // adaptive queue depth limit (0 = fixed U)
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
 
 // One row of a paged_attention_v1 menu (pa_table_*.inc).  The including unit defines VMI_APP: false for the plain
 // kernels, true for the fused-append kernels ("loads only" diagnostics stay plain).
-#define VMI_ROW(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT)                                           \
-  {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, BF,                                                          \
-   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), LO, false, BS, LOCK, BF, HPT, (VMI_APP) && !(LO)>, 0},
+#define VMI_ROW_A(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT, UMAX)                                            \
+  {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, BF,                                                                  \
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), LO, false, BS, LOCK, BF, HPT, (VMI_APP) && !(LO), UMAX>, 0, \
+   UMAX},
+#define VMI_ROW(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT) \
+  VMI_ROW_A(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT, 0)
 
 // kernels for the non-core (head size, block size) combinations live in pa_variants_extra.hip
 extern Variant g_extra_variants_v1[];

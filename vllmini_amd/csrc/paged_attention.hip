@@ -287,7 +287,7 @@ static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = a
   for (int id = 1; id <= nvariants_v1(); ++id) {
     const Variant& v = variant_v1(id);
     if (v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
-        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v))
+        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0)
       return id;
   }
   return 0;
@@ -307,12 +307,20 @@ static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }
 //    of {1,2,4} that keeps >= 24 KiB in flight per CU;
 //  * non-temporal page loads once the KV working set exceeds the 256 MiB Infinity Cache;
 //  * D = 128 with a full chip: multi-head waves in lockstep give HBM 16-64 KiB bursts (cfg4 660 -> 616 us).
+// mean_seq_len: optional hint from a caller that knows the lengths on the host (0 = unknown).  A batch whose mean
+// length is well below max_seq_len is RAGGED: with one resident wave per (sequence, head) nothing rebalances the
+// chip once the short sequences are done, so the heads are cut into 8 waves each — 8x the workgroups' waves, more
+// workgroups than fit at once, and the hardware dispatcher does the balancing
+// (profiles/r01g_ragged_batches.md: cfg3 U{1..1024} 98.7 -> 77.1 us, cfg4 446.8 -> 360.5 us).
 static int pick_variant(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
-                        bool bf = false) {
+                        bool bf = false, int mean_seq_len = 0) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
   while (wph < 16 && units * wph < 3072 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  const bool ragged = mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
+  if (ragged)
+    while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   const double kv_bytes = 4.0 * (double)units * (double)max_seq_len * head_size;
   const int nt = kv_bytes > 128e6 ? 1 : 0;
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {  // core table: full menu
@@ -320,6 +328,14 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
     const double tile_kib = head_size * 16 * 2 / 1024.0;
     int u = 1;
     while (u < 4 && waves_per_cu * u * tile_kib < 24.0) u *= 2;
+    if (wph == 1 && u == 1 && nt) {  // full chip, one wave per head: the adaptive-depth form where one is built
+      for (int id = 1; id <= nvariants_v1(); ++id) {
+        const Variant& c = variant_v1(id);
+        if (c.BF == bf && c.D == head_size && c.BS == 16 && c.UMAX > 0 && c.WPH == 1 && c.U == 1 &&
+            c.HPW == ((num_heads % 4 == 0) ? 4 : 1))
+          return id;
+      }
+    }
     if (wph == 1 && head_size == 128 && nt && num_heads % 16 == 0 && waves_per_cu >= 12.0) {
       for (int id = 1; id <= nvariants_v1(); ++id) {  // d128_mh4_h4_u1_nt1_lock
         const Variant& c = variant_v1(id);
@@ -728,6 +744,14 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
                                         int32_t block_size, int32_t max_seq_len) {
   if (!vmi::head_size_supported(head_size) || !vmi::block_size_supported(block_size)) return 0;
   return vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len);
+}
+
+int vmi_paged_attention_v1_pick_variant_hint(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                             int32_t block_size, int32_t max_seq_len,
+                                             int32_t mean_seq_len, int32_t is_bf16) {
+  if (!vmi::head_size_supported(head_size) || !vmi::block_size_supported(block_size)) return 0;
+  return vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, is_bf16 != 0,
+                           mean_seq_len);
 }
 
 int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cache,

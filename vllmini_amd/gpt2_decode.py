@@ -150,13 +150,16 @@ class GPT2PagedDecoder:
             p = f"transformer.h.{i}."
             q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)
             out = torch.empty((B, d.n_head, d.head_size), dtype=q.dtype, device=q.device)   # empty_like(q) is contiguous, gpt2.py:93
+            var = st.get("variant", 0)   # work decomposition chosen on the host from the batch's lengths (decode())
             if self.fused_append:
                 ops.paged_attention_v1_append(out, q, k, v, pool.key_cache, pool.value_cache, d.n_head, self.scale,
-                                              st["tables"][i], st["seq_lens"], pool.block_size, self.max_seq_len)
+                                              st["tables"][i], st["seq_lens"], pool.block_size, self.max_seq_len,
+                                              _variant=var)
             else:
                 cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i], "auto", 1.0)  # gpt2.py:44
                 ops.paged_attention_v1(out, q, pool.key_cache, pool.value_cache, d.n_head, self.scale, st["tables"][i],
-                                       st["seq_lens"], pool.block_size, self.max_seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0)
+                                       st["seq_lens"], pool.block_size, self.max_seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0,
+                                       _variant=var)
             x = x + F.linear(out.view(B, d.n_embd), self.sd[p + "attn.c_proj.weight"], self.sd[p + "attn.c_proj.bias"])
             x = x + self._mlp(self._ln(x, p + "ln_2"), p)
         return F.linear(self._ln(x, "transformer.ln_f"), self.sd["lm_head.weight"])   # [B, V]
@@ -185,6 +188,11 @@ class GPT2PagedDecoder:
         st["slots"].copy_(torch.from_numpy(np.ascontiguousarray(slots)), non_blocking=True)
         st["seq_lens"].copy_(torch.from_numpy(np.ascontiguousarray(lens.astype(np.int32))), non_blocking=True)
         st["position_ids"].copy_(torch.from_numpy(positions), non_blocking=True)
+        # the lengths are known here on the host: let the library's heuristic see the batch's true longest and mean
+        # length (a ragged batch gets the many-waves-per-head decomposition, vmi_paged_attention_v1_pick_variant_hint)
+        st["variant"] = ops.pick_variant(B, self.dims.n_head, self.dims.head_size, max(int(lens.max()), 1),
+                                         self.pool.block_size, mean_seq_len=max(int(lens.mean()), 1),
+                                         bf16=self.pool.key_cache.dtype == torch.bfloat16)
         if isinstance(input_ids, torch.Tensor):
             st["input_ids"].copy_(input_ids.to(torch.long), non_blocking=True)
         else:
@@ -198,6 +206,8 @@ class GPT2PagedDecoder:
         st = self.stage_step(seq_ids, input_ids)
         if not use_graph:
             return self._forward_decode(st)
+        if self._graph is not None and getattr(self, "_graph_variant", 0) != st["variant"]:
+            self._graph = None                   # the launch geometry is baked into the capture
         if self._graph is None:
             s = torch.cuda.Stream(self.device)
             s.wait_stream(torch.cuda.current_stream(self.device))
@@ -207,6 +217,7 @@ class GPT2PagedDecoder:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._graph_out = self._forward_decode(st)
+            self._graph_variant = st["variant"]
         self._graph.replay()
         return self._graph_out
 

@@ -355,6 +355,13 @@ def variant_names_v2() -> list[str]:
     return [lib.vmi_paged_attention_v2_variant_name(i + 1).decode() for i in range(n)]
 
 
-def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16) -> int:
-    return int(_lib.load().vmi_paged_attention_v1_pick_variant(num_seqs, num_heads, head_size, block_size,
-                                                                max_seq_len))
+def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16,
+                 mean_seq_len: int = 0, bf16: bool = False) -> int:
+    """The library's work-decomposition heuristic (what `_variant=0` runs).  A caller that knows the batch's
+    lengths on the host may pass their mean: a ragged batch (mean well below max_seq_len) then gets the
+    many-waves-per-head decomposition; pass the result as `_variant`."""
+    lib = _lib.load()
+    if mean_seq_len or bf16:
+        return int(lib.vmi_paged_attention_v1_pick_variant_hint(num_seqs, num_heads, head_size, block_size,
+                                                                max_seq_len, int(mean_seq_len), int(bool(bf16))))
+    return int(lib.vmi_paged_attention_v1_pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len))
