@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--sequential-tables", action="store_true",
                     help="physically sequential pages instead of a random permutation (diagnostic)")
     ap.add_argument("--ragged", action="store_true", help="seq_lens ~ U{1..L} (diagnostic)")
+    ap.add_argument("--matrix", action="store_true",
+                    help="attention kernel time for every (head size, block size) of the reference's dispatch set at "
+                         "this config's batch/heads/seq_len, fp16 and bf16 -> gpurun_out/matrix.json (diagnostic)")
     ap.add_argument("--hint-mean", action="store_true",
                     help="pass the batch's mean length to the heuristic (what a host-side scheduler can do)")
     return ap.parse_args()
@@ -261,6 +264,44 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
             json.dump(res, f, indent=1)
 
 
+def run_matrix(args, base, dev):
+    """Every (head size, block size, element type) the reference dispatches, at base's batch/heads/seq_len."""
+    import dataclasses
+
+    res = []
+    for dt in (torch.float16, torch.bfloat16):
+        for D in (64, 80, 96, 112, 128, 192, 256):
+            for bs in (8, 16, 32):
+                per = -(-base.seq_len // bs)
+                c = dataclasses.replace(base, name=f"m_d{D}_bs{bs}", head_size=D, block_size=bs,
+                                        num_blocks=2 * base.batch * per + 8)
+                wl = make_workload(c, dev, seed=5, table_sets=2)
+                if dt is torch.bfloat16:
+                    wl.key_cache, wl.value_cache, wl.qkv = (wl.key_cache.to(dt), wl.value_cache.to(dt), wl.qkv.to(dt))
+                out = torch.empty((c.batch, c.num_heads, D), dtype=dt, device=dev)
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                for i in range(args.warmup + args.steps):
+                    t = i % len(wl.tables)
+                    k = i - args.warmup
+                    if k >= 0:
+                        ev[k][0].record()
+                    attend(wl, out, t, 0)
+                    if k >= 0:
+                        ev[k][1].record()
+                torch.cuda.synchronize(dev)
+                us = statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
+                vid = ops.pick_variant(c.batch, c.num_heads, D, c.seq_len, bs, bf16=dt is torch.bfloat16)
+                row = {"dtype": str(dt).split(".")[-1], "head_size": D, "block_size": bs, "us_median": us,
+                       "gbps": c.algorithmic_bytes() / (us * 1e-6) / 1e9, "variant": ops.variant_names()[vid - 1]}
+                res.append(row)
+                print(json.dumps(row), file=sys.stderr, flush=True)
+                del wl, out
+                torch.cuda.empty_cache()
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "matrix.json"), "w") as f:
+        json.dump({"batch": base.batch, "num_heads": base.num_heads, "seq_len": base.seq_len, "rows": res}, f, indent=1)
+
+
 def main():
     args = parse_args()
     if not torch.cuda.is_available():
@@ -279,6 +320,9 @@ def main():
         per = -(-l_ // cfg.block_size)
         cfg = dataclasses.replace(cfg, name=f"{cfg.name}_b{b_}_l{l_}", batch=b_, seq_len=l_,
                                   num_blocks=max(2 * b_ * per, 64))
+    if args.matrix:
+        run_matrix(args, cfg, dev)
+        return
     if args.e2e:
         run_e2e(args, dist, rank, world, local_rank, dev)
         if dist is not None:
