@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--sequential-tables", action="store_true",
                     help="physically sequential pages instead of a random permutation (diagnostic)")
     ap.add_argument("--ragged", action="store_true", help="seq_lens ~ U{1..L} (diagnostic)")
+    ap.add_argument("--ragged-sorted", action="store_true", help="same lengths, longest sequence first (diagnostic)")
     ap.add_argument("--matrix", action="store_true",
                     help="attention kernel time for every (head size, block size) of the reference's dispatch set at "
                          "this config's batch/heads/seq_len, fp16 and bf16 -> gpurun_out/matrix.json (diagnostic)")
@@ -328,7 +329,7 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    wl = make_workload(cfg, dev, seed=1234 + rank, table_sets=2, ragged=args.ragged)
+    wl = make_workload(cfg, dev, seed=1234 + rank, table_sets=2, ragged=("sorted" if args.ragged_sorted else args.ragged))
     if args.sequential_tables:
         for t, tab in enumerate(wl.tables):
             per = cfg.num_blocks // len(wl.tables)

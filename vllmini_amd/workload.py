@@ -117,6 +117,8 @@ def make_workload(cfg: DecodeConfig, device: torch.device | str, seed: int = 0, 
     if ragged:
         lens = torch.randint(1, c.seq_len + 1, (c.batch,), generator=g, dtype=torch.int32)
         lens[0] = c.seq_len
+        if ragged == "sorted":      # longest first: what a length-aware caller could arrange (diagnostic)
+            lens = torch.sort(lens, descending=True).values
     else:
         lens = torch.full((c.batch,), c.seq_len, dtype=torch.int32)
 
