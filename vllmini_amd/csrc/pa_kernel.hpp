@@ -145,6 +145,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Workgroup barrier for waves that exchange data through LDS only.  __syncthreads() is a release/acquire fence at
+// workgroup scope plus s_barrier, and the fence makes every wave wait for ALL its outstanding global loads
+// (s_waitcnt vmcnt(0)) — here that would be the V pages requested just before the softmax, i.e. the prefetch would
+// overlap nothing.  Only this wave's LDS writes have to have landed (lgkmcnt(0)) before the others read them.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct PAParams {
   h16* out;
   const h16* q;
@@ -446,7 +454,15 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     // Register double buffer over page groups: group g+1 is in flight while group g is consumed.
     // (A third stage was measured and changed nothing; profiles/r01c_cfg3_variant_sweep.json.)
     u32x4 ra[UU][HPT][NL], rb[UU][HPT][NL];
-    {
+    // Latency regime (small batches): when everything this wave owns fits ONE register group, the V pages are
+    // requested together with the K pages (into the idle second buffer), so K and V cost one memory round trip
+    // between them instead of two in a row.
+    const bool single = (ngroups == 1);  // wave-uniform (and workgroup-uniform under LOCK)
+    if (single) {
+      load_group(ra, p.kc, 0);
+      load_group(rb, p.vc, 0);
+      compute_k(std::integral_constant<bool, APP>{}, ra, 0);
+    } else {
       if (ngroups > 0) load_group(ra, p.kc, 0);
       int g = 0;
       for (; g + 2 <= ngroups; g += 2) {
@@ -463,7 +479,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     }
 
     // first V group goes out now: HBM stays busy while the softmax runs
-    if (ngroups > 0) load_group(ra, p.vc, 0);
+    if (ngroups > 1) load_group(ra, p.vc, 0);
 
     // =========================== softmax over the logits in LDS ============================
     {
@@ -476,7 +492,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         }
       }
       if constexpr (WPH > 1) {
-        __syncthreads();  // also: every wave's logits are in LDS
+        lds_barrier();  // also: every wave's logits are in LDS
   #pragma unroll
         for (int hh = 0; hh < HPT; ++hh) {
           float mm = -FLT_MAX;
@@ -503,7 +519,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         }
       }
       if constexpr (WPH > 1) {
-        __syncthreads();
+        lds_barrier();
   #pragma unroll
         for (int hh = 0; hh < HPT; ++hh) {
           float ssum = 0.f;
@@ -561,7 +577,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
                     }
                   }
                 }
-                // held until the epilogue: with WPH > 1 a __syncthreads follows, and its fence would wait for the store
+                // held until the epilogue: with WPH > 1 a barrier follows; keeping the store behind it keeps the epilogue short
                 if constexpr (APP_TILE) {
                   if (b == lbA) {
 #pragma unroll
@@ -579,7 +595,9 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       }
     };
 
-    {
+    if (single) {
+      compute_v(std::true_type{}, rb, 0);
+    } else {
       int g = 0;
       for (; g + 2 <= ngroups; g += 2) {
         load_group(rb, p.vc, g + 1);
@@ -642,7 +660,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (sub == 0) {
 #pragma unroll
       for (int hh = 0; hh < HPT; ++hh) {
@@ -783,6 +801,7 @@ struct Variant {
   pa_kernel_t fn;
   int lds_attr_set;  // largest dynamic-LDS size already granted through hipFuncSetAttribute
   int UMAX;          // adaptive queue depth limit (0 = fixed U)
+  int lds_attr_dev;  // device that grant was made on (the attribute is per device)
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);

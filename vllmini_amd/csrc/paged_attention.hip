@@ -437,11 +437,12 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   DeviceGuard guard(device);
   hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  if (lds > 48 * 1024 && (int)lds > v.lds_attr_set) {
+  if (lds > 48 * 1024 && ((int)lds > v.lds_attr_set || device != v.lds_attr_dev)) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     v.lds_attr_set = (int)lds;
+    v.lds_attr_dev = device;
   }
 
   PAParams p;
