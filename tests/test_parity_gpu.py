@@ -1064,3 +1064,50 @@ def test_append_full_size_cfg3_step_equals_two_ops():
     assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16))
     assert torch.equal(wl.key_cache.view(torch.int16), kc2.view(torch.int16))
     assert torch.equal(wl.value_cache.view(torch.int16), vc2.view(torch.int16))
+
+
+# ------------------------------------------------------------------------------------------------
+# randomized sweep: shapes, strides, GQA, ALiBi, ragged lengths, table padding, forced decompositions —
+# 60 seeded cases, every one checked against the kernel model (v1, v2) and the call pair (append)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("chunk", range(6))
+def test_randomized_parity_sweep(chunk):
+    from vllmini_amd import ops
+
+    names = ops.variant_names()
+    for k in range(10):
+        seed = 1000 + chunk * 10 + k
+        rng = np.random.default_rng(seed)
+        D = int(rng.choice([64, 80, 96, 112, 128, 192, 256]))
+        bs = int(rng.choice([8, 16, 32]))
+        hkv = int(rng.choice([1, 2, 3, 4]))
+        H = hkv * int(rng.choice([1, 2, 4]))
+        S = int(rng.integers(1, 9))
+        top = int(rng.choice([bs, 3 * bs + 1, 200, 700, 1300]))
+        lens = rng.integers(0 if k % 3 == 0 else 1, top + 1, S).astype(np.int32)
+        lens[int(rng.integers(0, S))] = top
+        nblk_max = int((lens.max() + bs - 1) // bs)
+        case = make_case(rng, S, H, D, lens, num_kv_heads=hkv, block_size=bs, q_row_pad=int(rng.integers(0, 3)),
+                         poison_tail=bool(rng.integers(0, 2)), max_blocks=nblk_max + int(rng.integers(0, 5)),
+                         kv="normal" if k % 2 else "uniform")
+        alibi = (rng.uniform(0.0, 0.3, H)).astype(np.float32) if rng.integers(0, 3) == 0 else None
+        what = f"seed {seed}: S{S} H{H}/{hkv} D{D} bs{bs} lens<= {top} alibi={alibi is not None}"
+        # a valid forced decomposition half of the time
+        tag = (f"d{D}_" if bs == 16 else f"d{D}_bs{bs}_")
+        cands = [i + 1 for i, n in enumerate(names)
+                 if n.startswith(tag) and "LOADSONLY" not in n and (bs != 16 or "_bs" not in n)]
+        vid = int(rng.choice(cands)) if (cands and rng.integers(0, 2)) else 0
+        msl = int(max(lens.max(), 1)) + int(rng.integers(0, 40))
+        ref = run_model(case, alibi=alibi)
+        try:
+            got = run_hip(case, variant=vid, max_seq_len=msl, alibi=alibi)
+        except RuntimeError as e:                      # forced variant not applicable to this head count
+            assert "needs num_heads" in str(e), what
+            got = run_hip(case, variant=0, max_seq_len=msl, alibi=alibi)
+        assert_close(got, ref, what + f" v1 variant {names[vid - 1] if vid else 'auto'}")
+        if lens.max() > 0:
+            _check_v2(case, ((msl + 511) // 512) * 512, alibi=alibi, what=what + " v2")
+        if alibi is None and not case["kc"].dtype == np.float32:
+            clean = dict(case)
+            _append_vs_two_ops(clean, 0, seed=seed, what=what + " append")
+            _append_vs_two_ops(clean, 0, dtype=torch.bfloat16, seed=seed, what=what + " append bf16")
