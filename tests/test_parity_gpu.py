@@ -1111,3 +1111,41 @@ def test_randomized_parity_sweep(chunk):
             clean = dict(case)
             _append_vs_two_ops(clean, 0, seed=seed, what=what + " append")
             _append_vs_two_ops(clean, 0, dtype=torch.bfloat16, seed=seed, what=what + " append bf16")
+
+
+# ------------------------------------------------------------------------------------------------
+# reshape_and_cache at prefill scale: runs of block_size consecutive slots take the whole-tile path, everything
+# else (tails, out-of-order runs, padding, misaligned starts) the per-token path inside the same kernel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,D,bs", [(12, 64, 16), (4, 128, 16), (3, 80, 8), (2, 256, 32), (5, 112, 32), (2, 192, 8)])
+def test_reshape_and_cache_prefill_runs_bit_exact(H, D, bs):
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(H * 7 + D + bs)
+    NB = 40
+    blocks = rng.permutation(NB)
+    slots = []
+    slots += list(blocks[0] * bs + np.arange(bs))                 # whole aligned block
+    slots += list(blocks[1] * bs + np.arange(bs))                 # another
+    slots += list(blocks[2] * bs + np.arange(bs)[::-1])           # whole block, reversed order  -> per token
+    run = list(blocks[3] * bs + np.arange(bs))
+    run[bs // 2] = -1                                             # padding inside a run        -> per token
+    slots += run
+    slots += list(blocks[4] * bs + (np.arange(bs) + 1) % bs)      # rotated                     -> per token
+    slots += list(blocks[5] * bs + bs // 2 + np.arange(bs // 2)) + list(blocks[6] * bs + np.arange(bs // 2))  # misaligned
+    slots += list(blocks[7] * bs + np.arange(bs))                 # whole block again
+    slots += list(blocks[8] * bs + np.arange(bs - 3))             # prompt tail (T not a multiple of bs)
+    slots = np.asarray(slots, dtype=np.int64)
+    T = len(slots)
+    kc = rng.standard_normal((NB, H, D // 8, bs, 8)).astype(np.float16)
+    vc = rng.standard_normal((NB, H, D, bs)).astype(np.float16)
+    buf = rng.standard_normal((T, 3 * H * D)).astype(np.float16)
+    key, val = buf[:, H * D:2 * H * D].reshape(T, H, D), buf[:, 2 * H * D:].reshape(T, H, D)
+    t_buf = torch.from_numpy(buf).to(dev)
+    t_k, t_v = t_buf[:, H * D:2 * H * D].view(T, H, D), t_buf[:, 2 * H * D:].view(T, H, D)
+    t_kc, t_vc = torch.from_numpy(kc).to(dev), torch.from_numpy(vc).to(dev)
+    ext.cache_ops.reshape_and_cache(t_k, t_v, t_kc, t_vc, torch.from_numpy(slots).to(dev), "auto", 1.0)
+    torch.cuda.synchronize()
+    oracle.reshape_and_cache(np.ascontiguousarray(key), np.ascontiguousarray(val), kc, vc, slots)
+    assert np.array_equal(t_kc.cpu().numpy().view(np.uint16), kc.view(np.uint16))
+    assert np.array_equal(t_vc.cpu().numpy().view(np.uint16), vc.view(np.uint16))

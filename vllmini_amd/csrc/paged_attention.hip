@@ -142,6 +142,72 @@ __global__ void __launch_bounds__(256)
 
 
 // ----------------------------------------------------------------------------------------
+// reshape_and_cache, prefill form.  A prompt's tokens arrive with consecutive slots, so BS consecutive tokens
+// usually ARE one cache block.  The per-token kernel above then writes every 32-B V row in BS separate 2-byte
+// pieces (1.0-1.2 TB/s read+write on MI355X); here one workgroup takes a run of BS tokens, checks that their slots are
+// one aligned block in order, and writes whole (block, head) tiles: the K tile needs no transposition at all (lane
+// chunk*BS + tok loads 16 B of row tok and owns exactly that 16-B unit of the tile), the V tile is transposed
+// through LDS, one wave per head.  Runs that are not a whole aligned block (prompt tails, decode batches, padding)
+// take the per-token path inside the same kernel.  Same bytes as the kernel above (cache_kernels.cu:152-207).
+// ----------------------------------------------------------------------------------------
+template <int BS>
+__global__ void __launch_bounds__(256)
+    reshape_and_cache_blocks_kernel(const h16* __restrict__ key, const h16* __restrict__ value,
+                                    h16* __restrict__ kc, h16* __restrict__ vc,
+                                    const int64_t* __restrict__ slot_mapping, int64_t key_stride,
+                                    int64_t value_stride, int T, int H, int D) {
+  constexpr int UPR = BS / 8;  // 16-B units per V dim row
+  constexpr int PAD = 8;       // halves; keeps LDS rows 16-B aligned and the two 8-token halves on different banks
+  extern __shared__ __attribute__((aligned(16))) char blk_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = blockIdx.x * BS;
+  const int nt = (T - t0) < BS ? (T - t0) : BS;
+  const long long mine = (lane < nt) ? (long long)slot_mapping[t0 + lane] : -1;
+  const long long s0 = __shfl(mine, 0);
+  const bool in_order = lane >= BS || mine == s0 + lane;
+  const bool whole = nt == BS && s0 >= 0 && (s0 % BS) == 0 && __all(in_order);
+  const int units = D * BS / 8;  // 16-B units of one (block, head) tile, K and V alike
+  if (whole) {
+    const int64_t blk = s0 / BS;
+    h16* lds = reinterpret_cast<h16*>(blk_smem) + (size_t)wave * BS * (D + PAD);
+    for (int h = wave; h < H; h += 4) {
+      h16* ktile = kc + ((blk * H + h) * (int64_t)D) * BS;
+      h16* vtile = vc + ((blk * H + h) * (int64_t)D) * BS;
+      for (int u = lane; u < units; u += 64) {
+        const int c = u / BS, tok = u % BS;
+        const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + h * D + c * 8);
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + h * D + c * 8);
+        *reinterpret_cast<u32x4*>(ktile + (int64_t)u * 8) = kv;               // K[blk,h,c,tok,0..8)
+        *reinterpret_cast<u32x4*>(lds + tok * (D + PAD) + c * 8) = vv;        // V rows, token-major, for the transpose
+      }
+      for (int u = lane; u < units; u += 64) {
+        const int row = u / UPR, unit = u % UPR;
+        h16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = lds[(unit * 8 + e) * (D + PAD) + row];
+        *reinterpret_cast<u32x4*>(vtile + (int64_t)u * 8) = __builtin_bit_cast(u32x4, o);  // V[blk,h,row,unit*8..+8)
+      }
+    }
+    return;
+  }
+  // not a whole aligned block: token by token, as reshape_and_cache_kernel does
+  const int n8 = (H * D) >> 3;
+  for (int w = threadIdx.x; w < nt * n8; w += 256) {
+    const int tok = w / n8, c = w - tok * n8;
+    const int64_t slot = slot_mapping[t0 + tok];
+    if (slot < 0) continue;  // padding token (ref cache_kernels.cu:165-169)
+    const int64_t blk = slot / BS, off = slot % BS;
+    const int i = c << 3, h = i / D, d = i - h * D;
+    const h16x8 kv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + i));
+    const h16x8 vv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + i));
+    *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (D >> 3) + (d >> 3)) * BS + off) * 8) = __builtin_bit_cast(u32x4, kv);
+    h16* vdst = vc + ((blk * H + h) * (int64_t)D + d) * BS + off;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vdst[(int64_t)e * BS] = vv[e];
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // reshape_and_cache_flash: scatter new-token rows into the flash layout
 // [num_blocks, block_size, num_heads, head_size] — reference cache_kernels.cu:209-240 (kernel),
 // :283-317 (host).  A token's H*D row stays contiguous, so this is one 16-B copy per lane per chunk.
@@ -780,6 +846,29 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
   int threads = ((n8 + 63) / 64) * 64;
   if (threads > 256) threads = 256;
   dim3 grid(num_tokens), block(threads);
+  // prefill-sized calls with 16-B aligned rows: whole-block form (falls back per run inside the kernel)
+  if (vec && num_tokens >= 2 * block_size && (block_size == 8 || block_size == 16 || block_size == 32)) {
+    typedef void (*blocks_fn)(const h16*, const h16*, h16*, h16*, const int64_t*, int64_t, int64_t, int, int, int);
+    const blocks_fn fn = block_size == 8    ? (blocks_fn)reshape_and_cache_blocks_kernel<8>
+                         : block_size == 16 ? (blocks_fn)reshape_and_cache_blocks_kernel<16>
+                                            : (blocks_fn)reshape_and_cache_blocks_kernel<32>;
+    const size_t lds = (size_t)4 * block_size * (head_size + 8) * 2;
+    if (lds <= 160 * 1024) {
+      if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(reshape_and_cache_blocks)");
+      }
+      hipLaunchKernelGGL(fn, dim3((num_tokens + block_size - 1) / block_size), dim3(256), lds,
+                         static_cast<hipStream_t>(stream), static_cast<const h16*>(key),
+                         static_cast<const h16*>(value), static_cast<h16*>(key_cache),
+                         static_cast<h16*>(value_cache), slot_mapping, key_stride, value_stride, num_tokens,
+                         num_heads, head_size);
+      e = hipGetLastError();
+      if (e != hipSuccess) return hip_fail(e, "reshape_and_cache (blocks) launch");
+      return VMI_OK;
+    }
+  }
   if (vec) {
     hipLaunchKernelGGL(reshape_and_cache_kernel<true>, grid, block, 0,
                        static_cast<hipStream_t>(stream), static_cast<const h16*>(key),
