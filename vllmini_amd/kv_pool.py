@@ -166,13 +166,17 @@ class PagedKVPool:
             if n_new > len(self.free_blocks):
                 # hand out what the reference would have handed out before failing
                 order = order[: len(self.free_blocks)]
-            new_blocks = self._take(len(order))
-            for (b, l), blk in zip(order, new_blocks):
-                r = rows[b]
-                self._tables[l, r, self._nblocks[l, r]] = blk           # kv_cache.py:64-70
-                self._nblocks[l, r] += 1
-                self._filled[l, r] = 0
-                self.allocated_blocks[seq_ids[b]].append(blk)
+            new_blocks = np.asarray(self._take(len(order)), dtype=self._tables.dtype)
+            if len(order):
+                b_idx, l_idx = order[:, 0], order[:, 1]                     # (sequence, layer) pairs are distinct
+                r_idx = rows[b_idx]
+                self._tables[l_idx, r_idx, self._nblocks[l_idx, r_idx]] = new_blocks   # kv_cache.py:64-70
+                self._nblocks[l_idx, r_idx] += 1
+                self._filled[l_idx, r_idx] = 0
+                # per-sequence ownership lists, in hand-out order (order is sequence-major)
+                cuts = np.flatnonzero(np.diff(b_idx)) + 1
+                for seg_b, seg in zip(b_idx[np.r_[0, cuts]], np.split(new_blocks, cuts)):
+                    self.allocated_blocks[seq_ids[int(seg_b)]].extend(int(x) for x in seg)
             if len(order) < n_new:
                 raise RuntimeError("No free blocks available")          # kv_cache.py:57-58
             nb = self._nblocks[:, rows]
