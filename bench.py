@@ -173,6 +173,7 @@ def pmc_traffic(cfg_name: str, kernel_variant: str):
     profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE x1024 x2 per the
     gfx950 correction in MI355X_MICROARCH.md §HBM).  bench.py cannot run a profiler around itself, so
     the figure comes from the latest recorded pass for this workload and kernel variant, else None."""
+    cfg_name = cfg_name.replace("cfg5", "cfg3")   # cfg5 = the cfg3 launch over a larger pool (N > 1 runs)
     path = os.path.join(REPO, "profiles", f"pmc_{cfg_name}_latest.json")
     try:
         with open(path) as f:
