@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 5
+#define VMI_ABI_VERSION 6
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -174,6 +174,35 @@ int vmi_paged_attention_v1_append_bf16(
     int32_t device, void* stream,
     const void* key, const void* value, int64_t key_stride, int64_t value_stride,
     int32_t variant);
+
+/*
+ * fp8 KV cache — kv_cache_dtype "fp8" / "fp8_e4m3" of the reference surface (quantization/fp8/nvidia/quant_utils.cuh:
+ * 529-566; the reference build never defines ENABLE_FP8, so its own fp8 path is assert(false) — these entries follow
+ * its SOURCE: attention_kernels.cu:283-289, 410-418, cache_kernels.cu:200-205).
+ *   caches: E4M3 ("fn": no infinities, max 448) bytes, key_cache [NB, H, D/16, BS, 16], value_cache [NB, H, D, BS];
+ *           kv_block_stride / kv_head_stride in elements (= bytes), multiples of 16
+ *   store:  fp8(float(x) / kv_scale), round to nearest even, saturating (__NV_SATFINITE), x = 16
+ *   load:   float_to_half(float(fp8) * kv_scale), then the fp16 arithmetic of paged_attention_v1 unchanged
+ * query/out float16; head sizes as above; block sizes 16 and 32.  variant: 0 = heuristic ("fp8_" names).
+ */
+int vmi_paged_attention_v1_fp8(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream,
+    float kv_scale, int32_t variant);
+int vmi_reshape_and_cache_fp8(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping,
+    int32_t num_tokens, int32_t num_heads, int32_t head_size, int32_t block_size, int32_t x,
+    int64_t key_stride, int64_t value_stride, float kv_scale,
+    int32_t device, void* stream);
+int vmi_paged_attention_v1_pick_variant_fp8(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                            int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len);
 
 /* Number of tuning variants (valid ids are 1..count) and a short name for each. */
 int vmi_paged_attention_v1_variant_count(void);

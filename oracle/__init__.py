@@ -22,6 +22,11 @@ from .kernel_model import (  # noqa: F401
     paged_attention_v1,
     paged_attention_v2,
     reshape_and_cache,
+    # fp8 (E4M3) KV cache — kv_cache_dtype "fp8"
+    f32_to_fp8e4m3,
+    fp8e4m3_to_f32,
+    paged_attention_v1_fp8,
+    reshape_and_cache_fp8,
 )
 from .eager import (  # noqa: F401
     eager_paged_attention,

@@ -191,3 +191,83 @@ def reshape_and_cache(key: np.ndarray, value: np.ndarray, key_cache: np.ndarray,
         _base_ptr(slot_mapping), T, H, D, int(key_cache.shape[3]), int(key_cache.shape[4]),
         int(ks[0]), int(vs[0]))
     assert rc == 0
+
+
+# ---- fp8 (E4M3) KV cache: kv_cache_dtype "fp8" / "fp8_e4m3" of the reference surface ------------------------
+def fp8e4m3_to_f32(bits: np.ndarray) -> np.ndarray:
+    """Decode fp8 E4M3 ("fn") bytes exactly (quant_utils.cuh:295-300: __nv_cvt_fp8_to_halfraw)."""
+    lib = _load()
+    lib.vmi_oracle_fp8e4m3_to_f32.restype = ctypes.c_float
+    lib.vmi_oracle_fp8e4m3_to_f32.argtypes = [ctypes.c_uint8]
+    flat = np.asarray(bits, dtype=np.uint8).ravel()
+    return np.array([lib.vmi_oracle_fp8e4m3_to_f32(int(b)) for b in flat], dtype=np.float32).reshape(np.shape(bits))
+
+
+def f32_to_fp8e4m3(x: np.ndarray) -> np.ndarray:
+    """Encode float32 -> fp8 E4M3 bytes: round to nearest even, saturate to +-448 (__NV_SATFINITE,
+    quant_utils.cuh:458-464), NaN -> 0x7f | sign."""
+    lib = _load()
+    lib.vmi_oracle_f32_to_fp8e4m3.restype = ctypes.c_uint8
+    lib.vmi_oracle_f32_to_fp8e4m3.argtypes = [ctypes.c_float]
+    flat = np.asarray(x, dtype=np.float32).ravel()
+    return np.array([lib.vmi_oracle_f32_to_fp8e4m3(float(v)) for v in flat], dtype=np.uint8).reshape(np.shape(x))
+
+
+def reshape_and_cache_fp8(key: np.ndarray, value: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
+                          slot_mapping: np.ndarray, kv_scale: float = 1.0) -> None:
+    """In-place quantising scatter (cache_kernels.cu:200-205): float16 rows -> uint8 caches
+    key_cache [NB, H, D/16, BS, 16], value_cache [NB, H, D, BS]."""
+    assert key.dtype == value.dtype == np.float16 and key_cache.dtype == value_cache.dtype == np.uint8
+    assert key_cache.flags.c_contiguous and value_cache.flags.c_contiguous and key_cache.shape[4] == 16
+    T, H, D = key.shape
+    ks, vs = _elem_strides(key), _elem_strides(value)
+    assert ks[2] == 1 and ks[1] == D and vs[2] == 1 and vs[1] == D
+    slot_mapping = np.ascontiguousarray(slot_mapping, dtype=np.int64)
+    lib = _load()
+    lib.vmi_oracle_reshape_and_cache_fp8.restype = ctypes.c_int
+    lib.vmi_oracle_reshape_and_cache_fp8.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int32] * 5 + [
+        ctypes.c_int64, ctypes.c_int64, ctypes.c_float]
+    rc = lib.vmi_oracle_reshape_and_cache_fp8(
+        _base_ptr(key), _base_ptr(value), _base_ptr(key_cache), _base_ptr(value_cache), _base_ptr(slot_mapping),
+        T, H, D, int(key_cache.shape[3]), 16, int(ks[0]), int(vs[0]), float(kv_scale))
+    assert rc == 0
+
+
+def paged_attention_v1_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray, num_kv_heads: int,
+                           scale: float, block_tables: np.ndarray, seq_lens: np.ndarray, block_size: int,
+                           kv_scale: float = 1.0, alibi_slopes: np.ndarray | None = None,
+                           threads: int = 1) -> np.ndarray:
+    """Kernel model with an fp8 E4M3 cache: every cache element is first turned into
+    float_to_half(float(fp8) * kv_scale) (quant_utils.cuh:295-300), then the fp16 arithmetic of
+    paged_attention_v1 applies unchanged (attention_kernels.cu:283-289, 410-418)."""
+    assert query.dtype == np.float16 and key_cache.dtype == value_cache.dtype == np.uint8
+    assert key_cache.ndim == 5 and key_cache.shape[4] == 16 and value_cache.ndim == 4
+    S, H, D = query.shape
+    qs = _elem_strides(query)
+    assert qs[2] == 1 and qs[1] == D
+    key_cache, value_cache = np.ascontiguousarray(key_cache), np.ascontiguousarray(value_cache)
+    block_tables = np.ascontiguousarray(block_tables, dtype=np.int32)
+    seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    kb, kh = _elem_strides(key_cache)[:2]
+    out = np.zeros((S, H, D), dtype=np.float16)
+    alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
+    lib = _load()
+    lib.vmi_oracle_paged_attention_v1_fp8.restype = ctypes.c_int
+    lib.vmi_oracle_paged_attention_v1_fp8.argtypes = (
+        [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
+        [ctypes.c_int32] * 2 + [ctypes.c_void_p] + [ctypes.c_int64] * 3 + [ctypes.c_int32] * 2 + [ctypes.c_float])
+
+    def run(lo: int, hi: int) -> int:
+        return lib.vmi_oracle_paged_attention_v1_fp8(
+            _base_ptr(out), _base_ptr(query), _base_ptr(key_cache), _base_ptr(value_cache), S, H, D,
+            int(num_kv_heads), float(scale), _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size),
+            int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
+            lo, hi, float(kv_scale))
+
+    threads = max(1, min(int(threads), S))
+    bounds = np.linspace(0, S, threads + 1).astype(int)
+    with ThreadPoolExecutor(threads) as ex:
+        rcs = list(ex.map(lambda i: run(int(bounds[i]), int(bounds[i + 1])), range(threads)))
+    if any(rcs):
+        raise RuntimeError(f"oracle fp8 attention failed: {rcs}")
+    return out

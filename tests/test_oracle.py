@@ -16,6 +16,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 import oracle
 from helpers import BS, make_case
@@ -270,3 +271,75 @@ def test_seam_trace_fixture_is_self_consistent(golden_dir):
     assert np.array_equal(vc.view(np.uint16), z["final_value_cache"].view(np.uint16))
     # every block went back to the free list (kv_cache.py:81-86)
     assert sorted(meta["final_free_blocks"]) == list(range(NB))
+
+
+# ------------------------------------------------------------------------------------------------
+# fp8 E4M3 KV cache (kv_cache_dtype "fp8"): the reference compiles this path to assert(false)
+# (ENABLE_FP8 is never defined, setup.py:30-45), so its SOURCE is the only definition.  The oracle's
+# converters are pinned against torch's float8_e4m3fn (the same OCP format) on the CPU.
+# ------------------------------------------------------------------------------------------------
+def test_fp8_e4m3_converters_match_torch_float8_e4m3fn():
+    bits = np.arange(256, dtype=np.uint8)
+    mine = oracle.fp8e4m3_to_f32(bits)
+    ref = torch.from_numpy(bits.copy()).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+    nan = np.isnan(ref)
+    assert np.array_equal(nan, np.isnan(mine)) and nan.sum() == 2                # 0x7f, 0xff
+    assert np.array_equal(mine[~nan].view(np.uint32), ref[~nan].view(np.uint32))  # incl. -0.0
+    assert np.nanmax(mine) == 448.0
+    # encode: every float16 value (what reshape_and_cache converts), RNE; torch does not saturate (overflow -> NaN),
+    # the reference does (__NV_SATFINITE): compare where |x| rounds into range, check saturation separately
+    halves = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    enc = oracle.f32_to_fp8e4m3(halves)
+    tref = torch.from_numpy(halves.copy()).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    in_range = np.abs(halves) < 464.0                                             # midpoint between 448 and the next step
+    assert np.array_equal(enc[in_range], tref[in_range])
+    big = np.isfinite(halves) & (np.abs(halves) >= 464.0)
+    assert np.array_equal(enc[big], np.where(halves[big] > 0, 0x7e, 0xfe).astype(np.uint8))
+    inf = np.isinf(halves)
+    assert np.array_equal(enc[inf], np.where(halves[inf] > 0, 0x7e, 0xfe).astype(np.uint8))
+    assert (enc[np.isnan(halves)] & 0x7f == 0x7f).all()
+    # decode(encode(x)) is the nearest representable value: idempotent on representable inputs
+    rep = mine[~nan]
+    assert np.array_equal(oracle.fp8e4m3_to_f32(oracle.f32_to_fp8e4m3(rep)).view(np.uint32), rep.view(np.uint32))
+
+
+def test_fp8_kernel_model_is_the_f16_model_on_dequantised_caches():
+    """With an fp8 cache the kernel only changes how a cache element is fetched
+    (attention_kernels.cu:283-289, 410-418): model(fp8 cache, kv_scale) == model(fp16 cache holding
+    half(float(fp8) * kv_scale)) bit for bit; reshape_and_cache_fp8 == quantise-then-scatter."""
+    rng = np.random.default_rng(8)
+    S, H, Hkv, D, bs, NB = 5, 4, 2, 64, 16, 12
+    lens = np.array([1, 16, 17, 40, 33], dtype=np.int32)
+    tables = rng.permutation(NB)[: S * 2].reshape(S, 2).astype(np.int32) if False else \
+        np.stack([rng.permutation(NB)[:3] for _ in range(S)]).astype(np.int32)
+    q = rng.standard_normal((S, H, D)).astype(np.float16)
+    for kv_scale in (1.0, 0.37, 2.0):
+        kq = rng.integers(0, 256, (NB, Hkv, D // 16, bs, 16), dtype=np.uint8)
+        vq = rng.integers(0, 256, (NB, Hkv, D, bs), dtype=np.uint8)
+        kq[(kq & 0x7f) == 0x7f] = 0x3c          # no NaN codes
+        vq[(vq & 0x7f) == 0x7f] = 0x3c
+        got = oracle.paged_attention_v1_fp8(q, kq, vq, Hkv, D ** -0.5, tables, lens, bs, kv_scale=kv_scale)
+        k16 = (oracle.fp8e4m3_to_f32(kq) * np.float32(kv_scale)).astype(np.float16)   # RNE, as float_to_half
+        v16 = (oracle.fp8e4m3_to_f32(vq) * np.float32(kv_scale)).astype(np.float16)
+        # same values, fp16 layout [NB,H,D/8,bs,8]: chunk c of 16 dims -> chunks 2c, 2c+1 of 8 dims
+        k16 = k16.reshape(NB, Hkv, D // 16, bs, 2, 8).transpose(0, 1, 2, 4, 3, 5).reshape(NB, Hkv, D // 8, bs, 8)
+        ref = oracle.paged_attention_v1(q, np.ascontiguousarray(k16), v16, Hkv, D ** -0.5, tables, lens, bs)
+        assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), kv_scale
+    # reshape
+    T = 7
+    key = (rng.standard_normal((T, Hkv, D)) * 3).astype(np.float16)
+    val = (rng.standard_normal((T, Hkv, D)) * 300).astype(np.float16)      # some values saturate
+    slots = rng.permutation(NB * bs)[:T].astype(np.int64)
+    slots[2] = -1
+    kc = np.zeros((NB, Hkv, D // 16, bs, 16), dtype=np.uint8)
+    vc = np.zeros((NB, Hkv, D, bs), dtype=np.uint8)
+    oracle.reshape_and_cache_fp8(key, val, kc, vc, slots, kv_scale=0.5)
+    for t in range(T):
+        if slots[t] < 0:
+            continue
+        b, o = divmod(int(slots[t]), bs)
+        ek = oracle.f32_to_fp8e4m3(key[t].astype(np.float32) / np.float32(0.5))
+        ev = oracle.f32_to_fp8e4m3(val[t].astype(np.float32) / np.float32(0.5))
+        assert np.array_equal(kc[b, :, :, o, :].reshape(Hkv, D), ek)
+        assert np.array_equal(vc[b, :, :, o], ev)
+    assert (vc == 0x7e).any() or (vc == 0xfe).any()                          # saturation was exercised

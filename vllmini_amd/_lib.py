@@ -38,6 +38,10 @@ SIGNATURES = {
     "vmi_paged_attention_v2_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32]),
     "vmi_paged_attention_v1_append_f16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
     "vmi_paged_attention_v1_append_bf16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
+    "vmi_paged_attention_v1_fp8": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32]),
+    "vmi_reshape_and_cache_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                                 _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _c_void_p]),
+    "vmi_paged_attention_v1_pick_variant_fp8": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v1_variant_count": (ctypes.c_int, []),
     "vmi_paged_attention_v1_variant_name": (ctypes.c_char_p, [_i32]),
     "vmi_paged_attention_v1_pick_variant": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
@@ -60,7 +64,7 @@ SIGNATURES = {
     ]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lock = threading.Lock()
 _lib = None

@@ -23,7 +23,7 @@ typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));
 // ----------------------------------------------------------------------------------------
 
 template <bool NT>
-__device__ __forceinline__ u32x4 ld16(const h16* p) {
+__device__ __forceinline__ u32x4 ld16(const void* p) {
   if constexpr (NT) {
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
   } else {
@@ -73,6 +73,31 @@ __device__ __forceinline__ float dot8(const u32x4 q, const u32x4 k) {
     for (int e = 1; e < 8; ++e) a = __builtin_fmaf((float)qh[e], (float)kh[e], a);
     return a;
   }
+}
+
+// ---- fp8 E4M3 KV cache (kv_cache_dtype "fp8"): every cache element becomes float_to_half(float(fp8) * kv_scale)
+// first (reference quant_utils.cuh:295-300), then the fp16 arithmetic applies unchanged.  v_cvt_pk_f32_fp8 decodes
+// two OCP E4M3 bytes exactly on gfx950; the multiply and the RNE conversion to half are separate instructions
+// (-ffp-contract=off). ----
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// 8 fp8 bytes (two dwords) -> 8 halves packed like a 16-byte fp16 unit
+__device__ __forceinline__ u32x4 deq8(uint32_t w0, uint32_t w1, float s) {
+  h16x8 o;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t w = h ? w1 : w0;
+    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);  // bytes 0, 1
+    const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);   // bytes 2, 3
+    o[4 * h + 0] = (h16)(lo[0] * s);
+    o[4 * h + 1] = (h16)(lo[1] * s);
+    o[4 * h + 2] = (h16)(hi[0] * s);
+    o[4 * h + 3] = (h16)(hi[1] * s);
+  }
+  return __builtin_bit_cast(u32x4, o);
+}
+// q.k over one 16-byte fp8 chunk (16 dims): fp32 FMA chain on widened operands, like dot8
+__device__ __forceinline__ float dot16_f8(const u32x4 q0, const u32x4 q1, const u32x4 k, float s) {
+  return dot8<false>(q0, deq8(k[0], k[1], s)) + dot8<false>(q1, deq8(k[2], k[3], s));
 }
 
 // p.v over 8 tokens of one dim row.  e0/e1: the 8 exp values, is: 1/(sum+1e-6); `keep` = bit mask of the
@@ -181,6 +206,7 @@ struct PAParams {
   const h16* value;
   int64_t key_stride;
   int64_t value_stride;
+  float kv_scale;  // fp8 cache only (F8): cache element = fp8(x / kv_scale)
 };
 
 // ----------------------------------------------------------------------------------------
@@ -211,21 +237,27 @@ struct PAParams {
 // LDS  = HPW*HPT * ( lpad*4 (logits) + 2*WPH*4 (max/sum exchange) + WPH*D*4 (partial out) ).
 // ----------------------------------------------------------------------------------------
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
-          bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0>
+          bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0, bool F8 = false>
 __global__ void __launch_bounds__(HPW* WPH * 64)
     pa_v1_kernel(const PAParams p) {
   constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
-  constexpr int UNITS = D * BS / 8;       // 16-B units in one (block, head) tile of K — and of V
+  // F8: the caches hold fp8 E4M3 bytes — key_cache [NB, H, D/16, BS, 16], value_cache [NB, H, D, BS]
+  // (x = 16 / sizeof(cache_t), attention_kernels.cu:200): a 16-byte unit carries 16 elements instead of 8
+  constexpr int EPU = F8 ? 16 : 8;        // cache elements per 16-B unit
+  constexpr int ES = F8 ? 1 : 2;          // bytes per cache element
+  constexpr int UNITS = D * BS / EPU;     // 16-B units in one (block, head) tile of K — and of V
   constexpr int NL = (UNITS + 63) / 64;   // 1-KiB loads per tile
   constexpr int TAIL = UNITS - 64 * (NL - 1);  // active lanes of the last load (64 = full)
   constexpr int CPL = 64 / BS;            // K: chunks per load
-  constexpr int UPR = BS / 8;             // V: 16-B units per dim row
+  constexpr int UPR = BS / EPU;           // V: 16-B units per dim row
   constexpr int RPL = 64 / UPR;           // V: rows per load
   static_assert(D % 8 == 0, "head size must be a multiple of 8");
   static_assert(BS == 8 || BS == 16 || BS == 32, "block size 8, 16 or 32");
   static_assert(64 % U == 0, "U must divide 64");
   static_assert(!(LOCK && WPH > 1), "lockstep needs every wave to run the same number of page groups");
   static_assert(!(APP && (PART || LOADS_ONLY)), "the fused append exists for paged_attention_v1 only");
+  static_assert(!F8 || (BS >= 16 && D % 16 == 0 && !BF && !APP && !LOADS_ONLY),
+                "fp8 cache: fp16 query, block size 16 or 32 (a V row must fill whole 16-byte units)");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -295,16 +327,21 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   const int qpk = p.num_heads / p.num_kv_heads;
   int64_t hoff[HPT];
   float slope[HPT];
-  u32x4 qreg[HPT][NL];
+  u32x4 qreg[HPT][NL][F8 ? 2 : 1];  // the EPU dims of q that face this lane's chunk of each K load
 #pragma unroll
   for (int hh = 0; hh < HPT; ++hh) {
     const int head = head0 + (valid(hh) ? hh : 0);
-    hoff[hh] = (int64_t)(head / qpk) * p.kv_head_stride + lane * 8;
+    hoff[hh] = (int64_t)(head / qpk) * p.kv_head_stride + lane * EPU;
     slope[hh] = p.alibi ? p.alibi[head] : 0.f;
     const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      qreg[hh][i] = (i < NL - 1 || tail_ok) ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8) : zero4;
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int w = 0; w < (F8 ? 2 : 1); ++w)
+        qreg[hh][i][w] = (i < NL - 1 || tail_ok)
+                             ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * EPU + 8 * w)
+                             : zero4;
+    }
   }
 
   // ---- fused append (APP): this step's key/value rows, in the lane map of the K / V tiles.  They are patched
@@ -383,12 +420,12 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
         // (sc0/sc1 cache-policy bits and buffer- vs flat-addressed loads were measured neutral on
         //  this stream; only `nt` pays: profiles/r01_cfg3_sweep_cache_policy_bits.json)
-        const h16* blk = cache + phys * p.kv_block_stride;
+        const char* blk = reinterpret_cast<const char*>(cache) + phys * p.kv_block_stride * ES;
   #pragma unroll
         for (int hh = 0; hh < HPT; ++hh) {
   #pragma unroll
           for (int i = 0; i < NL; ++i)  // masked lanes / absent heads contribute zeros
-            r[j][hh][i] = (valid(hh) && (i < NL - 1 || tail_ok)) ? ld16<NT>(blk + hoff[hh] + i * 512) : zero4;
+            r[j][hh][i] = (valid(hh) && (i < NL - 1 || tail_ok)) ? ld16<NT>(blk + (hoff[hh] + i * 64 * EPU) * ES) : zero4;
         }
       }
     };
@@ -435,7 +472,10 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
               }
               float accv[NL];
   #pragma unroll
-              for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[hh][i], r[j][hh][i]);
+              for (int i = 0; i < NL; ++i) {
+                if constexpr (F8) accv[i] = dot16_f8(qreg[hh][i][0], qreg[hh][i][1], r[j][hh][i], p.kv_scale);
+                else accv[i] = dot8<BF>(qreg[hh][i][0], r[j][hh][i]);
+              }
               float acc = accv[0];
   #pragma unroll
               for (int i = 1; i < NL; ++i) acc += accv[i];
@@ -555,7 +595,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
         const int idx = g * UU + j;
         if (idx < nmy) {  // wave-uniform
           const int b = blk_lo + sub + idx * WPH;
-          const int token0 = b * BS + hf * 8;
+          const int token0 = b * BS + hf * EPU;
           const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
   #pragma unroll
           for (int hh = 0; hh < HPT; ++hh) {
@@ -588,7 +628,21 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
               PV8<BF> pv;
               pv.set(e0, e1, inv_sum[hh]);
   #pragma unroll
-              for (int i = 0; i < NL; ++i) acc[hh][i] += pv.template dot<MASK>(r[j][hh][i], last, token0, L);
+              for (int i = 0; i < NL; ++i) {
+                if constexpr (F8)  // first 8 of the unit's 16 tokens
+                  acc[hh][i] += pv.template dot<MASK>(deq8(r[j][hh][i][0], r[j][hh][i][1], p.kv_scale), last, token0, L);
+                else
+                  acc[hh][i] += pv.template dot<MASK>(r[j][hh][i], last, token0, L);
+              }
+              if constexpr (F8) {  // the other 8 tokens: their own fp16 probability vector, fp32 accumulation
+                const f32x4 e2 = *reinterpret_cast<const f32x4_alias*>(lg + 8);
+                const f32x4 e3 = *reinterpret_cast<const f32x4_alias*>(lg + 12);
+                PV8<BF> pw;
+                pw.set(e2, e3, inv_sum[hh]);
+#pragma unroll
+                for (int i = 0; i < NL; ++i)
+                  acc[hh][i] += pw.template dot<MASK>(deq8(r[j][hh][i][2], r[j][hh][i][3], p.kv_scale), last, token0 + 8, L);
+              }
             }
           }
         }
@@ -802,6 +856,7 @@ struct Variant {
   int lds_attr_set;  // largest dynamic-LDS size already granted through hipFuncSetAttribute
   int UMAX;          // adaptive queue depth limit (0 = fixed U)
   int lds_attr_dev;  // device that grant was made on (the attribute is per device)
+  bool F8;           // caches hold fp8 E4M3 bytes (kv_cache_dtype "fp8"); query/out fp16
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
@@ -812,6 +867,11 @@ typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const 
   {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, BF,                                                                  \
    (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), LO, false, BS, LOCK, BF, HPT, (VMI_APP) && !(LO), UMAX>, 0, \
    UMAX},
+// fp8-cache rows (pa_table_fp8.inc): fp16 query, no fused-append twin
+#define VMI_ROW_F8(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX)                                                  \
+  {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, false,                                                               \
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), false, false, BS, LOCK, false, HPT, false, UMAX, true>, 0, \
+   UMAX, 0, true},
 #define VMI_ROW(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT) \
   VMI_ROW_A(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT, 0)
 
@@ -833,6 +893,9 @@ extern Variant g_app_extra_variants[];
 extern const int g_app_extra_nvariants;
 extern Variant g_app_bf16_variants[];
 extern const int g_app_bf16_nvariants;
+// fp8 E4M3 cache (pa_variants_fp8.hip): ids continue after the bf16 menu; no append twins
+extern Variant g_fp8_variants_v1[];
+extern const int g_fp8_nvariants_v1;
 pa_reduce_t bf16_reduce_kernel(int head_size);
 
 }  // namespace vmi

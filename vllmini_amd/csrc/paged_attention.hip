@@ -142,6 +142,70 @@ __global__ void __launch_bounds__(256)
 
 
 // ----------------------------------------------------------------------------------------
+// reshape_and_cache with kv_cache_dtype "fp8": cache element = fp8_e4m3(float(x) / kv_scale), round to nearest
+// even, saturating at +-448, NaN kept (reference cache_kernels.cu:200-205 -> quant_utils.cuh:458-464,
+// __nv_cvt_float_to_fp8(..., __NV_SATFINITE, __NV_E4M3)).  Layout x = 16: K[blk, h, d/16, off, d%16], V[blk, h, d, off].
+// The conversion is integer arithmetic on the fp32 bit pattern (no dependence on a hardware rounding mode).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_to_fp8e4m3_satfinite(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  const uint32_t sign = (u >> 24) & 0x80u;
+  u &= 0x7fffffffu;
+  if (u > 0x7f800000u) return sign | 0x7fu;   // NaN
+  if (u >= 0x43e80000u) return sign | 0x7eu;  // |x| >= 464 (the midpoint past 448) and infinity: saturate
+  if (u < 0x3c800000u) {                      // |x| < 2^-6: subnormal range, step 2^-9; 8 * 2^-9 encodes as the smallest normal
+    return sign | (uint32_t)__builtin_rintf(__builtin_bit_cast(float, u) * 512.f);
+  }
+  u += 0x7ffffu + ((u >> 20) & 1u);           // RNE to 3 mantissa bits; a carry moves into the exponent
+  return sign | ((u >> 20) - ((127u - 7u) << 3));
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+    reshape_and_cache_fp8_kernel(const h16* __restrict__ key, const h16* __restrict__ value,
+                                 uint8_t* __restrict__ kc, uint8_t* __restrict__ vc,
+                                 const int64_t* __restrict__ slot_mapping, int64_t key_stride,
+                                 int64_t value_stride, int H, int D, int BS, float kv_scale) {
+  const int64_t token = blockIdx.x;
+  const int64_t slot = slot_mapping[token];
+  if (slot < 0) return;  // padding token (ref cache_kernels.cu:165-169)
+  const int64_t blk = slot / BS, off = slot % BS;
+  const h16* ksrc = key + token * key_stride;
+  const h16* vsrc = value + token * value_stride;
+  const int n16 = (H * D) >> 4;
+  for (int c = threadIdx.x; c < n16; c += blockDim.x) {
+    const int i = c << 4, h = i / D, d = i - h * D;
+    h16 kv[16], vv[16];
+    if constexpr (VEC) {
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(ksrc + i + 8 * w));
+        const h16x8 b = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(vsrc + i + 8 * w));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          kv[8 * w + e] = a[e];
+          vv[8 * w + e] = b[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        kv[e] = ksrc[i + e];
+        vv[e] = vsrc[i + e];
+      }
+    }
+    u32x4 kq = {0u, 0u, 0u, 0u};
+    uint8_t* vdst = vc + ((blk * H + h) * (int64_t)D + d) * BS + off;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      kq[e >> 2] |= f32_to_fp8e4m3_satfinite((float)kv[e] / kv_scale) << (8 * (e & 3));
+      vdst[(int64_t)e * BS] = (uint8_t)f32_to_fp8e4m3_satfinite((float)vv[e] / kv_scale);
+    }
+    *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (D >> 4) + (d >> 4)) * BS + off) * 16) = kq;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // reshape_and_cache, prefill form.  A prompt's tokens arrive with consecutive slots, so BS consecutive tokens
 // usually ARE one cache block.  The per-token kernel above then writes every 32-B V row in BS separate 2-byte
 // pieces (1.0-1.2 TB/s read+write on MI355X); here one workgroup takes a run of BS tokens, checks that their slots are
@@ -339,20 +403,23 @@ static Variant g_variants[] = {
 };
 static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
-static int nvariants_v1() { return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1; }
-static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf16]
+static int nvariants_v1() { return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1 + g_fp8_nvariants_v1; }
+static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf16][fp8 cache]
   if (id <= g_ncore) return g_variants[id - 1];
   if (id <= g_ncore + g_extra_nvariants_v1) return g_extra_variants_v1[id - 1 - g_ncore];
-  return g_bf16_variants_v1[id - 1 - g_ncore - g_extra_nvariants_v1];
+  if (id <= g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1)
+    return g_bf16_variants_v1[id - 1 - g_ncore - g_extra_nvariants_v1];
+  return g_fp8_variants_v1[id - 1 - g_ncore - g_extra_nvariants_v1 - g_bf16_nvariants_v1];
 }
 
 static bool is_diag(const Variant& v) { return strstr(v.name, "LOADSONLY") != nullptr; }
 static bool is_lock(const Variant& v) { return strstr(v.name, "_lock") != nullptr || v.HPT > 1; }
 
-static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = any */, bool bf = false) {
+static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = any */, bool bf = false,
+                        bool f8 = false) {
   for (int id = 1; id <= nvariants_v1(); ++id) {
     const Variant& v = variant_v1(id);
-    if (v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
+    if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
         (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0)
       return id;
   }
@@ -378,6 +445,28 @@ static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }
 // chip once the short sequences are done, so the heads are cut into 8 waves each — 8x the workgroups' waves, more
 // workgroups than fit at once, and the hardware dispatcher does the balancing
 // (profiles/r01g_ragged_batches.md: cfg3 U{1..1024} 98.7 -> 77.1 us, cfg4 446.8 -> 360.5 us).
+// fp8 cache: a (block, head) tile is half the bytes; measured picks in profiles/r01h_fp8_kv.md
+static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
+                            int mean_seq_len) {
+  const long units = (long)num_seqs * num_heads;
+  const int nblk = (max_seq_len + block_size - 1) / block_size;
+  int wph = 1;
+  while (wph < 16 && units * wph < 3072 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  if (mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3)
+    while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  int v = 0;
+  if (block_size == 16 && (head_size == 64 || head_size == 128)) {
+    if (wph == 1) {
+      v = find_variant(head_size, 16, (num_heads % 4 == 0) ? 4 : 1, 1, head_size == 64 ? 2 : 1, -1, false, true);
+    } else {
+      for (int ww = wph; ww >= 1 && !v; ww /= 2) v = find_variant(head_size, 16, 1, ww, -1, -1, false, true);
+    }
+  }
+  if (!v) v = find_variant(head_size, block_size, 1, wph == 1 ? 1 : 4, -1, -1, false, true);
+  if (!v) v = find_variant(head_size, block_size, 1, 1, -1, -1, false, true);
+  return v;
+}
+
 static int pick_variant(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
                         bool bf = false, int mean_seq_len = 0) {
   const long units = (long)num_seqs * num_heads;
@@ -436,7 +525,9 @@ static Variant* app_variant_v1(int id) {
     return nullptr;
   if (id <= g_ncore) return &g_app_core_variants[id - 1];
   if (id <= g_ncore + g_extra_nvariants_v1) return &g_app_extra_variants[id - 1 - g_ncore];
-  return &g_app_bf16_variants[id - 1 - g_ncore - g_extra_nvariants_v1];
+  if (id <= g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1)
+    return &g_app_bf16_variants[id - 1 - g_ncore - g_extra_nvariants_v1];
+  return nullptr;  // fp8-cache variants have no fused-append twin
 }
 
 static int launch_pa_v1(void* out, const void* query, const void* key_cache,
@@ -447,7 +538,8 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
                         int64_t kv_head_stride, int32_t device, void* stream, int32_t variant,
                         bool bf = false, bool append = false, const void* key = nullptr,
-                        const void* value = nullptr, int64_t key_stride = 0, int64_t value_stride = 0) {
+                        const void* value = nullptr, int64_t key_stride = 0, int64_t value_stride = 0,
+                        bool f8 = false, float kv_scale = 1.0f) {
   if (!out || !query || !key_cache || !value_cache || !block_tables || !seq_lens)
     return fail(VMI_E_NULL_POINTER, "paged_attention_v1: NULL tensor pointer");
   if (append) {
@@ -468,15 +560,21 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (num_kv_heads <= 0 || num_heads % num_kv_heads != 0)
     return fail(VMI_E_KV_HEADS, "paged_attention_v1: num_heads=%d not divisible by num_kv_heads=%d",
                 num_heads, num_kv_heads);
+  const int kv_am = f8 ? 15 : 7;  // cache strides are in elements: 16 bytes = 8 halves or 16 fp8 bytes
   if (!aligned16(query) || !aligned16(key_cache) || !aligned16(value_cache) || (q_stride & 7) ||
-      (kv_block_stride & 7) || (kv_head_stride & 7))
+      (kv_block_stride & kv_am) || (kv_head_stride & kv_am))
     return fail(VMI_E_ALIGNMENT, "paged_attention_v1: query/key_cache/value_cache and their "
                 "strides must be 16-byte aligned (q_stride=%lld kv_block_stride=%lld "
                 "kv_head_stride=%lld)", (long long)q_stride, (long long)kv_block_stride,
                 (long long)kv_head_stride);
   if (num_seqs == 0) return VMI_OK;
 
-  if (variant == 0) variant = pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
+  if (f8 && block_size == 8)
+    return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: 8 with an fp8 KV cache (a value row of 8 bytes does not "
+                "fill a 16-byte unit; block sizes 16 and 32 are built)");
+  if (variant == 0)
+    variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0)
+                 : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
   if (variant < 1 || variant > nvariants_v1())
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
   Variant* vp = append ? app_variant_v1(variant) : &variant_v1(variant);
@@ -484,6 +582,9 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   Variant& v = *vp;
   if (append && is_diag(v))
     return fail(VMI_E_VARIANT, "paged_attention_v1_append: %s is a bandwidth diagnostic", v.name);
+  if (v.F8 != f8)
+    return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s is for an %s KV cache", v.name,
+                v.F8 ? "fp8" : "fp16/bf16");
   if (v.BF != bf)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s is for %s elements", v.name,
                 v.BF ? "bfloat16" : "float16");
@@ -534,6 +635,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   p.value = append ? static_cast<const h16*>(value) : nullptr;
   p.key_stride = key_stride;
   p.value_stride = value_stride;
+  p.kv_scale = kv_scale;
 
   dim3 block(v.HPW * v.WPH * 64);
   // gridDim.y is limited to 65535: longer batches go out as consecutive launches over slices
@@ -685,6 +787,7 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   p.value = nullptr;
   p.key_stride = 0;
   p.value_stride = 0;
+  p.kv_scale = 1.0f;
   dim3 grid((num_heads + v.HPW - 1) / v.HPW, num_seqs, parts);  // :890
   hipLaunchKernelGGL(v.fn, grid, dim3(v.HPW * v.WPH * 64), lds, static_cast<hipStream_t>(stream), p);
   e = hipGetLastError();
@@ -783,6 +886,28 @@ int vmi_paged_attention_v1_append_bf16(void* out, const void* query, void* key_c
                            max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
                            kv_head_stride, device, stream, variant, true, true, key, value, key_stride,
                            value_stride);
+}
+
+int vmi_paged_attention_v1_fp8(void* out, const void* query, const void* key_cache, const void* value_cache,
+                               int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+                               float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                               int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+                               const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                               int64_t kv_head_stride, int32_t device, void* stream, float kv_scale,
+                               int32_t variant) {
+  if (!(kv_scale > 0.f) || kv_scale != kv_scale)
+    return vmi::fail(VMI_E_SHAPE, "paged_attention_v1 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, false, false, nullptr, nullptr, 0, 0,
+                           true, kv_scale);
+}
+
+int vmi_paged_attention_v1_pick_variant_fp8(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                            int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len) {
+  if (!vmi::head_size_supported(head_size) || (block_size != 16 && block_size != 32)) return 0;
+  return vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, mean_seq_len);
 }
 
 int vmi_paged_attention_v2_bf16(void* out, void* exp_sums, void* max_logits, void* tmp_out,
@@ -884,6 +1009,44 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
   }
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "reshape_and_cache launch");
+  return VMI_OK;
+}
+
+int vmi_reshape_and_cache_fp8(const void* key, const void* value, void* key_cache, void* value_cache,
+                              const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
+                              int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
+                              int64_t value_stride, float kv_scale, int32_t device, void* stream) {
+  using namespace vmi;
+  if (!key || !value || !key_cache || !value_cache || !slot_mapping)
+    return fail(VMI_E_NULL_POINTER, "reshape_and_cache (fp8): NULL tensor pointer");
+  if (x != 16) return fail(VMI_E_X, "reshape_and_cache (fp8): key_cache.size(4) must be 16, got %d", x);
+  if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || (head_size & 15))
+    return fail(VMI_E_SHAPE, "reshape_and_cache (fp8): bad sizes (num_tokens=%d num_heads=%d head_size=%d)",
+                num_tokens, num_heads, head_size);
+  if (block_size <= 0) return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: %d", block_size);
+  if (!(kv_scale > 0.f)) return fail(VMI_E_SHAPE, "reshape_and_cache (fp8): kv_scale must be positive, got %g", (double)kv_scale);
+  if (!aligned16(key_cache)) return fail(VMI_E_ALIGNMENT, "reshape_and_cache (fp8): key_cache must be 16-byte aligned");
+  if (num_tokens == 0) return VMI_OK;
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  const bool vec = aligned16(key) && aligned16(value) && !(key_stride & 7) && !(value_stride & 7);
+  const int n16 = (num_heads * head_size) >> 4;
+  int threads = ((n16 + 63) / 64) * 64;
+  if (threads > 256) threads = 256;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec)
+    hipLaunchKernelGGL(reshape_and_cache_fp8_kernel<true>, dim3(num_tokens), dim3(threads), 0, st,
+                       static_cast<const h16*>(key), static_cast<const h16*>(value),
+                       static_cast<uint8_t*>(key_cache), static_cast<uint8_t*>(value_cache), slot_mapping,
+                       key_stride, value_stride, num_heads, head_size, block_size, kv_scale);
+  else
+    hipLaunchKernelGGL(reshape_and_cache_fp8_kernel<false>, dim3(num_tokens), dim3(threads), 0, st,
+                       static_cast<const h16*>(key), static_cast<const h16*>(value),
+                       static_cast<uint8_t*>(key_cache), static_cast<uint8_t*>(value_cache), slot_mapping,
+                       key_stride, value_stride, num_heads, head_size, block_size, kv_scale);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "reshape_and_cache (fp8) launch");
   return VMI_OK;
 }
 

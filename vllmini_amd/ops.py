@@ -45,13 +45,19 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _check_kv_cache_dtype(kv_cache_dtype: str) -> None:
+_FP8_CACHE_TORCH_DTYPES = (torch.uint8, torch.float8_e4m3fn)
+
+
+def _check_kv_cache_dtype(kv_cache_dtype: str) -> bool:
+    """-> True when the caches hold fp8 E4M3 bytes.  The reference maps "fp8" and "fp8_e4m3" to E4M3 and
+    "fp8_e5m2" to E5M2 (quant_utils.cuh:529-566); E4M3 is built here (its own build never defines ENABLE_FP8, so
+    the reference's fp8 path is assert(false) — paged_attention_ext/setup.py:30-45 — and its source is the spec)."""
     if kv_cache_dtype in _SUPPORTED_KV_CACHE_DTYPES:
-        return
+        return False
+    if kv_cache_dtype in ("fp8", "fp8_e4m3"):
+        return True
     if kv_cache_dtype in _FP8_KV_CACHE_DTYPES:
-        raise RuntimeError(
-            f"Unsupported data type of kv cache: {kv_cache_dtype} (fp8 KV cache is not built; the "
-            "reference build never defines ENABLE_FP8 either, paged_attention_ext/setup.py:30-45)")
+        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype} (only the E4M3 fp8 format is built)")
     raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
 
 
@@ -78,7 +84,9 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
         # reference dispatches float/half/bf16 (quant_utils.cuh:529-566); half and bf16 are built here
         # (its callers only use half: gpt2.py, scheduler.py:13); fp32 has a different cache layout (x = 4)
         raise RuntimeError(f"Unsupported input type of paged attention: {query.dtype}")
-    _check_kv_cache_dtype(kv_cache_dtype)
+    fp8 = _check_kv_cache_dtype(kv_cache_dtype)
+    if fp8 and query.dtype != torch.float16:
+        raise RuntimeError("an fp8 KV cache is built for float16 query/out only")
     if int(blocksparse_vert_stride) > 1:
         raise RuntimeError("block-sparse paged attention (blocksparse_vert_stride > 1) is not "
                            "supported; reference callers always pass vert_stride=1 (gpt2.py:109-112)")
@@ -87,7 +95,10 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
     for name, t in (("out", out), ("key_cache", key_cache), ("value_cache", value_cache),
                     ("block_tables", block_tables), ("seq_lens", seq_lens)):
         _check_device(name, t, dev)
-    if key_cache.dtype != query.dtype or value_cache.dtype != query.dtype:
+    if fp8:
+        if key_cache.dtype not in _FP8_CACHE_TORCH_DTYPES or value_cache.dtype not in _FP8_CACHE_TORCH_DTYPES:
+            raise RuntimeError("key_cache/value_cache must be uint8 (or float8_e4m3fn) for kv_cache_dtype='fp8'")
+    elif key_cache.dtype != query.dtype or value_cache.dtype != query.dtype:
         raise RuntimeError(f"key_cache/value_cache must be {query.dtype} for kv_cache_dtype='auto'")
     if out.dtype != query.dtype:
         raise RuntimeError(f"out must be {query.dtype}, got {out.dtype}")
@@ -99,8 +110,8 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
         raise RuntimeError("key_cache must be [num_blocks, num_kv_heads, head_size/x, block_size, x] "
                            "and value_cache [num_blocks, num_kv_heads, head_size, block_size]")
     x = int(key_cache.shape[4])
-    if x != 8:
-        raise RuntimeError(f"key_cache innermost dimension must be 8 (16 bytes of fp16), got {x}")
+    if x != (16 if fp8 else 8):                                   # x = 16 / sizeof(cache_t), attention_kernels.cu:200
+        raise RuntimeError(f"key_cache innermost dimension must be {16 if fp8 else 8} (16 bytes per chunk), got {x}")
     if int(key_cache.shape[3]) != int(block_size) or int(value_cache.shape[3]) != int(block_size):
         raise RuntimeError(f"block_size={block_size} does not match the cache tensors "
                            f"({key_cache.shape[3]}, {value_cache.shape[3]})")
@@ -176,7 +187,9 @@ def paged_attention_v1(
                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
                       blocksparse_block_size, blocksparse_head_sliding_step)
     lib = _lib.load()
-    if query.dtype == torch.bfloat16:
+    if _check_kv_cache_dtype(kv_cache_dtype):      # fp8 E4M3 cache
+        rc = lib.vmi_paged_attention_v1_fp8(*args, float(kv_scale), int(_variant))
+    elif query.dtype == torch.bfloat16:
         rc = lib.vmi_paged_attention_v1_bf16(*args, int(_variant))
     elif _variant:
         rc = lib.vmi_paged_attention_v1_f16_variant(*args, int(_variant))
@@ -215,6 +228,8 @@ def paged_attention_v1_append(
     step's token (as in gpt2.py:99-104); its slot is derived from the block table, so no slot_mapping is passed.
     Caches and `out` are bit-identical to the two-op sequence (tests/test_parity_gpu.py).
     """
+    if _check_kv_cache_dtype(kv_cache_dtype):
+        raise RuntimeError("paged_attention_v1_append is not built for an fp8 KV cache")
     args = _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
                       seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, 0, 0, 1, 1, 0)
     num_seqs, _, head_size = (int(s) for s in query.shape)
@@ -265,6 +280,8 @@ def paged_attention_v2(
     :529-562 + :564-669 (kernels).  The reference exports it but no Python caller exists
     (SURVEY.md §2 #7); it is the right operator when num_seqs*num_heads is far below the CU count.
     """
+    if _check_kv_cache_dtype(kv_cache_dtype):
+        raise RuntimeError("paged_attention_v2 is not built for an fp8 KV cache (paged_attention_v1 is)")
     args = _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
                       seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale,
                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
@@ -300,16 +317,21 @@ def reshape_and_cache(
 
     Reference: cache_kernels.cu:256-281 (host), :152-207 (kernel).
     """
-    _check_kv_cache_dtype(kv_cache_dtype)
+    fp8 = _check_kv_cache_dtype(kv_cache_dtype)
     if key.dim() != 3 or value.dim() != 3 or key.shape != value.shape:
         raise RuntimeError("key and value must both be [num_tokens, num_heads, head_size]")
     if key.dtype not in (torch.float16, torch.bfloat16) or value.dtype != key.dtype:
         raise RuntimeError(f"Unsupported input type of reshape_and_cache: {key.dtype}")
+    if fp8 and key.dtype != torch.float16:
+        raise RuntimeError("an fp8 KV cache is built for float16 key/value only")
     dev = key.device
     for name, t in (("key", key), ("value", value), ("key_cache", key_cache),
                     ("value_cache", value_cache), ("slot_mapping", slot_mapping)):
         _check_device(name, t, dev)
-    if key_cache.dtype != key.dtype or value_cache.dtype != key.dtype:
+    if fp8:
+        if key_cache.dtype not in _FP8_CACHE_TORCH_DTYPES or value_cache.dtype not in _FP8_CACHE_TORCH_DTYPES:
+            raise RuntimeError("key_cache/value_cache must be uint8 (or float8_e4m3fn) for kv_cache_dtype='fp8'")
+    elif key_cache.dtype != key.dtype or value_cache.dtype != key.dtype:
         raise RuntimeError(f"key_cache/value_cache must be {key.dtype} for kv_cache_dtype='auto'")
     if slot_mapping.dtype != torch.int64:
         raise RuntimeError("slot_mapping must be int64")
@@ -331,6 +353,15 @@ def reshape_and_cache(
     if slot_mapping.numel() != num_tokens or not slot_mapping.is_contiguous():
         raise RuntimeError("slot_mapping must be a contiguous [num_tokens] tensor")
     stream = torch.cuda.current_stream(dev).cuda_stream
+    if fp8:                                                               # cache_kernels.cu:200-205
+        rc = _lib.load().vmi_reshape_and_cache_fp8(
+            key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+            slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
+            int(key.stride(0)), int(value.stride(0)), float(kv_scale),
+            dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+        if rc != 0:
+            _raise_native(rc)
+        return None
     rc = _lib.load().vmi_reshape_and_cache_f16(
         key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
         slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
@@ -356,11 +387,14 @@ def variant_names_v2() -> list[str]:
 
 
 def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16,
-                 mean_seq_len: int = 0, bf16: bool = False) -> int:
+                 mean_seq_len: int = 0, bf16: bool = False, fp8: bool = False) -> int:
     """The library's work-decomposition heuristic (what `_variant=0` runs).  A caller that knows the batch's
     lengths on the host may pass their mean: a ragged batch (mean well below max_seq_len) then gets the
     many-waves-per-head decomposition; pass the result as `_variant`."""
     lib = _lib.load()
+    if fp8:
+        return int(lib.vmi_paged_attention_v1_pick_variant_fp8(num_seqs, num_heads, head_size, block_size,
+                                                               max_seq_len, int(mean_seq_len)))
     if mean_seq_len or bf16:
         return int(lib.vmi_paged_attention_v1_pick_variant_hint(num_seqs, num_heads, head_size, block_size,
                                                                 max_seq_len, int(mean_seq_len), int(bool(bf16))))
