@@ -72,6 +72,9 @@ def parse_args():
                     help="physically sequential pages instead of a random permutation (diagnostic)")
     ap.add_argument("--ragged", action="store_true", help="seq_lens ~ U{1..L} (diagnostic)")
     ap.add_argument("--ragged-sorted", action="store_true", help="same lengths, longest sequence first (diagnostic)")
+    ap.add_argument("--kv", default="auto", choices=["auto", "fp8"],
+                    help="KV cache element type: auto = fp16 (the BASELINE metric); fp8 = E4M3 bytes (diagnostic line, "
+                         "SURVEY row f-4)")
     ap.add_argument("--matrix", action="store_true",
                     help="attention kernel time for every (head size, block size) of the reference's dispatch set at "
                          "this config's batch/heads/seq_len, fp16 and bf16 -> gpurun_out/matrix.json (diagnostic)")
@@ -115,6 +118,15 @@ def init_dist(n_gpus: int):
 
 _V2_SCRATCH = {}
 SKIP_RESHAPE = False
+KV_DTYPE = "auto"      # "fp8": byte caches in the x = 16 layout (--kv fp8)
+
+
+def alg_bytes(cfg):
+    """Algorithmic bytes per attention launch; an fp8 cache halves the K/V term."""
+    b = cfg.algorithmic_bytes()
+    if KV_DTYPE == "fp8":
+        b -= 2 * cfg.batch * cfg.num_heads * cfg.seq_len * cfg.head_size
+    return b
 
 
 def attend(wl, out, t, variant, op="v1"):
@@ -125,7 +137,7 @@ def attend(wl, out, t, variant, op="v1"):
         return
     if op == "v1":
         ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
-                               wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0,
+                               wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, KV_DTYPE, 1.0,
                                0, 0, 1, 1, 0, _variant=variant)
         return
     key = (c.name, out.device)
@@ -144,7 +156,7 @@ def one_step(wl, out, i, variant, op="v1"):
     """The reference's per-layer decode call pair, in its call order (gpt2.py:44, :62)."""
     t = i % len(wl.tables)
     if op != "fused" and not SKIP_RESHAPE:
-        cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
+        cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], KV_DTYPE, 1.0)
     attend(wl, out, t, variant, op)
 
 
@@ -157,7 +169,7 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
     def timed(i):
         t = i % len(wl.tables)
         if op != "fused" and not SKIP_RESHAPE:
-            cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
+            cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], KV_DTYPE, 1.0)
         ev[i][0].record()  # HIP events on the launch stream (torch's current stream)
         attend(wl, out, t, variant, op)
         ev[i][1].record()
@@ -337,6 +349,23 @@ def main():
             seq = torch.arange(cfg.batch * cfg.blocks_per_seq, dtype=torch.int32, device=dev) + t * per
             tab[:, : cfg.blocks_per_seq] = seq.view(cfg.batch, cfg.blocks_per_seq)
     out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
+    if args.kv == "fp8":
+        global KV_DTYPE
+        KV_DTYPE = "fp8"
+        if args.op != "v1":
+            raise SystemExit("--kv fp8 is built for --op v1")
+        args.no_fused = True
+        args.no_cpu_baseline = True
+        gk = torch.Generator(device=dev).manual_seed(99 + rank)
+        kshape = (cfg.num_blocks, cfg.num_heads, cfg.head_size // 16, cfg.block_size, 16)
+        vshape = (cfg.num_blocks, cfg.num_heads, cfg.head_size, cfg.block_size)
+        del wl.key_cache, wl.value_cache
+        torch.cuda.empty_cache()
+        # random E4M3 codes of magnitude < 2 (exponent field <= 7): no NaN codes, attention-like values
+        wl.key_cache = (torch.randint(0, 64, kshape, dtype=torch.uint8, device=dev, generator=gk)
+                        | (torch.randint(0, 2, kshape, dtype=torch.uint8, device=dev, generator=gk) << 7))
+        wl.value_cache = (torch.randint(0, 64, vshape, dtype=torch.uint8, device=dev, generator=gk)
+                          | (torch.randint(0, 2, vshape, dtype=torch.uint8, device=dev, generator=gk) << 7))
 
     if args.diag:
         from vllmini_amd import _lib
@@ -390,7 +419,7 @@ def main():
         names = ops.variant_names()
         res = []
         for vid, name in enumerate(names, start=1):
-            if not name.startswith(f"d{cfg.head_size}_"):
+            if not name.startswith(f"{'fp8_' if args.kv == 'fp8' else ''}d{cfg.head_size}_"):
                 continue
             try:
                 _, kern_ms = time_steps(wl, out, args.steps, args.warmup, vid, dist, dev)
@@ -399,14 +428,15 @@ def main():
                 continue
             us = statistics.mean(kern_ms) * 1e3
             res.append({"variant": vid, "name": name, "us_mean": us, "us_median": statistics.median(kern_ms) * 1e3,
-                        "us_min": min(kern_ms) * 1e3, "gbps": cfg.algorithmic_bytes() / (us * 1e-6) / 1e9})
+                        "us_min": min(kern_ms) * 1e3, "gbps": alg_bytes(cfg) / (us * 1e-6) / 1e9})
             if rank == 0:
                 print(json.dumps(res[-1]), file=sys.stderr, flush=True)
         if rank == 0:
             os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
             with open(os.path.join(REPO, "gpurun_out", f"sweep_{cfg.name}.json"), "w") as f:
-                json.dump({"config": cfg.name, "picked": ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size,
-                                                                           cfg.seq_len), "results": res}, f, indent=1)
+                json.dump({"config": cfg.name, "kv": args.kv,
+                           "picked": ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len,
+                                                      fp8=args.kv == "fp8"), "results": res}, f, indent=1)
         return
 
     global SKIP_RESHAPE
@@ -421,10 +451,11 @@ def main():
 
     tokens = cfg.batch * world * args.steps          # one new token per sequence per step
     ms_per_step = elapsed / args.steps * 1e3
-    achieved = cfg.algorithmic_bytes() / (kern_mean_ms * 1e-3) / 1e9
-    vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len)
+    achieved = alg_bytes(cfg) / (kern_mean_ms * 1e-3) / 1e9
+    vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len,
+                                           fp8=args.kv == "fp8")
     vname = ops.variant_names()[vid - 1] if args.op in ("v1", "fused") else f"paged_attention_v2 variant {args.variant or 'auto'}"
-    traffic, traffic_src = (pmc_traffic(cfg.name, vname) if args.op == "v1" else
+    traffic, traffic_src = (pmc_traffic(cfg.name + ("_fp8" if args.kv == "fp8" else ""), vname) if args.op == "v1" else
                             pmc_traffic(cfg.name + "_fused", vname) if args.op == "fused" else (None, None))
     line = {
         "metric": "decode_tokens_per_sec_paged_attention_v1_per_layer",
@@ -442,7 +473,8 @@ def main():
         "config": {
             "workload": f"{cfg.name}: paged_attention_v1+reshape_and_cache decode step, batch {cfg.batch}/GPU, "
                         f"seq_len {cfg.seq_len}, {cfg.num_heads} heads x {cfg.head_size}, block_size {cfg.block_size}, "
-                        f"num_blocks {cfg.num_blocks}/GPU, fp16 KV, random-permutation block tables"
+                        f"num_blocks {cfg.num_blocks}/GPU, {'fp8 E4M3' if args.kv == 'fp8' else 'fp16'} KV, "
+                        f"random-permutation block tables"
                         + (" (SEQUENTIAL tables)" if args.sequential_tables else "")
                         + (" (ragged lens)" if args.ragged else "")
                         + (" (DIAGNOSTIC: reshape_and_cache skipped)" if args.skip_reshape else ""),
@@ -463,7 +495,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_src,
             "kernel": "pa_v1_kernel",
-            "algorithmic_bytes_per_launch": cfg.algorithmic_bytes(),
+            "algorithmic_bytes_per_launch": alg_bytes(cfg),
         },
     }
     if args.op == "v1" and not args.no_fused:

@@ -17,6 +17,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // LDS logits are written as float and re-read 4 at a time: the vector view must alias float
 typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));
+typedef uint32_t u32x4_alias __attribute__((ext_vector_type(4), may_alias));
 
 // ----------------------------------------------------------------------------------------
 // device helpers
@@ -80,24 +81,61 @@ __device__ __forceinline__ float dot8(const u32x4 q, const u32x4 k) {
 // two OCP E4M3 bytes exactly on gfx950; the multiply and the RNE conversion to half are separate instructions
 // (-ffp-contract=off). ----
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// 8 fp8 bytes (two dwords) -> 8 halves packed like a 16-byte fp16 unit
+// 8 fp8 bytes (two dwords) -> 8 halves packed like a 16-byte fp16 unit.
+// S1 (kv_scale == 1): every E4M3 value is a float16 value, so half(float(fp8) * 1) is the byte's own value and
+// v_cvt_scalef32_pk_f16_fp8 with scale 1.0 produces it directly, two per instruction.
+typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
+template <bool S1>
 __device__ __forceinline__ u32x4 deq8(uint32_t w0, uint32_t w1, float s) {
-  h16x8 o;
+  if constexpr (S1) {
+    u32x4 o;
+    o[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w0, 1.0f, false));
+    o[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w0, 1.0f, true));
+    o[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w1, 1.0f, false));
+    o[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w1, 1.0f, true));
+    return o;
+  } else {
+    h16x8 o;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t w = h ? w1 : w0;
-    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);  // bytes 0, 1
-    const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);   // bytes 2, 3
-    o[4 * h + 0] = (h16)(lo[0] * s);
-    o[4 * h + 1] = (h16)(lo[1] * s);
-    o[4 * h + 2] = (h16)(hi[0] * s);
-    o[4 * h + 3] = (h16)(hi[1] * s);
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t w = h ? w1 : w0;
+      const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);  // bytes 0, 1
+      const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);   // bytes 2, 3
+      o[4 * h + 0] = (h16)(lo[0] * s);
+      o[4 * h + 1] = (h16)(lo[1] * s);
+      o[4 * h + 2] = (h16)(hi[0] * s);
+      o[4 * h + 3] = (h16)(hi[1] * s);
+    }
+    return __builtin_bit_cast(u32x4, o);
   }
-  return __builtin_bit_cast(u32x4, o);
 }
-// q.k over one 16-byte fp8 chunk (16 dims): fp32 FMA chain on widened operands, like dot8
+// q.k over one 16-byte fp8 chunk (16 dims): fp32 FMA chain on widened operands, like dot8.
+// S1: the fp32 decode IS the operand (half(fp8) widens back to the same fp32), so q (f16) x k (f32) goes straight
+// into v_fma_mix_f32 — 8 decodes + 16 FMAs for 16 dims.
+template <bool S1>
 __device__ __forceinline__ float dot16_f8(const u32x4 q0, const u32x4 q1, const u32x4 k, float s) {
-  return dot8<false>(q0, deq8(k[0], k[1], s)) + dot8<false>(q1, deq8(k[2], k[3], s));
+  if constexpr (S1) {
+    const h16x8 qa = __builtin_bit_cast(h16x8, q0), qb = __builtin_bit_cast(h16x8, q1);
+    float a0 = 0.f, a1 = 0.f;  // two chains: the 8 dims facing q0, the 8 facing q1
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)k[w], false);
+      const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)k[w], true);
+      const f32x2_t lo2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)k[2 + w], false);
+      const f32x2_t hi2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)k[2 + w], true);
+      a0 = __builtin_fmaf((float)qa[4 * w + 0], lo[0], a0);
+      a0 = __builtin_fmaf((float)qa[4 * w + 1], lo[1], a0);
+      a0 = __builtin_fmaf((float)qa[4 * w + 2], hi[0], a0);
+      a0 = __builtin_fmaf((float)qa[4 * w + 3], hi[1], a0);
+      a1 = __builtin_fmaf((float)qb[4 * w + 0], lo2[0], a1);
+      a1 = __builtin_fmaf((float)qb[4 * w + 1], lo2[1], a1);
+      a1 = __builtin_fmaf((float)qb[4 * w + 2], hi2[0], a1);
+      a1 = __builtin_fmaf((float)qb[4 * w + 3], hi2[1], a1);
+    }
+    return a0 + a1;
+  } else {
+    return dot8<false>(q0, deq8<false>(k[0], k[1], s)) + dot8<false>(q1, deq8<false>(k[2], k[3], s));
+  }
 }
 
 // p.v over 8 tokens of one dim row.  e0/e1: the 8 exp values, is: 1/(sum+1e-6); `keep` = bit mask of the
@@ -108,6 +146,18 @@ template <bool BF>
 struct PV8 {
   h16x8 ph;     // fp16 probabilities
   float pf[8];  // bf16-rounded probabilities held in fp32
+  // the 8 probabilities as the softmax left them in LDS: fp16 (bf16) bit patterns, already rounded
+  __device__ __forceinline__ void load(const u32x4 raw) {
+    if constexpr (BF) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        pf[2 * w] = bf_lo(raw[w]);
+        pf[2 * w + 1] = bf_hi(raw[w]);
+      }
+    } else {
+      ph = __builtin_bit_cast(h16x8, raw);
+    }
+  }
   __device__ __forceinline__ void set(const f32x4 e0, const f32x4 e1, float is) {
     if constexpr (BF) {
 #pragma unroll
@@ -234,11 +284,15 @@ struct PAParams {
 //   when D*BS/8 is not a multiple of 64 (head 80/112, ...) the last load of a tile is predicated.
 //
 // grid = (ceil(H / (HPW*HPT)), num_seqs[, partitions]), block = HPW*WPH*64.
-// LDS  = HPW*HPT * ( lpad*4 (logits) + 2*WPH*4 (max/sum exchange) + WPH*D*4 (partial out) ).
+// LDS  = HPW*HPT * ( lpad*4 (logits) + 2*WPH*4 (max/sum exchange) + WPH*D*4 (partial out)
+//                    + (WPH > 1 ? lpad*2 : 0) (fp16 probabilities; in place over the logits when WPH = 1) ).
 // ----------------------------------------------------------------------------------------
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
           bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0, bool F8 = false>
-__global__ void __launch_bounds__(HPW* WPH * 64)
+// (second launch bound = minimum waves per SIMD.  The adaptive-depth kernels are the full-chip defaults: 12 waves
+//  per CU = 3 per SIMD that must ALL be resident, i.e. stay under 170 VGPRs — the fused-append form had drifted to 180
+//  and ran 173 us instead of 125.  Not applied elsewhere: on the big-tile kernels it only forces spills.)
+__global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     pa_v1_kernel(const PAParams p) {
   constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
   // F8: the caches hold fp8 E4M3 bytes — key_cache [NB, H, D/16, BS, 16], value_cache [NB, H, D, BS]
@@ -303,6 +357,15 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   float* logits0 = smem_f + (size_t)(hl * HPT) * p.lpad;                                    // + hh*lpad
   float* red0 = smem_f + (size_t)HPW * HPT * p.lpad + (hl * HPT) * 2 * WPH;                 // + hh*2*WPH
   float* osm0 = smem_f + (size_t)HPW * HPT * p.lpad + HPW * HPT * 2 * WPH + (size_t)(hl * HPT) * WPH * D;
+  // Probabilities as fp16 / bf16 bit patterns, written ONCE per token after the softmax (the V pass used to convert
+  // exp * inv_sum again in every lane that met the token: D/8-fold redundant VALU work).  One wave per head: in
+  // place over the fp32 values (a value is read before any lane overwrites it — see the normalise loop); WPH waves
+  // per head: a region of their own behind the exchange buffers, because another wave may not have read yet.
+  const int ph_stride = WPH == 1 ? 2 * p.lpad : p.lpad;  // uint16 units between the heads of a slot
+  uint16_t* ph0 =
+      WPH == 1 ? reinterpret_cast<uint16_t*>(logits0)
+               : reinterpret_cast<uint16_t*>(smem_f + (size_t)HPW * HPT * p.lpad + HPW * HPT * 2 * WPH +
+                                             (size_t)HPW * HPT * WPH * D) + (size_t)(hl * HPT) * p.lpad;
 
   const int64_t ostride = PART ? (int64_t)p.max_num_partitions * D : D;  // out elements between heads
   uint16_t* out0 = reinterpret_cast<uint16_t*>(p.out) +
@@ -354,20 +417,28 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   bool own_last = false;              // wave-uniform: this wave met block lbA
   const int lbA = (Lfull - 1) / BS;   // block and in-block offset of the appended token
   const int offA = (Lfull - 1) % BS;
-  u32x4 knew[APP ? HPT : 1][APP ? NL : 1];
-  uint32_t vnew[APP ? HPT : 1][APP ? NL : 1];
-  if constexpr (APP) {
+  // The step's rows in the lane map of the K / V tiles: knew_at(hh, i) = this lane's 16-B chunk of load i,
+  // vnew_at(hh, i) = the element of this lane's dim row.  One head per wave (APP_TILE): preloaded next to q.
+  // Several heads per wave: fetched where they are used (once per wave, at its last block and in the epilogue) —
+  // holding them costs HPT*NL*5 registers, which pushed the 4-heads-per-wave kernel into spills.
+  auto knew_at = [&](int hh, int i) -> u32x4 {
+    const int kvh = (head0 + (valid(hh) ? hh : 0)) / qpk;
+    const h16* kr = p.key + (int64_t)seq * p.key_stride + (int64_t)kvh * D;
+    return (i < NL - 1 || tail_ok) ? *reinterpret_cast<const u32x4*>(kr + (CPL * i + c4) * 8) : zero4;
+  };
+  auto vnew_at = [&](int hh, int i) -> uint32_t {
+    const int kvh = (head0 + (valid(hh) ? hh : 0)) / qpk;
+    const h16* vr = p.value + (int64_t)seq * p.value_stride + (int64_t)kvh * D;
+    const int row = (64 / (BS / 8)) * i + lane / (BS / 8);
+    return row < D ? (uint32_t)__builtin_bit_cast(uint16_t, vr[row]) : 0u;
+  };
+  u32x4 knew[APP_TILE ? NL : 1];
+  uint32_t vnew[APP_TILE ? NL : 1];
+  if constexpr (APP_TILE) {
 #pragma unroll
-    for (int hh = 0; hh < HPT; ++hh) {
-      const int kvh = (head0 + (valid(hh) ? hh : 0)) / qpk;
-      const h16* kr = p.key + (int64_t)seq * p.key_stride + (int64_t)kvh * D;
-      const h16* vr = p.value + (int64_t)seq * p.value_stride + (int64_t)kvh * D;
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        knew[hh][i] = (i < NL - 1 || tail_ok) ? *reinterpret_cast<const u32x4*>(kr + (CPL * i + c4) * 8) : zero4;
-        const int row = (64 / (BS / 8)) * i + lane / (BS / 8);
-        vnew[hh][i] = row < D ? (uint32_t)__builtin_bit_cast(uint16_t, vr[row]) : 0u;
-      }
+    for (int i = 0; i < NL; ++i) {
+      knew[i] = knew_at(0, i);
+      vnew[i] = vnew_at(0, i);
     }
   }
 
@@ -398,8 +469,9 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   };
 
   // The K pass, the softmax and the V pass for a compile-time group size UU (blocks per register group).
-  auto run = [&](auto utag) {
+  auto run = [&](auto utag, auto s1tag) {
     constexpr int UU = decltype(utag)::value;
+    constexpr bool S1 = decltype(s1tag)::value;  // fp8 cache with kv_scale == 1: cheaper, bit-identical dequantisation
     const int ngroups = (nmy + UU - 1) / UU;
     auto table_for = [&](int g) {  // lane j: physical id of my block (bt_sg*64 + j)
       const int sg = (g * UU) >> 6;
@@ -464,7 +536,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
                 if (b == lbA) {  // wave-uniform, once per wave at most
   #pragma unroll
                   for (int i = 0; i < NL; ++i) {
-                    r[j][hh][i] = (tk == offA) ? knew[hh][i] : r[j][hh][i];
+                    const u32x4 kn = APP_TILE ? knew[APP_TILE ? i : 0] : knew_at(hh, i);
+                    r[j][hh][i] = (tk == offA) ? kn : r[j][hh][i];
                     if constexpr (APP_TILE) klast[i] = r[j][hh][i];
                   }
                   own_last = true;
@@ -473,7 +546,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
               float accv[NL];
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
-                if constexpr (F8) accv[i] = dot16_f8(qreg[hh][i][0], qreg[hh][i][1], r[j][hh][i], p.kv_scale);
+                if constexpr (F8) accv[i] = dot16_f8<S1>(qreg[hh][i][0], qreg[hh][i][1], r[j][hh][i], p.kv_scale);
                 else accv[i] = dot8<BF>(qreg[hh][i][0], r[j][hh][i]);
               }
               float acc = accv[0];
@@ -581,6 +654,25 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
       }
     }
 
+    // ---- normalise: p = exp * inv_sum -> fp16 (bf16), once per token, for the blocks THIS wave consumes below
+    //      (so no barrier is needed); positions past the context inside my last block become 0 ----
+    if constexpr (!LOADS_ONLY) {
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        if (valid(hh)) {
+          const float* lg = logits0 + hh * p.lpad;
+          uint16_t* ph = ph0 + hh * ph_stride;
+          for (int t = lane; t < nmy * BS; t += 64) {
+            const int i = (sub + (t / BS) * WPH) * BS + (t % BS);  // relative to tok_lo
+            const float e = lg[i];
+            // in place (WPH == 1, i == t): the 64 lanes read fp32 values [t0, t0+64) and then write bytes
+            // [2*t0, 2*t0+128), i.e. fp32 slots [t0/2, t0/2+32) — already consumed, or being read by this very access
+            ph[i] = i < Lloc ? to_elem<BF>(e * inv_sum[hh]) : (uint16_t)0;
+          }
+        }
+      }
+    }
+
     // =========================== V pass ====================================================
     // `masked` is a compile-time tag: only the LAST page group of a wave can contain the sequence's last
     // block, so only that call site compiles the tail masking in.
@@ -600,9 +692,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   #pragma unroll
           for (int hh = 0; hh < HPT; ++hh) {
             if (valid(hh)) {
-              const float* lg = logits0 + hh * p.lpad + token0 - tok_lo;
-              const f32x4 e0 = *reinterpret_cast<const f32x4_alias*>(lg);
-              const f32x4 e1 = *reinterpret_cast<const f32x4_alias*>(lg + 4);
+              const uint16_t* php = ph0 + hh * ph_stride + (token0 - tok_lo);
               if constexpr (APP && MASK) {  // the appended token lives in the sequence's last block -> final group only
                 if (b == lbA && hf == (offA >> 3)) {
                   const int e = offA & 7;
@@ -611,7 +701,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
   #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                       const uint32_t old = r[j][hh][i][w];
-                      const uint32_t vb = vnew[hh][i];
+                      const uint32_t vb = APP_TILE ? vnew[APP_TILE ? i : 0] : vnew_at(hh, i);
                       const uint32_t patched = (e & 1) ? ((old & 0x0000ffffu) | (vb << 16)) : ((old & 0xffff0000u) | vb);
                       r[j][hh][i][w] = ((e >> 1) == w) ? patched : old;
                     }
@@ -626,22 +716,20 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
                 }
               }
               PV8<BF> pv;
-              pv.set(e0, e1, inv_sum[hh]);
+              pv.load(*reinterpret_cast<const u32x4_alias*>(php));
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
                 if constexpr (F8)  // first 8 of the unit's 16 tokens
-                  acc[hh][i] += pv.template dot<MASK>(deq8(r[j][hh][i][0], r[j][hh][i][1], p.kv_scale), last, token0, L);
+                  acc[hh][i] += pv.template dot<MASK>(deq8<S1>(r[j][hh][i][0], r[j][hh][i][1], p.kv_scale), last, token0, L);
                 else
                   acc[hh][i] += pv.template dot<MASK>(r[j][hh][i], last, token0, L);
               }
               if constexpr (F8) {  // the other 8 tokens: their own fp16 probability vector, fp32 accumulation
-                const f32x4 e2 = *reinterpret_cast<const f32x4_alias*>(lg + 8);
-                const f32x4 e3 = *reinterpret_cast<const f32x4_alias*>(lg + 12);
                 PV8<BF> pw;
-                pw.set(e2, e3, inv_sum[hh]);
+                pw.load(*reinterpret_cast<const u32x4_alias*>(php + 8));
 #pragma unroll
                 for (int i = 0; i < NL; ++i)
-                  acc[hh][i] += pw.template dot<MASK>(deq8(r[j][hh][i][2], r[j][hh][i][3], p.kv_scale), last, token0 + 8, L);
+                  acc[hh][i] += pw.template dot<MASK>(deq8<S1>(r[j][hh][i][2], r[j][hh][i][3], p.kv_scale), last, token0 + 8, L);
               }
             }
           }
@@ -679,13 +767,16 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
     const float ratio = (float)Lfull / fmaxf(mean_len, 1.f);
     const int level = __builtin_amdgcn_readfirstlane(ratio >= 2.8f ? 2 : (ratio >= 1.4f ? 1 : 0));
     if (UMAX >= 4 * U && level == 2)
-      run(std::integral_constant<int, (UMAX >= 4 * U ? 4 * U : U)>{});
+      run(std::integral_constant<int, (UMAX >= 4 * U ? 4 * U : U)>{}, std::false_type{});
     else if (level >= 1)
-      run(std::integral_constant<int, 2 * U>{});
+      run(std::integral_constant<int, 2 * U>{}, std::false_type{});
     else
-      run(std::integral_constant<int, U>{});
+      run(std::integral_constant<int, U>{}, std::false_type{});
+  } else if constexpr (F8) {
+    if (p.kv_scale == 1.0f) run(std::integral_constant<int, U>{}, std::true_type{});
+    else run(std::integral_constant<int, U>{}, std::false_type{});
   } else {
-    run(std::integral_constant<int, U>{});
+    run(std::integral_constant<int, U>{}, std::false_type{});
   }
 
   if constexpr (LOADS_ONLY) {
@@ -765,11 +856,11 @@ __global__ void __launch_bounds__(HPW* WPH * 64)
 #pragma unroll
           for (int i = 0; i < NL; ++i) {
             // K: the lane holding (chunk, token offA) of load i owns exactly those 16 bytes of the tile
-            if (tk == offA && (i < NL - 1 || tail_ok)) *reinterpret_cast<u32x4*>(kdst + i * 512) = knew[hh][i];
+            if (tk == offA && (i < NL - 1 || tail_ok)) *reinterpret_cast<u32x4*>(kdst + i * 512) = knew_at(hh, i);
             // V: element offA of dim row `row`
             const int row = RPL * i + rowl;
             if (hf == (offA >> 3) && row < D)
-              reinterpret_cast<uint16_t*>(vtile)[row * BS + offA] = (uint16_t)vnew[hh][i];
+              reinterpret_cast<uint16_t*>(vtile)[row * BS + offA] = (uint16_t)vnew_at(hh, i);
           }
         }
       }

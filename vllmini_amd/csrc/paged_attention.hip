@@ -206,13 +206,16 @@ __global__ void __launch_bounds__(256)
 }
 
 // ----------------------------------------------------------------------------------------
-// reshape_and_cache, prefill form.  A prompt's tokens arrive with consecutive slots, so BS consecutive tokens
-// usually ARE one cache block.  The per-token kernel above then writes every 32-B V row in BS separate 2-byte
-// pieces (1.0-1.2 TB/s read+write on MI355X); here one workgroup takes a run of BS tokens, checks that their slots are
-// one aligned block in order, and writes whole (block, head) tiles: the K tile needs no transposition at all (lane
-// chunk*BS + tok loads 16 B of row tok and owns exactly that 16-B unit of the tile), the V tile is transposed
-// through LDS, one wave per head.  Runs that are not a whole aligned block (prompt tails, decode batches, padding)
-// take the per-token path inside the same kernel.  Same bytes as the kernel above (cache_kernels.cu:152-207).
+// reshape_and_cache, run form (calls of >= 2*block_size tokens).  A prompt's tokens arrive with consecutive slots, so
+// BS consecutive tokens usually ARE one cache block.  The per-token kernel above then writes every 32-B V row in BS
+// separate 2-byte pieces (1.0-1.2 TB/s read+write on MI355X).  Here a workgroup takes (a run of BS tokens) x (4 heads),
+// one wave per head.  Each wave checks that the run's slots are one aligned block in order and then writes the whole
+// (block, head) tiles: the K tile needs no transposition at all (lane chunk*BS + tok loads 16 B of row tok and owns
+// exactly that 16-B unit of the tile), the V tile is transposed through the wave's LDS slice.  A run that is not a whole
+// aligned block (prompt tails, decode batches, padding) is written token by token by the same waves.  No workgroup
+// is idle in either case, and none of the work is keyed to "every BS-th workgroup" (workgroups are placed round-robin
+// over the XCDs by index: that pattern put all the work on one XCD and ran 8x slower).
+// Same bytes as the kernel above (cache_kernels.cu:152-207).
 // ----------------------------------------------------------------------------------------
 template <int BS>
 __global__ void __launch_bounds__(256)
@@ -224,6 +227,8 @@ __global__ void __launch_bounds__(256)
   constexpr int PAD = 8;       // halves; keeps LDS rows 16-B aligned and the two 8-token halves on different banks
   extern __shared__ __attribute__((aligned(16))) char blk_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.y * 4 + wave;
+  if (h >= H) return;  // waves are independent: no workgroup barrier below
   const int t0 = blockIdx.x * BS;
   const int nt = (T - t0) < BS ? (T - t0) : BS;
   const long long mine = (lane < nt) ? (long long)slot_mapping[t0 + lane] : -1;
@@ -234,38 +239,36 @@ __global__ void __launch_bounds__(256)
   if (whole) {
     const int64_t blk = s0 / BS;
     h16* lds = reinterpret_cast<h16*>(blk_smem) + (size_t)wave * BS * (D + PAD);
-    for (int h = wave; h < H; h += 4) {
-      h16* ktile = kc + ((blk * H + h) * (int64_t)D) * BS;
-      h16* vtile = vc + ((blk * H + h) * (int64_t)D) * BS;
-      for (int u = lane; u < units; u += 64) {
-        const int c = u / BS, tok = u % BS;
-        const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + h * D + c * 8);
-        const u32x4 vv = *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + h * D + c * 8);
-        *reinterpret_cast<u32x4*>(ktile + (int64_t)u * 8) = kv;               // K[blk,h,c,tok,0..8)
-        *reinterpret_cast<u32x4*>(lds + tok * (D + PAD) + c * 8) = vv;        // V rows, token-major, for the transpose
-      }
-      for (int u = lane; u < units; u += 64) {
-        const int row = u / UPR, unit = u % UPR;
-        h16x8 o;
+    h16* ktile = kc + ((blk * H + h) * (int64_t)D) * BS;
+    h16* vtile = vc + ((blk * H + h) * (int64_t)D) * BS;
+    for (int u = lane; u < units; u += 64) {
+      const int c = u / BS, tok = u % BS;
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + h * D + c * 8);
+      const u32x4 vv = *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + h * D + c * 8);
+      *reinterpret_cast<u32x4*>(ktile + (int64_t)u * 8) = kv;               // K[blk,h,c,tok,0..8)
+      *reinterpret_cast<u32x4*>(lds + tok * (D + PAD) + c * 8) = vv;        // V rows, token-major, for the transpose
+    }
+    for (int u = lane; u < units; u += 64) {
+      const int row = u / UPR, unit = u % UPR;
+      h16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = lds[(unit * 8 + e) * (D + PAD) + row];
-        *reinterpret_cast<u32x4*>(vtile + (int64_t)u * 8) = __builtin_bit_cast(u32x4, o);  // V[blk,h,row,unit*8..+8)
-      }
+      for (int e = 0; e < 8; ++e) o[e] = lds[(unit * 8 + e) * (D + PAD) + row];
+      *reinterpret_cast<u32x4*>(vtile + (int64_t)u * 8) = __builtin_bit_cast(u32x4, o);  // V[blk,h,row,unit*8..+8)
     }
     return;
   }
-  // not a whole aligned block: token by token, as reshape_and_cache_kernel does
-  const int n8 = (H * D) >> 3;
-  for (int w = threadIdx.x; w < nt * n8; w += 256) {
-    const int tok = w / n8, c = w - tok * n8;
-    const int64_t slot = slot_mapping[t0 + tok];
+  // not a whole aligned block: token by token, as reshape_and_cache_kernel does (this wave: head h of the run's tokens)
+  const int c8 = D >> 3;
+  for (int u = lane; u < nt * c8; u += 64) {
+    const int tok = u / c8, c = u - tok * c8;
+    const int64_t slot = slot_mapping[t0 + tok];  // (not a shuffle of `mine`: the lane holding it may have left the loop)
     if (slot < 0) continue;  // padding token (ref cache_kernels.cu:165-169)
     const int64_t blk = slot / BS, off = slot % BS;
-    const int i = c << 3, h = i / D, d = i - h * D;
+    const int i = h * D + c * 8;
     const h16x8 kv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + i));
     const h16x8 vv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + i));
-    *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (D >> 3) + (d >> 3)) * BS + off) * 8) = __builtin_bit_cast(u32x4, kv);
-    h16* vdst = vc + ((blk * H + h) * (int64_t)D + d) * BS + off;
+    *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * c8 + c) * BS + off) * 8) = __builtin_bit_cast(u32x4, kv);
+    h16* vdst = vc + ((blk * H + h) * (int64_t)D + c * 8) * BS + off;
 #pragma unroll
     for (int e = 0; e < 8; ++e) vdst[(int64_t)e * BS] = vv[e];
   }
@@ -596,7 +599,8 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                 v.HPW * v.HPT);
 
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
-  const size_t lds = (size_t)v.HPW * v.HPT * ((size_t)lpad * 4 + 2 * v.WPH * 4 + (size_t)v.WPH * v.D * 4);
+  const size_t lds = (size_t)v.HPW * v.HPT *
+                     ((size_t)lpad * 4 + 2 * v.WPH * 4 + (size_t)v.WPH * v.D * 4 + (v.WPH > 1 ? (size_t)lpad * 2 : 0));
   if (lds > 160 * 1024)
     return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v1: max_seq_len=%d needs %zu B of LDS per "
                 "workgroup (variant %s), limit 163840", max_seq_len, lds, v.name);
@@ -763,7 +767,7 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
 
   const int lpad = 512;  // one partition of logits (:886)
   const size_t lds = (size_t)v.HPW * lpad * 4 + (size_t)v.HPW * 2 * v.WPH * 4 +
-                     (size_t)v.HPW * v.WPH * v.D * 4;
+                     (size_t)v.HPW * v.WPH * v.D * 4 + (v.WPH > 1 ? (size_t)v.HPW * lpad * 2 : 0);
   PAParams p;
   p.out = static_cast<h16*>(tmp_out);
   p.q = static_cast<const h16*>(query);
@@ -984,7 +988,7 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
                                 (int)lds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(reshape_and_cache_blocks)");
       }
-      hipLaunchKernelGGL(fn, dim3((num_tokens + block_size - 1) / block_size), dim3(256), lds,
+      hipLaunchKernelGGL(fn, dim3((num_tokens + block_size - 1) / block_size, (num_heads + 3) / 4), dim3(256), lds,
                          static_cast<hipStream_t>(stream), static_cast<const h16*>(key),
                          static_cast<const h16*>(value), static_cast<h16*>(key_cache),
                          static_cast<h16*>(value_cache), slot_mapping, key_stride, value_stride, num_tokens,
