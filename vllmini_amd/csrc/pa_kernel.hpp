@@ -114,28 +114,20 @@ __device__ __forceinline__ u32x4 deq8(uint32_t w0, uint32_t w1, float s) {
 // into v_fma_mix_f32 — 8 decodes + 16 FMAs for 16 dims.
 template <bool S1>
 __device__ __forceinline__ float dot16_f8(const u32x4 q0, const u32x4 q1, const u32x4 k, float s) {
-  if constexpr (S1) {
-    const h16x8 qa = __builtin_bit_cast(h16x8, q0), qb = __builtin_bit_cast(h16x8, q1);
-    float a0 = 0.f, a1 = 0.f;  // two chains: the 8 dims facing q0, the 8 facing q1
+  static_assert(!S1, "kv_scale == 1 uses dot16_f8_s1");
+  return dot8<false>(q0, deq8<false>(k[0], k[1], s)) + dot8<false>(q1, deq8<false>(k[2], k[3], s));
+}
+// kv_scale == 1: half(float(fp8)) widens back to the same fp32, so the fp32 decode IS the operand.  q is held as
+// fp32 pairs (converted once per wave), v_cvt_pk_f32_fp8 yields k as fp32 pairs, and v_pk_fma_f32 does two exact
+// fp32 FMAs per instruction: 8 decodes + 8 packed FMAs for 16 dims (even and odd dims are separate chains).
+__device__ __forceinline__ float dot16_f8_s1(const f32x2_t (&qf)[8], const u32x4 k) {
+  f32x2_t acc = {0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < 2; ++w) {
-      const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)k[w], false);
-      const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)k[w], true);
-      const f32x2_t lo2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)k[2 + w], false);
-      const f32x2_t hi2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)k[2 + w], true);
-      a0 = __builtin_fmaf((float)qa[4 * w + 0], lo[0], a0);
-      a0 = __builtin_fmaf((float)qa[4 * w + 1], lo[1], a0);
-      a0 = __builtin_fmaf((float)qa[4 * w + 2], hi[0], a0);
-      a0 = __builtin_fmaf((float)qa[4 * w + 3], hi[1], a0);
-      a1 = __builtin_fmaf((float)qb[4 * w + 0], lo2[0], a1);
-      a1 = __builtin_fmaf((float)qb[4 * w + 1], lo2[1], a1);
-      a1 = __builtin_fmaf((float)qb[4 * w + 2], hi2[0], a1);
-      a1 = __builtin_fmaf((float)qb[4 * w + 3], hi2[1], a1);
-    }
-    return a0 + a1;
-  } else {
-    return dot8<false>(q0, deq8<false>(k[0], k[1], s)) + dot8<false>(q1, deq8<false>(k[2], k[3], s));
+  for (int w = 0; w < 4; ++w) {
+    acc = __builtin_elementwise_fma(qf[2 * w], __builtin_amdgcn_cvt_pk_f32_fp8((int)k[w], false), acc);
+    acc = __builtin_elementwise_fma(qf[2 * w + 1], __builtin_amdgcn_cvt_pk_f32_fp8((int)k[w], true), acc);
   }
+  return acc[0] + acc[1];
 }
 
 // p.v over 8 tokens of one dim row.  e0/e1: the 8 exp values, is: 1/(sum+1e-6); `keep` = bit mask of the
@@ -472,6 +464,19 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   auto run = [&](auto utag, auto s1tag) {
     constexpr int UU = decltype(utag)::value;
     constexpr bool S1 = decltype(s1tag)::value;  // fp8 cache with kv_scale == 1: cheaper, bit-identical dequantisation
+    f32x2_t qf[S1 ? HPT : 1][S1 ? NL : 1][8];    // S1: q as fp32 pairs for v_pk_fma_f32
+    if constexpr (S1) {
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh)
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const h16x8 qh = __builtin_bit_cast(h16x8, qreg[hh][i][F8 ? w : 0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qf[hh][i][4 * w + e] = f32x2_t{(float)qh[2 * e], (float)qh[2 * e + 1]};
+          }
+    }
     const int ngroups = (nmy + UU - 1) / UU;
     auto table_for = [&](int g) {  // lane j: physical id of my block (bt_sg*64 + j)
       const int sg = (g * UU) >> 6;
@@ -546,7 +551,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
               float accv[NL];
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
-                if constexpr (F8) accv[i] = dot16_f8<S1>(qreg[hh][i][0], qreg[hh][i][1], r[j][hh][i], p.kv_scale);
+                if constexpr (F8 && S1) accv[i] = dot16_f8_s1(qf[hh][i], r[j][hh][i]);
+                else if constexpr (F8) accv[i] = dot16_f8<false>(qreg[hh][i][0], qreg[hh][i][1], r[j][hh][i], p.kv_scale);
                 else accv[i] = dot8<BF>(qreg[hh][i][0], r[j][hh][i]);
               }
               float acc = accv[0];
