@@ -244,10 +244,15 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
     mb = -(-(ctx0 + total_steps) // cfg.block_size) + 1
     blocks_needed = cfg.batch * dims.n_layer * (mb - 1)
     pool = PagedKVPool(blocks_needed + 64, dims.n_head, dims.head_size, cfg.block_size, mb, dims.n_layer, device=dev,
-                       max_seqs=cfg.batch, multi_block_prefill=True)
+                       max_seqs=cfg.batch, multi_block_prefill=True, kv_cache_dtype=args.kv)
     g = torch.Generator(device=dev).manual_seed(7 + rank)
-    pool.key_cache.uniform_(-1, 1, generator=g)
-    pool.value_cache.uniform_(-1, 1, generator=g)
+    if args.kv == "fp8":      # random E4M3 codes of magnitude < 2
+        for c in (pool.key_cache, pool.value_cache):
+            c.copy_(torch.randint(0, 64, c.shape, dtype=torch.uint8, device=dev, generator=g)
+                    | (torch.randint(0, 2, c.shape, dtype=torch.uint8, device=dev, generator=g) << 7))
+    else:
+        pool.key_cache.uniform_(-1, 1, generator=g)
+        pool.value_cache.uniform_(-1, 1, generator=g)
     # shuffle the free list so pages are scattered like a long-running pool's
     perm = np.random.default_rng(rank).permutation(pool.num_blocks)
     pool.free_blocks = perm.tolist()
@@ -274,7 +279,9 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
     if rank == 0:
         print(json.dumps(res), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(REPO, "gpurun_out", "e2e_fused.json" if args.e2e_fused else "e2e.json"), "w") as f:
+        res["kv_cache_dtype"] = args.kv
+        with open(os.path.join(REPO, "gpurun_out", "e2e_fused.json" if args.e2e_fused else
+                               ("e2e_fp8.json" if args.kv == "fp8" else "e2e.json")), "w") as f:
             json.dump(res, f, indent=1)
 
 

@@ -494,7 +494,7 @@ def test_errors_raise_runtimeerror():
 # ------------------------------------------------------------------------------------------------
 # the ops under their real caller: batched GPT-2 decode harness vs the REFERENCE model's logits
 # ------------------------------------------------------------------------------------------------
-def _tiny_gpt2(golden_dir, dev, max_seqs=8, off_by_one=True, fused=False):
+def _tiny_gpt2(golden_dir, dev, max_seqs=8, off_by_one=True, fused=False, kv="auto"):
     from vllmini_amd.gpt2_decode import GPT2Dims, GPT2PagedDecoder
     from vllmini_amd.kv_pool import PagedKVPool
 
@@ -504,7 +504,7 @@ def _tiny_gpt2(golden_dir, dev, max_seqs=8, off_by_one=True, fused=False):
                     n_layer=meta["n_layer"], n_head=meta["n_head"], layer_norm_epsilon=meta["layer_norm_epsilon"])
     sd = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("sd/")}
     pool = PagedKVPool(meta["num_blocks"] * 8, dims.n_head, dims.head_size, meta["block_size"],
-                       meta["max_blocks_per_seq"], dims.n_layer, device=dev, max_seqs=max_seqs)
+                       meta["max_blocks_per_seq"], dims.n_layer, device=dev, max_seqs=max_seqs, kv_cache_dtype=kv)
     return z, meta, GPT2PagedDecoder(dims, sd, pool, reference_off_by_one=off_by_one, fused_append=fused)
 
 
@@ -1297,3 +1297,36 @@ def test_fp8_round_trip_against_the_fp16_path():
     torch.cuda.synchronize()
     d = (o8.float() - o16.float()).abs().max().item()
     assert d <= 2e-3, d        # same values, same rounding points; only the fp32 summation order differs
+
+
+
+def test_gpt2_harness_with_fp8_pages_tracks_the_fp16_pages():
+    """The decode harness over an fp8 E4M3 pool: every K/V element carries <= 2^-4 relative quantisation error, so the
+    logits stay close to the fp16-page run (not equal), the argmax agrees where the fp16 run is decisive, and
+    eager and graph replay of the fp8 run are bit-identical."""
+    dev = _dev()
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    _, meta, a = _tiny_gpt2(gd, dev, off_by_one=False)
+    _, _, b = _tiny_gpt2(gd, dev, off_by_one=False, kv="fp8")
+    _, _, c = _tiny_gpt2(gd, dev, off_by_one=False, kv="fp8")
+    assert b.pool.key_cache.dtype == torch.uint8 and b.pool.key_cache.shape[-1] == 16
+    rng = np.random.default_rng(5)
+    prompts = {1: [5, 6, 7], 2: list(range(30, 45)), 3: [9], 4: list(range(60, 76))}
+    for sid, pr in prompts.items():
+        for d in (a, b, c):
+            d.prefill(sid, pr)
+    ids = list(prompts)
+    worst = 0.0
+    for step in range(20):
+        toks = rng.integers(0, meta["vocab_size"], len(ids)).tolist()
+        la = a.decode(ids, toks).float()
+        lb = b.decode(ids, toks).float()
+        lc = c.decode(ids, toks, use_graph=True).float()
+        torch.cuda.synchronize()
+        assert torch.equal(lb, lc), step
+        assert torch.isfinite(lb).all()
+        worst = max(worst, float((la - lb).abs().max() / la.abs().max()))
+        top2 = la.topk(2, dim=-1).values
+        decisive = (top2[:, 0] - top2[:, 1]) > 0.25 * la.abs().max()
+        assert (la.argmax(-1) == lb.argmax(-1))[decisive].all()
+    assert 0 < worst < 0.15, worst      # quantisation moves the logits, but not far

@@ -89,6 +89,8 @@ class GPT2PagedDecoder:
         # fused_append: one launch per layer (ops.paged_attention_v1_append) instead of the reference's call pair
         # reshape_and_cache + paged_attention_v1 (gpt2.py:44, :62); bit-identical caches and outputs.  It derives
         # the slot from seq_lens-1, so it cannot reproduce the reference caller's off-by-one seq_lens.
+        if fused_append and pool.kv_cache_dtype != "auto":
+            raise ValueError("fused_append is built for fp16/bf16 pages only")
         if fused_append and reference_off_by_one:
             raise ValueError("fused_append writes at position seq_lens-1; reference_off_by_one passes seq_lens-1 "
                              "as the length, so the two cannot be combined")
@@ -129,7 +131,8 @@ class GPT2PagedDecoder:
         for i in range(self.dims.n_layer):
             p = f"transformer.h.{i}."
             q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)
-            cache_ops.reshape_and_cache(k, v, self.pool.key_cache, self.pool.value_cache, slots_dev[i], "auto", 1.0)
+            cache_ops.reshape_and_cache(k, v, self.pool.key_cache, self.pool.value_cache, slots_dev[i],
+                                        self.pool.kv_cache_dtype, self.pool.kv_scale)
             qh, kh, vh = (t.transpose(0, 1) for t in (q, k, v))                       # [H, T, D]
             w = torch.matmul(qh, kh.transpose(-1, -2)) * self.scale + mask            # gpt2.py:72-74
             a = torch.matmul(F.softmax(w, dim=-1), vh)                                 # gpt2.py:76-78
@@ -156,9 +159,11 @@ class GPT2PagedDecoder:
                                               st["tables"][i], st["seq_lens"], pool.block_size, self.max_seq_len,
                                               _variant=var)
             else:
-                cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i], "auto", 1.0)  # gpt2.py:44
+                cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i],
+                                            pool.kv_cache_dtype, pool.kv_scale)                            # gpt2.py:44
                 ops.paged_attention_v1(out, q, pool.key_cache, pool.value_cache, d.n_head, self.scale, st["tables"][i],
-                                       st["seq_lens"], pool.block_size, self.max_seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0,
+                                       st["seq_lens"], pool.block_size, self.max_seq_len, None,
+                                       pool.kv_cache_dtype, pool.kv_scale, 0, 0, 1, 1, 0,
                                        _variant=var)
             x = x + F.linear(out.view(B, d.n_embd), self.sd[p + "attn.c_proj.weight"], self.sd[p + "attn.c_proj.bias"])
             x = x + self._mlp(self._ln(x, p + "ln_2"), p)
@@ -175,6 +180,16 @@ class GPT2PagedDecoder:
                 "seq_lens": torch.zeros(B, dtype=torch.int32, device=dev),
             }
             self._graph = None
+            # Two sets of PINNED host staging buffers: an upload from pageable memory is staged synchronously by the
+            # runtime behind everything already queued on the stream, which serialises host and GPU (the fp8 step, 1.7 ms
+            # of GPU work, ran 3.06 ms that way).  From pinned memory the copies are truly asynchronous and the host
+            # prepares step i+1 while the GPU runs step i; a set is reused only after its own copies have executed.
+            self._stage = None
+            if dev.type == "cuda":
+                self._stage = [{k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                                for k, v in self._static.items() if k != "input_ids"} for _ in range(2)]
+                self._stage_ev = [None, None]
+                self._stage_i = 0
         return self._static
 
     def stage_step(self, seq_ids: Sequence[int], input_ids) -> dict:
@@ -184,15 +199,27 @@ class GPT2PagedDecoder:
         positions = np.fromiter((self.pool.seq_len(s) for s in seq_ids), dtype=np.int64, count=B)  # scheduler.py:81
         tables, slots, ctx = self.pool.decode_step_batch(seq_ids)
         lens = ctx - 1 if self.reference_off_by_one else ctx
-        st["tables"].copy_(torch.from_numpy(np.ascontiguousarray(tables)), non_blocking=True)
-        st["slots"].copy_(torch.from_numpy(np.ascontiguousarray(slots)), non_blocking=True)
-        st["seq_lens"].copy_(torch.from_numpy(np.ascontiguousarray(lens.astype(np.int32))), non_blocking=True)
-        st["position_ids"].copy_(torch.from_numpy(positions), non_blocking=True)
+        host = {"tables": tables, "slots": slots, "seq_lens": lens.astype(np.int32), "position_ids": positions}
+        if self._stage is None:
+            for k, a in host.items():
+                st[k].copy_(torch.from_numpy(np.ascontiguousarray(a)), non_blocking=True)
+        else:
+            i = self._stage_i
+            if self._stage_ev[i] is not None:
+                self._stage_ev[i].synchronize()          # this set's previous uploads have run
+            for k, a in host.items():
+                self._stage[i][k].numpy()[...] = a
+                st[k].copy_(self._stage[i][k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stage_ev[i] = ev
+            self._stage_i = i ^ 1
         # the lengths are known here on the host: let the library's heuristic see the batch's true longest and mean
         # length (a ragged batch gets the many-waves-per-head decomposition, vmi_paged_attention_v1_pick_variant_hint)
         st["variant"] = ops.pick_variant(B, self.dims.n_head, self.dims.head_size, max(int(lens.max()), 1),
                                          self.pool.block_size, mean_seq_len=max(int(lens.mean()), 1),
-                                         bf16=self.pool.key_cache.dtype == torch.bfloat16)
+                                         bf16=self.pool.key_cache.dtype == torch.bfloat16,
+                                         fp8=self.pool.kv_cache_dtype != "auto")
         if isinstance(input_ids, torch.Tensor):
             st["input_ids"].copy_(input_ids.to(torch.long), non_blocking=True)
         else:

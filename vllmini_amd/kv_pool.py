@@ -42,7 +42,8 @@ X = 8  # halves per 16-byte K chunk (kv_cache.py:13: head_size // 8, ..., 8)
 class PagedKVPool:
     def __init__(self, num_blocks: int, num_heads: int, head_size: int, block_size: int,
                  max_blocks_per_seq: int, num_layers: int, device: torch.device | str = "cuda",
-                 allocate_tensors: bool = True, max_seqs: int = 64, multi_block_prefill: bool = False):
+                 allocate_tensors: bool = True, max_seqs: int = 64, multi_block_prefill: bool = False,
+                 kv_cache_dtype: str = "auto", kv_scale: float = 1.0):
         self.num_blocks = num_blocks
         self.num_heads = num_heads
         self.head_size = head_size
@@ -51,12 +52,16 @@ class PagedKVPool:
         self.num_layers = num_layers
         self.device = torch.device(device)
         self.multi_block_prefill = multi_block_prefill
+        # "auto": fp16 pages (kv_cache.py:13-14); "fp8": E4M3 byte pages in the x = 16 layout, half the bytes
+        # (the reference surface's kv_cache_dtype / kv_scale, passed through to both operators)
+        self.kv_cache_dtype, self.kv_scale = kv_cache_dtype, float(kv_scale)
         if allocate_tensors:
             # kv_cache.py:13-14 — ONE pool shared by all layers
-            self.key_cache = torch.zeros(num_blocks, num_heads, head_size // X, block_size, X,
-                                         dtype=torch.float16, device=self.device)
+            x, dt = (16, torch.uint8) if kv_cache_dtype in ("fp8", "fp8_e4m3") else (X, torch.float16)
+            self.key_cache = torch.zeros(num_blocks, num_heads, head_size // x, block_size, x,
+                                         dtype=dt, device=self.device)
             self.value_cache = torch.zeros(num_blocks, num_heads, head_size, block_size,
-                                           dtype=torch.float16, device=self.device)
+                                           dtype=dt, device=self.device)
         else:  # bookkeeping only (CPU tests)
             self.key_cache = self.value_cache = None
         self.free_blocks: List[int] = list(range(num_blocks))          # kv_cache.py:16, FIFO
