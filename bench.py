@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--e2e-context", type=int, default=1008, help="context length the e2e sequences start at")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-step measurement")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-KV-cache measurement")
     ap.add_argument("--skip-reshape", action="store_true",
                     help="DIAGNOSTIC (invalid as a bench line): attention launches back to back, no reshape_and_cache")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -324,6 +325,7 @@ def run_matrix(args, base, dev):
 
 
 def main():
+    global KV_DTYPE, SKIP_RESHAPE
     args = parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists for the product kernels)")
@@ -357,7 +359,6 @@ def main():
             tab[:, : cfg.blocks_per_seq] = seq.view(cfg.batch, cfg.blocks_per_seq)
     out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
     if args.kv == "fp8":
-        global KV_DTYPE
         KV_DTYPE = "fp8"
         if args.op != "v1":
             raise SystemExit("--kv fp8 is built for --op v1")
@@ -446,7 +447,6 @@ def main():
                                                       fp8=args.kv == "fp8"), "results": res}, f, indent=1)
         return
 
-    global SKIP_RESHAPE
     SKIP_RESHAPE = args.skip_reshape
     if args.hint_mean and not args.variant and args.op in ("v1", "fused"):
         lens_h = wl.seq_lens.cpu()
@@ -514,6 +514,32 @@ def main():
                               "value": tokens / f_elapsed, "unit": "tokens/s",
                               "ms_per_step": f_elapsed / args.steps * 1e3,
                               "kernel_us_mean": statistics.mean(f_kern) * 1e3}
+    if args.op == "v1" and args.kv == "auto" and not args.no_fp8 and not args.ragged and not args.ragged_sorted:
+        # the same step over an fp8 E4M3 KV cache (kv_cache_dtype "fp8"): half the K/V bytes.
+        # A different data format, so it is reported beside `value`, never as it.
+        k16, v16 = wl.key_cache, wl.value_cache
+        gk = torch.Generator(device=dev).manual_seed(99 + rank)
+        kshape = (cfg.num_blocks, cfg.num_heads, cfg.head_size // 16, cfg.block_size, 16)
+        wl.key_cache = (torch.randint(0, 64, kshape, dtype=torch.uint8, device=dev, generator=gk)
+                        | (torch.randint(0, 2, kshape, dtype=torch.uint8, device=dev, generator=gk) << 7))
+        wl.value_cache = (torch.randint(0, 64, v16.shape, dtype=torch.uint8, device=dev, generator=gk)
+                          | (torch.randint(0, 2, v16.shape, dtype=torch.uint8, device=dev, generator=gk) << 7))
+        KV_DTYPE = "fp8"
+        try:
+            q_elapsed, q_kern = time_steps(wl, out, args.steps, args.warmup, 0, dist, dev, op="v1")
+        finally:
+            KV_DTYPE = "auto"
+            wl.key_cache, wl.value_cache = k16, v16
+        q_elapsed = shard.max_over_ranks(q_elapsed, dist, dev)
+        q_us = statistics.mean(q_kern) * 1e3
+        KV_DTYPE = "fp8"
+        q_bytes = alg_bytes(cfg)
+        KV_DTYPE = "auto"
+        line["fp8_kv_step"] = {"op": "reshape_and_cache + paged_attention_v1, kv_cache_dtype='fp8' (E4M3), kv_scale 1.0",
+                               "value": tokens / q_elapsed, "unit": "tokens/s",
+                               "ms_per_step": q_elapsed / args.steps * 1e3, "kernel_us_mean": q_us,
+                               "achieved_GBps": q_bytes / (q_us * 1e-6) / 1e9,
+                               "frac_of_hbm_peak": q_bytes / (q_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps)
     elif rank == 0:

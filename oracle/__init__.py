@@ -26,6 +26,7 @@ from .kernel_model import (  # noqa: F401
     f32_to_fp8e4m3,
     fp8e4m3_to_f32,
     paged_attention_v1_fp8,
+    paged_attention_v2_fp8,
     reshape_and_cache_fp8,
 )
 from .eager import (  # noqa: F401

@@ -271,3 +271,37 @@ def paged_attention_v1_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache
     if any(rcs):
         raise RuntimeError(f"oracle fp8 attention failed: {rcs}")
     return out
+
+
+def paged_attention_v2_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray, num_kv_heads: int,
+                           scale: float, block_tables: np.ndarray, seq_lens: np.ndarray, block_size: int,
+                           max_seq_len: int, kv_scale: float = 1.0, alibi_slopes: np.ndarray | None = None):
+    """Split-KV kernel model over an fp8 E4M3 cache: (out, exp_sums, max_logits, tmp_out) as paged_attention_v2."""
+    assert query.dtype == np.float16 and key_cache.dtype == value_cache.dtype == np.uint8 and key_cache.shape[4] == 16
+    S, H, D = query.shape
+    qs = _elem_strides(query)
+    assert qs[2] == 1 and qs[1] == D
+    key_cache, value_cache = np.ascontiguousarray(key_cache), np.ascontiguousarray(value_cache)
+    block_tables = np.ascontiguousarray(block_tables, dtype=np.int32)
+    seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    kb, kh = _elem_strides(key_cache)[:2]
+    P = (int(max_seq_len) + 511) // 512
+    out = np.zeros((S, H, D), dtype=np.float16)
+    exp_sums = np.full((S, H, P), np.nan, dtype=np.float32)
+    max_logits = np.full((S, H, P), np.nan, dtype=np.float32)
+    tmp_out = np.full((S, H, P, D), np.nan, dtype=np.float16)
+    alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
+    lib = _load()
+    lib.vmi_oracle_paged_attention_v2_fp8.restype = ctypes.c_int
+    lib.vmi_oracle_paged_attention_v2_fp8.argtypes = (
+        [ctypes.c_void_p] * 7 + [ctypes.c_int32] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
+        [ctypes.c_int32] * 3 + [ctypes.c_void_p] + [ctypes.c_int64] * 3 + [ctypes.c_float])
+    rc = lib.vmi_oracle_paged_attention_v2_fp8(
+        _base_ptr(out), _base_ptr(exp_sums), _base_ptr(max_logits), _base_ptr(tmp_out), _base_ptr(query),
+        _base_ptr(key_cache), _base_ptr(value_cache), S, H, D, int(num_kv_heads), float(scale),
+        _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size), int(max_seq_len),
+        int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
+        float(kv_scale))
+    if rc:
+        raise RuntimeError(f"oracle fp8 v2 failed: {rc}")
+    return out, exp_sums, max_logits, tmp_out

@@ -40,7 +40,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 6
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 7
     assert typed.vmi_target_arch() == b"gfx950"
 
 
@@ -210,3 +210,17 @@ def test_heuristic_picks_follow_the_host_hint():
     assert pick(256, 12, 64, 1024, mean_seq_len=300, bf16=True) == "bf16_d64_bs16_h1_w8_u1_nt1"
     assert pick(256, 5, 80, 1024, 32) == "d80_bs32_h1_w4_u1_nt1"       # 1280 (seq, head) units do not fill 256 CUs
     assert pick(1024, 5, 80, 1024, 32) == "d80_bs32_h1_w1_u1_nt1"
+
+
+def test_driver_entry_points_compile_and_parse_arguments():
+    """bench.py / __graft_entry__.py are run by the driver on a GPU box: at least make sure they compile and that
+    bench.py's argument parser accepts the contract's flags (a SyntaxError there would lose the round's numbers)."""
+    import py_compile
+    import sys
+
+    for f in ("bench.py", "__graft_entry__.py"):
+        py_compile.compile(os.path.join(REPO, f), doraise=True)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in r.stdout

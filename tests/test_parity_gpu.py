@@ -1330,3 +1330,41 @@ def test_gpt2_harness_with_fp8_pages_tracks_the_fp16_pages():
         decisive = (top2[:, 0] - top2[:, 1]) > 0.25 * la.abs().max()
         assert (la.argmax(-1) == lb.argmax(-1))[decisive].all()
     assert 0 < worst < 0.15, worst      # quantisation moves the logits, but not far
+
+
+
+@pytest.mark.parametrize("D,bs", [(64, 16), (128, 16), (80, 32), (256, 32), (112, 16)])
+def test_pa_v2_fp8_matches_kernel_model(D, bs):
+    """Split-KV over fp8 pages: partitions' tmp_out / exp_sums / max_logits and the merged output vs the oracle,
+    every fp8 v2 variant of this (head size, block size)."""
+    from vllmini_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(1200 + D + bs)
+    lens = [3, 511, 513, 1100, 40]
+    case = _fp8_case(rng, len(lens), 4, D, lens, bs, num_kv_heads=2)
+    msl, kv_scale = 1536, 0.8
+    P = msl // 512
+    r_out, r_es, r_ml, r_tmp = oracle.paged_attention_v2_fp8(case["q"], case["kq"], case["vq"], 2, case["scale"],
+                                                             case["tables"], case["lens"], bs, msl, kv_scale=kv_scale)
+    S, H, _ = case["q"].shape
+    q = torch.from_numpy(case["qbuf"]).to(dev)[:, : H * D].view(S, H, D)
+    kq, vq = torch.from_numpy(case["kq"]).to(dev), torch.from_numpy(case["vq"]).to(dev)
+    tab, ln = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
+    vids = [0] + [i + 1 for i, n in enumerate(ops.variant_names_v2()) if n.startswith(f"fp8_v2_d{D}_bs{bs}_")]
+    assert len(vids) >= 3
+    for vid in vids:
+        out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=dev)
+        es = torch.full((S, H, P), float("nan"), dtype=torch.float32, device=dev)
+        ml = torch.full((S, H, P), float("nan"), dtype=torch.float32, device=dev)
+        tmp = torch.full((S, H, P, D), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v2(out, es, ml, tmp, q, kq, vq, 2, case["scale"], tab, ln, bs, msl, None, "fp8", kv_scale,
+                               0, 0, 1, 1, 0, _variant=vid)
+        torch.cuda.synchronize()
+        assert_close(out.cpu().numpy(), r_out, f"fp8 v2 D{D} bs{bs} variant {vid}", vmax=2 * kv_scale)
+        for s, L in enumerate(case["lens"]):
+            used = (int(L) + 511) // 512
+            assert np.allclose(ml.cpu().numpy()[s, :, :used], r_ml[s, :, :used], rtol=1e-5, atol=1e-5)
+            assert np.allclose(es.cpu().numpy()[s, :, :used], r_es[s, :, :used], rtol=2e-5, atol=1e-6)
+            assert_close(tmp.cpu().numpy()[s, :, :used], r_tmp[s, :, :used], "fp8 v2 tmp_out", vmax=2 * kv_scale)
+            assert torch.isnan(es[s, :, used:]).all() and torch.isnan(tmp[s, :, used:]).all()

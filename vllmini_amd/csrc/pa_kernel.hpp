@@ -16,7 +16,6 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // LDS logits are written as float and re-read 4 at a time: the vector view must alias float
-typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));
 typedef uint32_t u32x4_alias __attribute__((ext_vector_type(4), may_alias));
 
 // ----------------------------------------------------------------------------------------
@@ -130,8 +129,7 @@ __device__ __forceinline__ float dot16_f8_s1(const f32x2_t (&qf)[8], const u32x4
   return acc[0] + acc[1];
 }
 
-// p.v over 8 tokens of one dim row.  e0/e1: the 8 exp values, is: 1/(sum+1e-6); `keep` = bit mask of the
-// tokens inside the context (only consulted when `last`).
+// p.v over 8 tokens of one dim row; the probabilities come from LDS already rounded to fp16 / bf16.
 //   fp16: p -> fp16, 4 packed fp16 products, packed fp16 adds ((p0v0+p2v2)+p4v4)+p6v6 / odd, fp32 add of halves
 //   bf16: p -> bf16, products rounded to bf16, fp32 sums ((s01+s23)+s45)+s67
 template <bool BF>
@@ -148,21 +146,6 @@ struct PV8 {
       }
     } else {
       ph = __builtin_bit_cast(h16x8, raw);
-    }
-  }
-  __device__ __forceinline__ void set(const f32x4 e0, const f32x4 e1, float is) {
-    if constexpr (BF) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        pf[k] = bf_round(e0[k] * is);
-        pf[4 + k] = bf_round(e1[k] * is);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ph[k] = (h16)(e0[k] * is);
-        ph[4 + k] = (h16)(e1[k] * is);
-      }
     }
   }
   // MASK = false is the steady state: no tail handling is compiled in at all (the compiler would
@@ -993,6 +976,8 @@ extern const int g_app_bf16_nvariants;
 // fp8 E4M3 cache (pa_variants_fp8.hip): ids continue after the bf16 menu; no append twins
 extern Variant g_fp8_variants_v1[];
 extern const int g_fp8_nvariants_v1;
+extern Variant g_fp8_variants_v2[];
+extern const int g_fp8_nvariants_v2;
 pa_reduce_t bf16_reduce_kernel(int head_size);
 
 }  // namespace vmi

@@ -683,17 +683,19 @@ static Variant g_variants_v2[] = {
 };
 static const int g_ncore_v2 = (int)(sizeof(g_variants_v2) / sizeof(g_variants_v2[0]));
 
-static int nvariants_v2() { return g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2; }
-static Variant& variant_v2(int id) {
+static int nvariants_v2() { return g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2 + g_fp8_nvariants_v2; }
+static Variant& variant_v2(int id) {  // [core fp16][extra fp16][bf16][fp8 cache]
   if (id <= g_ncore_v2) return g_variants_v2[id - 1];
   if (id <= g_ncore_v2 + g_extra_nvariants_v2) return g_extra_variants_v2[id - 1 - g_ncore_v2];
-  return g_bf16_variants_v2[id - 1 - g_ncore_v2 - g_extra_nvariants_v2];
+  if (id <= g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2)
+    return g_bf16_variants_v2[id - 1 - g_ncore_v2 - g_extra_nvariants_v2];
+  return g_fp8_variants_v2[id - 1 - g_ncore_v2 - g_extra_nvariants_v2 - g_bf16_nvariants_v2];
 }
 
-static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false) {
+static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false, bool f8 = false) {
   for (int id = 1; id <= nvariants_v2(); ++id) {
     const Variant& v = variant_v2(id);
-    if (v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH) return id;
+    if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH) return id;
   }
   return 0;
 }
@@ -701,18 +703,18 @@ static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false) {
 // a partition holds 512 / block_size blocks; give each (seq, head, partition) 1..8 waves so that the
 // launch has >= ~2048 waves when the batch allows it
 static int pick_variant_v2(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
-                           bool bf = false) {
+                           bool bf = false, bool f8 = false) {
   const int parts = (max_seq_len + 511) / 512;
   const long units = (long)num_seqs * num_heads * (parts > 0 ? parts : 1);
   int wph = 1;
   while (wph < 8 && units * wph < 2048) wph *= 2;
   int v = 0;
   if (!bf && block_size == 16 && (head_size == 64 || head_size == 128)) {
-    v = (wph == 1) ? find_variant_v2(head_size, 16, (num_heads % 4 == 0) ? 4 : 1, 1)
-                   : find_variant_v2(head_size, 16, 1, wph);
+    v = (wph == 1) ? find_variant_v2(head_size, 16, (num_heads % 4 == 0) ? 4 : 1, 1, false, f8)
+                   : find_variant_v2(head_size, 16, 1, wph, false, f8);
   }
-  if (!v) v = find_variant_v2(head_size, block_size, 1, wph == 1 ? 1 : 4, bf);
-  return v ? v : find_variant_v2(head_size, block_size, 1, 1, bf);
+  if (!v) v = find_variant_v2(head_size, block_size, 1, wph == 1 ? 1 : 4, bf, f8);
+  return v ? v : find_variant_v2(head_size, block_size, 1, 1, bf, f8);
 }
 
 static pa_reduce_t reduce_kernel_for(int head_size, bool bf) {
@@ -728,7 +730,8 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
                         const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
                         int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
                         int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                        int32_t device, void* stream, int32_t variant, bool bf = false) {
+                        int32_t device, void* stream, int32_t variant, bool bf = false, bool f8 = false,
+                        float kv_scale = 1.0f) {
   if (!out || !exp_sums || !max_logits || !tmp_out || !query || !key_cache || !value_cache ||
       !block_tables || !seq_lens)
     return fail(VMI_E_NULL_POINTER, "paged_attention_v2: NULL tensor pointer");
@@ -743,16 +746,21 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   if (num_kv_heads <= 0 || num_heads % num_kv_heads != 0)
     return fail(VMI_E_KV_HEADS, "paged_attention_v2: num_heads=%d not divisible by num_kv_heads=%d",
                 num_heads, num_kv_heads);
+  const int kv_am = f8 ? 15 : 7;
   if (!aligned16(query) || !aligned16(key_cache) || !aligned16(value_cache) || (q_stride & 7) ||
-      (kv_block_stride & 7) || (kv_head_stride & 7))
+      (kv_block_stride & kv_am) || (kv_head_stride & kv_am))
     return fail(VMI_E_ALIGNMENT, "paged_attention_v2: pointers/strides must be 16-byte aligned");
+  if (f8 && block_size == 8)
+    return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: 8 with an fp8 KV cache (block sizes 16 and 32 are built)");
   const int parts = (max_seq_len + 511) / 512;  // attention_kernels.cu:885
   if (num_seqs == 0 || parts == 0) return VMI_OK;
   if (parts > 65535) return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v2: too many partitions");
-  if (variant == 0) variant = pick_variant_v2(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
+  if (variant == 0) variant = pick_variant_v2(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, f8);
   if (variant < 1 || variant > nvariants_v2())
     return fail(VMI_E_VARIANT, "paged_attention_v2: unknown variant %d", variant);
   Variant& v = variant_v2(variant);
+  if (v.F8 != f8)
+    return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s is for an %s KV cache", v.name, v.F8 ? "fp8" : "fp16/bf16");
   if (v.BF != bf)
     return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s is for %s elements", v.name,
                 v.BF ? "bfloat16" : "float16");
@@ -791,7 +799,7 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   p.value = nullptr;
   p.key_stride = 0;
   p.value_stride = 0;
-  p.kv_scale = 1.0f;
+  p.kv_scale = kv_scale;
   dim3 grid((num_heads + v.HPW - 1) / v.HPW, num_seqs, parts);  // :890
   hipLaunchKernelGGL(v.fn, grid, dim3(v.HPW * v.WPH * 64), lds, static_cast<hipStream_t>(stream), p);
   e = hipGetLastError();
@@ -906,6 +914,22 @@ int vmi_paged_attention_v1_fp8(void* out, const void* query, const void* key_cac
                            max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
                            kv_head_stride, device, stream, variant, false, false, nullptr, nullptr, 0, 0,
                            true, kv_scale);
+}
+
+int vmi_paged_attention_v2_fp8(void* out, void* exp_sums, void* max_logits, void* tmp_out, const void* query,
+                               const void* key_cache, const void* value_cache, int32_t num_seqs,
+                               int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
+                               const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
+                               int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                               int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                               int32_t device, void* stream, float kv_scale, int32_t variant) {
+  if (!(kv_scale > 0.f))
+    return vmi::fail(VMI_E_SHAPE, "paged_attention_v2 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
+  return vmi::launch_pa_v2(out, static_cast<float*>(exp_sums), static_cast<float*>(max_logits), tmp_out, query,
+                           key_cache, value_cache, num_seqs, num_heads, head_size, num_kv_heads, scale,
+                           block_tables, seq_lens, block_size, max_seq_len, max_num_blocks_per_seq, alibi_slopes,
+                           q_stride, kv_block_stride, kv_head_stride, device, stream, variant, false, true,
+                           kv_scale);
 }
 
 int vmi_paged_attention_v1_pick_variant_fp8(int32_t num_seqs, int32_t num_heads, int32_t head_size,

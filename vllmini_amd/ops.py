@@ -280,8 +280,7 @@ def paged_attention_v2(
     :529-562 + :564-669 (kernels).  The reference exports it but no Python caller exists
     (SURVEY.md §2 #7); it is the right operator when num_seqs*num_heads is far below the CU count.
     """
-    if _check_kv_cache_dtype(kv_cache_dtype):
-        raise RuntimeError("paged_attention_v2 is not built for an fp8 KV cache (paged_attention_v1 is)")
+    fp8 = _check_kv_cache_dtype(kv_cache_dtype)
     args = _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
                       seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale,
                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
@@ -296,9 +295,13 @@ def paged_attention_v2(
         if t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
             raise RuntimeError(f"{name} must be a contiguous {dt} tensor of shape {shape} "
                                f"(max_num_partitions = ceil(max_seq_len/512) = {parts})")
-    fn = _lib.load().vmi_paged_attention_v2_bf16 if query.dtype == torch.bfloat16 else \
-        _lib.load().vmi_paged_attention_v2_f16
-    rc = fn(args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:], int(_variant))
+    if fp8:
+        rc = _lib.load().vmi_paged_attention_v2_fp8(args[0], exp_sums.data_ptr(), max_logits.data_ptr(),
+                                                    tmp_out.data_ptr(), *args[1:], float(kv_scale), int(_variant))
+    else:
+        fn = _lib.load().vmi_paged_attention_v2_bf16 if query.dtype == torch.bfloat16 else \
+            _lib.load().vmi_paged_attention_v2_f16
+        rc = fn(args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:], int(_variant))
     if rc != 0:
         _raise_native(rc)
     return None
