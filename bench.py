@@ -287,19 +287,32 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
 
 
 def run_matrix(args, base, dev):
-    """Every (head size, block size, element type) the reference dispatches, at base's batch/heads/seq_len."""
+    """Every (head size, block size, element type / cache type) the operators are built for, at base's
+    batch/heads/seq_len: fp16, bf16, and fp16 query over an fp8 E4M3 cache."""
     import dataclasses
 
+    global KV_DTYPE
     res = []
-    for dt in (torch.float16, torch.bfloat16):
+    for kind in ("float16", "bfloat16", "fp8_kv"):
+        dt = torch.bfloat16 if kind == "bfloat16" else torch.float16
         for D in (64, 80, 96, 112, 128, 192, 256):
             for bs in (8, 16, 32):
+                if kind == "fp8_kv" and bs == 8:
+                    continue
                 per = -(-base.seq_len // bs)
                 c = dataclasses.replace(base, name=f"m_d{D}_bs{bs}", head_size=D, block_size=bs,
                                         num_blocks=2 * base.batch * per + 8)
                 wl = make_workload(c, dev, seed=5, table_sets=2)
-                if dt is torch.bfloat16:
+                KV_DTYPE = "auto"
+                if kind == "bfloat16":
                     wl.key_cache, wl.value_cache, wl.qkv = (wl.key_cache.to(dt), wl.value_cache.to(dt), wl.qkv.to(dt))
+                elif kind == "fp8_kv":
+                    KV_DTYPE = "fp8"
+                    gk = torch.Generator(device=dev).manual_seed(3)
+                    ks = (c.num_blocks, c.num_heads, D // 16, bs, 16)
+                    vs = (c.num_blocks, c.num_heads, D, bs)
+                    wl.key_cache = torch.randint(0, 64, ks, dtype=torch.uint8, device=dev, generator=gk)
+                    wl.value_cache = torch.randint(0, 64, vs, dtype=torch.uint8, device=dev, generator=gk)
                 out = torch.empty((c.batch, c.num_heads, D), dtype=dt, device=dev)
                 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
                 for i in range(args.warmup + args.steps):
@@ -312,13 +325,16 @@ def run_matrix(args, base, dev):
                         ev[k][1].record()
                 torch.cuda.synchronize(dev)
                 us = statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
-                vid = ops.pick_variant(c.batch, c.num_heads, D, c.seq_len, bs, bf16=dt is torch.bfloat16)
-                row = {"dtype": str(dt).split(".")[-1], "head_size": D, "block_size": bs, "us_median": us,
-                       "gbps": c.algorithmic_bytes() / (us * 1e-6) / 1e9, "variant": ops.variant_names()[vid - 1]}
+                vid = ops.pick_variant(c.batch, c.num_heads, D, c.seq_len, bs, bf16=kind == "bfloat16",
+                                       fp8=kind == "fp8_kv")
+                nbytes = alg_bytes(c)
+                row = {"dtype": kind, "head_size": D, "block_size": bs, "us_median": us,
+                       "gbps": nbytes / (us * 1e-6) / 1e9, "variant": ops.variant_names()[vid - 1]}
                 res.append(row)
                 print(json.dumps(row), file=sys.stderr, flush=True)
                 del wl, out
                 torch.cuda.empty_cache()
+    KV_DTYPE = "auto"
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", "matrix.json"), "w") as f:
         json.dump({"batch": base.batch, "num_heads": base.num_heads, "seq_len": base.seq_len, "rows": res}, f, indent=1)
