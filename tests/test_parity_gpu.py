@@ -72,14 +72,14 @@ def run_model(case, alibi=None):
 
 
 def assert_close(got, ref, what="", vmax=1.0):
-    """north_star tolerance (1e-3 abs) AND a tighter one: 2 fp16 ulp of the result, or 2e-4 * max|v| — one
+    """north_star tolerance (1e-3 abs) AND a tighter one: 2 fp16 ulp of the result, or 2.5e-4 * max|v| — one
     rounding flip of an fp16 probability (the fp32 softmax differs in summation order and exp implementation)
     moves an output by ulp(p) * |v|."""
     got64, ref64 = got.astype(np.float64), ref.astype(np.float64)
     assert np.isfinite(got64).all(), f"{what}: non-finite output"
     d = np.abs(got64 - ref64)
     assert d.max() <= ATOL * max(1.0, vmax), f"{what}: max|hip-model| = {d.max():.3e} > {ATOL}"
-    tight = np.maximum(2 * ulp16(ref64), 2e-4 * max(1.0, vmax))
+    tight = np.maximum(2 * ulp16(ref64), 2.5e-4 * max(1.0, vmax))   # 2.44e-4 = one flip of a probability in [0.25, 0.5)
     bad = d > tight
     assert not bad.any(), f"{what}: {bad.sum()} outputs off by more than 2 fp16 ulp (max {d.max():.3e})"
     return d.max(), float((d == 0).mean())
@@ -1368,3 +1368,16 @@ def test_pa_v2_fp8_matches_kernel_model(D, bs):
             assert np.allclose(es.cpu().numpy()[s, :, :used], r_es[s, :, :used], rtol=2e-5, atol=1e-6)
             assert_close(tmp.cpu().numpy()[s, :, :used], r_tmp[s, :, :used], "fp8 v2 tmp_out", vmax=2 * kv_scale)
             assert torch.isnan(es[s, :, used:]).all() and torch.isnan(tmp[s, :, used:]).all()
+
+
+def test_pa_v1_long_max_seq_len_falls_back_to_one_head_per_workgroup():
+    """max_seq_len = 32 768 (a capacity-style value): four heads' logits no longer fit one workgroup's LDS, so the
+    heuristic's 4-heads-per-workgroup pick must give way instead of failing; 40 000+ tokens do not fit at all and
+    are reported with a pointer to paged_attention_v2."""
+    rng = np.random.default_rng(41)
+    lens = [5, 300, 1000]
+    case = make_case(rng, len(lens), 8, 64, lens)
+    ref = run_model(case)
+    assert_close(run_hip(case, max_seq_len=32768), ref, "max_seq_len 32768")
+    with pytest.raises(RuntimeError, match="paged_attention_v2"):
+        run_hip(case, max_seq_len=50000)

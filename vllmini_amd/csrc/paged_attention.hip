@@ -575,9 +575,23 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (f8 && block_size == 8)
     return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: 8 with an fp8 KV cache (a value row of 8 bytes does not "
                 "fill a 16-byte unit; block sizes 16 and 32 are built)");
-  if (variant == 0)
+  const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
+  auto lds_of = [&](const Variant& c) {
+    return (size_t)c.HPW * c.HPT *
+           ((size_t)lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? (size_t)lpad * 2 : 0));
+  };
+  if (variant == 0) {
     variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0)
                  : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
+    // a long max_seq_len may not leave room for several heads' logits in one workgroup's LDS: fall back to one
+    // head per workgroup, then to one wave per head (no second copy of the probabilities) before giving up
+    if (variant >= 1 && variant <= nvariants_v1() && lds_of(variant_v1(variant)) > 160 * 1024) {
+      const int wph0 = variant_v1(variant).WPH;
+      int alt = find_variant(head_size, block_size, 1, wph0, -1, -1, bf, f8);
+      if (!alt || lds_of(variant_v1(alt)) > 160 * 1024) alt = find_variant(head_size, block_size, 1, 1, -1, -1, bf, f8);
+      if (alt) variant = alt;
+    }
+  }
   if (variant < 1 || variant > nvariants_v1())
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
   Variant* vp = append ? app_variant_v1(variant) : &variant_v1(variant);
@@ -598,12 +612,11 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s needs num_heads %% %d == 0", v.name,
                 v.HPW * v.HPT);
 
-  const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
-  const size_t lds = (size_t)v.HPW * v.HPT *
-                     ((size_t)lpad * 4 + 2 * v.WPH * 4 + (size_t)v.WPH * v.D * 4 + (v.WPH > 1 ? (size_t)lpad * 2 : 0));
+  const size_t lds = lds_of(v);
   if (lds > 160 * 1024)
     return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v1: max_seq_len=%d needs %zu B of LDS per "
-                "workgroup (variant %s), limit 163840", max_seq_len, lds, v.name);
+                "workgroup (variant %s), limit 163840 — paged_attention_v2 has no such limit", max_seq_len, lds,
+                v.name);
 
   DeviceGuard guard(device);
   hipError_t e = guard.err;
