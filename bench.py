@@ -467,7 +467,7 @@ def main():
     if args.hint_mean and not args.variant and args.op in ("v1", "fused"):
         lens_h = wl.seq_lens.cpu()
         args.variant = ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, int(lens_h.max()), cfg.block_size,
-                                        mean_seq_len=int(lens_h.float().mean()))
+                                        mean_seq_len=int(lens_h.float().mean()), fp8=args.kv == "fp8")
     elapsed, kern_ms = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op)
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     kern_mean_ms = shard.max_over_ranks(statistics.mean(kern_ms), dist, dev)
