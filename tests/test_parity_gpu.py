@@ -72,14 +72,14 @@ def run_model(case, alibi=None):
 
 
 def assert_close(got, ref, what="", vmax=1.0):
-    """north_star tolerance (1e-3 abs) AND a tighter one: 2 fp16 ulp of the result, or 2.5e-4 * max|v| — one
+    """north_star tolerance (1e-3 abs) AND a tighter one: 2 fp16 ulp of the result, or 5e-4 * max|v| — one
     rounding flip of an fp16 probability (the fp32 softmax differs in summation order and exp implementation)
     moves an output by ulp(p) * |v|."""
     got64, ref64 = got.astype(np.float64), ref.astype(np.float64)
     assert np.isfinite(got64).all(), f"{what}: non-finite output"
     d = np.abs(got64 - ref64)
     assert d.max() <= ATOL * max(1.0, vmax), f"{what}: max|hip-model| = {d.max():.3e} > {ATOL}"
-    tight = np.maximum(2 * ulp16(ref64), 2.5e-4 * max(1.0, vmax))   # 2.44e-4 = one flip of a probability in [0.25, 0.5)
+    tight = np.maximum(2 * ulp16(ref64), 5e-4 * max(1.0, vmax))   # 4.88e-4 = one flip of a probability in [0.5, 1)
     bad = d > tight
     assert not bad.any(), f"{what}: {bad.sum()} outputs off by more than 2 fp16 ulp (max {d.max():.3e})"
     return d.max(), float((d == 0).mean())
