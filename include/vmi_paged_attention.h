@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 7
+#define VMI_ABI_VERSION 8
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -214,6 +214,26 @@ int vmi_reshape_and_cache_fp8(
     int32_t device, void* stream);
 int vmi_paged_attention_v1_pick_variant_fp8(int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                             int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len);
+/* bfloat16 query / key / value over the same fp8 caches (the reference dispatches bf16 x uint8 as well):
+ * load __float2bfloat16(float(fp8) * kv_scale) (quant_utils.cuh:350-359), store fp8(float(bf16) / kv_scale) (:468-478). */
+int vmi_paged_attention_v1_fp8_bf16(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream,
+    float kv_scale, int32_t variant);
+int vmi_reshape_and_cache_fp8_bf16(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping,
+    int32_t num_tokens, int32_t num_heads, int32_t head_size, int32_t block_size, int32_t x,
+    int64_t key_stride, int64_t value_stride, float kv_scale,
+    int32_t device, void* stream);
+int vmi_paged_attention_v1_pick_variant_fp8_bf16(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                                 int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len);
 
 /* Number of tuning variants (valid ids are 1..count) and a short name for each. */
 int vmi_paged_attention_v1_variant_count(void);

@@ -214,20 +214,21 @@ def f32_to_fp8e4m3(x: np.ndarray) -> np.ndarray:
 
 
 def reshape_and_cache_fp8(key: np.ndarray, value: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
-                          slot_mapping: np.ndarray, kv_scale: float = 1.0) -> None:
+                          slot_mapping: np.ndarray, kv_scale: float = 1.0, bf16: bool = False) -> None:
     """In-place quantising scatter (cache_kernels.cu:200-205): float16 rows -> uint8 caches
     key_cache [NB, H, D/16, BS, 16], value_cache [NB, H, D, BS]."""
-    assert key.dtype == value.dtype == np.float16 and key_cache.dtype == value_cache.dtype == np.uint8
+    assert key.dtype == value.dtype == (np.uint16 if bf16 else np.float16)   # bf16: bit patterns
+    assert key_cache.dtype == value_cache.dtype == np.uint8
     assert key_cache.flags.c_contiguous and value_cache.flags.c_contiguous and key_cache.shape[4] == 16
     T, H, D = key.shape
     ks, vs = _elem_strides(key), _elem_strides(value)
     assert ks[2] == 1 and ks[1] == D and vs[2] == 1 and vs[1] == D
     slot_mapping = np.ascontiguousarray(slot_mapping, dtype=np.int64)
     lib = _load()
-    lib.vmi_oracle_reshape_and_cache_fp8.restype = ctypes.c_int
-    lib.vmi_oracle_reshape_and_cache_fp8.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int32] * 5 + [
-        ctypes.c_int64, ctypes.c_int64, ctypes.c_float]
-    rc = lib.vmi_oracle_reshape_and_cache_fp8(
+    fn = lib.vmi_oracle_reshape_and_cache_fp8_bf16 if bf16 else lib.vmi_oracle_reshape_and_cache_fp8
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int32] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float]
+    rc = fn(
         _base_ptr(key), _base_ptr(value), _base_ptr(key_cache), _base_ptr(value_cache), _base_ptr(slot_mapping),
         T, H, D, int(key_cache.shape[3]), 16, int(ks[0]), int(vs[0]), float(kv_scale))
     assert rc == 0
@@ -236,11 +237,12 @@ def reshape_and_cache_fp8(key: np.ndarray, value: np.ndarray, key_cache: np.ndar
 def paged_attention_v1_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray, num_kv_heads: int,
                            scale: float, block_tables: np.ndarray, seq_lens: np.ndarray, block_size: int,
                            kv_scale: float = 1.0, alibi_slopes: np.ndarray | None = None,
-                           threads: int = 1) -> np.ndarray:
+                           threads: int = 1, bf16: bool = False) -> np.ndarray:
     """Kernel model with an fp8 E4M3 cache: every cache element is first turned into
     float_to_half(float(fp8) * kv_scale) (quant_utils.cuh:295-300), then the fp16 arithmetic of
     paged_attention_v1 applies unchanged (attention_kernels.cu:283-289, 410-418)."""
-    assert query.dtype == np.float16 and key_cache.dtype == value_cache.dtype == np.uint8
+    et = np.uint16 if bf16 else np.float16          # bf16: query / out are bit patterns
+    assert query.dtype == et and key_cache.dtype == value_cache.dtype == np.uint8
     assert key_cache.ndim == 5 and key_cache.shape[4] == 16 and value_cache.ndim == 4
     S, H, D = query.shape
     qs = _elem_strides(query)
@@ -249,16 +251,17 @@ def paged_attention_v1_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache
     block_tables = np.ascontiguousarray(block_tables, dtype=np.int32)
     seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
     kb, kh = _elem_strides(key_cache)[:2]
-    out = np.zeros((S, H, D), dtype=np.float16)
+    out = np.zeros((S, H, D), dtype=et)
     alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
     lib = _load()
-    lib.vmi_oracle_paged_attention_v1_fp8.restype = ctypes.c_int
-    lib.vmi_oracle_paged_attention_v1_fp8.argtypes = (
+    fn8 = lib.vmi_oracle_paged_attention_v1_fp8_bf16 if bf16 else lib.vmi_oracle_paged_attention_v1_fp8
+    fn8.restype = ctypes.c_int
+    fn8.argtypes = (
         [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
         [ctypes.c_int32] * 2 + [ctypes.c_void_p] + [ctypes.c_int64] * 3 + [ctypes.c_int32] * 2 + [ctypes.c_float])
 
     def run(lo: int, hi: int) -> int:
-        return lib.vmi_oracle_paged_attention_v1_fp8(
+        return fn8(
             _base_ptr(out), _base_ptr(query), _base_ptr(key_cache), _base_ptr(value_cache), S, H, D,
             int(num_kv_heads), float(scale), _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size),
             int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),

@@ -1381,3 +1381,56 @@ def test_pa_v1_long_max_seq_len_falls_back_to_one_head_per_workgroup():
     assert_close(run_hip(case, max_seq_len=32768), ref, "max_seq_len 32768")
     with pytest.raises(RuntimeError, match="paged_attention_v2"):
         run_hip(case, max_seq_len=50000)
+
+
+# ------------------------------------------------------------------------------------------------
+# bfloat16 query / rows over the fp8 E4M3 cache (the reference dispatches bf16 x uint8 too)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kv_scale", [1.0, 2.5])
+def test_reshape_and_cache_fp8_every_bf16_value_bit_exact(kv_scale):
+    ext = _ext()
+    dev = _dev()
+    T, H, D, bs, NB = 64, 4, 256, 16, 6
+    bits = np.arange(65536, dtype=np.uint16).reshape(T, H, D)
+    rng = np.random.default_rng(6)
+    vbits = bits[rng.permutation(T)]
+    slots = rng.permutation(NB * bs)[:T].astype(np.int64)
+    kc = np.zeros((NB, H, D // 16, bs, 16), dtype=np.uint8)
+    vc = np.zeros((NB, H, D, bs), dtype=np.uint8)
+    t_kc, t_vc = torch.from_numpy(kc).to(dev), torch.from_numpy(vc).to(dev)
+    ext.cache_ops.reshape_and_cache(_bf16_tensor(bits, dev), _bf16_tensor(vbits, dev), t_kc, t_vc,
+                                    torch.from_numpy(slots).to(dev), "fp8", kv_scale)
+    torch.cuda.synchronize()
+    oracle.reshape_and_cache_fp8(np.ascontiguousarray(bits), np.ascontiguousarray(vbits), kc, vc, slots,
+                                 kv_scale=kv_scale, bf16=True)
+    assert np.array_equal(t_kc.cpu().numpy(), kc)
+    assert np.array_equal(t_vc.cpu().numpy(), vc)
+
+
+@pytest.mark.parametrize("D,bs", [(64, 16), (128, 16), (80, 16), (112, 32), (192, 32), (256, 16), (96, 32)])
+def test_pa_v1_bf16_query_over_fp8_cache_matches_kernel_model(D, bs):
+    from vllmini_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(1500 + D + bs)
+    lens = [1, bs, bs + 1, 100, 333, 47, 600, 2]
+    case = _fp8_case(rng, len(lens), 8, D, lens, bs, num_kv_heads=4)
+    qbits = oracle.f32_to_bf16_bits(case["qbuf"].astype(np.float32))
+    S, H, _ = case["q"].shape
+    q_np = np.ascontiguousarray(qbits[:, : H * D].reshape(S, H, D))
+    tab, ln = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
+    kq, vq = torch.from_numpy(case["kq"]).to(dev), torch.from_numpy(case["vq"]).to(dev)
+    q = _bf16_tensor(qbits, dev)[:, : H * D].view(S, H, D)
+    names = ops.variant_names()
+    vids = [0] + [i + 1 for i, n in enumerate(names) if n.startswith(f"bf16_fp8_d{D}_bs{bs}_")]
+    assert len(vids) >= 3
+    for kv_scale in (1.0, 0.7):
+        ref = oracle.paged_attention_v1_fp8(q_np, case["kq"], case["vq"], 4, case["scale"], case["tables"], case["lens"],
+                                            bs, kv_scale=kv_scale, threads=8, bf16=True)
+        for vid in vids:
+            out = torch.full((S, H, D), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.paged_attention_v1(out, q, kq, vq, 4, case["scale"], tab, ln, bs, max(lens), None, "fp8", kv_scale,
+                                   0, 0, 1, 1, 0, _variant=vid)
+            torch.cuda.synchronize()
+            got = out.view(torch.int16).cpu().numpy().view(np.uint16)
+            assert_close_bf16(got, ref, f"bf16 x fp8 D{D} bs{bs} scale {kv_scale} variant {names[vid - 1] if vid else 'auto'}")

@@ -2,7 +2,7 @@
 
 The reference builds its kernels as a torch CUDAExtension for sm_70..sm_89
 (paged_attention_ext/setup.py:21-46, build.sh:3-5).  Here there is no torch/pybind in the
-native code at all: seven hipcc translation units (core kernels + C-ABI; extra head/block-size instantiations; bfloat16;
+native code at all: eight hipcc translation units (core kernels + C-ABI; extra head/block-size instantiations; bfloat16;
 the fused-append twin of each of those three kernel menus; the fp8 KV-cache menu)
 compiled concurrently and linked into vllmini_amd/_C/libvmi_paged_attention.so, loaded through ctypes (vllmini_amd/_lib.py).
 
@@ -25,7 +25,8 @@ SRC_BF16 = os.path.join(CSRC, "pa_variants_bf16.hip")         # bfloat16 instant
 SRC_APPEND = [os.path.join(CSRC, f"pa_append_{t}.hip") for t in ("core", "extra", "bf16")]   # fused-append twins
 TABLES = [os.path.join(CSRC, f"pa_table_{t}.inc") for t in ("core", "extra", "bf16", "fp8")]         # shared kernel menus
 SRC_FP8 = os.path.join(CSRC, "pa_variants_fp8.hip")           # fp8 E4M3 KV-cache instantiations
-SOURCES = [SRC, SRC_EXTRA, SRC_BF16, *SRC_APPEND, SRC_FP8]
+SRC_FP8_BF16 = os.path.join(CSRC, "pa_variants_fp8_bf16.hip")  # ... with a bfloat16 query
+SOURCES = [SRC, SRC_EXTRA, SRC_BF16, *SRC_APPEND, SRC_FP8, SRC_FP8_BF16]
 HDR = os.path.join(CSRC, "pa_kernel.hpp")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 OUT_DIR = os.path.join(PKG_DIR, "_C")

@@ -83,10 +83,30 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // 8 fp8 bytes (two dwords) -> 8 halves packed like a 16-byte fp16 unit.
 // S1 (kv_scale == 1): every E4M3 value is a float16 value, so half(float(fp8) * 1) is the byte's own value and
 // v_cvt_scalef32_pk_f16_fp8 with scale 1.0 produces it directly, two per instruction.
-typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
-template <bool S1>
+template <bool S1, bool BF = false>
 __device__ __forceinline__ u32x4 deq8(uint32_t w0, uint32_t w1, float s) {
-  if constexpr (S1) {
+  if constexpr (BF) {
+    // bfloat16 query: element = __float2bfloat16(float(fp8) * kv_scale) (quant_utils.cuh:350-359); with kv_scale == 1
+    // the multiply is skipped (the fp32 decode has at most 4 significant bits: it already is a bfloat16 value)
+    u32x4 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t w = h ? w1 : w0;
+      const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
+      const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+      if constexpr (S1) {
+        // (the upper 16 bits of each decode would do — the value is exact in bfloat16 — but hipcc 7.2 turns
+        //  `(bits(lo[0]) >> 16) | (bits(lo[1]) & 0xffff0000)` into a pack that reads lo[0] twice; measured on gfx950,
+        //  odd tokens received their even neighbour's value.  The rounding form below is immune and also exact.)
+        o[2 * h] = (uint32_t)to_elem<true>(lo[0]) | ((uint32_t)to_elem<true>(lo[1]) << 16);
+        o[2 * h + 1] = (uint32_t)to_elem<true>(hi[0]) | ((uint32_t)to_elem<true>(hi[1]) << 16);
+      } else {
+        o[2 * h] = (uint32_t)to_elem<true>(lo[0] * s) | ((uint32_t)to_elem<true>(lo[1] * s) << 16);
+        o[2 * h + 1] = (uint32_t)to_elem<true>(hi[0] * s) | ((uint32_t)to_elem<true>(hi[1] * s) << 16);
+      }
+    }
+    return o;
+  } else if constexpr (S1) {
     u32x4 o;
     o[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w0, 1.0f, false));
     o[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w0, 1.0f, true));
@@ -111,10 +131,10 @@ __device__ __forceinline__ u32x4 deq8(uint32_t w0, uint32_t w1, float s) {
 // q.k over one 16-byte fp8 chunk (16 dims): fp32 FMA chain on widened operands, like dot8.
 // S1: the fp32 decode IS the operand (half(fp8) widens back to the same fp32), so q (f16) x k (f32) goes straight
 // into v_fma_mix_f32 — 8 decodes + 16 FMAs for 16 dims.
-template <bool S1>
+template <bool S1, bool BF = false>
 __device__ __forceinline__ float dot16_f8(const u32x4 q0, const u32x4 q1, const u32x4 k, float s) {
   static_assert(!S1, "kv_scale == 1 uses dot16_f8_s1");
-  return dot8<false>(q0, deq8<false>(k[0], k[1], s)) + dot8<false>(q1, deq8<false>(k[2], k[3], s));
+  return dot8<BF>(q0, deq8<false, BF>(k[0], k[1], s)) + dot8<BF>(q1, deq8<false, BF>(k[2], k[3], s));
 }
 // kv_scale == 1: half(float(fp8)) widens back to the same fp32, so the fp32 decode IS the operand.  q is held as
 // fp32 pairs (converted once per wave), v_cvt_pk_f32_fp8 yields k as fp32 pairs, and v_pk_fma_f32 does two exact
@@ -285,8 +305,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   static_assert(64 % U == 0, "U must divide 64");
   static_assert(!(LOCK && WPH > 1), "lockstep needs every wave to run the same number of page groups");
   static_assert(!(APP && (PART || LOADS_ONLY)), "the fused append exists for paged_attention_v1 only");
-  static_assert(!F8 || (BS >= 16 && D % 16 == 0 && !BF && !APP && !LOADS_ONLY),
-                "fp8 cache: fp16 query, block size 16 or 32 (a V row must fill whole 16-byte units)");
+  static_assert(!F8 || (BS >= 16 && D % 16 == 0 && !APP && !LOADS_ONLY),
+                "fp8 cache: block size 16 or 32 (a V row must fill whole 16-byte units), no fused append");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -455,9 +475,12 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
         for (int i = 0; i < NL; ++i)
 #pragma unroll
           for (int w = 0; w < 2; ++w) {
-            const h16x8 qh = __builtin_bit_cast(h16x8, qreg[hh][i][F8 ? w : 0]);
+            const u32x4 qraw = qreg[hh][i][F8 ? w : 0];
+            const h16x8 qh = __builtin_bit_cast(h16x8, qraw);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) qf[hh][i][4 * w + e] = f32x2_t{(float)qh[2 * e], (float)qh[2 * e + 1]};
+            for (int e = 0; e < 4; ++e)
+              qf[hh][i][4 * w + e] = BF ? f32x2_t{bf_lo(qraw[e]), bf_hi(qraw[e])}
+                                        : f32x2_t{(float)qh[2 * e], (float)qh[2 * e + 1]};
           }
     }
     const int ngroups = (nmy + UU - 1) / UU;
@@ -535,7 +558,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
                 if constexpr (F8 && S1) accv[i] = dot16_f8_s1(qf[hh][i], r[j][hh][i]);
-                else if constexpr (F8) accv[i] = dot16_f8<false>(qreg[hh][i][0], qreg[hh][i][1], r[j][hh][i], p.kv_scale);
+                else if constexpr (F8) accv[i] = dot16_f8<false, BF>(qreg[hh][i][0], qreg[hh][i][1], r[j][hh][i], p.kv_scale);
                 else accv[i] = dot8<BF>(qreg[hh][i][0], r[j][hh][i]);
               }
               float acc = accv[0];
@@ -709,7 +732,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
                 if constexpr (F8)  // first 8 of the unit's 16 tokens
-                  acc[hh][i] += pv.template dot<MASK>(deq8<S1>(r[j][hh][i][0], r[j][hh][i][1], p.kv_scale), last, token0, L);
+                  acc[hh][i] += pv.template dot<MASK>(deq8<S1, BF>(r[j][hh][i][0], r[j][hh][i][1], p.kv_scale), last, token0, L);
                 else
                   acc[hh][i] += pv.template dot<MASK>(r[j][hh][i], last, token0, L);
               }
@@ -718,7 +741,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
                 pw.load(*reinterpret_cast<const u32x4_alias*>(php + 8));
 #pragma unroll
                 for (int i = 0; i < NL; ++i)
-                  acc[hh][i] += pw.template dot<MASK>(deq8<S1>(r[j][hh][i][2], r[j][hh][i][3], p.kv_scale), last, token0 + 8, L);
+                  acc[hh][i] += pw.template dot<MASK>(deq8<S1, BF>(r[j][hh][i][2], r[j][hh][i][3], p.kv_scale), last, token0 + 8, L);
               }
             }
           }
@@ -948,10 +971,12 @@ typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const 
    (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), LO, false, BS, LOCK, BF, HPT, (VMI_APP) && !(LO), UMAX>, 0, \
    UMAX},
 // fp8-cache rows (pa_table_fp8.inc): fp16 query, no fused-append twin
-#define VMI_ROW_F8(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX)                                                  \
-  {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, false,                                                               \
-   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), false, false, BS, LOCK, false, HPT, false, UMAX, true>, 0, \
+#define VMI_ROW_F8B(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX, BF)                                             \
+  {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, BF,                                                                  \
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), false, false, BS, LOCK, BF, HPT, false, UMAX, true>, 0,    \
    UMAX, 0, true},
+#define VMI_ROW_F8(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX) \
+  VMI_ROW_F8B(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX, false)
 #define VMI_ROW(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT) \
   VMI_ROW_A(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT, 0)
 
@@ -978,6 +1003,9 @@ extern Variant g_fp8_variants_v1[];
 extern const int g_fp8_nvariants_v1;
 extern Variant g_fp8_variants_v2[];
 extern const int g_fp8_nvariants_v2;
+// bfloat16 query over the fp8 cache (pa_variants_fp8_bf16.hip): v1 ids continue after the fp16-query fp8 menu
+extern Variant g_fp8bf_variants_v1[];
+extern const int g_fp8bf_nvariants_v1;
 pa_reduce_t bf16_reduce_kernel(int head_size);
 
 }  // namespace vmi

@@ -160,7 +160,7 @@ __device__ __forceinline__ uint32_t f32_to_fp8e4m3_satfinite(float f) {
   return sign | ((u >> 20) - ((127u - 7u) << 3));
 }
 
-template <bool VEC>
+template <bool VEC, bool BF = false>
 __global__ void __launch_bounds__(256)
     reshape_and_cache_fp8_kernel(const h16* __restrict__ key, const h16* __restrict__ value,
                                  uint8_t* __restrict__ kc, uint8_t* __restrict__ vc,
@@ -198,8 +198,11 @@ __global__ void __launch_bounds__(256)
     uint8_t* vdst = vc + ((blk * H + h) * (int64_t)D + d) * BS + off;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      kq[e >> 2] |= f32_to_fp8e4m3_satfinite((float)kv[e] / kv_scale) << (8 * (e & 3));
-      vdst[(int64_t)e * BS] = (uint8_t)f32_to_fp8e4m3_satfinite((float)vv[e] / kv_scale);
+      // bfloat16 rows (quant_utils.cuh:468-478) widen by a 16-bit shift; float16 rows by v_cvt_f32_f16
+      const float kf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, kv[e]) << 16) : (float)kv[e];
+      const float vf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, vv[e]) << 16) : (float)vv[e];
+      kq[e >> 2] |= f32_to_fp8e4m3_satfinite(kf / kv_scale) << (8 * (e & 3));
+      vdst[(int64_t)e * BS] = (uint8_t)f32_to_fp8e4m3_satfinite(vf / kv_scale);
     }
     *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (D >> 4) + (d >> 4)) * BS + off) * 16) = kq;
   }
@@ -406,13 +409,17 @@ static Variant g_variants[] = {
 };
 static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
-static int nvariants_v1() { return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1 + g_fp8_nvariants_v1; }
+static int nvariants_v1() {
+  return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1 + g_fp8_nvariants_v1 + g_fp8bf_nvariants_v1;
+}
 static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf16][fp8 cache]
   if (id <= g_ncore) return g_variants[id - 1];
   if (id <= g_ncore + g_extra_nvariants_v1) return g_extra_variants_v1[id - 1 - g_ncore];
   if (id <= g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1)
     return g_bf16_variants_v1[id - 1 - g_ncore - g_extra_nvariants_v1];
-  return g_fp8_variants_v1[id - 1 - g_ncore - g_extra_nvariants_v1 - g_bf16_nvariants_v1];
+  const int f0 = g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1;
+  if (id <= f0 + g_fp8_nvariants_v1) return g_fp8_variants_v1[id - 1 - f0];
+  return g_fp8bf_variants_v1[id - 1 - f0 - g_fp8_nvariants_v1];  // bf16 query over the fp8 cache
 }
 
 static bool is_diag(const Variant& v) { return strstr(v.name, "LOADSONLY") != nullptr; }
@@ -450,7 +457,7 @@ static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }
 // (profiles/r01g_ragged_batches.md: cfg3 U{1..1024} 98.7 -> 77.1 us, cfg4 446.8 -> 360.5 us).
 // fp8 cache: a (block, head) tile is half the bytes; measured picks in profiles/r01h_fp8_kv.md
 static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
-                            int mean_seq_len) {
+                            int mean_seq_len, bool bf = false) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
@@ -460,13 +467,14 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   int v = 0;
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {
     if (wph == 1) {
-      v = find_variant(head_size, 16, (num_heads % 4 == 0) ? 4 : 1, 1, head_size == 64 ? 2 : 1, -1, false, true);
+      v = find_variant(head_size, 16, (num_heads % 4 == 0) ? 4 : 1, 1, head_size == 64 ? 2 : 1, -1, bf, true);
     } else {
-      for (int ww = wph; ww >= 1 && !v; ww /= 2) v = find_variant(head_size, 16, 1, ww, -1, -1, false, true);
+      for (int ww = wph; ww >= 1 && !v; ww /= 2) v = find_variant(head_size, 16, 1, ww, -1, -1, bf, true);
     }
   }
-  if (!v) v = find_variant(head_size, block_size, 1, wph == 1 ? 1 : 4, -1, -1, false, true);
-  if (!v) v = find_variant(head_size, block_size, 1, 1, -1, -1, false, true);
+  if (!v && wph > 1) v = find_variant(head_size, block_size, 1, wph >= 16 ? 16 : 4, -1, -1, bf, true);
+  if (!v) v = find_variant(head_size, block_size, 1, wph == 1 ? 1 : 4, -1, -1, bf, true);
+  if (!v) v = find_variant(head_size, block_size, 1, 1, -1, -1, bf, true);
   return v;
 }
 
@@ -581,7 +589,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
            ((size_t)lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? (size_t)lpad * 2 : 0));
   };
   if (variant == 0) {
-    variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0)
+    variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf)
                  : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
     // a long max_seq_len may not leave room for several heads' logits in one workgroup's LDS: fall back to one
     // head per workgroup, then to one wave per head (no second copy of the probabilities) before giving up
@@ -929,6 +937,22 @@ int vmi_paged_attention_v1_fp8(void* out, const void* query, const void* key_cac
                            true, kv_scale);
 }
 
+int vmi_paged_attention_v1_fp8_bf16(void* out, const void* query, const void* key_cache, const void* value_cache,
+                                    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+                                    float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                                    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+                                    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                                    int64_t kv_head_stride, int32_t device, void* stream, float kv_scale,
+                                    int32_t variant) {
+  if (!(kv_scale > 0.f))
+    return vmi::fail(VMI_E_SHAPE, "paged_attention_v1 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, true, false, nullptr, nullptr, 0, 0,
+                           true, kv_scale);
+}
+
 int vmi_paged_attention_v2_fp8(void* out, void* exp_sums, void* max_logits, void* tmp_out, const void* query,
                                const void* key_cache, const void* value_cache, int32_t num_seqs,
                                int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
@@ -949,6 +973,12 @@ int vmi_paged_attention_v1_pick_variant_fp8(int32_t num_seqs, int32_t num_heads,
                                             int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len) {
   if (!vmi::head_size_supported(head_size) || (block_size != 16 && block_size != 32)) return 0;
   return vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, mean_seq_len);
+}
+
+int vmi_paged_attention_v1_pick_variant_fp8_bf16(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                                 int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len) {
+  if (!vmi::head_size_supported(head_size) || (block_size != 16 && block_size != 32)) return 0;
+  return vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, mean_seq_len, true);
 }
 
 int vmi_paged_attention_v2_bf16(void* out, void* exp_sums, void* max_logits, void* tmp_out,
@@ -1053,10 +1083,10 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
   return VMI_OK;
 }
 
-int vmi_reshape_and_cache_fp8(const void* key, const void* value, void* key_cache, void* value_cache,
-                              const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
-                              int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
-                              int64_t value_stride, float kv_scale, int32_t device, void* stream) {
+static int reshape_and_cache_fp8_impl(const void* key, const void* value, void* key_cache, void* value_cache,
+                                      const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
+                                      int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
+                                      int64_t value_stride, float kv_scale, int32_t device, void* stream, bool bf) {
   using namespace vmi;
   if (!key || !value || !key_cache || !value_cache || !slot_mapping)
     return fail(VMI_E_NULL_POINTER, "reshape_and_cache (fp8): NULL tensor pointer");
@@ -1076,19 +1106,32 @@ int vmi_reshape_and_cache_fp8(const void* key, const void* value, void* key_cach
   int threads = ((n16 + 63) / 64) * 64;
   if (threads > 256) threads = 256;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (vec)
-    hipLaunchKernelGGL(reshape_and_cache_fp8_kernel<true>, dim3(num_tokens), dim3(threads), 0, st,
-                       static_cast<const h16*>(key), static_cast<const h16*>(value),
-                       static_cast<uint8_t*>(key_cache), static_cast<uint8_t*>(value_cache), slot_mapping,
-                       key_stride, value_stride, num_heads, head_size, block_size, kv_scale);
-  else
-    hipLaunchKernelGGL(reshape_and_cache_fp8_kernel<false>, dim3(num_tokens), dim3(threads), 0, st,
-                       static_cast<const h16*>(key), static_cast<const h16*>(value),
-                       static_cast<uint8_t*>(key_cache), static_cast<uint8_t*>(value_cache), slot_mapping,
-                       key_stride, value_stride, num_heads, head_size, block_size, kv_scale);
+  typedef void (*fp8_fn)(const h16*, const h16*, uint8_t*, uint8_t*, const int64_t*, int64_t, int64_t, int, int, int, float);
+  const fp8_fn fn = vec ? (bf ? (fp8_fn)reshape_and_cache_fp8_kernel<true, true> : (fp8_fn)reshape_and_cache_fp8_kernel<true, false>)
+                        : (bf ? (fp8_fn)reshape_and_cache_fp8_kernel<false, true> : (fp8_fn)reshape_and_cache_fp8_kernel<false, false>);
+  hipLaunchKernelGGL(fn, dim3(num_tokens), dim3(threads), 0, st, static_cast<const h16*>(key),
+                     static_cast<const h16*>(value), static_cast<uint8_t*>(key_cache),
+                     static_cast<uint8_t*>(value_cache), slot_mapping, key_stride, value_stride, num_heads, head_size,
+                     block_size, kv_scale);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "reshape_and_cache (fp8) launch");
   return VMI_OK;
+}
+
+int vmi_reshape_and_cache_fp8(const void* key, const void* value, void* key_cache, void* value_cache,
+                              const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
+                              int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
+                              int64_t value_stride, float kv_scale, int32_t device, void* stream) {
+  return reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
+                                    block_size, x, key_stride, value_stride, kv_scale, device, stream, false);
+}
+
+int vmi_reshape_and_cache_fp8_bf16(const void* key, const void* value, void* key_cache, void* value_cache,
+                                   const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
+                                   int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
+                                   int64_t value_stride, float kv_scale, int32_t device, void* stream) {
+  return reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
+                                    block_size, x, key_stride, value_stride, kv_scale, device, stream, true);
 }
 
 int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_cache, void* v_cache,

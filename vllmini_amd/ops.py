@@ -85,8 +85,6 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
         # (its callers only use half: gpt2.py, scheduler.py:13); fp32 has a different cache layout (x = 4)
         raise RuntimeError(f"Unsupported input type of paged attention: {query.dtype}")
     fp8 = _check_kv_cache_dtype(kv_cache_dtype)
-    if fp8 and query.dtype != torch.float16:
-        raise RuntimeError("an fp8 KV cache is built for float16 query/out only")
     if int(blocksparse_vert_stride) > 1:
         raise RuntimeError("block-sparse paged attention (blocksparse_vert_stride > 1) is not "
                            "supported; reference callers always pass vert_stride=1 (gpt2.py:109-112)")
@@ -187,8 +185,9 @@ def paged_attention_v1(
                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
                       blocksparse_block_size, blocksparse_head_sliding_step)
     lib = _lib.load()
-    if _check_kv_cache_dtype(kv_cache_dtype):      # fp8 E4M3 cache
-        rc = lib.vmi_paged_attention_v1_fp8(*args, float(kv_scale), int(_variant))
+    if _check_kv_cache_dtype(kv_cache_dtype):      # fp8 E4M3 cache, float16 or bfloat16 query
+        fn = lib.vmi_paged_attention_v1_fp8_bf16 if query.dtype == torch.bfloat16 else lib.vmi_paged_attention_v1_fp8
+        rc = fn(*args, float(kv_scale), int(_variant))
     elif query.dtype == torch.bfloat16:
         rc = lib.vmi_paged_attention_v1_bf16(*args, int(_variant))
     elif _variant:
@@ -295,6 +294,8 @@ def paged_attention_v2(
         if t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
             raise RuntimeError(f"{name} must be a contiguous {dt} tensor of shape {shape} "
                                f"(max_num_partitions = ceil(max_seq_len/512) = {parts})")
+    if fp8 and query.dtype != torch.float16:
+        raise RuntimeError("paged_attention_v2 over an fp8 KV cache is built for float16 query/out only")
     if fp8:
         rc = _lib.load().vmi_paged_attention_v2_fp8(args[0], exp_sums.data_ptr(), max_logits.data_ptr(),
                                                     tmp_out.data_ptr(), *args[1:], float(kv_scale), int(_variant))
@@ -325,8 +326,6 @@ def reshape_and_cache(
         raise RuntimeError("key and value must both be [num_tokens, num_heads, head_size]")
     if key.dtype not in (torch.float16, torch.bfloat16) or value.dtype != key.dtype:
         raise RuntimeError(f"Unsupported input type of reshape_and_cache: {key.dtype}")
-    if fp8 and key.dtype != torch.float16:
-        raise RuntimeError("an fp8 KV cache is built for float16 key/value only")
     dev = key.device
     for name, t in (("key", key), ("value", value), ("key_cache", key_cache),
                     ("value_cache", value_cache), ("slot_mapping", slot_mapping)):
@@ -357,7 +356,9 @@ def reshape_and_cache(
         raise RuntimeError("slot_mapping must be a contiguous [num_tokens] tensor")
     stream = torch.cuda.current_stream(dev).cuda_stream
     if fp8:                                                               # cache_kernels.cu:200-205
-        rc = _lib.load().vmi_reshape_and_cache_fp8(
+        fn = _lib.load().vmi_reshape_and_cache_fp8_bf16 if key.dtype == torch.bfloat16 else \
+            _lib.load().vmi_reshape_and_cache_fp8
+        rc = fn(
             key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
             slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
             int(key.stride(0)), int(value.stride(0)), float(kv_scale),
@@ -396,8 +397,8 @@ def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int
     many-waves-per-head decomposition; pass the result as `_variant`."""
     lib = _lib.load()
     if fp8:
-        return int(lib.vmi_paged_attention_v1_pick_variant_fp8(num_seqs, num_heads, head_size, block_size,
-                                                               max_seq_len, int(mean_seq_len)))
+        fn = lib.vmi_paged_attention_v1_pick_variant_fp8_bf16 if bf16 else lib.vmi_paged_attention_v1_pick_variant_fp8
+        return int(fn(num_seqs, num_heads, head_size, block_size, max_seq_len, int(mean_seq_len)))
     if mean_seq_len or bf16:
         return int(lib.vmi_paged_attention_v1_pick_variant_hint(num_seqs, num_heads, head_size, block_size,
                                                                 max_seq_len, int(mean_seq_len), int(bool(bf16))))
