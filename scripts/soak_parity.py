@@ -47,9 +47,10 @@ for seed in range(first, first + n_cases):
             if "needs num_heads" not in str(e):
                 raise
             got = T.run_hip(case, variant=0, max_seq_len=msl, alibi=alibi)
-        T.assert_close(got, ref, what + f" v1 {names[vid - 1] if vid else 'auto'}")
+        vmax = float(np.nanmax(np.abs(case["vc"].astype(np.float32))))
+        T.assert_close(got, ref, what + f" v1 {names[vid - 1] if vid else 'auto'}", vmax=vmax)
         if lens.max() > 0:
-            T._check_v2(case, ((msl + 511) // 512) * 512, alibi=alibi, what=what + " v2")
+            T._check_v2(case, ((msl + 511) // 512) * 512, alibi=alibi, what=what + " v2", vmax=vmax)
         if alibi is None:
             try:
                 T._append_vs_two_ops(case, vid if vid and "_bs" not in names[vid - 1] else 0, seed=seed, what=what + " append")
@@ -64,6 +65,19 @@ for seed in range(first, first + n_cases):
             r8 = oracle.paged_attention_v1_fp8(c8["q"], c8["kq"], c8["vq"], hkv, c8["scale"], c8["tables"], c8["lens"], bs,
                                                kv_scale=kvs, threads=4)
             T.assert_close(T._run_fp8(c8, kvs), r8, what + f" fp8 scale {kvs}", vmax=2 * kvs)
+            # bfloat16 query over the same fp8 pages
+            qbits = oracle.f32_to_bf16_bits(c8["qbuf"].astype(np.float32))
+            qn = np.ascontiguousarray(qbits[:, : H * D].reshape(S, H, D))
+            rb = oracle.paged_attention_v1_fp8(qn, c8["kq"], c8["vq"], hkv, c8["scale"], c8["tables"], c8["lens"], bs,
+                                               kv_scale=kvs, threads=4, bf16=True)
+            dev = T._dev()
+            ob = torch.full((S, H, D), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.paged_attention_v1(ob, T._bf16_tensor(qbits, dev)[:, : H * D].view(S, H, D),
+                                   torch.from_numpy(c8["kq"]).to(dev), torch.from_numpy(c8["vq"]).to(dev), hkv, c8["scale"],
+                                   torch.from_numpy(c8["tables"]).to(dev), torch.from_numpy(c8["lens"]).to(dev), bs,
+                                   int(c8["lens"].max()), None, "fp8", kvs)
+            torch.cuda.synchronize()
+            T.assert_close_bf16(ob.view(torch.int16).cpu().numpy().view(np.uint16), rb, what + f" bf16 x fp8 scale {kvs}", vmax=2 * kvs)
     except AssertionError as e:
         fails += 1
         print("FAIL", what, "|", str(e)[:300], flush=True)
