@@ -1,6 +1,15 @@
 // pa_kernel.hpp — kernel templates of the MI355X paged-attention decode path (gfx950 only).
-// Included by paged_attention.hip (core instantiations + host code + C-ABI) and by
-// pa_variants_extra.hip (the remaining head-size / block-size combinations).
+//
+//   device helpers        16-B loads, bf16 helpers, dot8, fp8 E4M3 decode (deq8, dot16_f8*), PV8, wave reductions
+//   PAParams              kernel argument block (v1, v2 partitions, fused append, fp8 scale)
+//   pa_v1_kernel          THE attention kernel: paged_attention_v1, the partition pass of paged_attention_v2 (PART),
+//                         the fused append (APP), fp16 / bf16 query (BF), fp16-sized or fp8 pages (F8)
+//   pa_v2_reduce_kernel   merge of the 512-token partitions
+//   Variant, VMI_ROW*     one row of a kernel menu (pa_table_*.inc) and the tables' extern declarations
+//
+// Instantiated by eight translation units (vllmini_amd/build.py): paged_attention.hip (core menu + host code + C-ABI),
+// pa_variants_extra.hip, pa_variants_bf16.hip, pa_append_{core,extra,bf16}.hip, pa_variants_fp8.hip,
+// pa_variants_fp8_bf16.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -15,7 +24,7 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// LDS logits are written as float and re-read 4 at a time: the vector view must alias float
+// LDS holds the probabilities as 16-bit patterns and they are read 8 at a time: the vector view must alias them
 typedef uint32_t u32x4_alias __attribute__((ext_vector_type(4), may_alias));
 
 // ----------------------------------------------------------------------------------------
