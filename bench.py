@@ -443,8 +443,8 @@ def main():
         names = ops.variant_names()
         res = []
         for vid, name in enumerate(names, start=1):
-            if not name.startswith(f"{'fp8_' if args.kv == 'fp8' else ''}d{cfg.head_size}_"):
-                continue
+            if not name.startswith(f"{'fp8_' if args.kv == 'fp8' else ''}d{cfg.head_size}_") or "_gq" in name:
+                continue            # (gq kernels need num_heads / num_kv_heads > 1: scripts/gqa_probe.py)
             try:
                 _, kern_ms = time_steps(wl, out, args.steps, args.warmup, vid, dist, dev)
             except RuntimeError as e:

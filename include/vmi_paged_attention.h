@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 8
+#define VMI_ABI_VERSION 9
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -241,6 +241,15 @@ const char* vmi_paged_attention_v1_variant_name(int32_t variant);
 /* Variant id the heuristic would choose for this shape (>=1), 0 for an unsupported head/block size. */
 int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                         int32_t block_size, int32_t max_seq_len);
+/*
+ * The heuristic as the operators apply it, i.e. knowing num_kv_heads and the element / cache types: with grouped-query
+ * attention (num_heads / num_kv_heads > 1) it selects a kernel that loads each K / V tile once for all the query
+ * heads of a KV head ("gq" variants) — the other pick functions describe the multi-head-attention menus only.
+ */
+int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
+                                            int32_t head_size, int32_t block_size, int32_t max_seq_len,
+                                            int32_t is_bf16, int32_t is_fp8);
+
 /*
  * The same heuristic with what a caller may know on the host: the batch's mean sequence length (0 = unknown) and
  * the element type.  mean_seq_len well below max_seq_len marks a ragged batch, for which a many-waves-per-head

@@ -37,7 +37,8 @@ for seed in range(first, first + n_cases):
         alibi = (rng.uniform(0.0, 0.3, H)).astype(np.float32) if rng.integers(0, 3) == 0 else None
         tag = (f"d{D}_" if bs == 16 else f"d{D}_bs{bs}_")
         cands = [i + 1 for i, n in enumerate(names)
-                 if n.startswith(tag) and "LOADSONLY" not in n and (bs != 16 or "_bs" not in n)]
+                 if n.startswith(tag) and "LOADSONLY" not in n and (bs != 16 or "_bs" not in n) and
+                 ("_gq" not in n or (H // hkv) % int(n.split("_gq")[1].split("_")[0]) == 0)]
         vid = int(rng.choice(cands)) if (cands and rng.integers(0, 2)) else 0
         msl = int(max(lens.max(), 1)) + int(rng.integers(0, 40))
         ref = T.run_model(case, alibi=alibi)

@@ -111,12 +111,17 @@ def test_pa_v1_matches_kernel_model_default_variant(shape):
     assert_close(got, ref, f"shape {shape}")
 
 
+def _gq_ok(name, qpk):
+    """gq<N> kernels share one KV head between N query heads: usable when num_heads / num_kv_heads % N == 0."""
+    return "_gq" not in name or qpk % int(name.split("_gq")[1].split("_")[0]) == 0
+
+
 def _variants_for(D):
     from vllmini_amd import ops
 
     # block-16 table of this head size; LOADSONLY = bandwidth diagnostics, wrong by design; _bs = other block sizes
     return [(i + 1, n) for i, n in enumerate(ops.variant_names())
-            if n.startswith(f"d{D}_") and "LOADSONLY" not in n and "_bs" not in n]
+            if n.startswith(f"d{D}_") and "LOADSONLY" not in n and "_bs" not in n and "_gq" not in n]   # gq: GQA only
 
 
 @pytest.mark.parametrize("D", [64, 128])
@@ -770,7 +775,8 @@ def test_every_head_and_block_size_v1_and_v2(D, bs):
     assert_close(run_hip(case), ref, f"v1 D{D} bs{bs} default")
     tag = f"d{D}_bs{bs}_" if not (bs == 16 and D in (64, 128)) else f"d{D}_"
     for vid, name in enumerate(ops.variant_names(), start=1):
-        if name.startswith(tag) and "LOADSONLY" not in name and (("_bs" in name) == ("_bs" in tag)):
+        if name.startswith(tag) and "LOADSONLY" not in name and (("_bs" in name) == ("_bs" in tag)) and \
+                ("_gq" not in name or 2 % int(name.split("_gq")[1].split("_")[0]) == 0):   # this case: 2 q heads per KV head
             assert_close(run_hip(case, variant=vid), ref, name)
     _check_v2(case, 1024, what=f"v2 D{D} bs{bs} default")
     tag2 = "v2_" + tag
@@ -1046,7 +1052,7 @@ def test_append_every_head_and_block_size_gqa_fp16_bf16(D, bs):
     for vid, name in enumerate(ops.variant_names(), start=1):
         if "LOADSONLY" in name:
             continue
-        if name.startswith(tag16) and (bs != 16 or "_bs" not in name):
+        if name.startswith(tag16) and (bs != 16 or "_bs" not in name) and _gq_ok(name, 2):
             _append_vs_two_ops(case, vid, what=name)
         elif name.startswith(tagbf):
             _append_vs_two_ops(case, vid, dtype=torch.bfloat16, what=name)
@@ -1103,7 +1109,8 @@ def test_randomized_parity_sweep(chunk):
         # a valid forced decomposition half of the time
         tag = (f"d{D}_" if bs == 16 else f"d{D}_bs{bs}_")
         cands = [i + 1 for i, n in enumerate(names)
-                 if n.startswith(tag) and "LOADSONLY" not in n and (bs != 16 or "_bs" not in n)]
+                 if n.startswith(tag) and "LOADSONLY" not in n and (bs != 16 or "_bs" not in n) and
+                 ("_gq" not in n or (H // hkv) % int(n.split("_gq")[1].split("_")[0]) == 0)]
         vid = int(rng.choice(cands)) if (cands and rng.integers(0, 2)) else 0
         msl = int(max(lens.max(), 1)) + int(rng.integers(0, 40))
         ref = run_model(case, alibi=alibi)
@@ -1264,7 +1271,7 @@ def test_pa_v1_fp8_matches_kernel_model(D, bs):
     ref = oracle.paged_attention_v1_fp8(case["q"], case["kq"], case["vq"], 4, case["scale"], case["tables"],
                                         case["lens"], bs, kv_scale=0.6, threads=8)
     for vid, name in enumerate(ops.variant_names(), start=1):
-        if name.startswith(tag):
+        if name.startswith(tag) and _gq_ok(name, 2):                       # this case: 2 query heads per KV head
             assert_close(_run_fp8(case, 0.6, variant=vid), ref, name, vmax=1.2)
 
 
@@ -1438,3 +1445,72 @@ def test_pa_v1_bf16_query_over_fp8_cache_matches_kernel_model(D, bs):
             torch.cuda.synchronize()
             got = out.view(torch.int16).cpu().numpy().view(np.uint16)
             assert_close_bf16(got, ref, f"bf16 x fp8 D{D} bs{bs} scale {kv_scale} variant {vid}", vmax=2 * kv_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# grouped-query attention: the "gq" kernels load each K / V tile once for the query heads that share it
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [64, 128])
+def test_gqa_shared_tile_kernels_match_kernel_model(D):
+    from vllmini_amd import ops
+
+    names = ops.variant_names()
+    rng = np.random.default_rng(1700 + D)
+    lens = [1, 16, 17, 100, 333, 1024, 47, 2, 0, 600]
+    for H, hkv in ((16, 4), (16, 2), (8, 4), (32, 8)):
+        qpk = H // hkv
+        case = make_case(rng, len(lens), H, D, lens, num_kv_heads=hkv, q_row_pad=1, poison_tail=True)
+        ref = run_model(case)
+        auto = names[ops.pick_variant(len(lens), H, D, 1024, 16, num_kv_heads=hkv) - 1]
+        assert f"_gq" in auto, auto                                  # the operator's own pick shares tiles
+        assert_close(run_hip(case), ref, f"gqa auto H{H}/{hkv} ({auto})")
+        ran = 0
+        for vid, name in enumerate(names, start=1):
+            if not name.startswith(f"d{D}_gq"):
+                continue
+            g = int(name.split("_gq")[1].split("_")[0])
+            if qpk % g:
+                with pytest.raises(RuntimeError, match="shares a KV head"):
+                    run_hip(case, variant=vid)
+                continue
+            try:
+                got = run_hip(case, variant=vid)
+            except RuntimeError as e:                                # heads not divisible by the workgroup's share
+                assert "needs num_heads" in str(e), name
+                continue
+            assert_close(got, ref, f"{name} H{H}/{hkv}")
+            _append_vs_two_ops(case, vid, seed=vid, what=f"append {name} H{H}/{hkv}")
+            ran += 1
+        assert ran >= 3, (H, hkv, ran)
+
+
+def test_gqa_shared_tile_kernels_bf16_and_fp8():
+    from vllmini_amd import ops
+
+    dev = _dev()
+    names = ops.variant_names()
+    rng = np.random.default_rng(1800)
+    lens = [1, 16, 17, 100, 333, 47, 2, 600]
+    H, hkv, bs = 16, 4, 16
+    for D in (64, 128):
+        # bf16
+        case = _to_bf16_case(make_case(rng, len(lens), H, D, lens, num_kv_heads=hkv, q_row_pad=1))
+        ref = oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], hkv, case["scale"], case["tables"], case["lens"],
+                                        bs, threads=8, bf16=True)
+        assert "_gq" in names[ops.pick_variant(len(lens), H, D, 600, 16, bf16=True, num_kv_heads=hkv) - 1]
+        assert_close_bf16(run_hip_bf16(case), ref, f"bf16 gqa auto D{D}")
+        for vid, name in enumerate(names, start=1):
+            if name.startswith(f"bf16_d{D}_gq4"):
+                assert_close_bf16(run_hip_bf16(case, variant=vid), ref, name)
+        # fp8 pages
+        c8 = _fp8_case(rng, len(lens), H, D, lens, bs, num_kv_heads=hkv)
+        r8 = oracle.paged_attention_v1_fp8(c8["q"], c8["kq"], c8["vq"], hkv, c8["scale"], c8["tables"], c8["lens"], bs,
+                                           kv_scale=0.8, threads=8)
+        assert "_gq" in names[ops.pick_variant(len(lens), H, D, 600, 16, fp8=True, num_kv_heads=hkv) - 1]
+        assert_close(_run_fp8(c8, 0.8), r8, f"fp8 gqa auto D{D}", vmax=1.6)
+        r8s = oracle.paged_attention_v1_fp8(c8["q"], c8["kq"], c8["vq"], hkv, c8["scale"], c8["tables"], c8["lens"], bs,
+                                            kv_scale=1.0, threads=8)
+        for vid, name in enumerate(names, start=1):
+            if name.startswith(f"fp8_d{D}_bs16_gq4"):
+                assert_close(_run_fp8(c8, 0.8, variant=vid), r8, name, vmax=1.6)
+                assert_close(_run_fp8(c8, 1.0, variant=vid), r8s, name + " scale 1", vmax=2.0)

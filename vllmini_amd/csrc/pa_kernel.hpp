@@ -271,6 +271,9 @@ struct PAParams {
 //   WPH   waves per slot                  (the blocks of a slot are dealt round-robin to them)
 //   HPT   ADJACENT heads per slot/wave    (a wave reads the HPT tiles of a block as one contiguous
 //                                          HPT*D*BS*2-byte chunk: bigger chunks are served faster by HBM)
+//   GQS   grouped-query attention: the HPT query heads of a slot share ONE KV head (num_heads / num_kv_heads is a
+//         multiple of HPT), so the wave loads each K / V tile ONCE and uses it for all HPT heads — the reference
+//         (one workgroup per query head, attention_kernels.cu:153) re-reads it per query head and leans on L2
 //   U     blocks per register group       (group g+1 is in flight while group g is consumed)
 //   UMAX  adaptive queue depth: a wave whose sequence is >= 1.4x / 2.8x the launch's mean length runs the
 //         2U / 4U-deep form of the same code (0 = fixed U) — see the selection code at the end of the kernel
@@ -292,7 +295,8 @@ struct PAParams {
 //                    + (WPH > 1 ? lpad*2 : 0) (fp16 probabilities; in place over the logits when WPH = 1) ).
 // ----------------------------------------------------------------------------------------
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
-          bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0, bool F8 = false>
+          bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0, bool F8 = false,
+          bool GQS = false>
 // (second launch bound = minimum waves per SIMD.  The adaptive-depth kernels are the full-chip defaults: 12 waves
 //  per CU = 3 per SIMD that must ALL be resident, i.e. stay under 170 VGPRs — the fused-append form had drifted to 180
 //  and ran 173 us instead of 125.  Not applied elsewhere: on the big-tile kernels it only forces spills.)
@@ -314,6 +318,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   static_assert(64 % U == 0, "U must divide 64");
   static_assert(!(LOCK && WPH > 1), "lockstep needs every wave to run the same number of page groups");
   static_assert(!(APP && (PART || LOADS_ONLY)), "the fused append exists for paged_attention_v1 only");
+  static_assert(!GQS || HPT > 1, "GQS shares one KV tile between HPT > 1 query heads");
+  constexpr int RH = GQS ? 1 : HPT;  // K / V register tiles per block: one per KV head this wave reads
   static_assert(!F8 || (BS >= 16 && D % 16 == 0 && !APP && !LOADS_ONLY),
                 "fp8 cache: block size 16 or 32 (a V row must fill whole 16-byte units), no fused append");
 
@@ -502,7 +508,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       }
     };
 
-    auto load_group = [&](u32x4(&r)[UU][HPT][NL], const h16* cache, int g) {
+    auto load_group = [&](u32x4(&r)[UU][RH][NL], const h16* cache, int g) {
       if constexpr (LOCK) __builtin_amdgcn_s_barrier();
       table_for(g);
   #pragma unroll
@@ -514,26 +520,26 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
         //  this stream; only `nt` pays: profiles/r01_cfg3_sweep_cache_policy_bits.json)
         const char* blk = reinterpret_cast<const char*>(cache) + phys * p.kv_block_stride * ES;
   #pragma unroll
-        for (int hh = 0; hh < HPT; ++hh) {
+        for (int hh = 0; hh < RH; ++hh) {
   #pragma unroll
           for (int i = 0; i < NL; ++i)  // masked lanes / absent heads contribute zeros
-            r[j][hh][i] = (valid(hh) && (i < NL - 1 || tail_ok)) ? ld16<NT>(blk + (hoff[hh] + i * 64 * EPU) * ES) : zero4;
+            r[j][GQS ? 0 : hh][i] = (valid(hh) && (i < NL - 1 || tail_ok)) ? ld16<NT>(blk + (hoff[hh] + i * 64 * EPU) * ES) : zero4;
         }
       }
     };
 
     // =========================== K pass: logits -> LDS, running max ========================
-    auto fold_all = [&](u32x4(&r)[UU][HPT][NL]) {
+    auto fold_all = [&](u32x4(&r)[UU][RH][NL]) {
   #pragma unroll
       for (int j = 0; j < UU; ++j)
   #pragma unroll
-        for (int hh = 0; hh < HPT; ++hh)
+        for (int hh = 0; hh < RH; ++hh)
   #pragma unroll
-          for (int i = 0; i < NL; ++i) fold ^= r[j][hh][i][0] ^ r[j][hh][i][1] ^ r[j][hh][i][2] ^ r[j][hh][i][3];
+          for (int i = 0; i < NL; ++i) fold ^= r[j][GQS ? 0 : hh][i][0] ^ r[j][GQS ? 0 : hh][i][1] ^ r[j][GQS ? 0 : hh][i][2] ^ r[j][GQS ? 0 : hh][i][3];
     };
     // `final_tag` is a compile-time tag: true only at the call sites that handle a wave's LAST page group — the
     // only place the appended token can be met — so the steady-state loop body carries no append code.
-    auto compute_k = [&](auto final_tag, u32x4(&r)[UU][HPT][NL], int g) {
+    auto compute_k = [&](auto final_tag, u32x4(&r)[UU][RH][NL], int g) {
       constexpr bool FINAL = decltype(final_tag)::value;
       if constexpr (LOADS_ONLY) {
         fold_all(r);
@@ -553,12 +559,12 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
               // fp16) — the reference's arithmetic (dtype_float16.cuh:292-298, 399-404).  One accumulator
               // per load keeps NL independent dependency chains in flight.
               if constexpr (APP && FINAL) {
-                if (b == lbA) {  // wave-uniform, once per wave at most
+                if (b == lbA && (!GQS || hh == 0)) {  // wave-uniform, once per wave (and per shared tile) at most
   #pragma unroll
                   for (int i = 0; i < NL; ++i) {
                     const u32x4 kn = APP_TILE ? knew[APP_TILE ? i : 0] : knew_at(hh, i);
-                    r[j][hh][i] = (tk == offA) ? kn : r[j][hh][i];
-                    if constexpr (APP_TILE) klast[i] = r[j][hh][i];
+                    r[j][GQS ? 0 : hh][i] = (tk == offA) ? kn : r[j][GQS ? 0 : hh][i];
+                    if constexpr (APP_TILE) klast[i] = r[j][GQS ? 0 : hh][i];
                   }
                   own_last = true;
                 }
@@ -566,9 +572,9 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
               float accv[NL];
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
-                if constexpr (F8 && S1) accv[i] = dot16_f8_s1(qf[hh][i], r[j][hh][i]);
-                else if constexpr (F8) accv[i] = dot16_f8<false, BF>(qreg[hh][i][0], qreg[hh][i][1], r[j][hh][i], p.kv_scale);
-                else accv[i] = dot8<BF>(qreg[hh][i][0], r[j][hh][i]);
+                if constexpr (F8 && S1) accv[i] = dot16_f8_s1(qf[hh][i], r[j][GQS ? 0 : hh][i]);
+                else if constexpr (F8) accv[i] = dot16_f8<false, BF>(qreg[hh][i][0], qreg[hh][i][1], r[j][GQS ? 0 : hh][i], p.kv_scale);
+                else accv[i] = dot8<BF>(qreg[hh][i][0], r[j][GQS ? 0 : hh][i]);
               }
               float acc = accv[0];
   #pragma unroll
@@ -587,7 +593,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
 
     // Register double buffer over page groups: group g+1 is in flight while group g is consumed.
     // (A third stage was measured and changed nothing; profiles/r01c_cfg3_variant_sweep.json.)
-    u32x4 ra[UU][HPT][NL], rb[UU][HPT][NL];
+    u32x4 ra[UU][RH][NL], rb[UU][RH][NL];
     // Latency regime (small batches): when everything this wave owns fits ONE register group, the V pages are
     // requested together with the K pages (into the idle second buffer), so K and V cost one memory round trip
     // between them instead of two in a row.
@@ -697,7 +703,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     // =========================== V pass ====================================================
     // `masked` is a compile-time tag: only the LAST page group of a wave can contain the sequence's last
     // block, so only that call site compiles the tail masking in.
-    auto compute_v = [&](auto masked, u32x4(&r)[UU][HPT][NL], int g) {
+    auto compute_v = [&](auto masked, u32x4(&r)[UU][RH][NL], int g) {
       constexpr bool MASK = decltype(masked)::value;
       if constexpr (LOADS_ONLY) {
         fold_all(r);
@@ -715,16 +721,16 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
             if (valid(hh)) {
               const uint16_t* php = ph0 + hh * ph_stride + (token0 - tok_lo);
               if constexpr (APP && MASK) {  // the appended token lives in the sequence's last block -> final group only
-                if (b == lbA && hf == (offA >> 3)) {
+                if (b == lbA && hf == (offA >> 3) && (!GQS || hh == 0)) {
                   const int e = offA & 7;
   #pragma unroll
                   for (int i = 0; i < NL; ++i) {
   #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                      const uint32_t old = r[j][hh][i][w];
+                      const uint32_t old = r[j][GQS ? 0 : hh][i][w];
                       const uint32_t vb = APP_TILE ? vnew[APP_TILE ? i : 0] : vnew_at(hh, i);
                       const uint32_t patched = (e & 1) ? ((old & 0x0000ffffu) | (vb << 16)) : ((old & 0xffff0000u) | vb);
-                      r[j][hh][i][w] = ((e >> 1) == w) ? patched : old;
+                      r[j][GQS ? 0 : hh][i][w] = ((e >> 1) == w) ? patched : old;
                     }
                   }
                 }
@@ -732,7 +738,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
                 if constexpr (APP_TILE) {
                   if (b == lbA) {
 #pragma unroll
-                    for (int i = 0; i < NL; ++i) vlast[i] = r[j][hh][i];
+                    for (int i = 0; i < NL; ++i) vlast[i] = r[j][GQS ? 0 : hh][i];
                   }
                 }
               }
@@ -741,16 +747,16 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
                 if constexpr (F8)  // first 8 of the unit's 16 tokens
-                  acc[hh][i] += pv.template dot<MASK>(deq8<S1, BF>(r[j][hh][i][0], r[j][hh][i][1], p.kv_scale), last, token0, L);
+                  acc[hh][i] += pv.template dot<MASK>(deq8<S1, BF>(r[j][GQS ? 0 : hh][i][0], r[j][GQS ? 0 : hh][i][1], p.kv_scale), last, token0, L);
                 else
-                  acc[hh][i] += pv.template dot<MASK>(r[j][hh][i], last, token0, L);
+                  acc[hh][i] += pv.template dot<MASK>(r[j][GQS ? 0 : hh][i], last, token0, L);
               }
               if constexpr (F8) {  // the other 8 tokens: their own fp16 probability vector, fp32 accumulation
                 PV8<BF> pw;
                 pw.load(*reinterpret_cast<const u32x4_alias*>(php + 8));
 #pragma unroll
                 for (int i = 0; i < NL; ++i)
-                  acc[hh][i] += pw.template dot<MASK>(deq8<S1, BF>(r[j][hh][i][2], r[j][hh][i][3], p.kv_scale), last, token0 + 8, L);
+                  acc[hh][i] += pw.template dot<MASK>(deq8<S1, BF>(r[j][GQS ? 0 : hh][i][2], r[j][GQS ? 0 : hh][i][3], p.kv_scale), last, token0 + 8, L);
               }
             }
           }
@@ -968,7 +974,8 @@ struct Variant {
   int lds_attr_set;  // largest dynamic-LDS size already granted through hipFuncSetAttribute
   int UMAX;          // adaptive queue depth limit (0 = fixed U)
   int lds_attr_dev;  // device that grant was made on (the attribute is per device)
-  bool F8;           // caches hold fp8 E4M3 bytes (kv_cache_dtype "fp8"); query/out fp16
+  bool F8;           // caches hold fp8 E4M3 bytes (kv_cache_dtype "fp8")
+  bool GQS;          // the HPT query heads of a wave share one KV head: num_heads / num_kv_heads % HPT == 0 required
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
@@ -983,9 +990,18 @@ typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const 
 #define VMI_ROW_F8B(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX, BF)                                             \
   {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, BF,                                                                  \
    (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), false, false, BS, LOCK, BF, HPT, false, UMAX, true>, 0,    \
-   UMAX, 0, true},
+   UMAX, 0, true, false},
+#define VMI_ROW_F8G(NAME, D, BS, HPW, WPH, U, HPT)  /* fp8 pages, grouped-query sharing, fp16 query */              \
+  {NAME, D, BS, HPW, WPH, U, true, HPT, false,                                                                     \
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, BS, false, false, HPT, false, 0, true, true>, 0,   \
+   0, 0, true, true},
 #define VMI_ROW_F8(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX) \
   VMI_ROW_F8B(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX, false)
+// grouped-query rows: HPT query heads of one KV head per wave, each tile loaded once
+#define VMI_ROW_G(NAME, D, BS, HPW, WPH, U, NT, LOCK, BF, HPT)                                                     \
+  {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, BF,                                                                  \
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), false, false, BS, LOCK, BF, HPT, VMI_APP, 0, false, true>, \
+   0, 0, 0, false, true},
 #define VMI_ROW(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT) \
   VMI_ROW_A(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT, 0)
 

@@ -430,7 +430,7 @@ static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = a
   for (int id = 1; id <= nvariants_v1(); ++id) {
     const Variant& v = variant_v1(id);
     if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
-        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0)
+        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0 && !v.GQS)
       return id;
   }
   return 0;
@@ -455,6 +455,38 @@ static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }
 // chip once the short sequences are done, so the heads are cut into 8 waves each — 8x the workgroups' waves, more
 // workgroups than fit at once, and the hardware dispatcher does the balancing
 // (profiles/r01g_ragged_batches.md: cfg3 U{1..1024} 98.7 -> 77.1 us, cfg4 446.8 -> 360.5 us).
+// Grouped-query attention (num_heads / num_kv_heads = qpk > 1): the largest built group size dividing qpk, one wave
+// per group when the launch fills the chip, four or eight waves per group otherwise.  0 = no such kernel.
+static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
+                            bool bf, bool f8) {
+  if (qpk < 2 || block_size != 16) return 0;
+  const int nblk = (max_seq_len + block_size - 1) / block_size;
+  for (int g = 8; g >= 2; g /= 2) {
+    if (qpk % g) continue;
+    const long units = (long)num_seqs * (num_heads / g);
+    int wph = 1;
+    while (wph < 8 && units * wph < 2048 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+    int best = 0;
+    for (int id = 1; id <= nvariants_v1(); ++id) {
+      const Variant& c = variant_v1(id);
+      if (!c.GQS || c.BF != bf || c.F8 != f8 || c.D != head_size || c.BS != block_size || c.HPT != g) continue;
+      if (wph == 1 ? (c.WPH == 1 && (num_heads / g) % c.HPW == 0) : (c.HPW == 1 && c.WPH <= wph)) {
+        if (!best || (wph == 1 ? c.HPW > variant_v1(best).HPW || (c.HPW == variant_v1(best).HPW && c.U < variant_v1(best).U)
+                               : c.WPH > variant_v1(best).WPH))
+          best = id;
+      }
+    }
+    if (best) return best;
+    for (int id = 1; id <= nvariants_v1(); ++id) {  // no kernel of the wanted shape: any kernel of this group size
+      const Variant& c = variant_v1(id);
+      if (c.GQS && c.BF == bf && c.F8 == f8 && c.D == head_size && c.BS == block_size && c.HPT == g &&
+          (num_heads / g) % c.HPW == 0)
+        return id;
+    }
+  }
+  return 0;
+}
+
 // fp8 cache: a (block, head) tile is half the bytes; measured picks in profiles/r01h_fp8_kv.md
 static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
                             int mean_seq_len, bool bf = false) {
@@ -589,8 +621,10 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
            ((size_t)lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? (size_t)lpad * 2 : 0));
   };
   if (variant == 0) {
-    variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf)
-                 : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
+    variant = pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size, max_seq_len, bf, f8);
+    if (!variant || (append && !app_variant_v1(variant)))
+      variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf)
+                   : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
     // a long max_seq_len may not leave room for several heads' logits in one workgroup's LDS: fall back to one
     // head per workgroup, then to one wave per head (no second copy of the probabilities) before giving up
     if (variant >= 1 && variant <= nvariants_v1() && lds_of(variant_v1(variant)) > 160 * 1024) {
@@ -619,6 +653,9 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (v.WPH > 1 && num_heads % (v.HPW * v.HPT) != 0)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s needs num_heads %% %d == 0", v.name,
                 v.HPW * v.HPT);
+  if (v.GQS && (num_heads / num_kv_heads) % v.HPT != 0)
+    return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s shares a KV head between %d query heads, got "
+                "num_heads / num_kv_heads = %d", v.name, v.HPT, num_heads / num_kv_heads);
 
   const size_t lds = lds_of(v);
   if (lds > 160 * 1024)
@@ -1007,6 +1044,19 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
                                         int32_t block_size, int32_t max_seq_len) {
   if (!vmi::head_size_supported(head_size) || !vmi::block_size_supported(block_size)) return 0;
   return vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len);
+}
+
+int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
+                                            int32_t head_size, int32_t block_size, int32_t max_seq_len,
+                                            int32_t is_bf16, int32_t is_fp8) {
+  if (!vmi::head_size_supported(head_size) || !vmi::block_size_supported(block_size) || num_kv_heads <= 0 ||
+      num_heads % num_kv_heads)
+    return 0;
+  const int v = vmi::pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size,
+                                      max_seq_len, is_bf16 != 0, is_fp8 != 0);
+  if (v) return v;
+  return is_fp8 ? vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, is_bf16 != 0)
+                : vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, is_bf16 != 0);
 }
 
 int vmi_paged_attention_v1_pick_variant_hint(int32_t num_seqs, int32_t num_heads, int32_t head_size,

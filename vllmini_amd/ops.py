@@ -391,11 +391,14 @@ def variant_names_v2() -> list[str]:
 
 
 def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16,
-                 mean_seq_len: int = 0, bf16: bool = False, fp8: bool = False) -> int:
+                 mean_seq_len: int = 0, bf16: bool = False, fp8: bool = False, num_kv_heads: int = 0) -> int:
     """The library's work-decomposition heuristic (what `_variant=0` runs).  A caller that knows the batch's
     lengths on the host may pass their mean: a ragged batch (mean well below max_seq_len) then gets the
     many-waves-per-head decomposition; pass the result as `_variant`."""
     lib = _lib.load()
+    if num_kv_heads and num_kv_heads != num_heads:      # grouped-query attention: what the operators pick themselves
+        return int(lib.vmi_paged_attention_v1_pick_variant_gqa(num_seqs, num_heads, int(num_kv_heads), head_size,
+                                                               block_size, max_seq_len, int(bool(bf16)), int(bool(fp8))))
     if fp8:
         fn = lib.vmi_paged_attention_v1_pick_variant_fp8_bf16 if bf16 else lib.vmi_paged_attention_v1_pick_variant_fp8
         return int(fn(num_seqs, num_heads, head_size, block_size, max_seq_len, int(mean_seq_len)))
