@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="override the config's batch (diagnostic sweeps)")
+    ap.add_argument("--kv-heads", type=int, default=0,
+                    help="grouped-query attention: num_kv_heads < num_heads (diagnostic; BASELINE configs are multi-head)")
     ap.add_argument("--seq-len", type=int, default=0, help="override the config's seq_len (diagnostic sweeps)")
     ap.add_argument("--op", default="v1", choices=["v1", "v2", "fused"],
                     help="attention operator in the step: paged_attention_v1 (headline) or the split-KV paged_attention_v2")
@@ -126,18 +128,18 @@ def alg_bytes(cfg):
     """Algorithmic bytes per attention launch; an fp8 cache halves the K/V term."""
     b = cfg.algorithmic_bytes()
     if KV_DTYPE == "fp8":
-        b -= 2 * cfg.batch * cfg.num_heads * cfg.seq_len * cfg.head_size
+        b -= 2 * cfg.batch * cfg.kv_heads * cfg.seq_len * cfg.head_size
     return b
 
 
 def attend(wl, out, t, variant, op="v1"):
     c = wl.cfg
     if op == "fused":   # reshape_and_cache + paged_attention_v1 in one launch (extension, include/vmi_paged_attention.h)
-        ops.paged_attention_v1_append(out, wl.query, wl.key, wl.value, wl.key_cache, wl.value_cache, c.num_heads,
+        ops.paged_attention_v1_append(out, wl.query, wl.key, wl.value, wl.key_cache, wl.value_cache, c.kv_heads,
                                       wl.scale, wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, _variant=variant)
         return
     if op == "v1":
-        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
+        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.kv_heads, wl.scale,
                                wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, KV_DTYPE, 1.0,
                                0, 0, 1, 1, 0, _variant=variant)
         return
@@ -148,7 +150,7 @@ def attend(wl, out, t, variant, op="v1"):
                             torch.empty((c.batch, c.num_heads, P), dtype=torch.float32, device=out.device),
                             torch.empty((c.batch, c.num_heads, P, c.head_size), dtype=torch.float16, device=out.device))
     es, ml, tmp = _V2_SCRATCH[key]
-    ops.paged_attention_v2(out, es, ml, tmp, wl.query, wl.key_cache, wl.value_cache, c.num_heads, wl.scale,
+    ops.paged_attention_v2(out, es, ml, tmp, wl.query, wl.key_cache, wl.value_cache, c.kv_heads, wl.scale,
                            wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0,
                            0, 0, 1, 1, 0, _variant=variant)
 
@@ -352,6 +354,10 @@ def main():
         # BASELINE.json configs[4]: batch 2048 over 8 GPUs = 256 sequences per GPU (the cfg3 shape) with a
         # per-GPU KV pool of 65536 blocks.  Same kernel work per GPU as N=1; only the pool is larger.
         cfg = CONFIGS["cfg5"]
+    if args.kv_heads:
+        import dataclasses
+        args.no_cpu_baseline = True      # the eager CPU baseline is written for the multi-head BASELINE configs
+        cfg = dataclasses.replace(cfg, name=f"{cfg.name}_kv{args.kv_heads}", num_kv_heads=args.kv_heads)
     if args.batch or args.seq_len:
         import dataclasses
         b_ = args.batch or cfg.batch
@@ -381,8 +387,8 @@ def main():
         args.no_fused = True
         args.no_cpu_baseline = True
         gk = torch.Generator(device=dev).manual_seed(99 + rank)
-        kshape = (cfg.num_blocks, cfg.num_heads, cfg.head_size // 16, cfg.block_size, 16)
-        vshape = (cfg.num_blocks, cfg.num_heads, cfg.head_size, cfg.block_size)
+        kshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size // 16, cfg.block_size, 16)
+        vshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size, cfg.block_size)
         del wl.key_cache, wl.value_cache
         torch.cuda.empty_cache()
         # random E4M3 codes of magnitude < 2 (exponent field <= 7): no NaN codes, attention-like values
@@ -476,7 +482,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     achieved = alg_bytes(cfg) / (kern_mean_ms * 1e-3) / 1e9
     vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len,
-                                           fp8=args.kv == "fp8")
+                                           fp8=args.kv == "fp8", num_kv_heads=cfg.kv_heads)
     vname = ops.variant_names()[vid - 1] if args.op in ("v1", "fused") else f"paged_attention_v2 variant {args.variant or 'auto'}"
     traffic, traffic_src = (pmc_traffic(cfg.name + ("_fp8" if args.kv == "fp8" else ""), vname) if args.op == "v1" else
                             pmc_traffic(cfg.name + "_fused", vname) if args.op == "fused" else (None, None))
@@ -495,7 +501,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{cfg.name}: paged_attention_v1+reshape_and_cache decode step, batch {cfg.batch}/GPU, "
-                        f"seq_len {cfg.seq_len}, {cfg.num_heads} heads x {cfg.head_size}, block_size {cfg.block_size}, "
+                        f"seq_len {cfg.seq_len}, {cfg.num_heads} heads"
+                        f"{'' if cfg.kv_heads == cfg.num_heads else ' (' + str(cfg.kv_heads) + ' KV heads)'} x {cfg.head_size}, "
+                        f"block_size {cfg.block_size}, "
                         f"num_blocks {cfg.num_blocks}/GPU, {'fp8 E4M3' if args.kv == 'fp8' else 'fp16'} KV, "
                         f"random-permutation block tables"
                         + (" (SEQUENTIAL tables)" if args.sequential_tables else "")
@@ -535,7 +543,7 @@ def main():
         # A different data format, so it is reported beside `value`, never as it.
         k16, v16 = wl.key_cache, wl.value_cache
         gk = torch.Generator(device=dev).manual_seed(99 + rank)
-        kshape = (cfg.num_blocks, cfg.num_heads, cfg.head_size // 16, cfg.block_size, 16)
+        kshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size // 16, cfg.block_size, 16)
         wl.key_cache = (torch.randint(0, 64, kshape, dtype=torch.uint8, device=dev, generator=gk)
                         | (torch.randint(0, 2, kshape, dtype=torch.uint8, device=dev, generator=gk) << 7))
         wl.value_cache = (torch.randint(0, 64, v16.shape, dtype=torch.uint8, device=dev, generator=gk)

@@ -24,8 +24,10 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));  // MFMA operand type only
 // LDS holds the probabilities as 16-bit patterns and they are read 8 at a time: the vector view must alias them
 typedef uint32_t u32x4_alias __attribute__((ext_vector_type(4), may_alias));
+typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));  // four logits written at once (MFMA path)
 
 // ----------------------------------------------------------------------------------------
 // device helpers
@@ -452,6 +454,24 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     }
   }
 
+  // ---- grouped-query kernels compute q.K^T on the matrix cores: with HPT query heads per tile it is a (16 tokens) x
+  //      (HPT heads, padded to 16) x (D dims) product, one v_mfma_f32_16x16x32 per 1-KiB K load.  The K tile is ALREADY
+  //      in the A-operand layout (lane = chunk*16 + token holds 8 dims of one token); B is q with lane & 15 = head.
+  //      Products of 16-bit operands are exact in fp32 and the accumulation is fp32 — the reference's arithmetic up to
+  //      summation order (dtype_float16.cuh:292-298).  The V pass keeps its fp16 rounding points on the VALU. ----
+  constexpr bool QK_MFMA = GQS && !F8 && BS == 16 && TAIL == 64 && !LOADS_ONLY;
+  u32x4 qB[QK_MFMA ? NL : 1];
+  float slopeB = 0.f;
+  if constexpr (QK_MFMA) {
+    const int n = lane & 15;
+    const bool has = n < HPT;
+    const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + (has ? n : 0)) * D;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) qB[i] = has ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8) : zero4;
+    slopeB = (has && p.alibi) ? p.alibi[head0 + n] : 0.f;
+  }
+  float qmaxB = -FLT_MAX;  // QK_MFMA: running max of head (lane & 15) over this lane's token rows
+
   // ---- my share of the blocks: b = blk_lo + sub + idx*WPH, idx in [0, nmy) ----------------
   const int nmy = nblk > sub ? (nblk - sub + WPH - 1) / WPH : 0;
 
@@ -552,6 +572,39 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
           const int b = blk_lo + sub + idx * WPH;
           const int token = b * BS + tk;
           const bool masked = token >= L;
+          if constexpr (QK_MFMA) {
+            if constexpr (APP && FINAL) {
+              if (b == lbA) {  // the appended token's K row goes into the tile before it is multiplied
+  #pragma unroll
+                for (int i = 0; i < NL; ++i) r[j][0][i] = (tk == offA) ? knew_at(0, i) : r[j][0][i];
+                own_last = true;
+              }
+            }
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+            for (int i = 0; i < NL; ++i) {
+              if constexpr (BF)
+                d4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[j][0][i]),
+                                                             __builtin_bit_cast(bf16x8, qB[i]), d4, 0, 0, 0);
+              else
+                d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, r[j][0][i]),
+                                                            __builtin_bit_cast(h16x8, qB[i]), d4, 0, 0, 0);
+            }
+            // C/D layout: column = lane & 15 (head), rows = 4*(lane >> 4) + reg (tokens of this block)
+            const int tok4 = b * BS + 4 * c4;
+            f32x4 lg4;
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float qk = p.scale * d4[e];
+              qk += (slopeB != 0.f) ? slopeB * (float)(tok4 + e - L + 1) : 0.f;
+              const bool m = tok4 + e >= L;
+              lg4[e] = m ? 0.f : qk;
+              qmaxB = m ? qmaxB : fmaxf(qmaxB, qk);
+            }
+            if ((lane & 15) < HPT)
+              *reinterpret_cast<f32x4_alias*>(logits0 + (lane & 15) * p.lpad + tok4 - tok_lo) = lg4;
+            continue;
+          }
   #pragma unroll
           for (int hh = 0; hh < HPT; ++hh) {
             if (valid(hh)) {
@@ -620,6 +673,13 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
 
     // first V group goes out now: HBM stays busy while the softmax runs
     if (ngroups > 1) load_group(ra, p.vc, 0);
+
+    if constexpr (QK_MFMA) {  // per-head maxima live in lanes (lane & 15) = head: fold the 4 row groups, then hand out
+      qmaxB = fmaxf(qmaxB, __shfl_xor(qmaxB, 16));
+      qmaxB = fmaxf(qmaxB, __shfl_xor(qmaxB, 32));
+  #pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) qk_max[hh] = __shfl(qmaxB, hh);
+    }
 
     // =========================== softmax over the logits in LDS ============================
     {

@@ -464,8 +464,12 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
   for (int g = 8; g >= 2; g /= 2) {
     if (qpk % g) continue;
     const long units = (long)num_seqs * (num_heads / g);
+    // g query heads per tile make the wave VALU-bound, so the group's blocks are dealt to several waves even on a
+    // full chip: measured best H32/Hkv8 B256 L1024 — D=128: 4 waves per group 189 us (1 wave: 237), D=64: 2 waves
+    // 125 us (scripts/gqa_probe.py)
+    const long want = head_size >= 128 ? 6144 : 4096;
     int wph = 1;
-    while (wph < 8 && units * wph < 2048 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+    while (wph < 8 && units * wph < want && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
     int best = 0;
     for (int id = 1; id <= nvariants_v1(); ++id) {
       const Variant& c = variant_v1(id);

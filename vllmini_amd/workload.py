@@ -27,6 +27,11 @@ class DecodeConfig:
     seq_len: int
     num_blocks: int     # pool size per GPU
     block_size: int = BLOCK_SIZE
+    num_kv_heads: int = 0   # 0 = num_heads (multi-head attention); smaller = grouped-query attention
+
+    @property
+    def kv_heads(self) -> int:
+        return self.num_kv_heads or self.num_heads
 
     @property
     def blocks_per_seq(self) -> int:
@@ -35,7 +40,7 @@ class DecodeConfig:
     def algorithmic_bytes(self) -> int:
         """2*B*H*L*D*2 (K,V) + 2*B*H*D*2 (q,out) + B*ceil(L/16)*4 (tables) + B*4 (lens)."""
         b, h, d = self.batch, self.num_heads, self.head_size
-        return 2 * b * h * self.seq_len * d * 2 + 2 * b * h * d * 2 + b * self.blocks_per_seq * 4 + b * 4
+        return 2 * b * self.kv_heads * self.seq_len * d * 2 + 2 * b * h * d * 2 + b * self.blocks_per_seq * 4 + b * 4
 
     def flops(self) -> int:
         return 4 * self.batch * self.num_heads * self.seq_len * self.head_size
@@ -73,14 +78,14 @@ class DecodeWorkload:
     @property
     def key(self) -> torch.Tensor:
         c = self.cfg
-        hd = c.num_heads * c.head_size
-        return self.qkv[:, hd: 2 * hd].view(c.batch, c.num_heads, c.head_size)
+        hd, kd = c.num_heads * c.head_size, c.kv_heads * c.head_size
+        return self.qkv[:, hd: hd + kd].view(c.batch, c.kv_heads, c.head_size)
 
     @property
     def value(self) -> torch.Tensor:
         c = self.cfg
-        hd = c.num_heads * c.head_size
-        return self.qkv[:, 2 * hd:].view(c.batch, c.num_heads, c.head_size)
+        hd, kd = c.num_heads * c.head_size, c.kv_heads * c.head_size
+        return self.qkv[:, hd + kd: hd + 2 * kd].view(c.batch, c.kv_heads, c.head_size)
 
 
 def make_workload(cfg: DecodeConfig, device: torch.device | str, seed: int = 0, table_sets: int = 2,
@@ -102,8 +107,8 @@ def make_workload(cfg: DecodeConfig, device: torch.device | str, seed: int = 0, 
     if need > c.num_blocks:
         raise ValueError(f"{c.name}: needs {need} blocks, pool has {c.num_blocks}")
 
-    kshape = (c.num_blocks, c.num_heads, c.head_size // X, c.block_size, X)
-    vshape = (c.num_blocks, c.num_heads, c.head_size, c.block_size)
+    kshape = (c.num_blocks, c.kv_heads, c.head_size // X, c.block_size, X)
+    vshape = (c.num_blocks, c.kv_heads, c.head_size, c.block_size)
     gd = torch.Generator(device=dev).manual_seed(seed) if dev.type == "cuda" else g
     if kv_dist == "uniform":
         key_cache = torch.empty(kshape, dtype=torch.float16, device=dev).uniform_(-1, 1, generator=gd)
@@ -111,7 +116,7 @@ def make_workload(cfg: DecodeConfig, device: torch.device | str, seed: int = 0, 
     else:
         key_cache = torch.empty(kshape, dtype=torch.float16, device=dev).normal_(0, 1, generator=gd)
         value_cache = torch.empty(vshape, dtype=torch.float16, device=dev).normal_(0, 1, generator=gd)
-    qkv = torch.empty((c.batch, 3 * c.num_heads * c.head_size), dtype=torch.float16,
+    qkv = torch.empty((c.batch, (c.num_heads + 2 * c.kv_heads) * c.head_size), dtype=torch.float16,
                       device=dev).normal_(0, 1, generator=gd)
 
     if ragged:
