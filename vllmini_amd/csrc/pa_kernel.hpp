@@ -459,15 +459,20 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   //      in the A-operand layout (lane = chunk*16 + token holds 8 dims of one token); B is q with lane & 15 = head.
   //      Products of 16-bit operands are exact in fp32 and the accumulation is fp32 — the reference's arithmetic up to
   //      summation order (dtype_float16.cuh:292-298).  The V pass keeps its fp16 rounding points on the VALU. ----
-  constexpr bool QK_MFMA = GQS && !F8 && BS == 16 && TAIL == 64 && !LOADS_ONLY;
-  u32x4 qB[QK_MFMA ? NL : 1];
+  //      (fp8 pages: the 16-byte chunk is decoded ONCE into two 8-dim operands, whatever the number of heads)
+  constexpr bool QK_MFMA = GQS && BS == 16 && TAIL == 64 && !LOADS_ONLY;
+  u32x4 qB[QK_MFMA ? NL : 1][F8 ? 2 : 1];
   float slopeB = 0.f;
   if constexpr (QK_MFMA) {
     const int n = lane & 15;
     const bool has = n < HPT;
     const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + (has ? n : 0)) * D;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) qB[i] = has ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8) : zero4;
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int w = 0; w < (F8 ? 2 : 1); ++w)
+        qB[i][w] = has ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * EPU + 8 * w) : zero4;
+    }
     slopeB = (has && p.alibi) ? p.alibi[head0 + n] : 0.f;
   }
   float qmaxB = -FLT_MAX;  // QK_MFMA: running max of head (lane & 15) over this lane's token rows
@@ -583,12 +588,17 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
             f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
   #pragma unroll
             for (int i = 0; i < NL; ++i) {
-              if constexpr (BF)
-                d4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r[j][0][i]),
-                                                             __builtin_bit_cast(bf16x8, qB[i]), d4, 0, 0, 0);
-              else
-                d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, r[j][0][i]),
-                                                            __builtin_bit_cast(h16x8, qB[i]), d4, 0, 0, 0);
+  #pragma unroll
+              for (int w = 0; w < (F8 ? 2 : 1); ++w) {
+                u32x4 a = r[j][0][i];
+                if constexpr (F8) a = deq8<S1, BF>(r[j][0][i][2 * w], r[j][0][i][2 * w + 1], p.kv_scale);
+                if constexpr (BF)
+                  d4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                               __builtin_bit_cast(bf16x8, qB[i][w]), d4, 0, 0, 0);
+                else
+                  d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a),
+                                                              __builtin_bit_cast(h16x8, qB[i][w]), d4, 0, 0, 0);
+              }
             }
             // C/D layout: column = lane & 15 (head), rows = 4*(lane >> 4) + reg (tokens of this block)
             const int tok4 = b * BS + 4 * c4;
