@@ -1470,7 +1470,7 @@ def test_gqa_shared_tile_kernels_match_kernel_model(D):
                 continue
             g = int(name.split("_gq")[1].split("_")[0])
             if qpk % g:
-                with pytest.raises(RuntimeError, match="shares a KV head"):
+                with pytest.raises(RuntimeError, match="shares a KV head|needs num_heads"):
                     run_hip(case, variant=vid)
                 continue
             try:
@@ -1514,3 +1514,22 @@ def test_gqa_shared_tile_kernels_bf16_and_fp8():
             if name.startswith(f"fp8_d{D}_bs16_gq4"):
                 assert_close(_run_fp8(c8, 0.8, variant=vid), r8, name, vmax=1.6)
                 assert_close(_run_fp8(c8, 1.0, variant=vid), r8s, name + " scale 1", vmax=2.0)
+
+
+def test_gqa_group_sizes_three_and_seven():
+    """28 query heads over 4 KV heads (7 per group) and 24 over 8 (3 per group), head size 128."""
+    from vllmini_amd import ops
+
+    names = ops.variant_names()
+    rng = np.random.default_rng(1900)
+    lens = [1, 16, 17, 100, 333, 47, 2, 600]
+    for H, hkv, g in ((28, 4, 7), (24, 8, 3), (12, 2, 3)):
+        case = make_case(rng, len(lens), H, 128, lens, num_kv_heads=hkv, q_row_pad=1, poison_tail=True)
+        ref = run_model(case)
+        auto = names[ops.pick_variant(len(lens), H, 128, 600, 16, num_kv_heads=hkv) - 1]
+        assert f"_gq{g}_" in auto or (g == 3 and "_gq" in auto), auto
+        assert_close(run_hip(case), ref, f"gqa auto H{H}/{hkv} ({auto})")
+        for vid, name in enumerate(names, start=1):
+            if name.startswith(f"d128_gq{g}_"):
+                assert_close(run_hip(case, variant=vid), ref, name)
+                _append_vs_two_ops(case, vid, seed=vid, what=f"append {name}")

@@ -209,7 +209,9 @@ struct PV8 {
       h16x2 c = h16x2{pr[0], pr[1]} + h16x2{pr[2], pr[3]};
       c = c + h16x2{pr[4], pr[5]};
       c = c + h16x2{pr[6], pr[7]};
-      return (float)c[0] + (float)c[1];
+      // (fp32 add of the two halves, dtype_float16.cuh:439-443 — written as fma(c0, 1, c1): the same single rounding,
+      //  and v_fma_mix_f32 takes the fp16 operands directly instead of two conversions and an add)
+      return __builtin_fmaf((float)c[0], 1.0f, (float)c[1]);
     }
   }
 };

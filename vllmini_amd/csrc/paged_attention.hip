@@ -461,7 +461,7 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
                             bool bf, bool f8) {
   if (qpk < 2 || block_size != 16) return 0;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
-  for (int g = 8; g >= 2; g /= 2) {
+  for (int g = 8; g >= 2; --g) {
     if (qpk % g) continue;
     const long units = (long)num_seqs * (num_heads / g);
     // g query heads per tile make the wave VALU-bound, so the group's blocks are dealt to several waves even on a
