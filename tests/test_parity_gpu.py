@@ -654,7 +654,7 @@ def test_pa_v2_every_variant(D):
     lens = [1, 600, 2000, 1025, 16]
     case = make_case(rng, len(lens), 4, D, lens, poison_tail=True)
     for vid, name in enumerate(ops.variant_names_v2(), start=1):
-        if name.startswith(f"v2_d{D}_") and "_bs" not in name:
+        if name.startswith(f"v2_d{D}_") and "_bs" not in name and "_gq" not in name:     # gq: grouped-query cases only
             _check_v2(case, 2048, variant=vid, what=name)
 
 
@@ -781,7 +781,7 @@ def test_every_head_and_block_size_v1_and_v2(D, bs):
     _check_v2(case, 1024, what=f"v2 D{D} bs{bs} default")
     tag2 = "v2_" + tag
     for vid, name in enumerate(ops.variant_names_v2(), start=1):
-        if name.startswith(tag2) and (("_bs" in name) == ("_bs" in tag2)):
+        if name.startswith(tag2) and (("_bs" in name) == ("_bs" in tag2)) and _gq_ok(name, 2):
             _check_v2(case, 1024, variant=vid, what=name)
 
 
@@ -1533,3 +1533,27 @@ def test_gqa_group_sizes_three_and_seven():
             if name.startswith(f"d128_gq{g}_"):
                 assert_close(run_hip(case, variant=vid), ref, name)
                 _append_vs_two_ops(case, vid, seed=vid, what=f"append {name}")
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_pa_v2_grouped_query_kernels(D):
+    """Split-KV with grouped-query tile sharing (q.K^T on MFMA inside each 512-token partition)."""
+    from vllmini_amd import ops
+
+    names = ops.variant_names_v2()
+    rng = np.random.default_rng(2100 + D)
+    lens = [3, 511, 513, 1100, 40, 2000]
+    for H, hkv in ((16, 4), (16, 2), (8, 4)) + (((28, 4), (24, 8)) if D == 128 else ()):
+        qpk = H // hkv
+        case = make_case(rng, len(lens), H, D, lens, num_kv_heads=hkv, q_row_pad=1, poison_tail=True)
+        _check_v2(case, 2048, what=f"v2 gqa auto D{D} H{H}/{hkv}")
+        ran = 0
+        for vid, name in enumerate(names, start=1):
+            if name.startswith(f"v2_d{D}_gq") and qpk % int(name.split("_gq")[1].split("_")[0]) == 0:
+                try:
+                    _check_v2(case, 2048, variant=vid, what=f"{name} H{H}/{hkv}")
+                except RuntimeError as e:
+                    assert "needs num_heads" in str(e), name
+                    continue
+                ran += 1
+        assert ran >= 1, (D, H, hkv)

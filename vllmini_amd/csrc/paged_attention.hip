@@ -742,6 +742,15 @@ static Variant g_variants_v2[] = {
     VMI_VARIANT_V2(128, 1, 2, 2, 1),  // 8
     VMI_VARIANT_V2(128, 1, 4, 2, 1),  // 9
     VMI_VARIANT_V2(128, 1, 8, 2, 1),  // 10
+    // grouped-query attention: gq<N> query heads of one KV head per wave, each tile loaded once, q.K^T on MFMA
+#define VMI_V2_GQ(D, WPH, HPT, U)                                                                              \
+  {"v2_d" #D "_gq" #HPT "_h1_w" #WPH "_u" #U "_nt1", D, 16, 1, WPH, U, true, HPT, false,                        \
+   (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, true, 16, false, false, HPT, false, 0, false, true>, 0, \
+   0, 0, false, true}
+    VMI_V2_GQ(128, 1, 4, 1), VMI_V2_GQ(128, 4, 4, 1), VMI_V2_GQ(128, 1, 8, 1), VMI_V2_GQ(128, 4, 8, 1),
+    VMI_V2_GQ(128, 1, 2, 1), VMI_V2_GQ(128, 4, 2, 1), VMI_V2_GQ(128, 4, 7, 1), VMI_V2_GQ(128, 4, 3, 1),
+    VMI_V2_GQ(64, 1, 4, 2), VMI_V2_GQ(64, 4, 4, 2), VMI_V2_GQ(64, 4, 8, 2), VMI_V2_GQ(64, 4, 2, 2),
+#undef VMI_V2_GQ
 };
 static const int g_ncore_v2 = (int)(sizeof(g_variants_v2) / sizeof(g_variants_v2[0]));
 
@@ -757,7 +766,7 @@ static Variant& variant_v2(int id) {  // [core fp16][extra fp16][bf16][fp8 cache
 static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false, bool f8 = false) {
   for (int id = 1; id <= nvariants_v2(); ++id) {
     const Variant& v = variant_v2(id);
-    if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH) return id;
+    if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && !v.GQS) return id;
   }
   return 0;
 }
@@ -765,8 +774,21 @@ static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false, boo
 // a partition holds 512 / block_size blocks; give each (seq, head, partition) 1..8 waves so that the
 // launch has >= ~2048 waves when the batch allows it
 static int pick_variant_v2(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
-                           bool bf = false, bool f8 = false) {
+                           bool bf = false, bool f8 = false, int qpk = 1) {
   const int parts = (max_seq_len + 511) / 512;
+  if (qpk > 1 && !bf && !f8 && block_size == 16) {  // grouped-query: largest built group size dividing qpk
+    for (int g = 8; g >= 2; --g) {
+      if (qpk % g) continue;
+      const long gunits = (long)num_seqs * (num_heads / g) * (parts > 0 ? parts : 1);
+      int best = 0;
+      for (int id = 1; id <= nvariants_v2(); ++id) {
+        const Variant& c = variant_v2(id);
+        if (!c.GQS || c.D != head_size || c.HPT != g) continue;
+        if (!best || (gunits >= 4096 ? c.WPH < variant_v2(best).WPH : c.WPH > variant_v2(best).WPH)) best = id;
+      }
+      if (best) return best;
+    }
+  }
   const long units = (long)num_seqs * num_heads * (parts > 0 ? parts : 1);
   int wph = 1;
   while (wph < 8 && units * wph < 2048) wph *= 2;
@@ -817,7 +839,8 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   const int parts = (max_seq_len + 511) / 512;  // attention_kernels.cu:885
   if (num_seqs == 0 || parts == 0) return VMI_OK;
   if (parts > 65535) return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v2: too many partitions");
-  if (variant == 0) variant = pick_variant_v2(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, f8);
+  if (variant == 0)
+    variant = pick_variant_v2(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, f8, num_heads / num_kv_heads);
   if (variant < 1 || variant > nvariants_v2())
     return fail(VMI_E_VARIANT, "paged_attention_v2: unknown variant %d", variant);
   Variant& v = variant_v2(variant);
@@ -829,15 +852,18 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   if (v.D != head_size || v.BS != block_size)
     return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s is for head size %d / block size %d", v.name,
                 v.D, v.BS);
-  if (v.WPH > 1 && num_heads % v.HPW != 0)
-    return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s needs num_heads %% %d == 0", v.name, v.HPW);
+  if (v.WPH > 1 && num_heads % (v.HPW * v.HPT) != 0)
+    return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s needs num_heads %% %d == 0", v.name, v.HPW * v.HPT);
+  if (v.GQS && (num_heads / num_kv_heads) % v.HPT != 0)
+    return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s shares a KV head between %d query heads, got "
+                "num_heads / num_kv_heads = %d", v.name, v.HPT, num_heads / num_kv_heads);
   DeviceGuard guard(device);
   hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
 
   const int lpad = 512;  // one partition of logits (:886)
-  const size_t lds = (size_t)v.HPW * lpad * 4 + (size_t)v.HPW * 2 * v.WPH * 4 +
-                     (size_t)v.HPW * v.WPH * v.D * 4 + (v.WPH > 1 ? (size_t)v.HPW * lpad * 2 : 0);
+  const size_t lds = (size_t)v.HPW * v.HPT *
+                     ((size_t)lpad * 4 + 2 * v.WPH * 4 + (size_t)v.WPH * v.D * 4 + (v.WPH > 1 ? (size_t)lpad * 2 : 0));
   PAParams p;
   p.out = static_cast<h16*>(tmp_out);
   p.q = static_cast<const h16*>(query);
@@ -862,7 +888,7 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   p.key_stride = 0;
   p.value_stride = 0;
   p.kv_scale = kv_scale;
-  dim3 grid((num_heads + v.HPW - 1) / v.HPW, num_seqs, parts);  // :890
+  dim3 grid((num_heads + v.HPW * v.HPT - 1) / (v.HPW * v.HPT), num_seqs, parts);  // :890
   hipLaunchKernelGGL(v.fn, grid, dim3(v.HPW * v.WPH * 64), lds, static_cast<hipStream_t>(stream), p);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "paged_attention_v2 launch");
