@@ -461,6 +461,11 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
                             bool bf, bool f8) {
   if (qpk < 2 || block_size != 16) return 0;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
+  const size_t lpad = (size_t)((max_seq_len + 31) / 32) * 32;
+  auto fits = [&](const Variant& c) {  // the group's logits (and, with several waves, probabilities) must fit LDS
+    return (size_t)c.HPW * c.HPT * (lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? lpad * 2 : 0)) <=
+           (size_t)160 * 1024;
+  };
   for (int g = 8; g >= 2; --g) {
     if (qpk % g) continue;
     const long units = (long)num_seqs * (num_heads / g);
@@ -473,7 +478,8 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
     int best = 0;
     for (int id = 1; id <= nvariants_v1(); ++id) {
       const Variant& c = variant_v1(id);
-      if (!c.GQS || c.BF != bf || c.F8 != f8 || c.D != head_size || c.BS != block_size || c.HPT != g) continue;
+      if (!c.GQS || c.BF != bf || c.F8 != f8 || c.D != head_size || c.BS != block_size || c.HPT != g || !fits(c))
+        continue;
       if (wph == 1 ? (c.WPH == 1 && (num_heads / g) % c.HPW == 0) : (c.HPW == 1 && c.WPH <= wph)) {
         if (!best || (wph == 1 ? c.HPW > variant_v1(best).HPW || (c.HPW == variant_v1(best).HPW && c.U < variant_v1(best).U)
                                : c.WPH > variant_v1(best).WPH))
@@ -484,7 +490,7 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
     for (int id = 1; id <= nvariants_v1(); ++id) {  // no kernel of the wanted shape: any kernel of this group size
       const Variant& c = variant_v1(id);
       if (c.GQS && c.BF == bf && c.F8 == f8 && c.D == head_size && c.BS == block_size && c.HPT == g &&
-          (num_heads / g) % c.HPW == 0)
+          (num_heads / g) % c.HPW == 0 && fits(c))
         return id;
     }
   }
