@@ -480,7 +480,8 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
       const Variant& c = variant_v1(id);
       if (!c.GQS || c.BF != bf || c.F8 != f8 || c.D != head_size || c.BS != block_size || c.HPT != g || !fits(c))
         continue;
-      if (wph == 1 ? (c.WPH == 1 && (num_heads / g) % c.HPW == 0) : (c.HPW == 1 && c.WPH <= wph)) {
+      if (wph == 1 ? (c.WPH == 1 && (num_heads / g) % c.HPW == 0)
+                   : (c.HPW == 1 && c.WPH <= wph && c.WPH * 4 >= wph)) {  // at most 4x fewer waves than wanted
         if (!best || (wph == 1 ? c.HPW > variant_v1(best).HPW || (c.HPW == variant_v1(best).HPW && c.U < variant_v1(best).U)
                                : c.WPH > variant_v1(best).WPH))
           best = id;
@@ -490,7 +491,7 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
     for (int id = 1; id <= nvariants_v1(); ++id) {  // no kernel of the wanted shape: any kernel of this group size
       const Variant& c = variant_v1(id);
       if (c.GQS && c.BF == bf && c.F8 == f8 && c.D == head_size && c.BS == block_size && c.HPT == g &&
-          (num_heads / g) % c.HPW == 0 && fits(c))
+          (num_heads / g) % c.HPW == 0 && fits(c) && units * c.WPH * 4 >= units * wph)  // at most 4x fewer waves than wanted
         return id;
     }
   }
