@@ -462,6 +462,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   //      Products of 16-bit operands are exact in fp32 and the accumulation is fp32 — the reference's arithmetic up to
   //      summation order (dtype_float16.cuh:292-298).  The V pass keeps its fp16 rounding points on the VALU. ----
   //      (fp8 pages: the 16-byte chunk is decoded ONCE into two 8-dim operands, whatever the number of heads)
+  //      (Tried for the one-head-per-wave fp8 kernels as well: no gain — 73 vs 67-71 us on cfg3 — a single useful MFMA
+  //       column does not pay for the different logits write pattern.)
   constexpr bool QK_MFMA = GQS && BS == 16 && TAIL == 64 && !LOADS_ONLY;
   u32x4 qB[QK_MFMA ? NL : 1][F8 ? 2 : 1];
   float slopeB = 0.f;
