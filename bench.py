@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="override the config's batch (diagnostic sweeps)")
+    ap.add_argument("--pv-mfma", action="store_true",
+                    help="with --kv-heads: opt into the grouped-query kernels that run P.V on the matrix cores too "
+                         "(ops.set_pv_mfma; north-star 1e-3 instead of 1-2 ulp)")
     ap.add_argument("--kv-heads", type=int, default=0,
                     help="grouped-query attention: num_kv_heads < num_heads (diagnostic; BASELINE configs are multi-head)")
     ap.add_argument("--seq-len", type=int, default=0, help="override the config's seq_len (diagnostic sweeps)")
@@ -354,6 +357,8 @@ def main():
         # BASELINE.json configs[4]: batch 2048 over 8 GPUs = 256 sequences per GPU (the cfg3 shape) with a
         # per-GPU KV pool of 65536 blocks.  Same kernel work per GPU as N=1; only the pool is larger.
         cfg = CONFIGS["cfg5"]
+    if args.pv_mfma:
+        ops.set_pv_mfma(True)
     if args.kv_heads:
         import dataclasses
         args.no_cpu_baseline = True      # the eager CPU baseline is written for the multi-head BASELINE configs

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 9
+#define VMI_ABI_VERSION 10
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -249,6 +249,17 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
 int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
                                             int32_t head_size, int32_t block_size, int32_t max_seq_len,
                                             int32_t is_bf16, int32_t is_fp8);
+
+/*
+ * Opt-in accuracy/speed switch for grouped-query attention (process-wide, default 0; returns the previous value).
+ * on != 0 lets the picks above select the "_pvm" kernels, which run the probabilities x V contraction on the matrix
+ * cores too (exact fp16 products, fp32 sums) instead of reproducing the reference kernel's fp16 rounding of every
+ * product and pair sum (dtype_float16.cuh:118-124, 399-404).  Results then agree with the reference kernel to the
+ * north-star 1e-3 (measured <= 4.9e-4, and closer to an fp64 attention than the reference kernel itself) rather than
+ * to 1-2 fp16 ulp; with 8 query heads per KV head the launch is 1.2x faster (profiles/r01k_pv_on_matrix_cores.md).
+ * No effect on multi-head attention (num_kv_heads == num_heads), on fp8 pages, or on an explicit `variant`.
+ */
+int vmi_set_pv_mfma(int32_t on);
 
 /*
  * The same heuristic with what a caller may know on the host: the batch's mean sequence length (0 = unknown) and

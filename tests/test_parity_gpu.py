@@ -71,7 +71,7 @@ def run_model(case, alibi=None):
                                      case["tables"], case["lens"], case.get("bs", BS), alibi_slopes=alibi, threads=8)
 
 
-def assert_close(got, ref, what="", vmax=1.0):
+def assert_close(got, ref, what="", vmax=1.0, tight=True):
     """north_star tolerance (1e-3 abs) AND a tighter one: 2 fp16 ulp of the result, or 5e-4 * max|v| — one
     rounding flip of an fp16 probability (the fp32 softmax differs in summation order and exp implementation)
     moves an output by ulp(p) * |v|."""
@@ -79,6 +79,8 @@ def assert_close(got, ref, what="", vmax=1.0):
     assert np.isfinite(got64).all(), f"{what}: non-finite output"
     d = np.abs(got64 - ref64)
     assert d.max() <= ATOL * max(1.0, vmax), f"{what}: max|hip-model| = {d.max():.3e} > {ATOL}"
+    if not tight:        # the opt-in "_pvm" kernels (P.V on the matrix cores): north-star bound only
+        return d.max(), float((d == 0).mean())
     tight = np.maximum(2 * ulp16(ref64), 5e-4 * max(1.0, vmax))   # 4.88e-4 = one flip of a probability in [0.5, 1)
     bad = d > tight
     assert not bad.any(), f"{what}: {bad.sum()} outputs off by more than 2 fp16 ulp (max {d.max():.3e})"
@@ -1110,6 +1112,7 @@ def test_randomized_parity_sweep(chunk):
         tag = (f"d{D}_" if bs == 16 else f"d{D}_bs{bs}_")
         cands = [i + 1 for i, n in enumerate(names)
                  if n.startswith(tag) and "LOADSONLY" not in n and (bs != 16 or "_bs" not in n) and
+                 "_pvm" not in n and          # opt-in kernels with their own (north-star) bound
                  ("_gq" not in n or (H // hkv) % int(n.split("_gq")[1].split("_")[0]) == 0)]
         vid = int(rng.choice(cands)) if (cands and rng.integers(0, 2)) else 0
         msl = int(max(lens.max(), 1)) + int(rng.integers(0, 40))
@@ -1478,10 +1481,46 @@ def test_gqa_shared_tile_kernels_match_kernel_model(D):
             except RuntimeError as e:                                # heads not divisible by the workgroup's share
                 assert "needs num_heads" in str(e), name
                 continue
-            assert_close(got, ref, f"{name} H{H}/{hkv}")
+            assert_close(got, ref, f"{name} H{H}/{hkv}", tight="_pvm" not in name)
             _append_vs_two_ops(case, vid, seed=vid, what=f"append {name} H{H}/{hkv}")
             ran += 1
         assert ran >= 3, (H, hkv, ran)
+
+
+def test_gqa_pv_on_matrix_cores_is_opt_in():
+    """vmi_set_pv_mfma: off by default (picks never name a _pvm kernel); on, grouped-query launches use them and stay
+    inside the north-star bound, for fp16 and bf16; multi-head attention and fp8 picks are unaffected."""
+    from vllmini_amd import ops
+
+    names = ops.variant_names()
+    rng = np.random.default_rng(99)
+    lens = [1, 16, 17, 100, 333, 1024, 47, 2, 0, 600, 31, 32, 33]
+    assert not ops.set_pv_mfma(False)
+    try:
+        for H, hkv, D in ((16, 4, 128), (32, 4, 128), (16, 4, 64)):
+            case = make_case(rng, len(lens), H, D, lens, num_kv_heads=hkv, q_row_pad=1, poison_tail=True)
+            ref = run_model(case)
+            assert "_pvm" not in names[ops.pick_variant(len(lens), H, D, 1024, 16, num_kv_heads=hkv) - 1]
+            exact = run_hip(case)
+            assert not ops.set_pv_mfma(True)
+            picked = names[ops.pick_variant(len(lens), H, D, 1024, 16, num_kv_heads=hkv) - 1]
+            assert "_pvm" in picked, picked
+            assert "_pvm" not in names[ops.pick_variant(len(lens), H, D, 1024, 16) - 1]                       # MHA
+            assert "_pvm" not in names[ops.pick_variant(len(lens), H, D, 1024, 16, fp8=True, num_kv_heads=hkv) - 1]
+            fast = run_hip(case)
+            assert_close(fast, ref, f"pvm auto H{H}/{hkv} D{D} ({picked})", tight=False)
+            assert np.abs(fast.astype(np.float64) - exact.astype(np.float64)).max() <= 1e-3
+            if D == 128:
+                cb = _to_bf16_case(case)
+                refb = oracle.paged_attention_v1(cb["q"], cb["kc"], cb["vc"], hkv, cb["scale"], cb["tables"], cb["lens"],
+                                                 16, threads=8, bf16=True)
+                pb = names[ops.pick_variant(len(lens), H, D, 1024, 16, bf16=True, num_kv_heads=hkv) - 1]
+                assert "_pvm" in pb and pb.startswith("bf16_"), pb
+                got = oracle.bf16_bits_to_f32(run_hip_bf16(case=cb, max_seq_len=1024)).astype(np.float64)
+                assert np.abs(got - oracle.bf16_bits_to_f32(refb)).max() <= 2.0 ** -7            # 2 bf16 ulp at 1.0
+            assert ops.set_pv_mfma(False)
+    finally:
+        ops.set_pv_mfma(False)
 
 
 def test_gqa_shared_tile_kernels_bf16_and_fp8():
@@ -1502,6 +1541,10 @@ def test_gqa_shared_tile_kernels_bf16_and_fp8():
         assert_close_bf16(run_hip_bf16(case), ref, f"bf16 gqa auto D{D}")
         for vid, name in enumerate(names, start=1):
             if name.startswith(f"bf16_d{D}_gq") and _gq_ok(name, qpk):
+                if "_pvm" in name:        # opt-in kernels: north-star bound (here: 2 bf16 ulp at 1.0)
+                    got = oracle.bf16_bits_to_f32(run_hip_bf16(case, variant=vid)).astype(np.float64)
+                    assert np.abs(got - oracle.bf16_bits_to_f32(ref)).max() <= 2.0 ** -7, name
+                    continue
                 assert_close_bf16(run_hip_bf16(case, variant=vid), ref, name)
         # fp8 pages
         c8 = _fp8_case(rng, len(lens), H, D, lens, bs, num_kv_heads=hkv)

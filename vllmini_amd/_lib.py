@@ -51,6 +51,7 @@ SIGNATURES = {
     "vmi_paged_attention_v1_variant_name": (ctypes.c_char_p, [_i32]),
     "vmi_paged_attention_v1_pick_variant": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v1_pick_variant_gqa": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "vmi_set_pv_mfma": (ctypes.c_int, [_i32]),
     "vmi_paged_attention_v1_pick_variant_hint": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v2_f16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32]),
     "vmi_paged_attention_v2_variant_count": (ctypes.c_int, []),
@@ -70,7 +71,7 @@ SIGNATURES = {
     ]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lock = threading.Lock()
 _lib = None

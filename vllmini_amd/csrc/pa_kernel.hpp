@@ -300,7 +300,7 @@ struct PAParams {
 // ----------------------------------------------------------------------------------------
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
           bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0, bool F8 = false,
-          bool GQS = false>
+          bool GQS = false, bool FPV = false>
 // (second launch bound = minimum waves per SIMD.  The adaptive-depth kernels are the full-chip defaults: 12 waves
 //  per CU = 3 per SIMD that must ALL be resident, i.e. stay under 170 VGPRs — the fused-append form had drifted to 180
 //  and ran 173 us instead of 125.  Not applied elsewhere: on the big-tile kernels it only forces spills.)
@@ -324,6 +324,12 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   static_assert(!(APP && (PART || LOADS_ONLY)), "the fused append exists for paged_attention_v1 only");
   static_assert(!GQS || HPT > 1, "GQS shares one KV tile between HPT > 1 query heads");
   constexpr int RH = GQS ? 1 : HPT;  // K / V register tiles per block: one per KV head this wave reads
+  // FPV ("fast P.V", opt-in, never picked automatically): grouped-query kernels that ALSO run the probabilities x V
+  // contraction on the matrix cores.  Exact fp16 products summed in fp32 — it drops the reference's fp16 rounding of
+  // every product and pair sum (dtype_float16.cuh:118-124, 399-404), so results sit within the north-star 1e-3 of the
+  // reference but not within an ulp of it.
+  static_assert(!FPV || (GQS && BS == 16 && D % 32 == 0 && U % 2 == 0 && !F8 && !LOADS_ONLY && UMAX == 0),
+                "FPV: grouped-query kernels, block size 16, pairs of blocks per register group");
   static_assert(!F8 || (BS >= 16 && D % 16 == 0 && !APP && !LOADS_ONLY),
                 "fp8 cache: block size 16 or 32 (a V row must fill whole 16-byte units), no fused append");
 
@@ -494,6 +500,11 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
     for (int i = 0; i < NL; ++i) acc[hh][i] = 0.f;
+  // FPV: out[head][dim] accumulators in the MFMA C/D layout — tile t covers dims 16t..16t+15; lane holds column
+  // (lane & 15) = dim, rows 4*(lane >> 4) + reg = head
+  f32x4 accM[FPV ? D / 16 : 1];
+#pragma unroll
+  for (int t = 0; t < (FPV ? D / 16 : 1); ++t) accM[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int hf = lane % UPR;   // which 8-token group of the block this lane owns
   const int rowl = lane / UPR;  // dim row within a load
 
@@ -555,6 +566,33 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
             r[j][GQS ? 0 : hh][i] = (valid(hh) && (i < NL - 1 || tail_ok)) ? ld16<NT>(blk + (hoff[hh] + i * 64 * EPU) * ES) : zero4;
         }
       }
+    };
+
+    // FPV: the V pages in the B-operand layout of v_mfma_f32_16x16x32 — K = 32 tokens = a PAIR of my blocks, N = 16
+    // dims per instruction.  Lane (n = lane & 15, kg = lane >> 4) takes dim row 16t+n, tokens 8*(kg & 1).. of block
+    // (kg >> 1) of the pair: still one 1-KiB request per instruction (two 512-B runs), D/16 = 2*NL of them per pair,
+    // kept in the register slots of the pair's two tiles.
+    const int vm_n = lane & 15, vm_mem = lane >> 5, vm_hf = (lane >> 4) & 1;
+    auto load_group_vm = [&](u32x4(&r)[UU][RH][NL], int g) {
+      if constexpr (LOCK) __builtin_amdgcn_s_barrier();
+      table_for(g);
+  #pragma unroll
+      for (int q = 0; q < UU / 2; ++q) {
+        int i0 = g * UU + 2 * q, i1 = i0 + 1;
+        i0 = i0 < nmy ? i0 : nmy - 1;
+        i1 = i1 < nmy ? i1 : nmy - 1;
+        const int64_t phys0 = __builtin_amdgcn_readlane(bt_reg, i0 & 63);
+        const int64_t phys1 = __builtin_amdgcn_readlane(bt_reg, i1 & 63);
+        const char* blk = reinterpret_cast<const char*>(p.vc) + (vm_mem ? phys1 : phys0) * p.kv_block_stride * ES;
+        const int64_t base = hoff[0] - lane * EPU;  // the KV head's tile
+  #pragma unroll
+        for (int t = 0; t < 2 * NL; ++t)
+          r[2 * q + t / NL][0][t % NL] = ld16<NT>(blk + (base + ((16 * t + vm_n) * 2 + vm_hf) * 8) * ES);
+      }
+    };
+    auto load_v = [&](u32x4(&r)[UU][RH][NL], int g) {
+      if constexpr (FPV) load_group_vm(r, g);
+      else load_group(r, p.vc, g);
     };
 
     // =========================== K pass: logits -> LDS, running max ========================
@@ -667,7 +705,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     const bool single = (ngroups == 1);  // wave-uniform (and workgroup-uniform under LOCK)
     if (single) {
       load_group(ra, p.kc, 0);
-      load_group(rb, p.vc, 0);
+      load_v(rb, 0);
       compute_k(std::integral_constant<bool, APP>{}, ra, 0);
     } else {
       if (ngroups > 0) load_group(ra, p.kc, 0);
@@ -686,7 +724,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     }
 
     // first V group goes out now: HBM stays busy while the softmax runs
-    if (ngroups > 1) load_group(ra, p.vc, 0);
+    if (ngroups > 1) load_v(ra, 0);
 
     if constexpr (QK_MFMA) {  // per-head maxima live in lanes (lane & 15) = head: fold the 4 row groups, then hand out
       qmaxB = fmaxf(qmaxB, __shfl_xor(qmaxB, 16));
@@ -783,6 +821,61 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
         fold_all(r);
         return;
       }
+      if constexpr (FPV) {
+  #pragma unroll
+        for (int q = 0; q < UU / 2; ++q) {
+          const int i0 = g * UU + 2 * q;
+          if (i0 < nmy) {  // wave-uniform
+            const bool live = vm_mem == 0 || i0 + 1 < nmy;  // an odd count leaves the pair's second block empty
+            const int b = blk_lo + sub + (i0 + vm_mem) * WPH;
+            const int token0 = b * BS + 8 * vm_hf;
+            // A operand: probabilities of head (lane & 15) for this lane's 8 tokens
+            const u32x4 pa = (live && vm_n < HPT)
+                                 ? *reinterpret_cast<const u32x4_alias*>(ph0 + vm_n * ph_stride + (token0 - tok_lo))
+                                 : zero4;
+            uint16_t vnew16[2 * NL];
+            bool patch = false;
+            if constexpr (APP && MASK) {
+              patch = live && b == lbA && vm_hf == (offA >> 3);
+              if (patch) {  // per lane: the half-wave that holds block lbA's tokens
+                const int kvh = head0 / qpk;
+                const h16* vr = p.value + (int64_t)seq * p.value_stride + (int64_t)kvh * D;
+  #pragma unroll
+                for (int t = 0; t < 2 * NL; ++t) vnew16[t] = __builtin_bit_cast(uint16_t, vr[16 * t + vm_n]);
+              }
+            }
+  #pragma unroll
+            for (int t = 0; t < 2 * NL; ++t) {
+              u32x4 v = live ? r[2 * q + t / NL][0][t % NL] : zero4;
+              if constexpr (APP && MASK) {
+                if (patch) {
+                  const int e = offA & 7;
+  #pragma unroll
+                  for (int w = 0; w < 4; ++w) {
+                    const uint32_t old = v[w], vb = vnew16[t];
+                    const uint32_t patched = (e & 1) ? ((old & 0x0000ffffu) | (vb << 16)) : ((old & 0xffff0000u) | vb);
+                    v[w] = ((e >> 1) == w) ? patched : old;
+                  }
+                }
+              }
+              if constexpr (MASK) {  // elements past the context are zeroed, as the reference does (:420-430): 0 * NaN
+  #pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                  const uint32_t keep = (token0 + 2 * w < L ? 0x0000ffffu : 0u) | (token0 + 2 * w + 1 < L ? 0xffff0000u : 0u);
+                  v[w] &= keep;
+                }
+              }
+              if constexpr (BF)
+                accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pa),
+                                                                  __builtin_bit_cast(bf16x8, v), accM[t], 0, 0, 0);
+              else
+                accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, pa),
+                                                                 __builtin_bit_cast(h16x8, v), accM[t], 0, 0, 0);
+            }
+          }
+        }
+        return;
+      }
   #pragma unroll
       for (int j = 0; j < UU; ++j) {
         const int idx = g * UU + j;
@@ -843,10 +936,10 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     } else {
       int g = 0;
       for (; g + 2 <= ngroups; g += 2) {
-        load_group(rb, p.vc, g + 1);
+        load_v(rb, g + 1);
         compute_v(std::false_type{}, ra, g);
         if (g + 2 < ngroups) {
-          load_group(ra, p.vc, g + 2);
+          load_v(ra, g + 2);
           compute_v(std::false_type{}, rb, g + 1);
         } else {
           compute_v(std::true_type{}, rb, g + 1);  // final group of an even count
@@ -886,17 +979,33 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   }
 
   // the UPR lanes of a row hold its 8-token groups
+  if constexpr (!FPV) {
 #pragma unroll
-  for (int hh = 0; hh < HPT; ++hh) {
+    for (int hh = 0; hh < HPT; ++hh) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
+      for (int i = 0; i < NL; ++i) {
 #pragma unroll
-      for (int m = 1; m < UPR; m <<= 1) acc[hh][i] += __shfl_xor(acc[hh][i], m);
+        for (int m = 1; m < UPR; m <<= 1) acc[hh][i] += __shfl_xor(acc[hh][i], m);
+      }
     }
   }
 
+  if constexpr (FPV) {  // accM: column (lane & 15) = dim 16t + n, rows 4*(lane >> 4) + reg = head
+    const int n = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int hh = 4 * g4 + e;
+        if (hh < HPT && valid(hh)) {
+          if constexpr (WPH > 1) osm0[(hh * WPH + sub) * D + 16 * t + n] = accM[t][e];
+          else out0[hh * ostride + 16 * t + n] = to_elem<BF>(accM[t][e]);
+        }
+      }
+    }
+  }
   if constexpr (WPH > 1) {
-    if (hf == 0) {
+    if (hf == 0 && !FPV) {
 #pragma unroll
       for (int hh = 0; hh < HPT; ++hh) {
 #pragma unroll
@@ -921,7 +1030,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       }
     }
   } else {
-    if (hf == 0) {
+    if (hf == 0 && !FPV) {
 #pragma unroll
       for (int hh = 0; hh < HPT; ++hh) {
         if (valid(hh)) {
@@ -1050,6 +1159,7 @@ struct Variant {
   int lds_attr_dev;  // device that grant was made on (the attribute is per device)
   bool F8;           // caches hold fp8 E4M3 bytes (kv_cache_dtype "fp8")
   bool GQS;          // the HPT query heads of a wave share one KV head: num_heads / num_kv_heads % HPT == 0 required
+  bool FPV;          // opt-in: probabilities x V on the matrix cores too (vmi_set_pv_mfma); north-star bound, not 1 ulp
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
@@ -1076,6 +1186,11 @@ typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const 
   {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, BF,                                                                  \
    (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), false, false, BS, LOCK, BF, HPT, VMI_APP, 0, false, true>, \
    0, 0, 0, false, true},
+// ... and with the probabilities x V contraction on the matrix cores as well (opt-in, "_pvm" names)
+#define VMI_ROW_GP(NAME, D, BS, HPW, WPH, U, BF, HPT)                                                              \
+  {NAME, D, BS, HPW, WPH, U, true, HPT, BF,                                                                        \
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, BS, false, BF, HPT, VMI_APP, 0, false, true, true>, \
+   0, 0, 0, false, true, true},
 #define VMI_ROW(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT) \
   VMI_ROW_A(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT, 0)
 

@@ -33,6 +33,7 @@
 //        -ffp-contract=off matters: the fp16 p*v products must round before they are added.
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -457,8 +458,23 @@ static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }
 // (profiles/r01g_ragged_batches.md: cfg3 U{1..1024} 98.7 -> 77.1 us, cfg4 446.8 -> 360.5 us).
 // Grouped-query attention (num_heads / num_kv_heads = qpk > 1): the largest built group size dividing qpk, one wave
 // per group when the launch fills the chip, four or eight waves per group otherwise.  0 = no such kernel.
+// Opt-in (vmi_set_pv_mfma): let the grouped-query picks use the "_pvm" kernels, which run probabilities x V on the
+// matrix cores as well.  Off by default: those results are within the north-star 1e-3 of the reference kernel, not
+// within an ulp of it (pa_kernel.hpp, FPV).
+static std::atomic<int> g_pv_mfma{0};
+
+static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
+                               bool bf, bool f8, bool fpv);
 static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
                             bool bf, bool f8) {
+  if (g_pv_mfma.load(std::memory_order_relaxed) && !f8) {
+    const int v = pick_variant_gqa_of(num_seqs, num_heads, qpk, head_size, block_size, max_seq_len, bf, f8, true);
+    if (v) return v;
+  }
+  return pick_variant_gqa_of(num_seqs, num_heads, qpk, head_size, block_size, max_seq_len, bf, f8, false);
+}
+static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
+                               bool bf, bool f8, bool fpv) {
   if (qpk < 2 || block_size != 16) return 0;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   const size_t lpad = (size_t)((max_seq_len + 31) / 32) * 32;
@@ -478,7 +494,8 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
     int best = 0;
     for (int id = 1; id <= nvariants_v1(); ++id) {
       const Variant& c = variant_v1(id);
-      if (!c.GQS || c.BF != bf || c.F8 != f8 || c.D != head_size || c.BS != block_size || c.HPT != g || !fits(c))
+      if (!c.GQS || c.FPV != fpv || c.BF != bf || c.F8 != f8 || c.D != head_size || c.BS != block_size || c.HPT != g ||
+          !fits(c))
         continue;
       if (wph == 1 ? (c.WPH == 1 && (num_heads / g) % c.HPW == 0)
                    : (c.HPW == 1 && c.WPH <= wph && c.WPH * 4 >= wph)) {  // at most 4x fewer waves than wanted
@@ -490,7 +507,7 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
     if (best) return best;
     for (int id = 1; id <= nvariants_v1(); ++id) {  // no kernel of the wanted shape: any kernel of this group size
       const Variant& c = variant_v1(id);
-      if (c.GQS && c.BF == bf && c.F8 == f8 && c.D == head_size && c.BS == block_size && c.HPT == g &&
+      if (c.GQS && c.FPV == fpv && c.BF == bf && c.F8 == f8 && c.D == head_size && c.BS == block_size && c.HPT == g &&
           (num_heads / g) % c.HPW == 0 && fits(c) && units * c.WPH * 4 >= units * wph)  // at most 4x fewer waves than wanted
         return id;
     }
@@ -1082,6 +1099,8 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
   if (!vmi::head_size_supported(head_size) || !vmi::block_size_supported(block_size)) return 0;
   return vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len);
 }
+
+int vmi_set_pv_mfma(int on) { return vmi::g_pv_mfma.exchange(on ? 1 : 0); }
 
 int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
                                             int32_t head_size, int32_t block_size, int32_t max_seq_len,

@@ -390,6 +390,14 @@ def variant_names_v2() -> list[str]:
     return [lib.vmi_paged_attention_v2_variant_name(i + 1).decode() for i in range(n)]
 
 
+def set_pv_mfma(on: bool) -> bool:
+    """Opt-in (process-wide, default off; returns the previous setting): with grouped-query attention let the
+    operators pick the "_pvm" kernels, which also run probabilities x V on the matrix cores.  Results then match
+    the reference kernel to the north-star 1e-3 instead of 1-2 fp16 ulp (include/vmi_paged_attention.h,
+    vmi_set_pv_mfma); 1.2x faster with 8 query heads per KV head."""
+    return bool(_lib.load().vmi_set_pv_mfma(int(bool(on))))
+
+
 def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16,
                  mean_seq_len: int = 0, bf16: bool = False, fp8: bool = False, num_kv_heads: int = 0) -> int:
     """The library's work-decomposition heuristic (what `_variant=0` runs).  A caller that knows the batch's
