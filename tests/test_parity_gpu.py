@@ -1506,7 +1506,8 @@ def test_gqa_pv_on_matrix_cores_is_opt_in():
             picked = names[ops.pick_variant(len(lens), H, D, 1024, 16, num_kv_heads=hkv) - 1]
             assert "_pvm" in picked, picked
             assert "_pvm" not in names[ops.pick_variant(len(lens), H, D, 1024, 16) - 1]                       # MHA
-            assert "_pvm" not in names[ops.pick_variant(len(lens), H, D, 1024, 16, fp8=True, num_kv_heads=hkv) - 1]
+            p8 = names[ops.pick_variant(len(lens), H, D, 1024, 16, fp8=True, num_kv_heads=hkv) - 1]
+            assert ("_pvm" in p8) == (D == 128), p8                      # fp8 pages: built for head size 128
             fast = run_hip(case)
             assert_close(fast, ref, f"pvm auto H{H}/{hkv} D{D} ({picked})", tight=False)
             assert np.abs(fast.astype(np.float64) - exact.astype(np.float64)).max() <= 1e-3
@@ -1518,6 +1519,11 @@ def test_gqa_pv_on_matrix_cores_is_opt_in():
                 assert "_pvm" in pb and pb.startswith("bf16_"), pb
                 got = oracle.bf16_bits_to_f32(run_hip_bf16(case=cb, max_seq_len=1024)).astype(np.float64)
                 assert np.abs(got - oracle.bf16_bits_to_f32(refb)).max() <= 2.0 ** -7            # 2 bf16 ulp at 1.0
+                c8 = _fp8_case(rng, len(lens), H, D, lens, 16, num_kv_heads=hkv)                 # fp8 pages
+                for kv_scale in (1.0, 0.8):
+                    r8 = oracle.paged_attention_v1_fp8(c8["q"], c8["kq"], c8["vq"], hkv, c8["scale"], c8["tables"],
+                                                       c8["lens"], 16, kv_scale=kv_scale, threads=8)
+                    assert_close(_run_fp8(c8, kv_scale), r8, f"fp8 pvm auto H{H}/{hkv} ({p8})", vmax=2 * kv_scale, tight=False)
             assert ops.set_pv_mfma(False)
     finally:
         ops.set_pv_mfma(False)
@@ -1556,8 +1562,8 @@ def test_gqa_shared_tile_kernels_bf16_and_fp8():
                                             kv_scale=1.0, threads=8)
         for vid, name in enumerate(names, start=1):
             if name.startswith(f"fp8_d{D}_bs16_gq") and _gq_ok(name, qpk):
-                assert_close(_run_fp8(c8, 0.8, variant=vid), r8, name, vmax=1.6)
-                assert_close(_run_fp8(c8, 1.0, variant=vid), r8s, name + " scale 1", vmax=2.0)
+                assert_close(_run_fp8(c8, 0.8, variant=vid), r8, name, vmax=1.6, tight="_pvm" not in name)
+                assert_close(_run_fp8(c8, 1.0, variant=vid), r8s, name + " scale 1", vmax=2.0, tight="_pvm" not in name)
 
 
 def test_gqa_group_sizes_three_and_seven():

@@ -328,8 +328,9 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   // contraction on the matrix cores.  Exact fp16 products summed in fp32 — it drops the reference's fp16 rounding of
   // every product and pair sum (dtype_float16.cuh:118-124, 399-404), so results sit within the north-star 1e-3 of the
   // reference but not within an ulp of it.
-  static_assert(!FPV || (GQS && BS == 16 && D % 32 == 0 && U % 2 == 0 && !F8 && !LOADS_ONLY && UMAX == 0),
-                "FPV: grouped-query kernels, block size 16, pairs of blocks per register group");
+  static_assert(!FPV || (GQS && BS == 16 && D % 32 == 0 && U % (F8 ? 4 : 2) == 0 && !LOADS_ONLY && UMAX == 0),
+                "FPV: grouped-query kernels, block size 16, pairs (fp8 pages: quads) of blocks per register group");
+  constexpr int VG = F8 ? 4 : 2;  // FPV: blocks that share one MFMA's K = 32 tokens (8 per block with fp8 pages, 16 else)
   static_assert(!F8 || (BS >= 16 && D % 16 == 0 && !APP && !LOADS_ONLY),
                 "fp8 cache: block size 16 or 32 (a V row must fill whole 16-byte units), no fused append");
 
@@ -568,26 +569,31 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       }
     };
 
-    // FPV: the V pages in the B-operand layout of v_mfma_f32_16x16x32 — K = 32 tokens = a PAIR of my blocks, N = 16
-    // dims per instruction.  Lane (n = lane & 15, kg = lane >> 4) takes dim row 16t+n, tokens 8*(kg & 1).. of block
-    // (kg >> 1) of the pair: still one 1-KiB request per instruction (two 512-B runs), D/16 = 2*NL of them per pair,
-    // kept in the register slots of the pair's two tiles.
-    const int vm_n = lane & 15, vm_mem = lane >> 5, vm_hf = (lane >> 4) & 1;
+    // FPV: the V pages in the B-operand layout of v_mfma_f32_16x16x32 — N = 16 dims per instruction, K = 32 tokens.
+    // 16-bit pages: lane (n = lane & 15, kg = lane >> 4) takes dim row 16t+n, tokens 8*(kg & 1).. of block (kg >> 1)
+    // of a PAIR of my blocks.  fp8 pages: a 16-byte unit is a whole 16-token row, so lane (n, kg) takes row 16t+n of
+    // block kg of a QUAD and feeds two instructions (tokens 0-7 and 8-15 of the four blocks).  Either way one 1-KiB
+    // request per load instruction (512-B / 256-B runs), D/16 = VG*NL of them per pair / quad, kept in the register
+    // slots of those VG tiles.
+    const int vm_n = lane & 15, vm_mem = F8 ? (lane >> 4) : (lane >> 5), vm_hf = F8 ? 0 : ((lane >> 4) & 1);
     auto load_group_vm = [&](u32x4(&r)[UU][RH][NL], int g) {
       if constexpr (LOCK) __builtin_amdgcn_s_barrier();
       table_for(g);
   #pragma unroll
-      for (int q = 0; q < UU / 2; ++q) {
-        int i0 = g * UU + 2 * q, i1 = i0 + 1;
-        i0 = i0 < nmy ? i0 : nmy - 1;
-        i1 = i1 < nmy ? i1 : nmy - 1;
-        const int64_t phys0 = __builtin_amdgcn_readlane(bt_reg, i0 & 63);
-        const int64_t phys1 = __builtin_amdgcn_readlane(bt_reg, i1 & 63);
-        const char* blk = reinterpret_cast<const char*>(p.vc) + (vm_mem ? phys1 : phys0) * p.kv_block_stride * ES;
-        const int64_t base = hoff[0] - lane * EPU;  // the KV head's tile
+      for (int q = 0; q < UU / VG; ++q) {
+        int64_t phys = 0;
   #pragma unroll
-        for (int t = 0; t < 2 * NL; ++t)
-          r[2 * q + t / NL][0][t % NL] = ld16<NT>(blk + (base + ((16 * t + vm_n) * 2 + vm_hf) * 8) * ES);
+        for (int k = 0; k < VG; ++k) {
+          int ik = g * UU + VG * q + k;
+          ik = ik < nmy ? ik : nmy - 1;
+          const int64_t pk = __builtin_amdgcn_readlane(bt_reg, ik & 63);
+          phys = (vm_mem == k) ? pk : phys;
+        }
+        const char* blk = reinterpret_cast<const char*>(p.vc) + phys * p.kv_block_stride * ES;
+        const int64_t base = (hoff[0] - lane * EPU) * ES;  // the KV head's tile, bytes
+  #pragma unroll
+        for (int t = 0; t < VG * NL; ++t)
+          r[VG * q + t / NL][0][t % NL] = ld16<NT>(blk + base + ((16 * t + vm_n) * UPR + vm_hf) * 16);
       }
     };
     auto load_v = [&](u32x4(&r)[UU][RH][NL], int g) {
@@ -823,17 +829,20 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       }
       if constexpr (FPV) {
   #pragma unroll
-        for (int q = 0; q < UU / 2; ++q) {
-          const int i0 = g * UU + 2 * q;
+        for (int q = 0; q < UU / VG; ++q) {
+          const int i0 = g * UU + VG * q;
           if (i0 < nmy) {  // wave-uniform
-            const bool live = vm_mem == 0 || i0 + 1 < nmy;  // an odd count leaves the pair's second block empty
+            const bool live = i0 + vm_mem < nmy;  // the last pair / quad may be partly empty
             const int b = blk_lo + sub + (i0 + vm_mem) * WPH;
-            const int token0 = b * BS + 8 * vm_hf;
-            // A operand: probabilities of head (lane & 15) for this lane's 8 tokens
-            const u32x4 pa = (live && vm_n < HPT)
-                                 ? *reinterpret_cast<const u32x4_alias*>(ph0 + vm_n * ph_stride + (token0 - tok_lo))
-                                 : zero4;
-            uint16_t vnew16[2 * NL];
+            const int tokb = b * BS + 8 * vm_hf;
+            // A operand: probabilities of head (lane & 15) for this lane's 8 tokens (fp8 pages: 8 + 8)
+            u32x4 pa[F8 ? 2 : 1];
+  #pragma unroll
+            for (int hs = 0; hs < (F8 ? 2 : 1); ++hs)
+              pa[hs] = (live && vm_n < HPT)
+                           ? *reinterpret_cast<const u32x4_alias*>(ph0 + vm_n * ph_stride + (tokb + 8 * hs - tok_lo))
+                           : zero4;
+            uint16_t vnew16[VG * NL];
             bool patch = false;
             if constexpr (APP && MASK) {
               patch = live && b == lbA && vm_hf == (offA >> 3);
@@ -841,36 +850,43 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
                 const int kvh = head0 / qpk;
                 const h16* vr = p.value + (int64_t)seq * p.value_stride + (int64_t)kvh * D;
   #pragma unroll
-                for (int t = 0; t < 2 * NL; ++t) vnew16[t] = __builtin_bit_cast(uint16_t, vr[16 * t + vm_n]);
+                for (int t = 0; t < VG * NL; ++t) vnew16[t] = __builtin_bit_cast(uint16_t, vr[16 * t + vm_n]);
               }
             }
   #pragma unroll
-            for (int t = 0; t < 2 * NL; ++t) {
-              u32x4 v = live ? r[2 * q + t / NL][0][t % NL] : zero4;
-              if constexpr (APP && MASK) {
-                if (patch) {
-                  const int e = offA & 7;
+            for (int t = 0; t < VG * NL; ++t) {
+              const u32x4 raw = r[VG * q + t / NL][0][t % NL];
   #pragma unroll
-                  for (int w = 0; w < 4; ++w) {
-                    const uint32_t old = v[w], vb = vnew16[t];
-                    const uint32_t patched = (e & 1) ? ((old & 0x0000ffffu) | (vb << 16)) : ((old & 0xffff0000u) | vb);
-                    v[w] = ((e >> 1) == w) ? patched : old;
+              for (int hs = 0; hs < (F8 ? 2 : 1); ++hs) {
+                u32x4 v = raw;
+                if constexpr (F8) v = deq8<S1, BF>(raw[2 * hs], raw[2 * hs + 1], p.kv_scale);
+                v = live ? v : zero4;
+                const int token0 = tokb + 8 * hs;
+                if constexpr (APP && MASK) {
+                  if (patch) {
+                    const int e = offA & 7;
+  #pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                      const uint32_t old = v[w], vb = vnew16[t];
+                      const uint32_t patched = (e & 1) ? ((old & 0x0000ffffu) | (vb << 16)) : ((old & 0xffff0000u) | vb);
+                      v[w] = ((e >> 1) == w) ? patched : old;
+                    }
                   }
                 }
-              }
-              if constexpr (MASK) {  // elements past the context are zeroed, as the reference does (:420-430): 0 * NaN
+                if constexpr (MASK) {  // elements past the context are zeroed, as the reference does (:420-430): 0 * NaN
   #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                  const uint32_t keep = (token0 + 2 * w < L ? 0x0000ffffu : 0u) | (token0 + 2 * w + 1 < L ? 0xffff0000u : 0u);
-                  v[w] &= keep;
+                  for (int w = 0; w < 4; ++w) {
+                    const uint32_t keep = (token0 + 2 * w < L ? 0x0000ffffu : 0u) | (token0 + 2 * w + 1 < L ? 0xffff0000u : 0u);
+                    v[w] &= keep;
+                  }
                 }
+                if constexpr (BF)
+                  accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pa[hs]),
+                                                                    __builtin_bit_cast(bf16x8, v), accM[t], 0, 0, 0);
+                else
+                  accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, pa[hs]),
+                                                                   __builtin_bit_cast(h16x8, v), accM[t], 0, 0, 0);
               }
-              if constexpr (BF)
-                accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pa),
-                                                                  __builtin_bit_cast(bf16x8, v), accM[t], 0, 0, 0);
-              else
-                accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, pa),
-                                                                 __builtin_bit_cast(h16x8, v), accM[t], 0, 0, 0);
             }
           }
         }
@@ -1179,6 +1195,10 @@ typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const 
   {NAME, D, BS, HPW, WPH, U, true, HPT, false,                                                                     \
    (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, BS, false, false, HPT, false, 0, true, true>, 0,   \
    0, 0, true, true},
+#define VMI_ROW_F8GP(NAME, D, BS, HPW, WPH, U, HPT)  /* ... and P.V on the matrix cores too (opt-in "_pvm") */      \
+  {NAME, D, BS, HPW, WPH, U, true, HPT, false,                                                                           \
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, BS, false, false, HPT, false, 0, true, true, true>, 0, \
+   0, 0, true, true, true},
 #define VMI_ROW_F8(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX) \
   VMI_ROW_F8B(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX, false)
 // grouped-query rows: HPT query heads of one KV head per wave, each tile loaded once

@@ -467,7 +467,7 @@ static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_si
                                bool bf, bool f8, bool fpv);
 static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
                             bool bf, bool f8) {
-  if (g_pv_mfma.load(std::memory_order_relaxed) && !f8) {
+  if (g_pv_mfma.load(std::memory_order_relaxed)) {
     const int v = pick_variant_gqa_of(num_seqs, num_heads, qpk, head_size, block_size, max_seq_len, bf, f8, true);
     if (v) return v;
   }
