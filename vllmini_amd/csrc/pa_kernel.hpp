@@ -322,6 +322,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   static_assert(64 % U == 0, "U must divide 64");
   static_assert(!(LOCK && WPH > 1), "lockstep needs every wave to run the same number of page groups");
   static_assert(!(APP && (PART || LOADS_ONLY)), "the fused append exists for paged_attention_v1 only");
+  // (GQS with HPT == 1 — multi-head attention through the matrix-core code paths — was measured over fp8 pages:
+  //  cfg3 67.1 -> 63.9 us, cfg4 338 -> 339 us; those kernels are bound by the 2-KiB tile request pattern, not the VALU)
   static_assert(!GQS || HPT > 1, "GQS shares one KV tile between HPT > 1 query heads");
   constexpr int RH = GQS ? 1 : HPT;  // K / V register tiles per block: one per KV head this wave reads
   // FPV ("fast P.V", opt-in, never picked automatically): grouped-query kernels that ALSO run the probabilities x V
