@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 10
+#define VMI_ABI_VERSION 11
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -69,9 +69,9 @@ const char* vmi_target_arch(void);
  * Replaces: paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale,
  *           block_tables, seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
  *           kv_scale, tp_rank, blocksparse_*)          — attention_kernels.cu:805-826.
- * The kv_cache_dtype/kv_scale/tp_rank/blocksparse arguments have no C counterpart: the
- * Python mirror rejects every value other than the ones the reference callers pass
- * ("auto", block-sparse disabled; vllmini/model/gpt2.py:94-113) before calling in.
+ * kv_cache_dtype / kv_scale select the _fp8 entries below; tp_rank and the blocksparse arguments only matter with
+ * blocksparse_vert_stride > 1, which is vmi_paged_attention_v1_blocksparse (the reference callers pass "auto" and
+ * block-sparse disabled; vllmini/model/gpt2.py:94-113).
  *
  *   out            [num_seqs, num_heads, head_size] fp16, contiguous          (written)
  *   query          [num_seqs, num_heads, head_size] fp16, row stride q_stride (may be 3*hidden)
@@ -94,6 +94,44 @@ int vmi_paged_attention_v1_f16(
     const float* alibi_slopes,
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     int32_t device, void* stream);
+
+/*
+ * Block-sparse attention: paged_attention_v1 / paged_attention_v2 called with blocksparse_vert_stride > 1
+ * (is_block_sparse, attention_kernels.cu:822 / :987; kernel :209-254, :385-393).  fp16 or bf16 tensors
+ * (is_bf16), "auto" cache.  A cache block is read when the sparse block (blocksparse_block_size tokens) holding its
+ * first token is
+ *   "remote": (sparse_block + offset) % blocksparse_vert_stride == 0, with
+ *             offset = (tp_rank * num_heads + head) * head_sliding_step + 1             (head_sliding_step >= 0)
+ *                    = (tp_rank * num_kv_heads + kv_head) * (-head_sliding_step) + 1    (head_sliding_step <  0), or
+ *   "local":  sparse_block > (seq_len - 1) / blocksparse_block_size - blocksparse_local_blocks;
+ * every other block is skipped: not loaded, logits -FLT_MAX, no P.V contribution.  Same results as the dense
+ * operator's arithmetic restricted to the attended blocks (oracle/pa_kernel_model.c, checked against a masked fp64
+ * attention).  blocksparse_vert_stride <= 1 is an error here (call the dense entry).  No tuning variants.
+ * The reference's own callers never enable this (gpt2.py:109-112 passes 0, 1, 1, 0).
+ */
+int vmi_paged_attention_v1_blocksparse(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream, int32_t is_bf16, int32_t tp_rank,
+    int32_t blocksparse_local_blocks, int32_t blocksparse_vert_stride,
+    int32_t blocksparse_block_size, int32_t blocksparse_head_sliding_step);
+int vmi_paged_attention_v2_blocksparse(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream, int32_t is_bf16, int32_t tp_rank,
+    int32_t blocksparse_local_blocks, int32_t blocksparse_vert_stride,
+    int32_t blocksparse_block_size, int32_t blocksparse_head_sliding_step);
 
 /*
  * Same operator with an explicit tuning variant (work decomposition only — results are

@@ -38,9 +38,13 @@ def _load() -> ctypes.CDLL:
             vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, vp, i64, i64, i64, i32, i32]
         lib.vmi_oracle_paged_attention_v1.restype = ctypes.c_int
         lib.vmi_oracle_paged_attention_v1.argtypes = lib.vmi_oracle_paged_attention_v1_f16.argtypes + [i32]
+        lib.vmi_oracle_paged_attention_v1_blocksparse.restype = ctypes.c_int
+        lib.vmi_oracle_paged_attention_v1_blocksparse.argtypes = lib.vmi_oracle_paged_attention_v1.argtypes + [i32] * 5
         lib.vmi_oracle_paged_attention_v2.restype = ctypes.c_int
         lib.vmi_oracle_paged_attention_v2.argtypes = [
             vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, i32, i32, vp, i64, i64, i64, i32]
+        lib.vmi_oracle_paged_attention_v2_blocksparse.restype = ctypes.c_int
+        lib.vmi_oracle_paged_attention_v2_blocksparse.argtypes = lib.vmi_oracle_paged_attention_v2.argtypes + [i32] * 5
         lib.vmi_oracle_f2b.restype = ctypes.c_uint16
         lib.vmi_oracle_f2b.argtypes = [f32]
         lib.vmi_oracle_b2f.restype = f32
@@ -81,8 +85,11 @@ def _base_ptr(a: np.ndarray) -> int:
 def paged_attention_v1(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
                        num_kv_heads: int, scale: float, block_tables: np.ndarray,
                        seq_lens: np.ndarray, block_size: int,
-                       alibi_slopes: np.ndarray | None = None, threads: int = 1, bf16: bool = False) -> np.ndarray:
+                       alibi_slopes: np.ndarray | None = None, threads: int = 1, bf16: bool = False,
+                       blocksparse: tuple | None = None, tp_rank: int = 0) -> np.ndarray:
     """Kernel-model output [num_seqs, num_heads, head_size] float16 (uint16 bit patterns when bf16=True).
+    blocksparse = (local_blocks, vert_stride, block_size, head_sliding_step), the operator's last four arguments
+    (attention_kernels.cu:209-254, 385-393); vert_stride <= 1 or None = dense.
 
     `query` may be a strided view (row stride = query.strides[0]); caches are float16 arrays in
     the reference layout (uint16 arrays holding bfloat16 bit patterns when bf16=True);
@@ -107,11 +114,14 @@ def paged_attention_v1(query: np.ndarray, key_cache: np.ndarray, value_cache: np
     lib = _load()
 
     def run(lo: int, hi: int) -> int:
-        return lib.vmi_oracle_paged_attention_v1(
-            _base_ptr(out), _base_ptr(query), _base_ptr(key_cache), _base_ptr(value_cache),
-            S, H, D, int(num_kv_heads), float(scale), _base_ptr(block_tables), _base_ptr(seq_lens),
-            int(block_size), int(block_tables.shape[1]),
-            None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh), lo, hi, 1 if bf16 else 0)
+        args = (_base_ptr(out), _base_ptr(query), _base_ptr(key_cache), _base_ptr(value_cache),
+                S, H, D, int(num_kv_heads), float(scale), _base_ptr(block_tables), _base_ptr(seq_lens),
+                int(block_size), int(block_tables.shape[1]),
+                None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh), lo, hi, 1 if bf16 else 0)
+        if blocksparse is not None:
+            loc, vert, bsz, step = (int(v) for v in blocksparse)
+            return lib.vmi_oracle_paged_attention_v1_blocksparse(*args, int(tp_rank), loc, vert, bsz, step)
+        return lib.vmi_oracle_paged_attention_v1(*args)
 
     threads = max(1, min(int(threads), S))
     if threads == 1:
@@ -131,7 +141,7 @@ def paged_attention_v1(query: np.ndarray, key_cache: np.ndarray, value_cache: np
 def paged_attention_v2(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
                        num_kv_heads: int, scale: float, block_tables: np.ndarray, seq_lens: np.ndarray,
                        block_size: int, max_seq_len: int, alibi_slopes: np.ndarray | None = None,
-                       bf16: bool = False):
+                       bf16: bool = False, blocksparse: tuple | None = None, tp_rank: int = 0):
     """Kernel model of the split-KV operator (attention_kernels.cu:966-990): returns
     (out [S,H,D] f16, exp_sums [S,H,P] f32, max_logits [S,H,P] f32, tmp_out [S,H,P,D] f16) with
     P = ceil(max_seq_len / 512).  Partitions past a sequence's context keep their fill value (NaN)."""
@@ -151,12 +161,16 @@ def paged_attention_v2(query: np.ndarray, key_cache: np.ndarray, value_cache: np
     max_logits = np.full((S, H, P), np.nan, dtype=np.float32)
     tmp_out = np.full((S, H, P, D), 0x7FC0 if bf16 else np.nan, dtype=et)   # NaN fill in either encoding
     alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
-    rc = _load().vmi_oracle_paged_attention_v2(
-        _base_ptr(out), _base_ptr(exp_sums), _base_ptr(max_logits), _base_ptr(tmp_out), _base_ptr(query),
-        _base_ptr(key_cache), _base_ptr(value_cache), S, H, D, int(num_kv_heads), float(scale),
-        _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size), int(max_seq_len),
-        int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
-        1 if bf16 else 0)
+    args = (_base_ptr(out), _base_ptr(exp_sums), _base_ptr(max_logits), _base_ptr(tmp_out), _base_ptr(query),
+            _base_ptr(key_cache), _base_ptr(value_cache), S, H, D, int(num_kv_heads), float(scale),
+            _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size), int(max_seq_len),
+            int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
+            1 if bf16 else 0)
+    if blocksparse is not None:
+        loc, vert, bsz, step = (int(v) for v in blocksparse)
+        rc = _load().vmi_oracle_paged_attention_v2_blocksparse(*args, int(tp_rank), loc, vert, bsz, step)
+    else:
+        rc = _load().vmi_oracle_paged_attention_v2(*args)
     if rc == 1:
         raise RuntimeError(f"Unsupported head size / block size: {D} / {block_size}")
     if rc != 0:

@@ -343,3 +343,56 @@ def test_fp8_kernel_model_is_the_f16_model_on_dequantised_caches():
         assert np.array_equal(kc[b, :, :, o, :].reshape(Hkv, D), ek)
         assert np.array_equal(vc[b, :, :, o], ev)
     assert (vc == 0x7e).any() or (vc == 0xfe).any()                          # saturation was exercised
+
+
+# ------------------------------------------------------------------------------------------------
+# block-sparse attention (blocksparse_vert_stride > 1): the restatement of attention_kernels.cu:209-254, 385-393
+# against an independently written masked fp64 attention.  The reference holds no fixture for this mode (its callers
+# never enable it, gpt2.py:109-112) — "parity unpinned" for these five arguments beyond this check.
+# ------------------------------------------------------------------------------------------------
+def masked_exact_attention(case, H, hkv, D, bs, sparse, tp_rank):
+    loc, vert, bsz, step = sparse
+    NB = case["kc"].shape[0]
+    kk = case["kc"].astype(np.float64).transpose(0, 1, 3, 2, 4).reshape(NB, hkv, bs, D)
+    vv = case["vc"].astype(np.float64).transpose(0, 1, 3, 2)
+    out = np.zeros((len(case["lens"]), H, D))
+    skipped = 0
+    for s, L in enumerate(case["lens"]):
+        if L == 0:
+            continue
+        nb = (L + bs - 1) // bs
+        for h in range(H):
+            kvh = h // (H // hkv)
+            K = kk[case["tables"][s, :nb], kvh].reshape(-1, D)[:L]
+            V = vv[case["tables"][s, :nb], kvh].reshape(-1, D)[:L]
+            off = (tp_rank * H + h) * step + 1 if step >= 0 else (tp_rank * hkv + kvh) * (-step) + 1
+            tok = np.arange(L)
+            sparse_blk = (tok // bs) * bs // bsz                 # classified per cache block, by its first token
+            att = ((sparse_blk + off) % vert == 0) | (sparse_blk > (L - 1) // bsz - loc)
+            skipped += int((~att).sum())
+            if att.any():
+                lg = np.where(att, (K @ case["q"][s, h].astype(np.float64)) * case["scale"], -np.inf)
+                pr = np.exp(lg - lg.max())
+                out[s, h] = (pr / pr.sum()) @ V
+    return out, skipped
+
+
+@pytest.mark.parametrize("cfg", [(4, 4, 64, 16, (2, 4, 64, 1), 0), (8, 2, 128, 16, (1, 3, 32, -1), 1),
+                                 (4, 2, 64, 8, (0, 2, 16, 2), 0), (3, 3, 80, 32, (4, 8, 64, 0), 0)],
+                         ids=lambda c: f"H{c[0]}_{c[1]}_D{c[2]}_bs{c[3]}_sp{'_'.join(map(str, c[4]))}")
+def test_blocksparse_kernel_model_matches_masked_attention(cfg):
+    H, hkv, D, bs, sparse, tp = cfg
+    rng = np.random.default_rng(H * D + bs)
+    lens = np.array([1, 17, 200, 700, 64, 0, 333], np.int32)
+    case = make_case(rng, len(lens), H, D, lens, num_kv_heads=hkv, block_size=bs)
+    exact, skipped = masked_exact_attention(case, H, hkv, D, bs, sparse, tp)
+    assert skipped > 500                                          # the pattern really drops tokens
+    a = (case["q"], case["kc"], case["vc"], hkv, case["scale"], case["tables"], case["lens"], bs)
+    v1 = oracle.paged_attention_v1(*a, blocksparse=sparse, tp_rank=tp, threads=4).astype(np.float64)
+    v2 = oracle.paged_attention_v2(*a, 1024, blocksparse=sparse, tp_rank=tp)[0].astype(np.float64)
+    dense = oracle.paged_attention_v1(*a, threads=4).astype(np.float64)
+    assert np.abs(v1 - exact).max() < 1e-3 and np.abs(v2 - exact).max() < 1e-3
+    assert np.abs(v1 - dense).max() > 1e-2                        # ... and that changes the answer
+    # vert_stride <= 1 is the dense operator
+    same = oracle.paged_attention_v1(*a, blocksparse=(sparse[0], 1, sparse[2], sparse[3]), tp_rank=tp, threads=4)
+    assert np.array_equal(same, dense.astype(np.float16))

@@ -487,8 +487,7 @@ def test_errors_raise_runtimeerror():
         call(good, kvd="fp8")                                        # fp8 needs byte caches
     with pytest.raises(RuntimeError, match="kv cache"):
         call(good, kvd="int4")                                       # quant_utils.cuh:564
-    with pytest.raises(RuntimeError, match="block-sparse"):
-        call(good, vert=2)
+    call(good, vert=2)                                               # block-sparse attention is built (test_blocksparse_*)
     with pytest.raises(RuntimeError, match="int32"):
         call(good, lens=torch.from_numpy(good["lens"].astype(np.int64)).to(dev))
     with pytest.raises(RuntimeError, match="Unsupported input type"):
@@ -1485,6 +1484,95 @@ def test_gqa_shared_tile_kernels_match_kernel_model(D):
             _append_vs_two_ops(case, vid, seed=vid, what=f"append {name} H{H}/{hkv}")
             ran += 1
         assert ran >= 3, (H, hkv, ran)
+
+
+# ------------------------------------------------------------------------------------------------
+# block-sparse attention: the operators called with blocksparse_vert_stride > 1
+# ------------------------------------------------------------------------------------------------
+def _run_sparse(case, sparse, tp_rank=0, alibi=None, bf16=False, v2_msl=0):
+    ext = _ext()
+    dev = _dev()
+    S, H, D = case["q"].shape
+    bs = case.get("bs", BS)
+    if bf16:
+        q = _bf16_tensor(case["qbuf"], dev)[:, : H * D].view(S, H, D)
+        kc, vc = _bf16_tensor(case["kc"], dev), _bf16_tensor(case["vc"], dev)
+    else:
+        q = torch.from_numpy(case["qbuf"]).to(dev)[:, : H * D].view(S, H, D)
+        kc, vc = torch.from_numpy(case["kc"]).to(dev), torch.from_numpy(case["vc"]).to(dev)
+    tab, lens = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
+    al = None if alibi is None else torch.from_numpy(alibi).to(dev)
+    out = torch.full((S, H, D), float("nan"), dtype=q.dtype, device=dev)
+    loc, vert, bsz, step = sparse
+    if v2_msl:
+        P = (v2_msl + 511) // 512
+        es = torch.full((S, H, P), float("nan"), dtype=torch.float32, device=dev)
+        ml = torch.full((S, H, P), float("nan"), dtype=torch.float32, device=dev)
+        tmp = torch.full((S, H, P, D), float("nan"), dtype=q.dtype, device=dev)
+        ext.paged_attention_v2(out, es, ml, tmp, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, bs, v2_msl,
+                               al, "auto", 1.0, tp_rank, loc, vert, bsz, step)
+    else:
+        ext.paged_attention_v1(out, q, kc, vc, case["num_kv_heads"], case["scale"], tab, lens, bs,
+                               max(int(case["lens"].max()), 1), al, "auto", 1.0, tp_rank, loc, vert, bsz, step)
+    torch.cuda.synchronize()
+    return out.view(torch.int16).cpu().numpy().view(np.uint16) if bf16 else out.cpu().numpy()
+
+
+SPARSE_PATTERNS = [((2, 4, 64, 1), 0), ((1, 3, 32, -1), 1), ((0, 2, 16, 2), 0), ((4, 8, 64, 0), 3), ((1, 2, 128, 1), 0)]
+
+
+@pytest.mark.parametrize("bs", ALL_BLOCKS)
+@pytest.mark.parametrize("D", ALL_HEADS)
+def test_blocksparse_every_head_and_block_size(D, bs):
+    """v1 and v2, fp16 and bf16, grouped KV heads, against the kernel model with the same five arguments."""
+    rng = np.random.default_rng(31 * D + bs)
+    lens = [1, bs + 1, 200, 700, 64, 0, 333, 1024]
+    case = make_case(rng, len(lens), 4, D, lens, q_row_pad=1, poison_tail=True, block_size=bs, num_kv_heads=2)
+    sparse, tp = SPARSE_PATTERNS[(D // 16 + bs) % len(SPARSE_PATTERNS)]
+    a = (case["q"], case["kc"], case["vc"], 2, case["scale"], case["tables"], case["lens"], bs)
+    ref = oracle.paged_attention_v1(*a, blocksparse=sparse, tp_rank=tp, threads=8)
+    dense = oracle.paged_attention_v1(*a, threads=8)
+    assert np.abs(ref.astype(np.float32) - dense.astype(np.float32)).max() > 1e-2       # the pattern bites
+    assert_close(_run_sparse(case, sparse, tp), ref, f"sparse v1 D{D} bs{bs} {sparse}")
+    ref2 = oracle.paged_attention_v2(*a, 1024, blocksparse=sparse, tp_rank=tp)[0]
+    assert_close(_run_sparse(case, sparse, tp, v2_msl=1024), ref2, f"sparse v2 D{D} bs{bs} {sparse}")
+    cb = _to_bf16_case(case)
+    ab = (cb["q"], cb["kc"], cb["vc"], 2, cb["scale"], cb["tables"], cb["lens"], bs)
+    refb = oracle.paged_attention_v1(*ab, blocksparse=sparse, tp_rank=tp, threads=8, bf16=True)
+    assert_close_bf16(_run_sparse(cb, sparse, tp, bf16=True), refb, f"sparse bf16 v1 D{D} bs{bs}")
+    refb2 = oracle.paged_attention_v2(*ab, 1024, blocksparse=sparse, tp_rank=tp, bf16=True)[0]
+    assert_close_bf16(_run_sparse(cb, sparse, tp, bf16=True, v2_msl=1024), refb2, f"sparse bf16 v2 D{D} bs{bs}")
+
+
+def test_blocksparse_patterns_alibi_small_and_large_batches():
+    """Every pattern incl. all-blocks-skipped heads (local_blocks = 0), ALiBi, a batch large enough for the
+    one-wave-per-head kernels and one small enough for four waves per head."""
+    rng = np.random.default_rng(77)
+    alibi = (2.0 ** -np.arange(1, 13)).astype(np.float32)
+    for S, lens_top in ((3, 900), (300, 130)):
+        lens = rng.integers(1, lens_top + 1, S).astype(np.int32)
+        lens[0] = lens_top
+        case = make_case(rng, S, 12, 64, lens, poison_tail=True)
+        a = (case["q"], case["kc"], case["vc"], 12, case["scale"], case["tables"], case["lens"], 16)
+        for sparse, tp in SPARSE_PATTERNS:
+            for al in (None, alibi):
+                ref = oracle.paged_attention_v1(*a, alibi_slopes=al, blocksparse=sparse, tp_rank=tp, threads=8)
+                assert_close(_run_sparse(case, sparse, tp, alibi=al), ref, f"sparse S{S} {sparse} alibi={al is not None}")
+
+
+def test_blocksparse_argument_errors():
+    rng = np.random.default_rng(5)
+    case = make_case(rng, 2, 4, 64, [40, 70])
+    with pytest.raises(RuntimeError, match="blocksparse_block_size"):
+        _run_sparse(case, (1, 2, 0, 1))
+    c8 = _fp8_case(rng, 2, 4, 64, [40, 70], 16)
+    from vllmini_amd import ops
+    dev = _dev()
+    q = torch.from_numpy(c8["qbuf"]).to(dev)[:, : 4 * 64].view(2, 4, 64)
+    with pytest.raises(RuntimeError, match="block-sparse"):
+        ops.paged_attention_v1(torch.empty_like(q), q, torch.from_numpy(c8["kq"]).to(dev), torch.from_numpy(c8["vq"]).to(dev),
+                               4, 0.125, torch.from_numpy(c8["tables"]).to(dev), torch.from_numpy(c8["lens"]).to(dev),
+                               16, 70, None, "fp8", 1.0, 0, 1, 2, 16, 1)
 
 
 def test_gqa_pv_on_matrix_cores_is_opt_in():

@@ -36,6 +36,8 @@ SIGNATURES = {
     "vmi_paged_attention_v1_f16_variant": (ctypes.c_int, list(_PA_ARGS) + [_i32]),
     "vmi_paged_attention_v1_bf16": (ctypes.c_int, list(_PA_ARGS) + [_i32]),
     "vmi_paged_attention_v2_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32]),
+    "vmi_paged_attention_v1_blocksparse": (ctypes.c_int, list(_PA_ARGS) + [_i32] * 6),
+    "vmi_paged_attention_v2_blocksparse": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32] * 6),
     "vmi_paged_attention_v1_append_f16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
     "vmi_paged_attention_v1_append_bf16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
     "vmi_paged_attention_v1_fp8": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32]),
@@ -71,7 +73,7 @@ SIGNATURES = {
     ]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lock = threading.Lock()
 _lib = None

@@ -265,6 +265,9 @@ struct PAParams {
   int64_t key_stride;
   int64_t value_stride;
   float kv_scale;  // fp8 cache only (F8): cache element = fp8(x / kv_scale)
+  // block-sparse attention (SPARSE kernels only; the operator's tp_rank + four blocksparse_* arguments,
+  // attention_kernels.cu:108-110): a cache block is read when its sparse block is "remote" or "local" (:232-254)
+  int32_t bs_tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -300,7 +303,7 @@ struct PAParams {
 // ----------------------------------------------------------------------------------------
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
           bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0, bool F8 = false,
-          bool GQS = false, bool FPV = false>
+          bool GQS = false, bool FPV = false, bool SPARSE = false>
 // (second launch bound = minimum waves per SIMD.  The adaptive-depth kernels are the full-chip defaults: 12 waves
 //  per CU = 3 per SIMD that must ALL be resident, i.e. stay under 170 VGPRs — the fused-append form had drifted to 180
 //  and ran 173 us instead of 125.  Not applied elsewhere: on the big-tile kernels it only forces spills.)
@@ -332,6 +335,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   // reference but not within an ulp of it.
   static_assert(!FPV || (GQS && BS == 16 && D % 32 == 0 && U % (F8 ? 4 : 2) == 0 && !LOADS_ONLY && UMAX == 0),
                 "FPV: grouped-query kernels, block size 16, pairs (fp8 pages: quads) of blocks per register group");
+  static_assert(!SPARSE || (HPT == 1 && !APP && !F8 && !LOADS_ONLY && UMAX == 0 && !LOCK),
+                "block-sparse kernels: one head per wave (the stripe pattern slides per head), 16-bit caches");
   constexpr int VG = F8 ? 4 : 2;  // FPV: blocks that share one MFMA's K = 32 tokens (8 per block with fp8 pages, 16 else)
   static_assert(!F8 || (BS >= 16 && D % 16 == 0 && !APP && !LOADS_ONLY),
                 "fp8 cache: block size 16 or 32 (a V row must fill whole 16-byte units), no fused append");
@@ -411,6 +416,22 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   const bool tail_ok = (TAIL == 64) || lane < TAIL;  // this lane takes part in the last load of a tile
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int qpk = p.num_heads / p.num_kv_heads;
+  // SPARSE (attention_kernels.cu:209-254, 385-393): cache block b is attended when the sparse block holding its first
+  // token is "remote" — on this head's vertical stripe — or "local" — within local_blocks of the query's sparse block.
+  // The attended blocks are listed up front (ablk, below) and the passes walk that list, so the loads in flight are
+  // all useful ones; skipped blocks get logits -FLT_MAX (exp -> 0) and no P.V contribution.
+  int bs_off = 0, q_bs = 0;
+  if constexpr (SPARSE) {
+    q_bs = (L - 1) / p.bs_block_size;  // :215
+    bs_off = p.bs_head_sliding_step >= 0
+                 ? (p.bs_tp_rank * p.num_heads + head0) * p.bs_head_sliding_step + 1          // :216-219
+                 : (p.bs_tp_rank * p.num_kv_heads + head0 / qpk) * (-p.bs_head_sliding_step) + 1;  // :220-224
+  }
+  auto attended = [&](int b) -> bool {
+    if constexpr (!SPARSE) return true;
+    const int kb = b * BS / p.bs_block_size;  // :235
+    return ((kb + bs_off) % p.bs_vert_stride == 0) || (kb > q_bs - p.bs_local_blocks);
+  };
   int64_t hoff[HPT];
   float slope[HPT];
   u32x4 qreg[HPT][NL][F8 ? 2 : 1];  // the EPU dims of q that face this lane's chunk of each K load
@@ -491,7 +512,35 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   float qmaxB = -FLT_MAX;  // QK_MFMA: running max of head (lane & 15) over this lane's token rows
 
   // ---- my share of the blocks: b = blk_lo + sub + idx*WPH, idx in [0, nmy) ----------------
-  const int nmy = nblk > sub ? (nblk - sub + WPH - 1) / WPH : 0;
+  //      (SPARSE: the idx-th block of this wave is entry sub + idx*WPH of the list of attended blocks)
+  int natt = nblk;
+  int32_t* ablk = nullptr;
+  if constexpr (SPARSE) {
+    // every wave builds the same ascending list (same values to the same LDS words: no barrier needed before a wave
+    // reads what it wrote itself); the -FLT_MAX fill of skipped blocks is shared out by 64-block chunk and is
+    // complete at the barrier in front of the softmax
+    ablk = reinterpret_cast<int32_t*>(smem_f + (size_t)HPW * HPT * p.lpad + HPW * HPT * 2 * WPH +
+                                      (size_t)HPW * HPT * WPH * D + (WPH > 1 ? (size_t)HPW * HPT * p.lpad / 2 : 0)) +
+           (size_t)hl * (p.lpad / 8);
+    natt = 0;
+    for (int c = 0; c * 64 < nblk; ++c) {
+      const int b = blk_lo + c * 64 + lane;
+      const bool in = c * 64 + lane < nblk;
+      const bool att = in && attended(b);
+      const uint64_t m = __ballot(att);
+      if (att) ablk[natt + __popcll(m & ((1ull << lane) - 1ull))] = b;
+      if (in && !att && (c % WPH) == sub) {  // :240-252
+        for (int t = 0; t < BS; ++t) logits0[(b - blk_lo) * BS + t] = -FLT_MAX;
+      }
+      natt += __popcll(m);
+    }
+    bt_sg = -1;  // the table prefetch above was for the dense order
+  }
+  const int nmy = natt > sub ? (natt - sub + WPH - 1) / WPH : 0;
+  auto block_of = [&](int idx) -> int {  // wave-uniform
+    if constexpr (SPARSE) return __builtin_amdgcn_readfirstlane(ablk[sub + idx * WPH]);
+    else return blk_lo + sub + idx * WPH;
+  };
 
   float qk_max[HPT];
 #pragma unroll
@@ -545,7 +594,11 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     auto table_for = [&](int g) {  // lane j: physical id of my block (bt_sg*64 + j)
       const int sg = (g * UU) >> 6;
       if (sg != bt_sg) {
-        const int b = blk_lo + sub + (sg * 64 + lane) * WPH;
+        int b = blk_lo + sub + (sg * 64 + lane) * WPH;
+        if constexpr (SPARSE) {
+          const int a = sub + (sg * 64 + lane) * WPH;
+          b = a < natt ? ablk[a] : 0;
+        }
         bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
         bt_sg = sg;
       }
@@ -624,7 +677,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       for (int j = 0; j < UU; ++j) {
         const int idx = g * UU + j;
         if (idx < nmy) {  // wave-uniform
-          const int b = blk_lo + sub + idx * WPH;
+          const int b = block_of(idx);
           const int token = b * BS + tk;
           const bool masked = token >= L;
           if constexpr (QK_MFMA) {
@@ -810,7 +863,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
           const float* lg = logits0 + hh * p.lpad;
           uint16_t* ph = ph0 + hh * ph_stride;
           for (int t = lane; t < nmy * BS; t += 64) {
-            const int i = (sub + (t / BS) * WPH) * BS + (t % BS);  // relative to tok_lo
+            int i = (sub + (t / BS) * WPH) * BS + (t % BS);  // relative to tok_lo
+            if constexpr (SPARSE) i = (ablk[sub + (t / BS) * WPH] - blk_lo) * BS + (t % BS);
             const float e = lg[i];
             // in place (WPH == 1, i == t): the 64 lanes read fp32 values [t0, t0+64) and then write bytes
             // [2*t0, 2*t0+128), i.e. fp32 slots [t0/2, t0/2+32) — already consumed, or being read by this very access
@@ -898,7 +952,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       for (int j = 0; j < UU; ++j) {
         const int idx = g * UU + j;
         if (idx < nmy) {  // wave-uniform
-          const int b = blk_lo + sub + idx * WPH;
+          const int b = block_of(idx);
           const int token0 = b * BS + hf * EPU;
           const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
   #pragma unroll
@@ -1178,6 +1232,7 @@ struct Variant {
   bool F8;           // caches hold fp8 E4M3 bytes (kv_cache_dtype "fp8")
   bool GQS;          // the HPT query heads of a wave share one KV head: num_heads / num_kv_heads % HPT == 0 required
   bool FPV;          // opt-in: probabilities x V on the matrix cores too (vmi_set_pv_mfma); north-star bound, not 1 ulp
+  bool SPARSE;       // block-sparse attention (blocksparse_vert_stride > 1); menus of their own (pa_variants_sparse.hip)
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
@@ -1215,6 +1270,16 @@ typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const 
    0, 0, 0, false, true, true},
 #define VMI_ROW(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT) \
   VMI_ROW_A(NAME, D, BS, HPW, WPH, U, NT, LO, LOCK, BF, HPT, 0)
+
+// block-sparse rows (pa_variants_sparse.hip): one head per wave, v1 (PART = false) and v2 partitions (PART = true)
+#define VMI_ROW_SP(NAME, D, BS, WPH, U, BF, PART)                                                                  \
+  {NAME, D, BS, 1, WPH, U, true, 1, BF,                                                                            \
+   (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, PART, BS, false, BF, 1, false, 0, false, false, false, true>, \
+   0, 0, 0, false, false, false, true},
+extern Variant g_sparse_variants[];
+extern const int g_sparse_nvariants;
+extern Variant g_sparse_bf16_variants[];
+extern const int g_sparse_bf16_nvariants;
 
 // kernels for the non-core (head size, block size) combinations live in pa_variants_extra.hip
 extern Variant g_extra_variants_v1[];

@@ -601,6 +601,30 @@ static Variant* app_variant_v1(int id) {
   return nullptr;  // fp8-cache variants have no fused-append twin
 }
 
+// ---- block-sparse attention (blocksparse_vert_stride > 1): kernels of their own (pa_variants_sparse*.hip) ----
+// bsp = {tp_rank, local_blocks, vert_stride, blocksparse_block_size, head_sliding_step}
+static Variant* find_sparse(int D, int BS, int WPH, bool bf, bool part) {
+  Variant* tab = bf ? g_sparse_bf16_variants : g_sparse_variants;
+  const int n = bf ? g_sparse_bf16_nvariants : g_sparse_nvariants;
+  for (int i = 0; i < n; ++i) {
+    const bool is_part = strstr(tab[i].name, "_v2_") != nullptr;
+    if (tab[i].D == D && tab[i].BS == BS && tab[i].WPH == WPH && is_part == part) return &tab[i];
+  }
+  return nullptr;
+}
+static int check_sparse(const char* op, const int32_t* bsp) {
+  if (bsp[2] <= 1) return fail(VMI_E_SHAPE, "%s: blocksparse_vert_stride=%d does not enable block-sparse attention", op, bsp[2]);
+  if (bsp[3] <= 0) return fail(VMI_E_SHAPE, "%s: blocksparse_block_size=%d must be positive", op, bsp[3]);
+  return VMI_OK;
+}
+static void fill_sparse(PAParams& p, const int32_t* bsp) {
+  p.bs_tp_rank = bsp ? bsp[0] : 0;
+  p.bs_local_blocks = bsp ? bsp[1] : 0;
+  p.bs_vert_stride = bsp ? bsp[2] : 1;
+  p.bs_block_size = bsp ? bsp[3] : 1;
+  p.bs_head_sliding_step = bsp ? bsp[4] : 0;
+}
+
 static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         const void* value_cache, int32_t num_seqs, int32_t num_heads,
                         int32_t head_size, int32_t num_kv_heads, float scale,
@@ -610,9 +634,13 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         int64_t kv_head_stride, int32_t device, void* stream, int32_t variant,
                         bool bf = false, bool append = false, const void* key = nullptr,
                         const void* value = nullptr, int64_t key_stride = 0, int64_t value_stride = 0,
-                        bool f8 = false, float kv_scale = 1.0f) {
+                        bool f8 = false, float kv_scale = 1.0f, const int32_t* bsp = nullptr) {
   if (!out || !query || !key_cache || !value_cache || !block_tables || !seq_lens)
     return fail(VMI_E_NULL_POINTER, "paged_attention_v1: NULL tensor pointer");
+  if (bsp) {
+    if (int rc = check_sparse("paged_attention_v1", bsp)) return rc;
+    if (append || f8) return fail(VMI_E_VARIANT, "paged_attention_v1: block-sparse attention is built for fp16 / bf16 caches, without the fused append");
+  }
   if (append) {
     if (!key || !value) return fail(VMI_E_NULL_POINTER, "paged_attention_v1_append: NULL key/value pointer");
     // the fused kernel moves a key row as 16-B chunks (the stand-alone reshape_and_cache has a scalar path)
@@ -646,9 +674,17 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
   auto lds_of = [&](const Variant& c) {
     return (size_t)c.HPW * c.HPT *
-           ((size_t)lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? (size_t)lpad * 2 : 0));
+           ((size_t)lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? (size_t)lpad * 2 : 0) +
+            (c.SPARSE ? (size_t)lpad / 2 : 0));  // SPARSE: the list of attended blocks, one int per block (BS >= 8)
   };
-  if (variant == 0) {
+  Variant* sparse_v = nullptr;
+  if (bsp) {  // one or four waves per head, by how many (seq, head) units there are to fill the chip with
+    const int nblk = (max_seq_len + block_size - 1) / block_size;
+    const bool many = (long)num_seqs * num_heads >= 3072 || nblk < 4;
+    sparse_v = find_sparse(head_size, block_size, many ? 1 : 4, bf, false);
+    if (sparse_v && lds_of(*sparse_v) > 160 * 1024) sparse_v = find_sparse(head_size, block_size, 1, bf, false);
+    if (!sparse_v) return fail(VMI_E_VARIANT, "paged_attention_v1: no block-sparse kernel for head size %d / block size %d", head_size, block_size);
+  } else if (variant == 0) {
     variant = pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size, max_seq_len, bf, f8);
     if (!variant || (append && !app_variant_v1(variant)))
       variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf)
@@ -662,9 +698,9 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
       if (alt) variant = alt;
     }
   }
-  if (variant < 1 || variant > nvariants_v1())
+  if (!sparse_v && (variant < 1 || variant > nvariants_v1()))
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
-  Variant* vp = append ? app_variant_v1(variant) : &variant_v1(variant);
+  Variant* vp = sparse_v ? sparse_v : (append ? app_variant_v1(variant) : &variant_v1(variant));
   if (!vp) return fail(VMI_E_VARIANT, "paged_attention_v1_append: kernel menus out of step (build error)");
   Variant& v = *vp;
   if (append && is_diag(v))
@@ -726,6 +762,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   p.key_stride = key_stride;
   p.value_stride = value_stride;
   p.kv_scale = kv_scale;
+  fill_sparse(p, bsp);
 
   dim3 block(v.HPW * v.WPH * 64);
   // gridDim.y is limited to 65535: longer batches go out as consecutive launches over slices
@@ -839,7 +876,11 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
                         int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
                         int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
                         int32_t device, void* stream, int32_t variant, bool bf = false, bool f8 = false,
-                        float kv_scale = 1.0f) {
+                        float kv_scale = 1.0f, const int32_t* bsp = nullptr) {
+  if (bsp) {
+    if (int rc = check_sparse("paged_attention_v2", bsp)) return rc;
+    if (f8) return fail(VMI_E_VARIANT, "paged_attention_v2: block-sparse attention is built for fp16 / bf16 caches");
+  }
   if (!out || !exp_sums || !max_logits || !tmp_out || !query || !key_cache || !value_cache ||
       !block_tables || !seq_lens)
     return fail(VMI_E_NULL_POINTER, "paged_attention_v2: NULL tensor pointer");
@@ -863,11 +904,16 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   const int parts = (max_seq_len + 511) / 512;  // attention_kernels.cu:885
   if (num_seqs == 0 || parts == 0) return VMI_OK;
   if (parts > 65535) return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v2: too many partitions");
-  if (variant == 0)
+  Variant* sparse_v = nullptr;
+  if (bsp) {
+    sparse_v = find_sparse(head_size, block_size, (long)num_seqs * num_heads * parts >= 3072 ? 1 : 4, bf, true);
+    if (!sparse_v) return fail(VMI_E_VARIANT, "paged_attention_v2: no block-sparse kernel for head size %d / block size %d", head_size, block_size);
+  } else if (variant == 0) {
     variant = pick_variant_v2(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, f8, num_heads / num_kv_heads);
-  if (variant < 1 || variant > nvariants_v2())
+  }
+  if (!sparse_v && (variant < 1 || variant > nvariants_v2()))
     return fail(VMI_E_VARIANT, "paged_attention_v2: unknown variant %d", variant);
-  Variant& v = variant_v2(variant);
+  Variant& v = sparse_v ? *sparse_v : variant_v2(variant);
   if (v.F8 != f8)
     return fail(VMI_E_VARIANT, "paged_attention_v2: variant %s is for an %s KV cache", v.name, v.F8 ? "fp8" : "fp16/bf16");
   if (v.BF != bf)
@@ -887,7 +933,8 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
 
   const int lpad = 512;  // one partition of logits (:886)
   const size_t lds = (size_t)v.HPW * v.HPT *
-                     ((size_t)lpad * 4 + 2 * v.WPH * 4 + (size_t)v.WPH * v.D * 4 + (v.WPH > 1 ? (size_t)lpad * 2 : 0));
+                     ((size_t)lpad * 4 + 2 * v.WPH * 4 + (size_t)v.WPH * v.D * 4 + (v.WPH > 1 ? (size_t)lpad * 2 : 0) +
+                      (v.SPARSE ? (size_t)lpad / 2 : 0));
   PAParams p;
   p.out = static_cast<h16*>(tmp_out);
   p.q = static_cast<const h16*>(query);
@@ -912,6 +959,7 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   p.key_stride = 0;
   p.value_stride = 0;
   p.kv_scale = kv_scale;
+  fill_sparse(p, bsp);
   dim3 grid((num_heads + v.HPW * v.HPT - 1) / (v.HPW * v.HPT), num_seqs, parts);  // :890
   hipLaunchKernelGGL(v.fn, grid, dim3(v.HPW * v.WPH * 64), lds, static_cast<hipStream_t>(stream), p);
   e = hipGetLastError();
@@ -952,6 +1000,43 @@ int vmi_paged_attention_v1_f16(void* out, const void* query, const void* key_cac
                            num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
                            max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
                            kv_head_stride, device, stream, 0);
+}
+
+int vmi_paged_attention_v1_blocksparse(void* out, const void* query, const void* key_cache,
+                                       const void* value_cache, int32_t num_seqs, int32_t num_heads,
+                                       int32_t head_size, int32_t num_kv_heads, float scale,
+                                       const int32_t* block_tables, const int32_t* seq_lens,
+                                       int32_t block_size, int32_t max_seq_len,
+                                       int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                                       int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                       int32_t device, void* stream, int32_t is_bf16, int32_t tp_rank,
+                                       int32_t blocksparse_local_blocks, int32_t blocksparse_vert_stride,
+                                       int32_t blocksparse_block_size, int32_t blocksparse_head_sliding_step) {
+  const int32_t bsp[5] = {tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                          blocksparse_head_sliding_step};
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, 0, is_bf16 != 0, false, nullptr, nullptr, 0, 0, false,
+                           1.0f, bsp);
+}
+
+int vmi_paged_attention_v2_blocksparse(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                                       const void* query, const void* key_cache, const void* value_cache,
+                                       int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                       int32_t num_kv_heads, float scale, const int32_t* block_tables,
+                                       const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
+                                       int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                                       int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                       int32_t device, void* stream, int32_t is_bf16, int32_t tp_rank,
+                                       int32_t blocksparse_local_blocks, int32_t blocksparse_vert_stride,
+                                       int32_t blocksparse_block_size, int32_t blocksparse_head_sliding_step) {
+  const int32_t bsp[5] = {tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                          blocksparse_head_sliding_step};
+  return vmi::launch_pa_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
+                           head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride, kv_head_stride,
+                           device, stream, 0, is_bf16 != 0, false, 1.0f, bsp);
 }
 
 int vmi_paged_attention_v1_f16_variant(void* out, const void* query, const void* key_cache,

@@ -85,9 +85,12 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
         # (its callers only use half: gpt2.py, scheduler.py:13); fp32 has a different cache layout (x = 4)
         raise RuntimeError(f"Unsupported input type of paged attention: {query.dtype}")
     fp8 = _check_kv_cache_dtype(kv_cache_dtype)
-    if int(blocksparse_vert_stride) > 1:
-        raise RuntimeError("block-sparse paged attention (blocksparse_vert_stride > 1) is not "
-                           "supported; reference callers always pass vert_stride=1 (gpt2.py:109-112)")
+    if int(blocksparse_vert_stride) > 1:          # is_block_sparse, attention_kernels.cu:822 — kernels of their own
+        if fp8:
+            raise RuntimeError("block-sparse paged attention (blocksparse_vert_stride > 1) is built for "
+                               "kv_cache_dtype='auto' (fp16 / bf16 caches) only")
+        if int(blocksparse_block_size) <= 0:
+            raise RuntimeError(f"blocksparse_block_size must be positive, got {blocksparse_block_size}")
     dev = query.device
     _check_device("query", query, dev)
     for name, t in (("out", out), ("key_cache", key_cache), ("value_cache", value_cache),
@@ -185,7 +188,13 @@ def paged_attention_v1(
                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
                       blocksparse_block_size, blocksparse_head_sliding_step)
     lib = _lib.load()
-    if _check_kv_cache_dtype(kv_cache_dtype):      # fp8 E4M3 cache, float16 or bfloat16 query
+    if int(blocksparse_vert_stride) > 1:           # block-sparse attention: its own kernels, no tuning variants
+        if _variant:
+            raise RuntimeError("_variant does not apply to block-sparse attention")
+        rc = lib.vmi_paged_attention_v1_blocksparse(
+            *args, int(query.dtype == torch.bfloat16), int(tp_rank), int(blocksparse_local_blocks),
+            int(blocksparse_vert_stride), int(blocksparse_block_size), int(blocksparse_head_sliding_step))
+    elif _check_kv_cache_dtype(kv_cache_dtype):      # fp8 E4M3 cache, float16 or bfloat16 query
         fn = lib.vmi_paged_attention_v1_fp8_bf16 if query.dtype == torch.bfloat16 else lib.vmi_paged_attention_v1_fp8
         rc = fn(*args, float(kv_scale), int(_variant))
     elif query.dtype == torch.bfloat16:
@@ -296,7 +305,14 @@ def paged_attention_v2(
                                f"(max_num_partitions = ceil(max_seq_len/512) = {parts})")
     if fp8 and query.dtype != torch.float16:
         raise RuntimeError("paged_attention_v2 over an fp8 KV cache is built for float16 query/out only")
-    if fp8:
+    if int(blocksparse_vert_stride) > 1:
+        if _variant:
+            raise RuntimeError("_variant does not apply to block-sparse attention")
+        rc = _lib.load().vmi_paged_attention_v2_blocksparse(
+            args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:],
+            int(query.dtype == torch.bfloat16), int(tp_rank), int(blocksparse_local_blocks),
+            int(blocksparse_vert_stride), int(blocksparse_block_size), int(blocksparse_head_sliding_step))
+    elif fp8:
         rc = _lib.load().vmi_paged_attention_v2_fp8(args[0], exp_sums.data_ptr(), max_logits.data_ptr(),
                                                     tmp_out.data_ptr(), *args[1:], float(kv_scale), int(_variant))
     else:
