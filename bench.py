@@ -78,7 +78,7 @@ def parse_args():
                     help="physically sequential pages instead of a random permutation (diagnostic)")
     ap.add_argument("--ragged", action="store_true", help="seq_lens ~ U{1..L} (diagnostic)")
     ap.add_argument("--ragged-sorted", action="store_true", help="same lengths, longest sequence first (diagnostic)")
-    ap.add_argument("--kv", default="auto", choices=["auto", "fp8"],
+    ap.add_argument("--kv", default="auto", choices=["auto", "fp8", "fp8_e5m2"],
                     help="KV cache element type: auto = fp16 (the BASELINE metric); fp8 = E4M3 bytes (diagnostic line, "
                          "SURVEY row f-4)")
     ap.add_argument("--matrix", action="store_true",
@@ -124,13 +124,16 @@ def init_dist(n_gpus: int):
 
 _V2_SCRATCH = {}
 SKIP_RESHAPE = False
-KV_DTYPE = "auto"      # "fp8": byte caches in the x = 16 layout (--kv fp8)
+KV_DTYPE = "auto"      # "fp8" / "fp8_e5m2": byte caches in the x = 16 layout (--kv)
+KV_PREFIX = {"auto": "", "fp8": "fp8_", "fp8_e5m2": "fp8e5m2_"}          # variant-name prefixes
+FP8_ARG = {"auto": False, "fp8": True, "fp8_e5m2": "e5m2"}               # ops.pick_variant(fp8=...)
+KV_LABEL = {"auto": "fp16", "fp8": "fp8 E4M3", "fp8_e5m2": "fp8 E5M2"}
 
 
 def alg_bytes(cfg):
     """Algorithmic bytes per attention launch; an fp8 cache halves the K/V term."""
     b = cfg.algorithmic_bytes()
-    if KV_DTYPE == "fp8":
+    if KV_DTYPE.startswith("fp8"):
         b -= 2 * cfg.batch * cfg.kv_heads * cfg.seq_len * cfg.head_size
     return b
 
@@ -252,7 +255,7 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
     pool = PagedKVPool(blocks_needed + 64, dims.n_head, dims.head_size, cfg.block_size, mb, dims.n_layer, device=dev,
                        max_seqs=cfg.batch, multi_block_prefill=True, kv_cache_dtype=args.kv)
     g = torch.Generator(device=dev).manual_seed(7 + rank)
-    if args.kv == "fp8":      # random E4M3 codes of magnitude < 2
+    if args.kv.startswith("fp8"):      # random E4M3 / E5M2 codes of magnitude < 2 (codes 0..63 in either format)
         for c in (pool.key_cache, pool.value_cache):
             c.copy_(torch.randint(0, 64, c.shape, dtype=torch.uint8, device=dev, generator=g)
                     | (torch.randint(0, 2, c.shape, dtype=torch.uint8, device=dev, generator=g) << 7))
@@ -287,7 +290,7 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
         res["kv_cache_dtype"] = args.kv
         with open(os.path.join(REPO, "gpurun_out", "e2e_fused.json" if args.e2e_fused else
-                               ("e2e_fp8.json" if args.kv == "fp8" else "e2e.json")), "w") as f:
+                               ("e2e_fp8.json" if args.kv == "fp8" else ("e2e_fp8_e5m2.json" if args.kv == "fp8_e5m2" else "e2e.json"))), "w") as f:
             json.dump(res, f, indent=1)
 
 
@@ -385,8 +388,8 @@ def main():
             seq = torch.arange(cfg.batch * cfg.blocks_per_seq, dtype=torch.int32, device=dev) + t * per
             tab[:, : cfg.blocks_per_seq] = seq.view(cfg.batch, cfg.blocks_per_seq)
     out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
-    if args.kv == "fp8":
-        KV_DTYPE = "fp8"
+    if args.kv.startswith("fp8"):
+        KV_DTYPE = args.kv
         if args.op != "v1":
             raise SystemExit("--kv fp8 is built for --op v1")
         args.no_fused = True
@@ -396,7 +399,7 @@ def main():
         vshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size, cfg.block_size)
         del wl.key_cache, wl.value_cache
         torch.cuda.empty_cache()
-        # random E4M3 codes of magnitude < 2 (exponent field <= 7): no NaN codes, attention-like values
+        # random codes 0..63 + sign: magnitude < 2 in E4M3 (exponent field <= 7) and in E5M2 (<= 15), no NaN codes
         wl.key_cache = (torch.randint(0, 64, kshape, dtype=torch.uint8, device=dev, generator=gk)
                         | (torch.randint(0, 2, kshape, dtype=torch.uint8, device=dev, generator=gk) << 7))
         wl.value_cache = (torch.randint(0, 64, vshape, dtype=torch.uint8, device=dev, generator=gk)
@@ -454,7 +457,7 @@ def main():
         names = ops.variant_names()
         res = []
         for vid, name in enumerate(names, start=1):
-            if not name.startswith(f"{'fp8_' if args.kv == 'fp8' else ''}d{cfg.head_size}_") or "_gq" in name:
+            if not name.startswith(f"{KV_PREFIX[args.kv]}d{cfg.head_size}_") or "_gq" in name:
                 continue            # (gq kernels need num_heads / num_kv_heads > 1: scripts/gqa_probe.py)
             try:
                 _, kern_ms = time_steps(wl, out, args.steps, args.warmup, vid, dist, dev)
@@ -471,14 +474,14 @@ def main():
             with open(os.path.join(REPO, "gpurun_out", f"sweep_{cfg.name}.json"), "w") as f:
                 json.dump({"config": cfg.name, "kv": args.kv,
                            "picked": ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len,
-                                                      fp8=args.kv == "fp8"), "results": res}, f, indent=1)
+                                                      fp8=FP8_ARG[args.kv]), "results": res}, f, indent=1)
         return
 
     SKIP_RESHAPE = args.skip_reshape
     if args.hint_mean and not args.variant and args.op in ("v1", "fused"):
         lens_h = wl.seq_lens.cpu()
         args.variant = ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, int(lens_h.max()), cfg.block_size,
-                                        mean_seq_len=int(lens_h.float().mean()), fp8=args.kv == "fp8")
+                                        mean_seq_len=int(lens_h.float().mean()), fp8=FP8_ARG[args.kv])
     elapsed, kern_ms = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op)
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     kern_mean_ms = shard.max_over_ranks(statistics.mean(kern_ms), dist, dev)
@@ -487,9 +490,9 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     achieved = alg_bytes(cfg) / (kern_mean_ms * 1e-3) / 1e9
     vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len,
-                                           fp8=args.kv == "fp8", num_kv_heads=cfg.kv_heads)
+                                           fp8=FP8_ARG[args.kv], num_kv_heads=cfg.kv_heads)
     vname = ops.variant_names()[vid - 1] if args.op in ("v1", "fused") else f"paged_attention_v2 variant {args.variant or 'auto'}"
-    traffic, traffic_src = (pmc_traffic(cfg.name + ("_fp8" if args.kv == "fp8" else ""), vname) if args.op == "v1" else
+    traffic, traffic_src = (pmc_traffic(cfg.name + {"auto": "", "fp8": "_fp8", "fp8_e5m2": "_fp8_e5m2"}[args.kv], vname) if args.op == "v1" else
                             pmc_traffic(cfg.name + "_fused", vname) if args.op == "fused" else (None, None))
     line = {
         "metric": "decode_tokens_per_sec_paged_attention_v1_per_layer",
@@ -509,7 +512,7 @@ def main():
                         f"seq_len {cfg.seq_len}, {cfg.num_heads} heads"
                         f"{'' if cfg.kv_heads == cfg.num_heads else ' (' + str(cfg.kv_heads) + ' KV heads)'} x {cfg.head_size}, "
                         f"block_size {cfg.block_size}, "
-                        f"num_blocks {cfg.num_blocks}/GPU, {'fp8 E4M3' if args.kv == 'fp8' else 'fp16'} KV, "
+                        f"num_blocks {cfg.num_blocks}/GPU, {KV_LABEL[args.kv]} KV, "
                         f"random-permutation block tables"
                         + (" (SEQUENTIAL tables)" if args.sequential_tables else "")
                         + (" (ragged lens)" if args.ragged else "")

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 11
+#define VMI_ABI_VERSION 12
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -273,6 +273,45 @@ int vmi_reshape_and_cache_fp8_bf16(
 int vmi_paged_attention_v1_pick_variant_fp8_bf16(int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                                  int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len);
 
+/*
+ * kv_cache_dtype "fp8_e5m2" (Fp8KVCacheDataType::kFp8E5M2, __NV_E5M2: quant_utils.cuh:552-558): the same operators
+ * over fp8 E5M2 bytes — an E5M2 byte is the upper byte of an IEEE half, infinities and NaNs included.  Element seen
+ * by the attention arithmetic = half(float(fp8) * kv_scale) (bfloat16 query: bf16(float(fp8) * kv_scale)), cache
+ * byte written by reshape_and_cache = fp8(float(x) / kv_scale), round to nearest even, saturating at +-57344
+ * (__NV_SATFINITE).  Same layouts and limits as the E4M3 entries above (x = 16; block sizes 16 and 32);
+ * is_bf16 selects bfloat16 query / rows.  Variant ids: the "fp8e5m2_" / "bf16_fp8e5m2_" names.
+ */
+int vmi_paged_attention_v1_fp8_e5m2(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream,
+    float kv_scale, int32_t variant, int32_t is_bf16);
+int vmi_paged_attention_v2_fp8_e5m2(   /* float16 query */
+    void* out, void* exp_sums, void* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream,
+    float kv_scale, int32_t variant);
+int vmi_reshape_and_cache_fp8_e5m2(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping,
+    int32_t num_tokens, int32_t num_heads, int32_t head_size, int32_t block_size, int32_t x,
+    int64_t key_stride, int64_t value_stride, float kv_scale,
+    int32_t device, void* stream, int32_t is_bf16);
+int vmi_paged_attention_v1_pick_variant_fp8_e5m2(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                                 int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len,
+                                                 int32_t is_bf16);
+
 /* Number of tuning variants (valid ids are 1..count) and a short name for each. */
 int vmi_paged_attention_v1_variant_count(void);
 const char* vmi_paged_attention_v1_variant_name(int32_t variant);
@@ -286,7 +325,7 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
  */
 int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
                                             int32_t head_size, int32_t block_size, int32_t max_seq_len,
-                                            int32_t is_bf16, int32_t is_fp8);
+                                            int32_t is_bf16, int32_t is_fp8 /* 0, 1 = E4M3, 2 = E5M2 */);
 
 /*
  * Opt-in accuracy/speed switch for grouped-query attention (process-wide, default 0; returns the previous value).

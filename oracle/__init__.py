@@ -24,6 +24,8 @@ from .kernel_model import (  # noqa: F401
     reshape_and_cache,
     # fp8 (E4M3) KV cache — kv_cache_dtype "fp8"
     f32_to_fp8e4m3,
+    f32_to_fp8e5m2,
+    fp8e5m2_to_f32,
     fp8e4m3_to_f32,
     paged_attention_v1_fp8,
     paged_attention_v2_fp8,

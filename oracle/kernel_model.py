@@ -227,8 +227,24 @@ def f32_to_fp8e4m3(x: np.ndarray) -> np.ndarray:
     return np.array([lib.vmi_oracle_f32_to_fp8e4m3(float(v)) for v in flat], dtype=np.uint8).reshape(np.shape(x))
 
 
+def fp8e5m2_to_f32(bits: np.ndarray) -> np.ndarray:
+    """Decode fp8 E5M2 bytes exactly: the upper byte of an IEEE half (kv_cache_dtype "fp8_e5m2", __NV_E5M2)."""
+    b = np.ascontiguousarray(bits, dtype=np.uint8)
+    return (b.astype(np.uint16) << 8).view(np.float16).astype(np.float32).reshape(np.shape(bits))
+
+
+def f32_to_fp8e5m2(x: np.ndarray) -> np.ndarray:
+    """Encode float32 -> fp8 E5M2 bytes: round to nearest even, saturate to +-57344 (__NV_SATFINITE), NaN -> 0x7f | sign."""
+    lib = _load()
+    lib.vmi_oracle_f32_to_fp8e5m2.restype = ctypes.c_uint8
+    lib.vmi_oracle_f32_to_fp8e5m2.argtypes = [ctypes.c_float]
+    flat = np.asarray(x, dtype=np.float32).ravel()
+    return np.array([lib.vmi_oracle_f32_to_fp8e5m2(float(v)) for v in flat], dtype=np.uint8).reshape(np.shape(x))
+
+
 def reshape_and_cache_fp8(key: np.ndarray, value: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
-                          slot_mapping: np.ndarray, kv_scale: float = 1.0, bf16: bool = False) -> None:
+                          slot_mapping: np.ndarray, kv_scale: float = 1.0, bf16: bool = False,
+                          e5m2: bool = False) -> None:
     """In-place quantising scatter (cache_kernels.cu:200-205): float16 rows -> uint8 caches
     key_cache [NB, H, D/16, BS, 16], value_cache [NB, H, D, BS]."""
     assert key.dtype == value.dtype == (np.uint16 if bf16 else np.float16)   # bf16: bit patterns
@@ -239,20 +255,25 @@ def reshape_and_cache_fp8(key: np.ndarray, value: np.ndarray, key_cache: np.ndar
     assert ks[2] == 1 and ks[1] == D and vs[2] == 1 and vs[1] == D
     slot_mapping = np.ascontiguousarray(slot_mapping, dtype=np.int64)
     lib = _load()
-    fn = lib.vmi_oracle_reshape_and_cache_fp8_bf16 if bf16 else lib.vmi_oracle_reshape_and_cache_fp8
-    fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int32] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float]
-    rc = fn(
-        _base_ptr(key), _base_ptr(value), _base_ptr(key_cache), _base_ptr(value_cache), _base_ptr(slot_mapping),
-        T, H, D, int(key_cache.shape[3]), 16, int(ks[0]), int(vs[0]), float(kv_scale))
+    args = (_base_ptr(key), _base_ptr(value), _base_ptr(key_cache), _base_ptr(value_cache), _base_ptr(slot_mapping),
+            T, H, D, int(key_cache.shape[3]), 16, int(ks[0]), int(vs[0]), float(kv_scale))
+    base_types = [ctypes.c_void_p] * 5 + [ctypes.c_int32] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float]
+    if e5m2:
+        fn = lib.vmi_oracle_reshape_and_cache_fp8x
+        fn.restype, fn.argtypes = ctypes.c_int, base_types + [ctypes.c_int32] * 2
+        rc = fn(*args, 1 if bf16 else 0, 2)
+    else:
+        fn = lib.vmi_oracle_reshape_and_cache_fp8_bf16 if bf16 else lib.vmi_oracle_reshape_and_cache_fp8
+        fn.restype, fn.argtypes = ctypes.c_int, base_types
+        rc = fn(*args)
     assert rc == 0
 
 
 def paged_attention_v1_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray, num_kv_heads: int,
                            scale: float, block_tables: np.ndarray, seq_lens: np.ndarray, block_size: int,
                            kv_scale: float = 1.0, alibi_slopes: np.ndarray | None = None,
-                           threads: int = 1, bf16: bool = False) -> np.ndarray:
-    """Kernel model with an fp8 E4M3 cache: every cache element is first turned into
+                           threads: int = 1, bf16: bool = False, e5m2: bool = False) -> np.ndarray:
+    """Kernel model with an fp8 cache (E4M3, or E5M2 with e5m2=True): every cache element is first turned into
     float_to_half(float(fp8) * kv_scale) (quant_utils.cuh:295-300), then the fp16 arithmetic of
     paged_attention_v1 applies unchanged (attention_kernels.cu:283-289, 410-418)."""
     et = np.uint16 if bf16 else np.float16          # bf16: query / out are bit patterns
@@ -268,18 +289,23 @@ def paged_attention_v1_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache
     out = np.zeros((S, H, D), dtype=et)
     alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
     lib = _load()
-    fn8 = lib.vmi_oracle_paged_attention_v1_fp8_bf16 if bf16 else lib.vmi_oracle_paged_attention_v1_fp8
-    fn8.restype = ctypes.c_int
-    fn8.argtypes = (
-        [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
-        [ctypes.c_int32] * 2 + [ctypes.c_void_p] + [ctypes.c_int64] * 3 + [ctypes.c_int32] * 2 + [ctypes.c_float])
+    base_types = ([ctypes.c_void_p] * 4 + [ctypes.c_int32] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
+                  [ctypes.c_int32] * 2 + [ctypes.c_void_p] + [ctypes.c_int64] * 3 + [ctypes.c_int32] * 2 + [ctypes.c_float])
+    extra = ()
+    if e5m2:
+        fn8 = lib.vmi_oracle_paged_attention_v1_fp8x
+        fn8.restype, fn8.argtypes = ctypes.c_int, base_types + [ctypes.c_int32] * 2
+        extra = (1 if bf16 else 0, 2)
+    else:
+        fn8 = lib.vmi_oracle_paged_attention_v1_fp8_bf16 if bf16 else lib.vmi_oracle_paged_attention_v1_fp8
+        fn8.restype, fn8.argtypes = ctypes.c_int, base_types
 
     def run(lo: int, hi: int) -> int:
         return fn8(
             _base_ptr(out), _base_ptr(query), _base_ptr(key_cache), _base_ptr(value_cache), S, H, D,
             int(num_kv_heads), float(scale), _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size),
             int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
-            lo, hi, float(kv_scale))
+            lo, hi, float(kv_scale), *extra)
 
     threads = max(1, min(int(threads), S))
     bounds = np.linspace(0, S, threads + 1).astype(int)
@@ -292,8 +318,9 @@ def paged_attention_v1_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache
 
 def paged_attention_v2_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray, num_kv_heads: int,
                            scale: float, block_tables: np.ndarray, seq_lens: np.ndarray, block_size: int,
-                           max_seq_len: int, kv_scale: float = 1.0, alibi_slopes: np.ndarray | None = None):
-    """Split-KV kernel model over an fp8 E4M3 cache: (out, exp_sums, max_logits, tmp_out) as paged_attention_v2."""
+                           max_seq_len: int, kv_scale: float = 1.0, alibi_slopes: np.ndarray | None = None,
+                           e5m2: bool = False):
+    """Split-KV kernel model over an fp8 E4M3 (e5m2=True: E5M2) cache: (out, exp_sums, max_logits, tmp_out) as paged_attention_v2."""
     assert query.dtype == np.float16 and key_cache.dtype == value_cache.dtype == np.uint8 and key_cache.shape[4] == 16
     S, H, D = query.shape
     qs = _elem_strides(query)
@@ -309,16 +336,21 @@ def paged_attention_v2_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache
     tmp_out = np.full((S, H, P, D), np.nan, dtype=np.float16)
     alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
     lib = _load()
-    lib.vmi_oracle_paged_attention_v2_fp8.restype = ctypes.c_int
-    lib.vmi_oracle_paged_attention_v2_fp8.argtypes = (
-        [ctypes.c_void_p] * 7 + [ctypes.c_int32] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
-        [ctypes.c_int32] * 3 + [ctypes.c_void_p] + [ctypes.c_int64] * 3 + [ctypes.c_float])
-    rc = lib.vmi_oracle_paged_attention_v2_fp8(
-        _base_ptr(out), _base_ptr(exp_sums), _base_ptr(max_logits), _base_ptr(tmp_out), _base_ptr(query),
-        _base_ptr(key_cache), _base_ptr(value_cache), S, H, D, int(num_kv_heads), float(scale),
-        _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size), int(max_seq_len),
-        int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
-        float(kv_scale))
+    base_types = ([ctypes.c_void_p] * 7 + [ctypes.c_int32] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
+                  [ctypes.c_int32] * 3 + [ctypes.c_void_p] + [ctypes.c_int64] * 3 + [ctypes.c_float])
+    args = (_base_ptr(out), _base_ptr(exp_sums), _base_ptr(max_logits), _base_ptr(tmp_out), _base_ptr(query),
+            _base_ptr(key_cache), _base_ptr(value_cache), S, H, D, int(num_kv_heads), float(scale),
+            _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size), int(max_seq_len),
+            int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
+            float(kv_scale))
+    if e5m2:
+        fn = lib.vmi_oracle_paged_attention_v2_fp8x
+        fn.restype, fn.argtypes = ctypes.c_int, base_types + [ctypes.c_int32] * 2
+        rc = fn(*args, 0, 2)
+    else:
+        lib.vmi_oracle_paged_attention_v2_fp8.restype = ctypes.c_int
+        lib.vmi_oracle_paged_attention_v2_fp8.argtypes = base_types
+        rc = lib.vmi_oracle_paged_attention_v2_fp8(*args)
     if rc:
         raise RuntimeError(f"oracle fp8 v2 failed: {rc}")
     return out, exp_sums, max_logits, tmp_out

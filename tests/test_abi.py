@@ -40,7 +40,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 11
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 12
     assert typed.vmi_target_arch() == b"gfx950"
 
 
@@ -115,8 +115,8 @@ def test_argument_validation_before_any_launch():
     call = lambda **o: ext.paged_attention_v1(  # noqa: E731
         o.get("out", a["out"]), o.get("q", a["q"]), a["kc"], a["vc"], a["H"], 0.125, a["tab"], a["lens"], 16, 64, None,
         o.get("kvd", "auto"), 1.0, 0, 0, o.get("vert", 1), 1, 0)
-    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache: fp8_e5m2"):
-        call(kvd="fp8_e5m2")                                 # only the E4M3 interpretation of "fp8" is built
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache: fp8_e3m4"):
+        call(kvd="fp8_e3m4")                                 # "fp8" / "fp8_e4m3" / "fp8_e5m2" are the reference's fp8 names
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache: int8"):
         call(kvd="int8")                                     # quant_utils.cuh:564
     with pytest.raises(RuntimeError, match="Unsupported input type"):
@@ -124,7 +124,7 @@ def test_argument_validation_before_any_launch():
     with pytest.raises(RuntimeError, match="block-sparse"):
         call(vert=2, kvd="fp8")                              # block-sparse attention: 16-bit caches only
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
-        ext.cache_ops.reshape_and_cache(a["q"], a["q"], a["kc"], a["vc"], torch.zeros(2, dtype=torch.int64), "fp8_e5m2", 1.0)
+        ext.cache_ops.reshape_and_cache(a["q"], a["q"], a["kc"], a["vc"], torch.zeros(2, dtype=torch.int64), "fp8_e3m4", 1.0)
 
 
 def test_native_library_missing_is_a_loud_error(tmp_path, monkeypatch):
@@ -166,7 +166,7 @@ def test_c_abi_validation_codes_without_gpu():
     assert lib.vmi_paged_attention_v1_pick_variant(1, 12, 64, 64, 64) == 0
     n = lib.vmi_paged_attention_v1_variant_count()
     names = [lib.vmi_paged_attention_v1_variant_name(i + 1).decode() for i in range(n)]
-    assert len(set(names)) == n and all(nm.startswith(("d", "bf16_d", "fp8_d", "bf16_fp8_d")) for nm in names)
+    assert len(set(names)) == n and all(nm.startswith(("d", "bf16_d", "fp8_d", "bf16_fp8_d", "fp8e5m2_d", "bf16_fp8e5m2_d")) for nm in names)
     # every (head size, block size) of the reference's dispatch set has a kernel
     for d in (64, 80, 96, 112, 128, 192, 256):
         for bs in (8, 16, 32):

@@ -396,3 +396,62 @@ def test_blocksparse_kernel_model_matches_masked_attention(cfg):
     # vert_stride <= 1 is the dense operator
     same = oracle.paged_attention_v1(*a, blocksparse=(sparse[0], 1, sparse[2], sparse[3]), tp_rank=tp, threads=4)
     assert np.array_equal(same, dense.astype(np.float16))
+
+
+# ------------------------------------------------------------------------------------------------
+# fp8 E5M2 KV cache (kv_cache_dtype "fp8_e5m2", __NV_E5M2: quant_utils.cuh:552-558)
+# ------------------------------------------------------------------------------------------------
+def test_fp8_e5m2_converters_match_torch_float8_e5m2():
+    bits = np.arange(256, dtype=np.uint8)
+    mine = oracle.fp8e5m2_to_f32(bits)
+    ref = torch.from_numpy(bits.copy()).view(torch.float8_e5m2).to(torch.float32).numpy()
+    nan = np.isnan(ref)
+    assert np.array_equal(nan, np.isnan(mine)) and nan.sum() == 6                # 0x7d-0x7f, 0xfd-0xff
+    assert np.array_equal(mine[~nan].view(np.uint32), ref[~nan].view(np.uint32))  # incl. -0.0 and +-inf
+    # encode every float16 value; torch rounds to nearest even without saturating (overflow -> inf):
+    # compare below the midpoint past the largest finite value, check saturation separately
+    halves = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    enc = oracle.f32_to_fp8e5m2(halves)
+    tref = torch.from_numpy(halves.copy()).to(torch.float8_e5m2).view(torch.uint8).numpy()
+    in_range = np.abs(halves) < 61440.0
+    assert np.array_equal(enc[in_range], tref[in_range])
+    big = ~np.isnan(halves) & (np.abs(halves) >= 61440.0)                         # incl. +-inf: __NV_SATFINITE
+    assert np.array_equal(enc[big], np.where(halves[big] > 0, 0x7b, 0xfb).astype(np.uint8))
+    assert (enc[np.isnan(halves)] & 0x7f > 0x7c).all()                            # a NaN code
+    fin = np.isfinite(mine)
+    assert np.array_equal(oracle.fp8e5m2_to_f32(oracle.f32_to_fp8e5m2(mine[fin])).view(np.uint32), mine[fin].view(np.uint32))
+
+
+def test_fp8_e5m2_kernel_model_is_the_f16_model_on_dequantised_caches():
+    rng = np.random.default_rng(18)
+    S, H, Hkv, D, bs, NB = 5, 4, 2, 64, 16, 12
+    lens = np.array([1, 16, 17, 40, 33], dtype=np.int32)
+    tables = np.stack([rng.permutation(NB)[:3] for _ in range(S)]).astype(np.int32)
+    q = rng.standard_normal((S, H, D)).astype(np.float16)
+    for kv_scale in (1.0, 0.37, 2.0):
+        kq = rng.integers(0, 256, (NB, Hkv, D // 16, bs, 16), dtype=np.uint8)
+        vq = rng.integers(0, 256, (NB, Hkv, D, bs), dtype=np.uint8)
+        # |x| < 2 (exponent field <= 15): no inf / NaN codes, finite logits and outputs
+        kq = np.where((kq & 0x7c) > 0x3c, (kq & 0x83) | 0x38, kq).astype(np.uint8)
+        vq = np.where((vq & 0x7c) > 0x3c, (vq & 0x83) | 0x38, vq).astype(np.uint8)
+        got = oracle.paged_attention_v1_fp8(q, kq, vq, Hkv, D ** -0.5, tables, lens, bs, kv_scale=kv_scale, e5m2=True)
+        k16 = (oracle.fp8e5m2_to_f32(kq) * np.float32(kv_scale)).astype(np.float16)
+        v16 = (oracle.fp8e5m2_to_f32(vq) * np.float32(kv_scale)).astype(np.float16)
+        k16 = k16.reshape(NB, Hkv, D // 16, bs, 2, 8).transpose(0, 1, 2, 4, 3, 5).reshape(NB, Hkv, D // 8, bs, 8)
+        ref = oracle.paged_attention_v1(q, np.ascontiguousarray(k16), v16, Hkv, D ** -0.5, tables, lens, bs)
+        assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), kv_scale
+        assert np.isfinite(got.astype(np.float32)).all()
+    T = 7
+    key = (rng.standard_normal((T, Hkv, D)) * 3).astype(np.float16)
+    val = (rng.standard_normal((T, Hkv, D)) * 300).astype(np.float16)
+    slots = rng.permutation(NB * bs)[:T].astype(np.int64)
+    slots[2] = -1
+    kc = np.zeros((NB, Hkv, D // 16, bs, 16), np.uint8)
+    vc = np.zeros((NB, Hkv, D, bs), np.uint8)
+    oracle.reshape_and_cache_fp8(key, val, kc, vc, slots, kv_scale=0.5, e5m2=True)
+    for t in range(T):
+        if slots[t] < 0:
+            continue
+        b, o = divmod(int(slots[t]), bs)
+        assert np.array_equal(kc[b, :, :, o, :].reshape(Hkv, D), oracle.f32_to_fp8e5m2(key[t].astype(np.float32) / np.float32(0.5)))
+        assert np.array_equal(vc[b, :, :, o], oracle.f32_to_fp8e5m2(val[t].astype(np.float32) / np.float32(0.5)))

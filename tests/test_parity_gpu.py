@@ -482,7 +482,7 @@ def test_errors_raise_runtimeerror():
     with pytest.raises(RuntimeError, match="Unsupported head size"):
         call(make_case(rng, 1, 4, 72, [5], max_blocks=4))            # attention_kernels.cu:763-765
     with pytest.raises(RuntimeError, match="kv cache"):
-        call(good, kvd="fp8_e5m2")                                   # only E4M3 is built for "fp8"
+        call(good, kvd="fp8_e3m4")                                   # not one of the reference's names
     with pytest.raises(RuntimeError, match="uint8"):
         call(good, kvd="fp8")                                        # fp8 needs byte caches
     with pytest.raises(RuntimeError, match="kv cache"):
@@ -1484,6 +1484,158 @@ def test_gqa_shared_tile_kernels_match_kernel_model(D):
             _append_vs_two_ops(case, vid, seed=vid, what=f"append {name} H{H}/{hkv}")
             ran += 1
         assert ran >= 3, (H, hkv, ran)
+
+
+# ------------------------------------------------------------------------------------------------
+# fp8 E5M2 KV cache (kv_cache_dtype "fp8_e5m2")
+# ------------------------------------------------------------------------------------------------
+def _e5m2_case(rng, S, H, D, lens, bs, num_kv_heads=None):
+    """make_case + random E5M2 cache bytes of magnitude < 2 (exponent field <= 15: no inf / NaN codes)."""
+    hkv = num_kv_heads or H
+    case = make_case(rng, S, H, D, lens, num_kv_heads=hkv, block_size=bs, q_row_pad=1, kv="normal")
+    NB = case["kc"].shape[0]
+    for name, shape in (("kq", (NB, hkv, D // 16, bs, 16)), ("vq", (NB, hkv, D, bs))):
+        b = rng.integers(0, 256, shape, dtype=np.uint8)
+        case[name] = np.where((b & 0x7c) > 0x3c, (b & 0x83) | 0x38, b).astype(np.uint8)
+    return case
+
+
+def _run_e5m2(case, kv_scale, variant=0, alibi=None, bf16=False, v2_msl=0):
+    from vllmini_amd import ops
+
+    dev = _dev()
+    S, H, D = case["q"].shape
+    if bf16:
+        q = _bf16_tensor(oracle.f32_to_bf16_bits(case["qbuf"].astype(np.float32)), dev)[:, : H * D].view(S, H, D)
+    else:
+        q = torch.from_numpy(case["qbuf"]).to(dev)[:, : H * D].view(S, H, D)
+    out = torch.full((S, H, D), float("nan"), dtype=q.dtype, device=dev)
+    al = None if alibi is None else torch.from_numpy(alibi).to(dev)
+    a = (q, torch.from_numpy(case["kq"]).to(dev), torch.from_numpy(case["vq"]).to(dev), case["num_kv_heads"],
+         case["scale"], torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev), case["bs"])
+    if v2_msl:
+        P = (v2_msl + 511) // 512
+        es = torch.full((S, H, P), float("nan"), dtype=torch.float32, device=dev)
+        ml = torch.full((S, H, P), float("nan"), dtype=torch.float32, device=dev)
+        tmp = torch.full((S, H, P, D), float("nan"), dtype=q.dtype, device=dev)
+        ops.paged_attention_v2(out, es, ml, tmp, *a, v2_msl, al, "fp8_e5m2", kv_scale, 0, 0, 1, 1, 0, _variant=variant)
+    else:
+        ops.paged_attention_v1(out, *a, max(int(case["lens"].max()), 1), al, "fp8_e5m2", kv_scale, 0, 0, 1, 1, 0,
+                               _variant=variant)
+    torch.cuda.synchronize()
+    return out.view(torch.int16).cpu().numpy().view(np.uint16) if bf16 else out.cpu().numpy()
+
+
+def test_fp8_e5m2_hardware_decode_for_every_code():
+    """One token per sequence => out[d] = half(1.0 * v[d]): all 250 non-NaN E5M2 codes (infinities included)
+    decode to the upper-byte-of-a-half value, at kv_scale 1 (byte shuffle path) and at other scales."""
+    from vllmini_amd import ops
+
+    dev = _dev()
+    D, bs = 256, 16
+    codes = np.arange(256, dtype=np.uint8)
+    codes[(codes & 0x7f) > 0x7c] = 0x38                                  # the six NaN codes
+    vq = np.zeros((1, 1, D, bs), dtype=np.uint8)
+    vq[0, 0, :, 0] = codes
+    kq = np.zeros((1, 1, D // 16, bs, 16), dtype=np.uint8)
+    q = torch.zeros((1, 1, D), dtype=torch.float16, device=dev)
+    out = torch.empty_like(q)
+    tab = torch.zeros((1, 1), dtype=torch.int32, device=dev)
+    lens = torch.ones(1, dtype=torch.int32, device=dev)
+    for kv_scale in (1.0, 0.25, 3.0):
+        ops.paged_attention_v1(out, q, torch.from_numpy(kq).to(dev), torch.from_numpy(vq).to(dev), 1, 1.0, tab, lens,
+                               bs, 1, None, "fp8_e5m2", kv_scale)
+        torch.cuda.synchronize()
+        with np.errstate(over="ignore"):
+            want = (oracle.fp8e5m2_to_f32(codes) * np.float32(kv_scale)).astype(np.float16)
+        got = out.cpu().numpy().reshape(D)
+        nz = want != 0                                                    # -0.0: sign lost to the masked tokens' +0.0
+        assert np.array_equal(got[nz].view(np.uint16), want[nz].view(np.uint16)), kv_scale
+        assert (got[~nz] == 0).all()
+
+
+@pytest.mark.parametrize("kv_scale", [1.0, 0.5, 3.7])
+def test_reshape_and_cache_fp8_e5m2_every_half_and_bf16_value_bit_exact(kv_scale):
+    ext = _ext()
+    dev = _dev()
+    T, H, D, bs, NB = 64, 4, 256, 16, 6
+    bits = np.arange(65536, dtype=np.uint16).reshape(T, H, D)
+    rng = np.random.default_rng(14)
+    vbits = bits[rng.permutation(T)]
+    slots = rng.permutation(NB * bs)[:T].astype(np.int64)
+    slots[5] = -1
+    for bf16 in (False, True):
+        kc = np.zeros((NB, H, D // 16, bs, 16), dtype=np.uint8)
+        vc = np.zeros((NB, H, D, bs), dtype=np.uint8)
+        t_kc, t_vc = torch.from_numpy(kc).to(dev), torch.from_numpy(vc).to(dev)
+        tk = _bf16_tensor(bits, dev) if bf16 else torch.from_numpy(bits.view(np.float16).copy()).to(dev)
+        tv = _bf16_tensor(vbits, dev) if bf16 else torch.from_numpy(vbits.view(np.float16).copy()).to(dev)
+        ext.cache_ops.reshape_and_cache(tk, tv, t_kc, t_vc, torch.from_numpy(slots).to(dev), "fp8_e5m2", kv_scale)
+        torch.cuda.synchronize()
+        k_np = np.ascontiguousarray(bits if bf16 else bits.view(np.float16))
+        v_np = np.ascontiguousarray(vbits if bf16 else vbits.view(np.float16))
+        oracle.reshape_and_cache_fp8(k_np, v_np, kc, vc, slots, kv_scale=kv_scale, bf16=bf16, e5m2=True)
+        assert np.array_equal(t_kc.cpu().numpy(), kc), bf16
+        assert np.array_equal(t_vc.cpu().numpy(), vc), bf16
+
+
+@pytest.mark.parametrize("D", [64, 80, 96, 112, 128, 192, 256])
+@pytest.mark.parametrize("bs", [16, 32])
+def test_pa_fp8_e5m2_matches_kernel_model(D, bs):
+    """v1 (every E5M2 kernel of this head x block size, fp16 and bf16 query), ALiBi, three scales, and v2."""
+    from vllmini_amd import ops
+
+    rng = np.random.default_rng(2100 + D + bs)
+    lens = [1, bs, bs + 1, 100, 333, 47, 700, 2]
+    case = _e5m2_case(rng, len(lens), 8, D, lens, bs, num_kv_heads=4)
+    a = (case["kq"], case["vq"], 4, case["scale"], case["tables"], case["lens"], bs)
+    alibi = (2.0 ** -np.arange(1, 9)).astype(np.float32)
+    for kv_scale, al in ((1.0, None), (0.6, None), (2.0, alibi)):
+        ref = oracle.paged_attention_v1_fp8(case["q"], *a, kv_scale=kv_scale, alibi_slopes=al, threads=8, e5m2=True)
+        assert_close(_run_e5m2(case, kv_scale, alibi=al), ref, f"e5m2 D{D} bs{bs} scale {kv_scale}", vmax=2 * kv_scale)
+    names = ops.variant_names()
+    qb = np.ascontiguousarray(oracle.f32_to_bf16_bits(case["qbuf"].astype(np.float32))[:, : 8 * D].reshape(len(lens), 8, D))
+    for kv_scale in (1.0, 0.6):
+        ref = oracle.paged_attention_v1_fp8(case["q"], *a, kv_scale=kv_scale, threads=8, e5m2=True)
+        refb = oracle.paged_attention_v1_fp8(qb, *a, kv_scale=kv_scale, threads=8, bf16=True, e5m2=True)
+        ran = 0
+        for vid, name in enumerate(names, start=1):
+            if name.startswith(f"fp8e5m2_d{D}_bs{bs}_") and _gq_ok(name, 2):
+                assert_close(_run_e5m2(case, kv_scale, variant=vid), ref, name, vmax=2 * kv_scale, tight="_pvm" not in name)
+                ran += 1
+            elif name.startswith(f"bf16_fp8e5m2_d{D}_bs{bs}_"):
+                assert_close_bf16(_run_e5m2(case, kv_scale, variant=vid, bf16=True), refb, name, vmax=2 * kv_scale)
+                ran += 1
+        assert ran >= 4, ran
+        assert_close_bf16(_run_e5m2(case, kv_scale, bf16=True), refb, f"bf16 x e5m2 auto D{D} bs{bs}", vmax=2 * kv_scale)
+    r2 = oracle.paged_attention_v2_fp8(case["q"], *a, 1024, kv_scale=0.8, e5m2=True)[0]
+    assert_close(_run_e5m2(case, 0.8, v2_msl=1024), r2, f"e5m2 v2 D{D} bs{bs}", vmax=1.6)
+    for vid, name in enumerate(ops.variant_names_v2(), start=1):
+        if name.startswith(f"fp8e5m2_v2_d{D}_bs{bs}_"):
+            assert_close(_run_e5m2(case, 0.8, variant=vid, v2_msl=1024), r2, name, vmax=1.6)
+
+
+def test_fp8_e5m2_grouped_query_kernels_and_opt_in():
+    from vllmini_amd import ops
+
+    names = ops.variant_names()
+    rng = np.random.default_rng(2300)
+    lens = [1, 16, 17, 100, 333, 1024, 47, 2, 0, 600]
+    for H, hkv in ((16, 4), (32, 4)):
+        case = _e5m2_case(rng, len(lens), H, 128, lens, 16, num_kv_heads=hkv)
+        a = (case["q"], case["kq"], case["vq"], hkv, case["scale"], case["tables"], case["lens"], 16)
+        for kv_scale in (1.0, 0.7):
+            ref = oracle.paged_attention_v1_fp8(*a, kv_scale=kv_scale, threads=8, e5m2=True)
+            auto = names[ops.pick_variant(len(lens), H, 128, 1024, 16, fp8="e5m2", num_kv_heads=hkv) - 1]
+            assert auto.startswith("fp8e5m2_") and "_gq" in auto and "_pvm" not in auto, auto
+            assert_close(_run_e5m2(case, kv_scale), ref, f"e5m2 gqa auto ({auto})", vmax=2 * kv_scale)
+            ops.set_pv_mfma(True)
+            try:
+                fast = names[ops.pick_variant(len(lens), H, 128, 1024, 16, fp8="e5m2", num_kv_heads=hkv) - 1]
+                assert "_pvm" in fast and fast.startswith("fp8e5m2_"), fast
+                assert_close(_run_e5m2(case, kv_scale), ref, f"e5m2 gqa opt-in ({fast})", vmax=2 * kv_scale, tight=False)
+            finally:
+                ops.set_pv_mfma(False)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -91,10 +91,25 @@ __device__ __forceinline__ float dot8(const u32x4 q, const u32x4 k) {
 // two OCP E4M3 bytes exactly on gfx950; the multiply and the RNE conversion to half are separate instructions
 // (-ffp-contract=off). ----
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// E5 = the cache bytes are fp8 E5M2 (kv_cache_dtype "fp8_e5m2": the upper byte of an IEEE half, "bf8" in the ISA)
+// instead of E4M3; same element definition half(float(fp8) * kv_scale), same instruction count.
+template <bool E5, bool HI>
+__device__ __forceinline__ f32x2_t cvt2_f32_f8(uint32_t w) {  // bytes (0,1) or (2,3) of w -> two floats, exact
+  if constexpr (E5) return __builtin_amdgcn_cvt_pk_f32_bf8((int)w, HI);
+  else return __builtin_amdgcn_cvt_pk_f32_fp8((int)w, HI);
+}
+template <bool E5, bool HI>
+__device__ __forceinline__ uint32_t cvt2_f16_f8(uint32_t w) {  // ... -> two halves (every fp8 value is a half value)
+  if constexpr (E5) {  // an E5M2 byte IS the upper byte of its half
+    return HI ? (((w >> 8) & 0x0000ff00u) | (w & 0xff000000u)) : (((w & 0xffu) << 8) | ((w & 0xff00u) << 16));
+  } else {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w, 1.0f, HI));
+  }
+}
 // 8 fp8 bytes (two dwords) -> 8 halves packed like a 16-byte fp16 unit.
 // S1 (kv_scale == 1): every E4M3 value is a float16 value, so half(float(fp8) * 1) is the byte's own value and
 // v_cvt_scalef32_pk_f16_fp8 with scale 1.0 produces it directly, two per instruction.
-template <bool S1, bool BF = false>
+template <bool S1, bool BF = false, bool E5 = false>
 __device__ __forceinline__ u32x4 deq8(uint32_t w0, uint32_t w1, float s) {
   if constexpr (BF) {
     // bfloat16 query: element = __float2bfloat16(float(fp8) * kv_scale) (quant_utils.cuh:350-359); with kv_scale == 1
@@ -103,8 +118,8 @@ __device__ __forceinline__ u32x4 deq8(uint32_t w0, uint32_t w1, float s) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t w = h ? w1 : w0;
-      const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
-      const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+      const f32x2_t lo = cvt2_f32_f8<E5, false>(w);
+      const f32x2_t hi = cvt2_f32_f8<E5, true>(w);
       if constexpr (S1) {
         // (the upper 16 bits of each decode would do — the value is exact in bfloat16 — but hipcc 7.2 turns
         //  `(bits(lo[0]) >> 16) | (bits(lo[1]) & 0xffff0000)` into a pack that reads lo[0] twice; measured on gfx950,
@@ -119,18 +134,18 @@ __device__ __forceinline__ u32x4 deq8(uint32_t w0, uint32_t w1, float s) {
     return o;
   } else if constexpr (S1) {
     u32x4 o;
-    o[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w0, 1.0f, false));
-    o[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w0, 1.0f, true));
-    o[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w1, 1.0f, false));
-    o[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w1, 1.0f, true));
+    o[0] = cvt2_f16_f8<E5, false>(w0);
+    o[1] = cvt2_f16_f8<E5, true>(w0);
+    o[2] = cvt2_f16_f8<E5, false>(w1);
+    o[3] = cvt2_f16_f8<E5, true>(w1);
     return o;
   } else {
     h16x8 o;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t w = h ? w1 : w0;
-      const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);  // bytes 0, 1
-      const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);   // bytes 2, 3
+      const f32x2_t lo = cvt2_f32_f8<E5, false>(w);  // bytes 0, 1
+      const f32x2_t hi = cvt2_f32_f8<E5, true>(w);   // bytes 2, 3
       o[4 * h + 0] = (h16)(lo[0] * s);
       o[4 * h + 1] = (h16)(lo[1] * s);
       o[4 * h + 2] = (h16)(hi[0] * s);
@@ -142,20 +157,21 @@ __device__ __forceinline__ u32x4 deq8(uint32_t w0, uint32_t w1, float s) {
 // q.k over one 16-byte fp8 chunk (16 dims): fp32 FMA chain on widened operands, like dot8.
 // S1: the fp32 decode IS the operand (half(fp8) widens back to the same fp32), so q (f16) x k (f32) goes straight
 // into v_fma_mix_f32 — 8 decodes + 16 FMAs for 16 dims.
-template <bool S1, bool BF = false>
+template <bool S1, bool BF = false, bool E5 = false>
 __device__ __forceinline__ float dot16_f8(const u32x4 q0, const u32x4 q1, const u32x4 k, float s) {
   static_assert(!S1, "kv_scale == 1 uses dot16_f8_s1");
-  return dot8<BF>(q0, deq8<false, BF>(k[0], k[1], s)) + dot8<BF>(q1, deq8<false, BF>(k[2], k[3], s));
+  return dot8<BF>(q0, deq8<false, BF, E5>(k[0], k[1], s)) + dot8<BF>(q1, deq8<false, BF, E5>(k[2], k[3], s));
 }
 // kv_scale == 1: half(float(fp8)) widens back to the same fp32, so the fp32 decode IS the operand.  q is held as
 // fp32 pairs (converted once per wave), v_cvt_pk_f32_fp8 yields k as fp32 pairs, and v_pk_fma_f32 does two exact
 // fp32 FMAs per instruction: 8 decodes + 8 packed FMAs for 16 dims (even and odd dims are separate chains).
+template <bool E5 = false>
 __device__ __forceinline__ float dot16_f8_s1(const f32x2_t (&qf)[8], const u32x4 k) {
   f32x2_t acc = {0.f, 0.f};
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    acc = __builtin_elementwise_fma(qf[2 * w], __builtin_amdgcn_cvt_pk_f32_fp8((int)k[w], false), acc);
-    acc = __builtin_elementwise_fma(qf[2 * w + 1], __builtin_amdgcn_cvt_pk_f32_fp8((int)k[w], true), acc);
+    acc = __builtin_elementwise_fma(qf[2 * w], cvt2_f32_f8<E5, false>(k[w]), acc);
+    acc = __builtin_elementwise_fma(qf[2 * w + 1], cvt2_f32_f8<E5, true>(k[w]), acc);
   }
   return acc[0] + acc[1];
 }
@@ -302,7 +318,7 @@ struct PAParams {
 //                    + (WPH > 1 ? lpad*2 : 0) (fp16 probabilities; in place over the logits when WPH = 1) ).
 // ----------------------------------------------------------------------------------------
 template <int D, int HPW, int WPH, int U, bool NT, bool LOADS_ONLY = false, bool PART = false, int BS = 16,
-          bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0, bool F8 = false,
+          bool LOCK = false, bool BF = false, int HPT = 1, bool APP = false, int UMAX = 0, int F8 = 0,
           bool GQS = false, bool FPV = false, bool SPARSE = false>
 // (second launch bound = minimum waves per SIMD.  The adaptive-depth kernels are the full-chip defaults: 12 waves
 //  per CU = 3 per SIMD that must ALL be resident, i.e. stay under 170 VGPRs — the fused-append form had drifted to 180
@@ -312,6 +328,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   constexpr int PBLK = 512 / BS;          // blocks per partition (PARTITION_SIZE = 512, :847)
   // F8: the caches hold fp8 E4M3 bytes — key_cache [NB, H, D/16, BS, 16], value_cache [NB, H, D, BS]
   // (x = 16 / sizeof(cache_t), attention_kernels.cu:200): a 16-byte unit carries 16 elements instead of 8
+  constexpr bool E5 = F8 == 2;            // F8: 0 = 16-bit caches, 1 = fp8 E4M3 bytes, 2 = fp8 E5M2 bytes
   constexpr int EPU = F8 ? 16 : 8;        // cache elements per 16-B unit
   constexpr int ES = F8 ? 1 : 2;          // bytes per cache element
   constexpr int UNITS = D * BS / EPU;     // 16-B units in one (block, head) tile of K — and of V
@@ -694,7 +711,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   #pragma unroll
               for (int w = 0; w < (F8 ? 2 : 1); ++w) {
                 u32x4 a = r[j][0][i];
-                if constexpr (F8) a = deq8<S1, BF>(r[j][0][i][2 * w], r[j][0][i][2 * w + 1], p.kv_scale);
+                if constexpr (F8) a = deq8<S1, BF, E5>(r[j][0][i][2 * w], r[j][0][i][2 * w + 1], p.kv_scale);
                 if constexpr (BF)
                   d4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                                __builtin_bit_cast(bf16x8, qB[i][w]), d4, 0, 0, 0);
@@ -738,8 +755,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
               float accv[NL];
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
-                if constexpr (F8 && S1) accv[i] = dot16_f8_s1(qf[hh][i], r[j][GQS ? 0 : hh][i]);
-                else if constexpr (F8) accv[i] = dot16_f8<false, BF>(qreg[hh][i][0], qreg[hh][i][1], r[j][GQS ? 0 : hh][i], p.kv_scale);
+                if constexpr (F8 && S1) accv[i] = dot16_f8_s1<E5>(qf[hh][i], r[j][GQS ? 0 : hh][i]);
+                else if constexpr (F8) accv[i] = dot16_f8<false, BF, E5>(qreg[hh][i][0], qreg[hh][i][1], r[j][GQS ? 0 : hh][i], p.kv_scale);
                 else accv[i] = dot8<BF>(qreg[hh][i][0], r[j][GQS ? 0 : hh][i]);
               }
               float acc = accv[0];
@@ -915,7 +932,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   #pragma unroll
               for (int hs = 0; hs < (F8 ? 2 : 1); ++hs) {
                 u32x4 v = raw;
-                if constexpr (F8) v = deq8<S1, BF>(raw[2 * hs], raw[2 * hs + 1], p.kv_scale);
+                if constexpr (F8) v = deq8<S1, BF, E5>(raw[2 * hs], raw[2 * hs + 1], p.kv_scale);
                 v = live ? v : zero4;
                 const int token0 = tokb + 8 * hs;
                 if constexpr (APP && MASK) {
@@ -986,7 +1003,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
                 if constexpr (F8)  // first 8 of the unit's 16 tokens
-                  acc[hh][i] += pv.template dot<MASK>(deq8<S1, BF>(r[j][GQS ? 0 : hh][i][0], r[j][GQS ? 0 : hh][i][1], p.kv_scale), last, token0, L);
+                  acc[hh][i] += pv.template dot<MASK>(deq8<S1, BF, E5>(r[j][GQS ? 0 : hh][i][0], r[j][GQS ? 0 : hh][i][1], p.kv_scale), last, token0, L);
                 else
                   acc[hh][i] += pv.template dot<MASK>(r[j][GQS ? 0 : hh][i], last, token0, L);
               }
@@ -995,7 +1012,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
                 pw.load(*reinterpret_cast<const u32x4_alias*>(php + 8));
 #pragma unroll
                 for (int i = 0; i < NL; ++i)
-                  acc[hh][i] += pw.template dot<MASK>(deq8<S1, BF>(r[j][GQS ? 0 : hh][i][2], r[j][GQS ? 0 : hh][i][3], p.kv_scale), last, token0 + 8, L);
+                  acc[hh][i] += pw.template dot<MASK>(deq8<S1, BF, E5>(r[j][GQS ? 0 : hh][i][2], r[j][GQS ? 0 : hh][i][3], p.kv_scale), last, token0 + 8, L);
               }
             }
           }
@@ -1229,7 +1246,7 @@ struct Variant {
   int lds_attr_set;  // largest dynamic-LDS size already granted through hipFuncSetAttribute
   int UMAX;          // adaptive queue depth limit (0 = fixed U)
   int lds_attr_dev;  // device that grant was made on (the attribute is per device)
-  bool F8;           // caches hold fp8 E4M3 bytes (kv_cache_dtype "fp8")
+  int F8;            // caches hold fp8 bytes: 1 = E4M3 (kv_cache_dtype "fp8" / "fp8_e4m3"), 2 = E5M2 ("fp8_e5m2"); 0 = 16-bit
   bool GQS;          // the HPT query heads of a wave share one KV head: num_heads / num_kv_heads % HPT == 0 required
   bool FPV;          // opt-in: probabilities x V on the matrix cores too (vmi_set_pv_mfma); north-star bound, not 1 ulp
   bool SPARSE;       // block-sparse attention (blocksparse_vert_stride > 1); menus of their own (pa_variants_sparse.hip)
@@ -1244,18 +1261,23 @@ typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const 
    (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), LO, false, BS, LOCK, BF, HPT, (VMI_APP) && !(LO), UMAX>, 0, \
    UMAX},
 // fp8-cache rows (pa_table_fp8.inc): fp16 query, no fused-append twin
+// (the including unit may define VMI_F8_FMT = 2 and VMI_F8_PFX = "fp8e5m2_" for the E5M2 menus)
+#ifndef VMI_F8_FMT
+#define VMI_F8_FMT 1
+#define VMI_F8_PFX "fp8_"
+#endif
 #define VMI_ROW_F8B(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX, BF)                                             \
   {NAME, D, BS, HPW, WPH, U, (bool)(NT), HPT, BF,                                                                  \
-   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), false, false, BS, LOCK, BF, HPT, false, UMAX, true>, 0,    \
-   UMAX, 0, true, false},
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, (bool)(NT), false, false, BS, LOCK, BF, HPT, false, UMAX, VMI_F8_FMT>, 0, \
+   UMAX, 0, VMI_F8_FMT, false},
 #define VMI_ROW_F8G(NAME, D, BS, HPW, WPH, U, HPT)  /* fp8 pages, grouped-query sharing, fp16 query */              \
   {NAME, D, BS, HPW, WPH, U, true, HPT, false,                                                                     \
-   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, BS, false, false, HPT, false, 0, true, true>, 0,   \
-   0, 0, true, true},
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, BS, false, false, HPT, false, 0, VMI_F8_FMT, true>, 0, \
+   0, 0, VMI_F8_FMT, true},
 #define VMI_ROW_F8GP(NAME, D, BS, HPW, WPH, U, HPT)  /* ... and P.V on the matrix cores too (opt-in "_pvm") */      \
   {NAME, D, BS, HPW, WPH, U, true, HPT, false,                                                                           \
-   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, BS, false, false, HPT, false, 0, true, true, true>, 0, \
-   0, 0, true, true, true},
+   (pa_kernel_t)pa_v1_kernel<D, HPW, WPH, U, true, false, false, BS, false, false, HPT, false, 0, VMI_F8_FMT, true, true>, 0, \
+   0, 0, VMI_F8_FMT, true, true},
 #define VMI_ROW_F8(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX) \
   VMI_ROW_F8B(NAME, D, BS, HPW, WPH, U, NT, LOCK, HPT, UMAX, false)
 // grouped-query rows: HPT query heads of one KV head per wave, each tile loaded once
@@ -1307,6 +1329,13 @@ extern const int g_fp8_nvariants_v2;
 // bfloat16 query over the fp8 cache (pa_variants_fp8_bf16.hip): v1 ids continue after the fp16-query fp8 menu
 extern Variant g_fp8bf_variants_v1[];
 extern const int g_fp8bf_nvariants_v1;
+// the same menus over fp8 E5M2 bytes (kv_cache_dtype "fp8_e5m2")
+extern Variant g_fp8_variants_v1_e5m2[];
+extern const int g_fp8_nvariants_v1_e5m2;
+extern Variant g_fp8_variants_v2_e5m2[];
+extern const int g_fp8_nvariants_v2_e5m2;
+extern Variant g_fp8bf_variants_v1_e5m2[];
+extern const int g_fp8bf_nvariants_v1_e5m2;
 pa_reduce_t bf16_reduce_kernel(int head_size);
 
 }  // namespace vmi

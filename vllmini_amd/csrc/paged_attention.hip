@@ -161,7 +161,22 @@ __device__ __forceinline__ uint32_t f32_to_fp8e4m3_satfinite(float f) {
   return sign | ((u >> 20) - ((127u - 7u) << 3));
 }
 
-template <bool VEC, bool BF = false>
+// fp8 E5M2 (kv_cache_dtype "fp8_e5m2"): the upper byte of an IEEE half.  RNE on 2 mantissa bits, saturating at +-57344
+// (__NV_SATFINITE: infinities saturate too), NaN kept as a NaN code.  Integer arithmetic on the fp32 bit pattern.
+__device__ __forceinline__ uint32_t f32_to_fp8e5m2_satfinite(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  const uint32_t sign = (u >> 24) & 0x80u;
+  u &= 0x7fffffffu;
+  if (u > 0x7f800000u) return sign | 0x7fu;   // NaN
+  if (u >= 0x47700000u) return sign | 0x7bu;  // |x| >= 61440 (the midpoint past 57344) and infinity: saturate
+  if (u < 0x38800000u) {                      // |x| < 2^-14: subnormal range, step 2^-16; 4 * 2^-16 encodes as the smallest normal
+    return sign | (uint32_t)__builtin_rintf(__builtin_bit_cast(float, u) * 65536.f);
+  }
+  u += 0xfffffu + ((u >> 21) & 1u);           // RNE to 2 mantissa bits; a carry moves into the exponent
+  return sign | ((u >> 21) - ((127u - 15u) << 2));
+}
+
+template <bool VEC, bool BF = false, bool E5 = false>
 __global__ void __launch_bounds__(256)
     reshape_and_cache_fp8_kernel(const h16* __restrict__ key, const h16* __restrict__ value,
                                  uint8_t* __restrict__ kc, uint8_t* __restrict__ vc,
@@ -202,8 +217,8 @@ __global__ void __launch_bounds__(256)
       // bfloat16 rows (quant_utils.cuh:468-478) widen by a 16-bit shift; float16 rows by v_cvt_f32_f16
       const float kf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, kv[e]) << 16) : (float)kv[e];
       const float vf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, vv[e]) << 16) : (float)vv[e];
-      kq[e >> 2] |= f32_to_fp8e4m3_satfinite(kf / kv_scale) << (8 * (e & 3));
-      vdst[(int64_t)e * BS] = (uint8_t)f32_to_fp8e4m3_satfinite(vf / kv_scale);
+      kq[e >> 2] |= (E5 ? f32_to_fp8e5m2_satfinite(kf / kv_scale) : f32_to_fp8e4m3_satfinite(kf / kv_scale)) << (8 * (e & 3));
+      vdst[(int64_t)e * BS] = (uint8_t)(E5 ? f32_to_fp8e5m2_satfinite(vf / kv_scale) : f32_to_fp8e4m3_satfinite(vf / kv_scale));
     }
     *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (D >> 4) + (d >> 4)) * BS + off) * 16) = kq;
   }
@@ -411,7 +426,8 @@ static Variant g_variants[] = {
 static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
 static int nvariants_v1() {
-  return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1 + g_fp8_nvariants_v1 + g_fp8bf_nvariants_v1;
+  return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1 + g_fp8_nvariants_v1 + g_fp8bf_nvariants_v1 +
+         g_fp8_nvariants_v1_e5m2 + g_fp8bf_nvariants_v1_e5m2;
 }
 static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf16][fp8 cache]
   if (id <= g_ncore) return g_variants[id - 1];
@@ -420,14 +436,18 @@ static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf
     return g_bf16_variants_v1[id - 1 - g_ncore - g_extra_nvariants_v1];
   const int f0 = g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1;
   if (id <= f0 + g_fp8_nvariants_v1) return g_fp8_variants_v1[id - 1 - f0];
-  return g_fp8bf_variants_v1[id - 1 - f0 - g_fp8_nvariants_v1];  // bf16 query over the fp8 cache
+  const int f1 = f0 + g_fp8_nvariants_v1;
+  if (id <= f1 + g_fp8bf_nvariants_v1) return g_fp8bf_variants_v1[id - 1 - f1];  // bf16 query over the fp8 cache
+  const int f2 = f1 + g_fp8bf_nvariants_v1;                                        // ... and the E5M2 menus
+  if (id <= f2 + g_fp8_nvariants_v1_e5m2) return g_fp8_variants_v1_e5m2[id - 1 - f2];
+  return g_fp8bf_variants_v1_e5m2[id - 1 - f2 - g_fp8_nvariants_v1_e5m2];
 }
 
 static bool is_diag(const Variant& v) { return strstr(v.name, "LOADSONLY") != nullptr; }
 static bool is_lock(const Variant& v) { return strstr(v.name, "_lock") != nullptr || v.HPT > 1; }
 
 static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = any */, bool bf = false,
-                        bool f8 = false) {
+                        int f8 = false) {
   for (int id = 1; id <= nvariants_v1(); ++id) {
     const Variant& v = variant_v1(id);
     if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
@@ -464,9 +484,9 @@ static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }
 static std::atomic<int> g_pv_mfma{0};
 
 static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
-                               bool bf, bool f8, bool fpv);
+                               bool bf, int f8, bool fpv);
 static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
-                            bool bf, bool f8) {
+                            bool bf, int f8) {
   if (g_pv_mfma.load(std::memory_order_relaxed)) {
     const int v = pick_variant_gqa_of(num_seqs, num_heads, qpk, head_size, block_size, max_seq_len, bf, f8, true);
     if (v) return v;
@@ -474,7 +494,7 @@ static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size,
   return pick_variant_gqa_of(num_seqs, num_heads, qpk, head_size, block_size, max_seq_len, bf, f8, false);
 }
 static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
-                               bool bf, bool f8, bool fpv) {
+                               bool bf, int f8, bool fpv) {
   if (qpk < 2 || block_size != 16) return 0;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   const size_t lpad = (size_t)((max_seq_len + 31) / 32) * 32;
@@ -517,7 +537,7 @@ static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_si
 
 // fp8 cache: a (block, head) tile is half the bytes; measured picks in profiles/r01h_fp8_kv.md
 static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
-                            int mean_seq_len, bool bf = false) {
+                            int mean_seq_len, bool bf = false, int fmt = 1) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
@@ -527,14 +547,14 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   int v = 0;
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {
     if (wph == 1) {
-      v = find_variant(head_size, 16, (num_heads % 4 == 0) ? 4 : 1, 1, head_size == 64 ? 2 : 1, -1, bf, true);
+      v = find_variant(head_size, 16, (num_heads % 4 == 0) ? 4 : 1, 1, head_size == 64 ? 2 : 1, -1, bf, fmt);
     } else {
-      for (int ww = wph; ww >= 1 && !v; ww /= 2) v = find_variant(head_size, 16, 1, ww, -1, -1, bf, true);
+      for (int ww = wph; ww >= 1 && !v; ww /= 2) v = find_variant(head_size, 16, 1, ww, -1, -1, bf, fmt);
     }
   }
-  if (!v && wph > 1) v = find_variant(head_size, block_size, 1, wph >= 16 ? 16 : 4, -1, -1, bf, true);
-  if (!v) v = find_variant(head_size, block_size, 1, wph == 1 ? 1 : 4, -1, -1, bf, true);
-  if (!v) v = find_variant(head_size, block_size, 1, 1, -1, -1, bf, true);
+  if (!v && wph > 1) v = find_variant(head_size, block_size, 1, wph >= 16 ? 16 : 4, -1, -1, bf, fmt);
+  if (!v) v = find_variant(head_size, block_size, 1, wph == 1 ? 1 : 4, -1, -1, bf, fmt);
+  if (!v) v = find_variant(head_size, block_size, 1, 1, -1, -1, bf, fmt);
   return v;
 }
 
@@ -634,7 +654,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         int64_t kv_head_stride, int32_t device, void* stream, int32_t variant,
                         bool bf = false, bool append = false, const void* key = nullptr,
                         const void* value = nullptr, int64_t key_stride = 0, int64_t value_stride = 0,
-                        bool f8 = false, float kv_scale = 1.0f, const int32_t* bsp = nullptr) {
+                        int f8 = false, float kv_scale = 1.0f, const int32_t* bsp = nullptr) {
   if (!out || !query || !key_cache || !value_cache || !block_tables || !seq_lens)
     return fail(VMI_E_NULL_POINTER, "paged_attention_v1: NULL tensor pointer");
   if (bsp) {
@@ -687,7 +707,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   } else if (variant == 0) {
     variant = pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size, max_seq_len, bf, f8);
     if (!variant || (append && !app_variant_v1(variant)))
-      variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf)
+      variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf, f8)
                    : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
     // a long max_seq_len may not leave room for several heads' logits in one workgroup's LDS: fall back to one
     // head per workgroup, then to one wave per head (no second copy of the probabilities) before giving up
@@ -707,7 +727,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     return fail(VMI_E_VARIANT, "paged_attention_v1_append: %s is a bandwidth diagnostic", v.name);
   if (v.F8 != f8)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s is for an %s KV cache", v.name,
-                v.F8 ? "fp8" : "fp16/bf16");
+                v.F8 == 2 ? "fp8 E5M2" : (v.F8 ? "fp8 E4M3" : "fp16/bf16"));
   if (v.BF != bf)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s is for %s elements", v.name,
                 v.BF ? "bfloat16" : "float16");
@@ -815,16 +835,20 @@ static Variant g_variants_v2[] = {
 };
 static const int g_ncore_v2 = (int)(sizeof(g_variants_v2) / sizeof(g_variants_v2[0]));
 
-static int nvariants_v2() { return g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2 + g_fp8_nvariants_v2; }
+static int nvariants_v2() {
+  return g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2 + g_fp8_nvariants_v2 + g_fp8_nvariants_v2_e5m2;
+}
 static Variant& variant_v2(int id) {  // [core fp16][extra fp16][bf16][fp8 cache]
   if (id <= g_ncore_v2) return g_variants_v2[id - 1];
   if (id <= g_ncore_v2 + g_extra_nvariants_v2) return g_extra_variants_v2[id - 1 - g_ncore_v2];
   if (id <= g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2)
     return g_bf16_variants_v2[id - 1 - g_ncore_v2 - g_extra_nvariants_v2];
-  return g_fp8_variants_v2[id - 1 - g_ncore_v2 - g_extra_nvariants_v2 - g_bf16_nvariants_v2];
+  const int f0 = g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2;
+  if (id <= f0 + g_fp8_nvariants_v2) return g_fp8_variants_v2[id - 1 - f0];
+  return g_fp8_variants_v2_e5m2[id - 1 - f0 - g_fp8_nvariants_v2];
 }
 
-static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false, bool f8 = false) {
+static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false, int f8 = false) {
   for (int id = 1; id <= nvariants_v2(); ++id) {
     const Variant& v = variant_v2(id);
     if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && !v.GQS) return id;
@@ -835,7 +859,7 @@ static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false, boo
 // a partition holds 512 / block_size blocks; give each (seq, head, partition) 1..8 waves so that the
 // launch has >= ~2048 waves when the batch allows it
 static int pick_variant_v2(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
-                           bool bf = false, bool f8 = false, int qpk = 1) {
+                           bool bf = false, int f8 = false, int qpk = 1) {
   const int parts = (max_seq_len + 511) / 512;
   if (qpk > 1 && !bf && !f8 && block_size == 16) {  // grouped-query: largest built group size dividing qpk
     for (int g = 8; g >= 2; --g) {
@@ -875,7 +899,7 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
                         const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
                         int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
                         int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                        int32_t device, void* stream, int32_t variant, bool bf = false, bool f8 = false,
+                        int32_t device, void* stream, int32_t variant, bool bf = false, int f8 = false,
                         float kv_scale = 1.0f, const int32_t* bsp = nullptr) {
   if (bsp) {
     if (int rc = check_sparse("paged_attention_v2", bsp)) return rc;
@@ -1145,6 +1169,46 @@ int vmi_paged_attention_v2_fp8(void* out, void* exp_sums, void* max_logits, void
                            kv_scale);
 }
 
+// ---- fp8 E5M2 cache (kv_cache_dtype "fp8_e5m2"): the same operators over E5M2 bytes ----
+int vmi_paged_attention_v1_fp8_e5m2(void* out, const void* query, const void* key_cache, const void* value_cache,
+                                    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+                                    float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                                    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+                                    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                                    int64_t kv_head_stride, int32_t device, void* stream, float kv_scale,
+                                    int32_t variant, int32_t is_bf16) {
+  if (!(kv_scale > 0.f))
+    return vmi::fail(VMI_E_SHAPE, "paged_attention_v1 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, is_bf16 != 0, false, nullptr, nullptr, 0, 0,
+                           2, kv_scale);
+}
+
+int vmi_paged_attention_v2_fp8_e5m2(void* out, void* exp_sums, void* max_logits, void* tmp_out, const void* query,
+                                    const void* key_cache, const void* value_cache, int32_t num_seqs,
+                                    int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
+                                    const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
+                                    int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                                    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                    int32_t device, void* stream, float kv_scale, int32_t variant) {
+  if (!(kv_scale > 0.f))
+    return vmi::fail(VMI_E_SHAPE, "paged_attention_v2 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
+  return vmi::launch_pa_v2(out, static_cast<float*>(exp_sums), static_cast<float*>(max_logits), tmp_out, query,
+                           key_cache, value_cache, num_seqs, num_heads, head_size, num_kv_heads, scale,
+                           block_tables, seq_lens, block_size, max_seq_len, max_num_blocks_per_seq, alibi_slopes,
+                           q_stride, kv_block_stride, kv_head_stride, device, stream, variant, false, 2,
+                           kv_scale);
+}
+
+int vmi_paged_attention_v1_pick_variant_fp8_e5m2(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                                 int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len,
+                                                 int32_t is_bf16) {
+  if (!vmi::head_size_supported(head_size) || (block_size != 16 && block_size != 32)) return 0;
+  return vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, mean_seq_len, is_bf16 != 0, 2);
+}
+
 int vmi_paged_attention_v1_pick_variant_fp8(int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                             int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len) {
   if (!vmi::head_size_supported(head_size) || (block_size != 16 && block_size != 32)) return 0;
@@ -1194,9 +1258,10 @@ int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads,
       num_heads % num_kv_heads)
     return 0;
   const int v = vmi::pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size,
-                                      max_seq_len, is_bf16 != 0, is_fp8 != 0);
+                                      max_seq_len, is_bf16 != 0, is_fp8 == 2 ? 2 : (is_fp8 != 0));
   if (v) return v;
-  return is_fp8 ? vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, is_bf16 != 0)
+  return is_fp8 ? vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, is_bf16 != 0,
+                                        is_fp8 == 2 ? 2 : 1)
                 : vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, is_bf16 != 0);
 }
 
@@ -1277,7 +1342,8 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
 static int reshape_and_cache_fp8_impl(const void* key, const void* value, void* key_cache, void* value_cache,
                                       const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
                                       int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
-                                      int64_t value_stride, float kv_scale, int32_t device, void* stream, bool bf) {
+                                      int64_t value_stride, float kv_scale, int32_t device, void* stream, bool bf,
+                                      bool e5 = false) {
   using namespace vmi;
   if (!key || !value || !key_cache || !value_cache || !slot_mapping)
     return fail(VMI_E_NULL_POINTER, "reshape_and_cache (fp8): NULL tensor pointer");
@@ -1298,8 +1364,11 @@ static int reshape_and_cache_fp8_impl(const void* key, const void* value, void* 
   if (threads > 256) threads = 256;
   hipStream_t st = static_cast<hipStream_t>(stream);
   typedef void (*fp8_fn)(const h16*, const h16*, uint8_t*, uint8_t*, const int64_t*, int64_t, int64_t, int, int, int, float);
-  const fp8_fn fn = vec ? (bf ? (fp8_fn)reshape_and_cache_fp8_kernel<true, true> : (fp8_fn)reshape_and_cache_fp8_kernel<true, false>)
-                        : (bf ? (fp8_fn)reshape_and_cache_fp8_kernel<false, true> : (fp8_fn)reshape_and_cache_fp8_kernel<false, false>);
+  const fp8_fn fns[8] = {(fp8_fn)reshape_and_cache_fp8_kernel<false, false, false>, (fp8_fn)reshape_and_cache_fp8_kernel<true, false, false>,
+                         (fp8_fn)reshape_and_cache_fp8_kernel<false, true, false>,  (fp8_fn)reshape_and_cache_fp8_kernel<true, true, false>,
+                         (fp8_fn)reshape_and_cache_fp8_kernel<false, false, true>,  (fp8_fn)reshape_and_cache_fp8_kernel<true, false, true>,
+                         (fp8_fn)reshape_and_cache_fp8_kernel<false, true, true>,   (fp8_fn)reshape_and_cache_fp8_kernel<true, true, true>};
+  const fp8_fn fn = fns[(e5 ? 4 : 0) + (bf ? 2 : 0) + (vec ? 1 : 0)];
   hipLaunchKernelGGL(fn, dim3(num_tokens), dim3(threads), 0, st, static_cast<const h16*>(key),
                      static_cast<const h16*>(value), static_cast<uint8_t*>(key_cache),
                      static_cast<uint8_t*>(value_cache), slot_mapping, key_stride, value_stride, num_heads, head_size,
@@ -1323,6 +1392,14 @@ int vmi_reshape_and_cache_fp8_bf16(const void* key, const void* value, void* key
                                    int64_t value_stride, float kv_scale, int32_t device, void* stream) {
   return reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
                                     block_size, x, key_stride, value_stride, kv_scale, device, stream, true);
+}
+
+int vmi_reshape_and_cache_fp8_e5m2(const void* key, const void* value, void* key_cache, void* value_cache,
+                                   const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
+                                   int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
+                                   int64_t value_stride, float kv_scale, int32_t device, void* stream, int32_t is_bf16) {
+  return reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
+                                    block_size, x, key_stride, value_stride, kv_scale, device, stream, is_bf16 != 0, true);
 }
 
 int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_cache, void* v_cache,

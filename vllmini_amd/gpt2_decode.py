@@ -219,7 +219,7 @@ class GPT2PagedDecoder:
         st["variant"] = ops.pick_variant(B, self.dims.n_head, self.dims.head_size, max(int(lens.max()), 1),
                                          self.pool.block_size, mean_seq_len=max(int(lens.mean()), 1),
                                          bf16=self.pool.key_cache.dtype == torch.bfloat16,
-                                         fp8=self.pool.kv_cache_dtype != "auto")
+                                         fp8={"auto": False, "fp8_e5m2": "e5m2"}.get(self.pool.kv_cache_dtype, True))
         if isinstance(input_ids, torch.Tensor):
             st["input_ids"].copy_(input_ids.to(torch.long), non_blocking=True)
         else:

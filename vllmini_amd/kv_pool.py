@@ -52,12 +52,12 @@ class PagedKVPool:
         self.num_layers = num_layers
         self.device = torch.device(device)
         self.multi_block_prefill = multi_block_prefill
-        # "auto": fp16 pages (kv_cache.py:13-14); "fp8": E4M3 byte pages in the x = 16 layout, half the bytes
+        # "auto": fp16 pages (kv_cache.py:13-14); "fp8" / "fp8_e5m2": E4M3 / E5M2 byte pages in the x = 16 layout, half the bytes
         # (the reference surface's kv_cache_dtype / kv_scale, passed through to both operators)
         self.kv_cache_dtype, self.kv_scale = kv_cache_dtype, float(kv_scale)
         if allocate_tensors:
             # kv_cache.py:13-14 — ONE pool shared by all layers
-            x, dt = (16, torch.uint8) if kv_cache_dtype in ("fp8", "fp8_e4m3") else (X, torch.float16)
+            x, dt = (16, torch.uint8) if kv_cache_dtype in ("fp8", "fp8_e4m3", "fp8_e5m2") else (X, torch.float16)
             self.key_cache = torch.zeros(num_blocks, num_heads, head_size // x, block_size, x,
                                          dtype=dt, device=self.device)
             self.value_cache = torch.zeros(num_blocks, num_heads, head_size, block_size,

@@ -45,20 +45,26 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-_FP8_CACHE_TORCH_DTYPES = (torch.uint8, torch.float8_e4m3fn)
 
 
-def _check_kv_cache_dtype(kv_cache_dtype: str) -> bool:
-    """-> True when the caches hold fp8 E4M3 bytes.  The reference maps "fp8" and "fp8_e4m3" to E4M3 and
-    "fp8_e5m2" to E5M2 (quant_utils.cuh:529-566); E4M3 is built here (its own build never defines ENABLE_FP8, so
-    the reference's fp8 path is assert(false) — paged_attention_ext/setup.py:30-45 — and its source is the spec)."""
+def _check_kv_cache_dtype(kv_cache_dtype: str) -> int:
+    """-> 0 for 16-bit caches ("auto"), 1 when the caches hold fp8 E4M3 bytes, 2 for fp8 E5M2 bytes.  The reference maps
+    "fp8" and "fp8_e4m3" to E4M3 and "fp8_e5m2" to E5M2 (quant_utils.cuh:529-566); both are built here (the reference's
+    own build never defines ENABLE_FP8, so its fp8 path is assert(false) — paged_attention_ext/setup.py:30-45 — and its
+    source is the spec)."""
     if kv_cache_dtype in _SUPPORTED_KV_CACHE_DTYPES:
-        return False
+        return 0
     if kv_cache_dtype in ("fp8", "fp8_e4m3"):
-        return True
-    if kv_cache_dtype in _FP8_KV_CACHE_DTYPES:
-        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype} (only the E4M3 fp8 format is built)")
+        return 1
+    if kv_cache_dtype == "fp8_e5m2":
+        return 2
     raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+
+
+def _check_fp8_cache_dtype(fp8: int, key_cache: torch.Tensor, value_cache: torch.Tensor, kv_cache_dtype: str) -> None:
+    ok = (torch.uint8, torch.float8_e5m2 if fp8 == 2 else torch.float8_e4m3fn)
+    if key_cache.dtype not in ok or value_cache.dtype not in ok:
+        raise RuntimeError(f"key_cache/value_cache must be uint8 (or {ok[1]}) for kv_cache_dtype='{kv_cache_dtype}'")
 
 
 def _check_device(name: str, t: torch.Tensor, device: torch.device) -> None:
@@ -97,8 +103,7 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
                     ("block_tables", block_tables), ("seq_lens", seq_lens)):
         _check_device(name, t, dev)
     if fp8:
-        if key_cache.dtype not in _FP8_CACHE_TORCH_DTYPES or value_cache.dtype not in _FP8_CACHE_TORCH_DTYPES:
-            raise RuntimeError("key_cache/value_cache must be uint8 (or float8_e4m3fn) for kv_cache_dtype='fp8'")
+        _check_fp8_cache_dtype(fp8, key_cache, value_cache, kv_cache_dtype)
     elif key_cache.dtype != query.dtype or value_cache.dtype != query.dtype:
         raise RuntimeError(f"key_cache/value_cache must be {query.dtype} for kv_cache_dtype='auto'")
     if out.dtype != query.dtype:
@@ -194,6 +199,8 @@ def paged_attention_v1(
         rc = lib.vmi_paged_attention_v1_blocksparse(
             *args, int(query.dtype == torch.bfloat16), int(tp_rank), int(blocksparse_local_blocks),
             int(blocksparse_vert_stride), int(blocksparse_block_size), int(blocksparse_head_sliding_step))
+    elif _check_kv_cache_dtype(kv_cache_dtype) == 2:   # fp8 E5M2 cache
+        rc = lib.vmi_paged_attention_v1_fp8_e5m2(*args, float(kv_scale), int(_variant), int(query.dtype == torch.bfloat16))
     elif _check_kv_cache_dtype(kv_cache_dtype):      # fp8 E4M3 cache, float16 or bfloat16 query
         fn = lib.vmi_paged_attention_v1_fp8_bf16 if query.dtype == torch.bfloat16 else lib.vmi_paged_attention_v1_fp8
         rc = fn(*args, float(kv_scale), int(_variant))
@@ -313,8 +320,9 @@ def paged_attention_v2(
             int(query.dtype == torch.bfloat16), int(tp_rank), int(blocksparse_local_blocks),
             int(blocksparse_vert_stride), int(blocksparse_block_size), int(blocksparse_head_sliding_step))
     elif fp8:
-        rc = _lib.load().vmi_paged_attention_v2_fp8(args[0], exp_sums.data_ptr(), max_logits.data_ptr(),
-                                                    tmp_out.data_ptr(), *args[1:], float(kv_scale), int(_variant))
+        fn8 = _lib.load().vmi_paged_attention_v2_fp8_e5m2 if fp8 == 2 else _lib.load().vmi_paged_attention_v2_fp8
+        rc = fn8(args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:],
+                 float(kv_scale), int(_variant))
     else:
         fn = _lib.load().vmi_paged_attention_v2_bf16 if query.dtype == torch.bfloat16 else \
             _lib.load().vmi_paged_attention_v2_f16
@@ -347,8 +355,7 @@ def reshape_and_cache(
                     ("value_cache", value_cache), ("slot_mapping", slot_mapping)):
         _check_device(name, t, dev)
     if fp8:
-        if key_cache.dtype not in _FP8_CACHE_TORCH_DTYPES or value_cache.dtype not in _FP8_CACHE_TORCH_DTYPES:
-            raise RuntimeError("key_cache/value_cache must be uint8 (or float8_e4m3fn) for kv_cache_dtype='fp8'")
+        _check_fp8_cache_dtype(fp8, key_cache, value_cache, kv_cache_dtype)
     elif key_cache.dtype != key.dtype or value_cache.dtype != key.dtype:
         raise RuntimeError(f"key_cache/value_cache must be {key.dtype} for kv_cache_dtype='auto'")
     if slot_mapping.dtype != torch.int64:
@@ -372,13 +379,16 @@ def reshape_and_cache(
         raise RuntimeError("slot_mapping must be a contiguous [num_tokens] tensor")
     stream = torch.cuda.current_stream(dev).cuda_stream
     if fp8:                                                               # cache_kernels.cu:200-205
-        fn = _lib.load().vmi_reshape_and_cache_fp8_bf16 if key.dtype == torch.bfloat16 else \
-            _lib.load().vmi_reshape_and_cache_fp8
-        rc = fn(
-            key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
-            slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
-            int(key.stride(0)), int(value.stride(0)), float(kv_scale),
-            dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+        a8 = (key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+              slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
+              int(key.stride(0)), int(value.stride(0)), float(kv_scale),
+              dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+        if fp8 == 2:
+            rc = _lib.load().vmi_reshape_and_cache_fp8_e5m2(*a8, int(key.dtype == torch.bfloat16))
+        else:
+            fn = _lib.load().vmi_reshape_and_cache_fp8_bf16 if key.dtype == torch.bfloat16 else \
+                _lib.load().vmi_reshape_and_cache_fp8
+            rc = fn(*a8)
         if rc != 0:
             _raise_native(rc)
         return None
@@ -415,14 +425,18 @@ def set_pv_mfma(on: bool) -> bool:
 
 
 def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16,
-                 mean_seq_len: int = 0, bf16: bool = False, fp8: bool = False, num_kv_heads: int = 0) -> int:
+                 mean_seq_len: int = 0, bf16: bool = False, fp8=False, num_kv_heads: int = 0) -> int:
     """The library's work-decomposition heuristic (what `_variant=0` runs).  A caller that knows the batch's
     lengths on the host may pass their mean: a ragged batch (mean well below max_seq_len) then gets the
-    many-waves-per-head decomposition; pass the result as `_variant`."""
+    many-waves-per-head decomposition; pass the result as `_variant`.  fp8: False / True (E4M3) / "e5m2"."""
     lib = _lib.load()
+    fp8 = 2 if fp8 in (2, "e5m2", "fp8_e5m2") else int(bool(fp8))
     if num_kv_heads and num_kv_heads != num_heads:      # grouped-query attention: what the operators pick themselves
         return int(lib.vmi_paged_attention_v1_pick_variant_gqa(num_seqs, num_heads, int(num_kv_heads), head_size,
-                                                               block_size, max_seq_len, int(bool(bf16)), int(bool(fp8))))
+                                                               block_size, max_seq_len, int(bool(bf16)), fp8))
+    if fp8 == 2:
+        return int(lib.vmi_paged_attention_v1_pick_variant_fp8_e5m2(num_seqs, num_heads, head_size, block_size,
+                                                                    max_seq_len, int(mean_seq_len), int(bool(bf16))))
     if fp8:
         fn = lib.vmi_paged_attention_v1_pick_variant_fp8_bf16 if bf16 else lib.vmi_paged_attention_v1_pick_variant_fp8
         return int(fn(num_seqs, num_heads, head_size, block_size, max_seq_len, int(mean_seq_len)))
