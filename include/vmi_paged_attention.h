@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 12
+#define VMI_ABI_VERSION 13
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -403,6 +403,15 @@ int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_c
                                    const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
                                    int32_t head_size, int32_t block_size, int64_t block_stride,
                                    int64_t key_stride, int64_t value_stride, int32_t device, void* stream);
+
+/*
+ * cache_ops.convert_fp8(dst_cache, src_cache, kv_scale, kv_cache_dtype) — cache_kernels.cu:320-392 ("only for
+ * testing" in the reference; compiled to assert(false) in its shipped build).  Elementwise over num_elements contiguous
+ * elements: to_fp8 != 0: dst (uint8 E4M3) = fp8(float(src) / kv_scale), RNE, saturating; to_fp8 == 0: dst =
+ * half / bfloat16 / float of (float(fp8) * kv_scale).  kind: 0 = half, 1 = bfloat16, 2 = float (the non-fp8 side).
+ */
+int vmi_convert_fp8(void* dst, const void* src, int64_t num_elements, float kv_scale, int32_t kind, int32_t to_fp8,
+                    int32_t device, void* stream);
 
 /*
  * cache_ops.copy_blocks — cache_kernels.cu:96-148 (kernel :68-94).  For every layer l and pair p:

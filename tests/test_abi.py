@@ -40,7 +40,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 12
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 13
     assert typed.vmi_target_arch() == b"gfx950"
 
 
@@ -83,8 +83,11 @@ def test_python_surface_matches_reference_signatures():
         assert hasattr(ext.cache_ops, name)
     assert list(inspect.signature(ext.cache_ops.swap_blocks).parameters) == ["src", "dst", "block_mapping"]
     assert list(inspect.signature(ext.cache_ops.copy_blocks).parameters) == ["key_caches", "value_caches", "block_mapping"]
-    with pytest.raises(NotImplementedError):
-        ext.cache_ops.convert_fp8()
+    assert list(inspect.signature(ext.cache_ops.convert_fp8).parameters) == ["dst_cache", "src_cache", "kv_scale", "kv_cache_dtype"]
+    with pytest.raises(RuntimeError, match="Unsupported data type: int8"):                  # cache_kernels.cu:389-391
+        ext.cache_ops.convert_fp8(torch.zeros(4, dtype=torch.uint8), torch.zeros(4, dtype=torch.float16), 1.0, "int8")
+    with pytest.raises(RuntimeError, match="src must be on a GPU"):                         # :345
+        ext.cache_ops.convert_fp8(torch.zeros(4, dtype=torch.uint8), torch.zeros(4, dtype=torch.float16), 1.0, "fp8")
     v2 = [p.name for p in inspect.signature(ext.paged_attention_v2).parameters.values()
           if p.kind is not inspect.Parameter.KEYWORD_ONLY]
     assert v2 == ["out", "exp_sums", "max_logits", "tmp_out"] + pa[1:]                      # .cpp:27-47

@@ -1486,6 +1486,48 @@ def test_gqa_shared_tile_kernels_match_kernel_model(D):
         assert ran >= 3, (H, hkv, ran)
 
 
+def test_convert_fp8_every_value_both_directions():
+    """cache_ops.convert_fp8 (cache_kernels.cu:320-392): half / bfloat16 / float -> fp8 E4M3 and back, every 16-bit
+    pattern and every fp8 code, against the oracle's converters."""
+    ext = _ext()
+    dev = _dev()
+    bits = np.arange(65536, dtype=np.uint16)
+    for kv_scale in (1.0, 0.37):
+        s32 = np.float32(kv_scale)
+        # to fp8
+        for name, src_t, as_f32 in (("half", torch.from_numpy(bits.view(np.float16).copy()).to(dev), bits.view(np.float16).astype(np.float32)),
+                                    ("bf16", _bf16_tensor(bits, dev), oracle.bf16_bits_to_f32(bits))):
+            dst = torch.zeros(65536, dtype=torch.uint8, device=dev)
+            ext.cache_ops.convert_fp8(dst, src_t, kv_scale, "fp8")
+            torch.cuda.synchronize()
+            with np.errstate(over="ignore", invalid="ignore"):
+                want = oracle.f32_to_fp8e4m3(as_f32 / s32)
+            assert np.array_equal(dst.cpu().numpy(), want), (name, kv_scale)
+        f32 = np.concatenate([np.linspace(-500, 500, 4001, dtype=np.float32), np.float32([0.0, -0.0, 1e-8, 3e38, -3e38, np.inf, -np.inf])])
+        dst = torch.zeros(f32.size, dtype=torch.float8_e4m3fn, device=dev)             # float8 view of the same bytes
+        ext.cache_ops.convert_fp8(dst, torch.from_numpy(f32).to(dev), kv_scale, "fp8_e4m3")
+        torch.cuda.synchronize()
+        with np.errstate(over="ignore"):
+            assert np.array_equal(dst.view(torch.uint8).cpu().numpy(), oracle.f32_to_fp8e4m3(f32 / s32)), kv_scale
+        # from fp8
+        codes = np.arange(256, dtype=np.uint8)
+        dec = oracle.fp8e4m3_to_f32(codes) * s32
+        ok = ~np.isnan(dec)
+        src = torch.from_numpy(codes).to(dev)
+        out_h = torch.zeros(256, dtype=torch.float16, device=dev)
+        out_b = torch.zeros(256, dtype=torch.bfloat16, device=dev)
+        out_f = torch.zeros(256, dtype=torch.float32, device=dev)
+        for o in (out_h, out_b, out_f):
+            ext.cache_ops.convert_fp8(o, src, kv_scale, "fp8")
+        torch.cuda.synchronize()
+        assert np.array_equal(out_h.cpu().numpy()[ok].view(np.uint16), dec.astype(np.float16)[ok].view(np.uint16))
+        assert np.array_equal(out_b.view(torch.int16).cpu().numpy().view(np.uint16)[ok], oracle.f32_to_bf16_bits(dec)[ok])
+        assert np.array_equal(out_f.cpu().numpy()[ok].view(np.uint32), dec[ok].view(np.uint32))
+        assert torch.isnan(out_h[~torch.from_numpy(ok).to(dev)]).all()
+    with pytest.raises(RuntimeError, match="Unsupported data type: auto"):
+        ext.cache_ops.convert_fp8(dst, torch.zeros(dst.numel(), dtype=torch.float16, device=dev), 1.0, "auto")
+
+
 # ------------------------------------------------------------------------------------------------
 # fp8 E5M2 KV cache (kv_cache_dtype "fp8_e5m2")
 # ------------------------------------------------------------------------------------------------

@@ -4,7 +4,8 @@
   copy_blocks         cache_kernels.cu:96-148    multi-layer block copy (copy-on-write / forking)
   swap_blocks         cache_kernels.cu:24-63     block moves device<->device / device<->host (preemption)
   reshape_and_cache_flash  cache_kernels.cu:283-317  scatter into the flash layout [NB, block_size, H, D]
-  convert_fp8              exported by the reference, compiled to assert(false) there (ENABLE_FP8 undefined), not built
+  convert_fp8              cache_kernels.cu:320-392  whole-cache conversion fp8 E4M3 <-> float / half / bfloat16
+                           ("only for testing" in the reference, compiled to assert(false) in its shipped build)
 """
 from __future__ import annotations
 
@@ -121,13 +122,34 @@ def reshape_and_cache_flash(key: torch.Tensor, value: torch.Tensor, k_cache: tor
     return None
 
 
-def _not_built(name: str, where: str):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(
-            f"cache_ops.{name} is outside the decode hot path (reference {where} has no Python "
-            "caller) and is not built")
-    fn.__name__ = name
-    return fn
-
-
-convert_fp8 = _not_built("convert_fp8", "cache_kernels.cu:335-392")
+def convert_fp8(dst_cache: torch.Tensor, src_cache: torch.Tensor, kv_scale: float = 1.0,
+                kv_cache_dtype: str = "auto") -> None:
+    """dst_cache = scaled_convert(src_cache, kv_scale), elementwise (cache_kernels.cu:320-392): a float / half /
+    bfloat16 cache to fp8 E4M3 bytes (fp8(x / kv_scale), RNE, saturating) or back (float(fp8) * kv_scale, rounded to
+    dst's type).  kv_cache_dtype "fp8" / "fp8_e4m3"; the reference's "auto" branch selects a conversion that does not
+    exist (kAuto, quant_utils.cuh:512-525) and every other name is its "Unsupported data type"."""
+    if kv_cache_dtype not in ("fp8", "fp8_e4m3"):
+        raise RuntimeError(f"Unsupported data type: {kv_cache_dtype}")                    # :389-391
+    if not src_cache.is_cuda:
+        raise RuntimeError("src must be on a GPU")                                        # :345
+    if not dst_cache.is_cuda:
+        raise RuntimeError("dst must be on a GPU")                                        # :346
+    if src_cache.device != dst_cache.device:
+        raise RuntimeError("src and dst must be on the same GPU")                         # :347-348
+    kinds = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+    fp8_types = (torch.uint8, torch.float8_e4m3fn)
+    if src_cache.dtype in kinds and dst_cache.dtype in fp8_types:
+        kind, to_fp8 = kinds[src_cache.dtype], 1
+    elif src_cache.dtype in fp8_types and dst_cache.dtype in kinds:
+        kind, to_fp8 = kinds[dst_cache.dtype], 0
+    else:
+        raise RuntimeError(f"convert_fp8: unsupported dtype pair {src_cache.dtype} -> {dst_cache.dtype}")
+    if src_cache.numel() != dst_cache.numel() or not src_cache.is_contiguous() or not dst_cache.is_contiguous():
+        raise RuntimeError("convert_fp8: src and dst must be contiguous and hold the same number of elements")
+    dev = src_cache.device
+    rc = _lib.load().vmi_convert_fp8(dst_cache.data_ptr(), src_cache.data_ptr(), int(src_cache.numel()), float(kv_scale),
+                                     kind, to_fp8, dev.index if dev.index is not None else torch.cuda.current_device(),
+                                     torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        _raise_native(rc)
+    return None

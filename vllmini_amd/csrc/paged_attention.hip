@@ -225,6 +225,43 @@ __global__ void __launch_bounds__(256)
 }
 
 // ----------------------------------------------------------------------------------------
+// convert_fp8 (cache_kernels.cu:320-392, "only for testing" there): elementwise conversion of a whole cache between
+// fp8 E4M3 bytes and float / half / bfloat16 — dst = scaled_convert(src, kv_scale) (quant_utils.cuh):
+//   to fp8:   fp8(float(x) / kv_scale), RNE, saturating      from fp8:  half(float(fp8) * kv_scale), bf16(...), float(...)
+// KIND: 0 half, 1 bfloat16, 2 float.  Pure streaming: 16 elements per thread.
+// ----------------------------------------------------------------------------------------
+template <int KIND, bool TO_FP8>
+__global__ void __launch_bounds__(256)
+    convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, int64_t n, float kv_scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 16;
+  for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i0 < n; i0 += stride) {
+    const int cnt = (n - i0) < 16 ? (int)(n - i0) : 16;
+    for (int e = 0; e < cnt; ++e) {
+      const int64_t i = i0 + e;
+      if constexpr (TO_FP8) {
+        float x;
+        if constexpr (KIND == 0) x = (float)static_cast<const h16*>(src)[i];
+        else if constexpr (KIND == 1) x = __builtin_bit_cast(float, (uint32_t)static_cast<const uint16_t*>(src)[i] << 16);
+        else x = static_cast<const float*>(src)[i];
+        static_cast<uint8_t*>(dst)[i] = (uint8_t)f32_to_fp8e4m3_satfinite(x / kv_scale);
+      } else {
+        const uint32_t b = static_cast<const uint8_t*>(src)[i];
+        const float f = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false)[0];  // exact
+        // the two zero codes are written as signed zeros directly: hipcc fuses half(f * s) into v_fma_mixlo_f16(s, f, +0),
+        // and (-0 * s) + (+0) is +0 — invisible inside the attention sums, visible in a bit-exact conversion
+        const bool zero = (b & 0x7fu) == 0;
+        if constexpr (KIND == 0)
+          static_cast<uint16_t*>(dst)[i] = zero ? (uint16_t)(b << 8) : __builtin_bit_cast(uint16_t, (h16)(f * kv_scale));
+        else if constexpr (KIND == 1)
+          static_cast<uint16_t*>(dst)[i] = zero ? (uint16_t)(b << 8) : to_elem<true>(f * kv_scale);
+        else
+          static_cast<float*>(dst)[i] = zero ? __builtin_bit_cast(float, b << 24) : f * kv_scale;
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // reshape_and_cache, run form (calls of >= 2*block_size tokens).  A prompt's tokens arrive with consecutive slots, so
 // BS consecutive tokens usually ARE one cache block.  The per-token kernel above then writes every 32-B V row in BS
 // separate 2-byte pieces (1.0-1.2 TB/s read+write on MI355X).  Here a workgroup takes (a run of BS tokens) x (4 heads),
@@ -1400,6 +1437,29 @@ int vmi_reshape_and_cache_fp8_e5m2(const void* key, const void* value, void* key
                                    int64_t value_stride, float kv_scale, int32_t device, void* stream, int32_t is_bf16) {
   return reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
                                     block_size, x, key_stride, value_stride, kv_scale, device, stream, is_bf16 != 0, true);
+}
+
+int vmi_convert_fp8(void* dst, const void* src, int64_t num_elements, float kv_scale, int32_t kind, int32_t to_fp8,
+                    int32_t device, void* stream) {
+  using namespace vmi;
+  if (num_elements < 0 || kind < 0 || kind > 2) return fail(VMI_E_SHAPE, "convert_fp8: bad arguments (n=%lld kind=%d)", (long long)num_elements, kind);
+  if (!(kv_scale > 0.f)) return fail(VMI_E_SHAPE, "convert_fp8: kv_scale must be positive, got %g", (double)kv_scale);
+  if (num_elements == 0) return VMI_OK;
+  if (!dst || !src) return fail(VMI_E_NULL_POINTER, "convert_fp8: NULL tensor pointer");
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  typedef void (*cv_fn)(void*, const void*, int64_t, float);
+  const cv_fn fns[6] = {(cv_fn)convert_fp8_kernel<0, false>, (cv_fn)convert_fp8_kernel<0, true>,
+                        (cv_fn)convert_fp8_kernel<1, false>, (cv_fn)convert_fp8_kernel<1, true>,
+                        (cv_fn)convert_fp8_kernel<2, false>, (cv_fn)convert_fp8_kernel<2, true>};
+  int64_t blocks = (num_elements + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(fns[2 * kind + (to_fp8 ? 1 : 0)], dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dst, src, num_elements, kv_scale);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "convert_fp8 launch");
+  return VMI_OK;
 }
 
 int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_cache, void* v_cache,
