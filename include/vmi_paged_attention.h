@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 13
+#define VMI_ABI_VERSION 14
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -403,6 +403,29 @@ int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_c
                                    const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
                                    int32_t head_size, int32_t block_size, int64_t block_stride,
                                    int64_t key_stride, int64_t value_stride, int32_t device, void* stream);
+
+/*
+ * float32 tensors — the (float, float) branch of the reference's dispatch (quant_utils.cuh:529-535): query / out /
+ * caches float32, x = 16 / sizeof(float) = 4: key_cache [NB, H, D/4, BS, 4], value_cache [NB, H, D, BS]; strides in
+ * elements; every operation in fp32 (dtype_float32.cuh).  The reference's callers never use it (scheduler.py:13 runs the
+ * model in half): one plain kernel per (head size, block size), no tuning variants, paged_attention_v1 and
+ * reshape_and_cache only.
+ */
+int vmi_paged_attention_v1_f32(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream);
+int vmi_reshape_and_cache_f32(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int64_t* slot_mapping,
+    int32_t num_tokens, int32_t num_heads, int32_t head_size, int32_t block_size, int32_t x,
+    int64_t key_stride, int64_t value_stride,
+    int32_t device, void* stream);
 
 /*
  * cache_ops.convert_fp8(dst_cache, src_cache, kv_scale, kv_cache_dtype) — cache_kernels.cu:320-392 ("only for

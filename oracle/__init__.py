@@ -20,6 +20,8 @@ from .kernel_model import (  # noqa: F401
     f2h,
     h2f,
     paged_attention_v1,
+    paged_attention_v1_f32,
+    reshape_and_cache_f32,
     paged_attention_v2,
     reshape_and_cache,
     # fp8 (E4M3) KV cache — kv_cache_dtype "fp8"

@@ -178,6 +178,58 @@ def paged_attention_v2(query: np.ndarray, key_cache: np.ndarray, value_cache: np
     return out, exp_sums, max_logits, tmp_out
 
 
+def paged_attention_v1_f32(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray, num_kv_heads: int,
+                           scale: float, block_tables: np.ndarray, seq_lens: np.ndarray, block_size: int,
+                           alibi_slopes: np.ndarray | None = None, threads: int = 1) -> np.ndarray:
+    """Kernel model for float32 tensors (the (float, float) dispatch branch): key_cache [NB, H, D/4, BS, 4],
+    value_cache [NB, H, D, BS], everything fp32 (dtype_float32.cuh)."""
+    assert query.dtype == key_cache.dtype == value_cache.dtype == np.float32
+    assert query.ndim == 3 and key_cache.ndim == 5 and key_cache.shape[4] == 4 and value_cache.ndim == 4
+    S, H, D = query.shape
+    qs = _elem_strides(query)
+    assert qs[2] == 1 and qs[1] == D
+    key_cache, value_cache = np.ascontiguousarray(key_cache), np.ascontiguousarray(value_cache)
+    block_tables = np.ascontiguousarray(block_tables, dtype=np.int32)
+    seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    kb, kh = _elem_strides(key_cache)[:2]
+    out = np.zeros((S, H, D), dtype=np.float32)
+    alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
+    fn = _load().vmi_oracle_paged_attention_v1_f32
+    fn.restype = ctypes.c_int
+    fn.argtypes = ([ctypes.c_void_p] * 4 + [ctypes.c_int32] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
+                   [ctypes.c_int32] * 2 + [ctypes.c_void_p] + [ctypes.c_int64] * 3 + [ctypes.c_int32] * 2)
+
+    def run(lo: int, hi: int) -> int:
+        return fn(_base_ptr(out), _base_ptr(query), _base_ptr(key_cache), _base_ptr(value_cache), S, H, D,
+                  int(num_kv_heads), float(scale), _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size),
+                  int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
+                  lo, hi)
+
+    threads = max(1, min(int(threads), S))
+    bounds = np.linspace(0, S, threads + 1).astype(int)
+    with ThreadPoolExecutor(threads) as ex:
+        rcs = list(ex.map(lambda i: run(int(bounds[i]), int(bounds[i + 1])), range(threads)))
+    if any(rc == 1 for rc in rcs):
+        raise RuntimeError(f"Unsupported head size / block size: {D} / {block_size}")
+    if any(rcs):
+        raise MemoryError("oracle allocation failed")
+    return out
+
+
+def reshape_and_cache_f32(key: np.ndarray, value: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray,
+                          slot_mapping: np.ndarray) -> None:
+    """cache_kernels.cu:164-199 for float32 tensors (x = 4): a pure copy, written with numpy indexing."""
+    assert key.dtype == value.dtype == key_cache.dtype == value_cache.dtype == np.float32 and key_cache.shape[4] == 4
+    T, H, D = key.shape
+    bs = key_cache.shape[3]
+    for t, slot in enumerate(np.asarray(slot_mapping, dtype=np.int64)):
+        if slot < 0:
+            continue                                                     # :165-169
+        blk, off = divmod(int(slot), bs)
+        key_cache[blk, :, :, off, :] = key[t].reshape(H, D // 4, 4)
+        value_cache[blk, :, :, off] = value[t]
+
+
 def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
     """float32 -> bfloat16 bit patterns (uint16), round-to-nearest-even (numpy side of f2b)."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)

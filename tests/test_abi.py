@@ -40,7 +40,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 13
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 14
     assert typed.vmi_target_arch() == b"gfx950"
 
 
@@ -123,7 +123,7 @@ def test_argument_validation_before_any_launch():
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache: int8"):
         call(kvd="int8")                                     # quant_utils.cuh:564
     with pytest.raises(RuntimeError, match="Unsupported input type"):
-        call(q=a["q"].float())                               # fp32 uses another cache layout (x = 4): not built
+        call(q=a["q"].double())                              # float / half / bfloat16 are the reference's element types
     with pytest.raises(RuntimeError, match="block-sparse"):
         call(vert=2, kvd="fp8")                              # block-sparse attention: 16-bit caches only
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):

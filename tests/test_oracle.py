@@ -455,3 +455,63 @@ def test_fp8_e5m2_kernel_model_is_the_f16_model_on_dequantised_caches():
         b, o = divmod(int(slots[t]), bs)
         assert np.array_equal(kc[b, :, :, o, :].reshape(Hkv, D), oracle.f32_to_fp8e5m2(key[t].astype(np.float32) / np.float32(0.5)))
         assert np.array_equal(vc[b, :, :, o], oracle.f32_to_fp8e5m2(val[t].astype(np.float32) / np.float32(0.5)))
+
+
+# ------------------------------------------------------------------------------------------------
+# float32 tensors: the (float, float) branch of the dispatch (x = 4 cache layout, all-fp32 arithmetic)
+# ------------------------------------------------------------------------------------------------
+def f32_case(rng, S, H, hkv, D, bs, lens):
+    lens = np.asarray(lens, np.int32)
+    nb = max((int(lens.max()) + bs - 1) // bs, 1)
+    NB = S * nb + 2
+    return dict(q=rng.standard_normal((S, H, D)).astype(np.float32),
+                kc=rng.standard_normal((NB, hkv, D // 4, bs, 4)).astype(np.float32),
+                vc=rng.standard_normal((NB, hkv, D, bs)).astype(np.float32),
+                tables=rng.permutation(NB)[: S * nb].reshape(S, nb).astype(np.int32), lens=lens, hkv=hkv, bs=bs,
+                scale=float(D) ** -0.5)
+
+
+def f32_exact(case, alibi=None):
+    q, kc, vc, tables, lens, hkv, bs = (case[k] for k in ("q", "kc", "vc", "tables", "lens", "hkv", "bs"))
+    S, H, D = q.shape
+    NB = kc.shape[0]
+    kk = kc.astype(np.float64).transpose(0, 1, 3, 2, 4).reshape(NB, hkv, bs, D)
+    vv = vc.astype(np.float64).transpose(0, 1, 3, 2)
+    out = np.zeros((S, H, D))
+    for s, L in enumerate(lens):
+        n = (L + bs - 1) // bs
+        for h in range(H):
+            if L == 0:
+                continue
+            kvh = h // (H // hkv)
+            K = kk[tables[s, :n], kvh].reshape(-1, D)[:L]
+            V = vv[tables[s, :n], kvh].reshape(-1, D)[:L]
+            lg = (K @ q[s, h].astype(np.float64)) * case["scale"]
+            if alibi is not None:
+                lg = lg + alibi[h] * (np.arange(L) - L + 1)
+            pr = np.exp(lg - lg.max())
+            out[s, h] = (pr / pr.sum()) @ V
+    return out
+
+
+@pytest.mark.parametrize("D,bs,H,hkv", [(64, 16, 4, 2), (80, 8, 3, 3), (128, 32, 4, 1), (256, 16, 2, 2), (112, 16, 2, 1)])
+def test_f32_kernel_model_matches_exact_attention(D, bs, H, hkv):
+    rng = np.random.default_rng(D + bs)
+    case = f32_case(rng, 6, H, hkv, D, bs, [1, bs, bs + 1, 100, 333, 0])
+    al = rng.uniform(0, 0.2, H).astype(np.float32)
+    got = oracle.paged_attention_v1_f32(case["q"], case["kc"], case["vc"], hkv, case["scale"], case["tables"], case["lens"],
+                                        bs, alibi_slopes=al, threads=4)
+    assert np.abs(got - f32_exact(case, al)).max() < 2e-5
+    assert (got[5] == 0).all()                                       # seq_len 0
+    # reshape: rows land where the attention reads them
+    T = 5
+    key = rng.standard_normal((T, hkv, D)).astype(np.float32)
+    val = rng.standard_normal((T, hkv, D)).astype(np.float32)
+    slots = np.array([3, 0, -1, 2 * bs + 1, bs - 1], np.int64)
+    kc2, vc2 = np.zeros_like(case["kc"]), np.zeros_like(case["vc"])
+    oracle.reshape_and_cache_f32(key, val, kc2, vc2, slots)
+    for t, sl in enumerate(slots):
+        if sl < 0:
+            continue
+        b, o = divmod(int(sl), bs)
+        assert np.array_equal(kc2[b, :, :, o, :].reshape(hkv, D), key[t]) and np.array_equal(vc2[b, :, :, o], val[t])

@@ -491,7 +491,9 @@ def test_errors_raise_runtimeerror():
     with pytest.raises(RuntimeError, match="int32"):
         call(good, lens=torch.from_numpy(good["lens"].astype(np.int64)).to(dev))
     with pytest.raises(RuntimeError, match="Unsupported input type"):
-        call(good, q=torch.from_numpy(good["q"].astype(np.float32)).to(dev))
+        call(good, q=torch.from_numpy(good["q"].astype(np.float64)).to(dev))
+    with pytest.raises(RuntimeError, match="must be torch.float32"):
+        call(good, q=torch.from_numpy(good["q"].astype(np.float32)).to(dev))     # float32 query needs float32 caches (x = 4)
     with pytest.raises(RuntimeError, match="no CPU path"):
         call(good, q=torch.from_numpy(good["q"].copy()))
     torch.cuda.synchronize()
@@ -1484,6 +1486,75 @@ def test_gqa_shared_tile_kernels_match_kernel_model(D):
             _append_vs_two_ops(case, vid, seed=vid, what=f"append {name} H{H}/{hkv}")
             ran += 1
         assert ran >= 3, (H, hkv, ran)
+
+
+# ------------------------------------------------------------------------------------------------
+# float32 tensors: the (float, float) dispatch branch (x = 4)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bs", ALL_BLOCKS)
+@pytest.mark.parametrize("D", ALL_HEADS)
+def test_f32_every_head_and_block_size(D, bs):
+    """paged_attention_v1 + reshape_and_cache over float32 tensors against the fp32 kernel model (same arithmetic up to
+    fp32 summation order: rtol 2e-5) — strided query rows, grouped KV heads, ALiBi, NaN-poisoned tails, empty sequences."""
+    from test_oracle import f32_case
+
+    ext = _ext()
+    dev = _dev()
+    rng = np.random.default_rng(50 * D + bs)
+    lens = [1, bs, bs + 1, 100, 333, 0, 700, 2]
+    S, H, hkv = len(lens), 4, 2
+    case = f32_case(rng, S, H, hkv, D, bs, lens)
+    # poison everything past each context inside its last block
+    for s_, L in enumerate(lens):
+        if L % bs:
+            blk = case["tables"][s_, L // bs]
+            case["kc"][blk, :, :, L % bs:, :] = np.nan
+            case["vc"][blk, :, :, L % bs:] = np.nan
+    al = rng.uniform(0, 0.2, H).astype(np.float32)
+    qbuf = np.zeros((S, 3 * H * D), np.float32)
+    qbuf[:, : H * D] = case["q"].reshape(S, -1)
+    q = torch.from_numpy(qbuf).to(dev)[:, : H * D].view(S, H, D)                  # row stride 3 * hidden
+    kc, vc = torch.from_numpy(case["kc"]).to(dev), torch.from_numpy(case["vc"]).to(dev)
+    tab, ln = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
+    for alibi in (None, al):
+        ref = oracle.paged_attention_v1_f32(case["q"], case["kc"], case["vc"], hkv, case["scale"], case["tables"],
+                                            case["lens"], bs, alibi_slopes=alibi, threads=8)
+        out = torch.full((S, H, D), float("nan"), dtype=torch.float32, device=dev)
+        ext.paged_attention_v1(out, q, kc, vc, hkv, case["scale"], tab, ln, bs, max(lens),
+                               None if alibi is None else torch.from_numpy(alibi).to(dev), "auto", 1.0, 0, 0, 1, 1, 0)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (D, bs, np.abs(got - ref).max())
+    # reshape_and_cache: bit-exact copy, then attention over the written rows
+    T = 6
+    key = torch.from_numpy(rng.standard_normal((T, 3, hkv, D)).astype(np.float32)).to(dev)
+    k_rows, v_rows = key[:, 0], key[:, 1]                                           # strided views (fused qkv style)
+    slots = np.array([5, 0, -1, 2 * bs + 1, bs - 1, 3 * bs], np.int64)
+    kc2, vc2 = torch.zeros_like(kc), torch.zeros_like(vc)
+    ext.cache_ops.reshape_and_cache(k_rows, v_rows, kc2, vc2, torch.from_numpy(slots).to(dev), "auto", 1.0)
+    torch.cuda.synchronize()
+    rk, rv = np.zeros_like(case["kc"]), np.zeros_like(case["vc"])
+    oracle.reshape_and_cache_f32(k_rows.cpu().numpy(), v_rows.cpu().numpy(), rk, rv, slots)
+    assert np.array_equal(kc2.cpu().numpy(), rk) and np.array_equal(vc2.cpu().numpy(), rv)
+
+
+def test_f32_limits_are_runtime_errors():
+    from test_oracle import f32_case
+
+    ext = _ext()
+    dev = _dev()
+    case = f32_case(np.random.default_rng(1), 2, 4, 4, 64, 16, [5, 40])
+    q, kc, vc = (torch.from_numpy(case[k]).to(dev) for k in ("q", "kc", "vc"))
+    tab, ln = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
+    out = torch.empty_like(q)
+    with pytest.raises(RuntimeError, match="float32"):                              # split-KV is not built for float32
+        ext.paged_attention_v2(out, torch.empty((2, 4, 1), device=dev), torch.empty((2, 4, 1), device=dev),
+                               torch.empty((2, 4, 1, 64), device=dev), q, kc, vc, 4, 0.125, tab, ln, 16, 64, None, "auto",
+                               1.0, 0, 0, 1, 1, 0)
+    with pytest.raises(RuntimeError, match="innermost dimension must be 4"):
+        ext.paged_attention_v1(out, q, kc.view(kc.shape[0], 4, 8, 16, 8), vc, 4, 0.125, tab, ln, 16, 64, None, "auto", 1.0,
+                               0, 0, 1, 1, 0)
 
 
 def test_convert_fp8_every_value_both_directions():

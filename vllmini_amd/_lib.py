@@ -49,6 +49,9 @@ SIGNATURES = {
     "vmi_reshape_and_cache_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                                  _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _c_void_p]),
     "vmi_paged_attention_v1_pick_variant_fp8": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "vmi_paged_attention_v1_f32": (ctypes.c_int, list(_PA_ARGS)),
+    "vmi_reshape_and_cache_f32": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                                 _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _c_void_p]),
     "vmi_convert_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _f32, _i32, _i32, _i32, _c_void_p]),
     "vmi_paged_attention_v1_fp8_e5m2": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32, _i32]),
     "vmi_paged_attention_v2_fp8_e5m2": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32]),
@@ -79,7 +82,7 @@ SIGNATURES = {
     ]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lock = threading.Lock()
 _lib = None

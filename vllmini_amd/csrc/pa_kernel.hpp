@@ -1303,6 +1303,27 @@ extern const int g_sparse_nvariants;
 extern Variant g_sparse_bf16_variants[];
 extern const int g_sparse_bf16_nvariants;
 
+// float32 tensors (pa_f32.hip): the (float, float) branch of the reference's dispatch, x = 4
+struct PAF32Params {
+  float* out;
+  const float* q;
+  const float* kc;
+  const float* vc;
+  const int32_t* block_tables;
+  const int32_t* seq_lens;
+  const float* alibi;
+  int32_t num_heads, num_kv_heads;
+  float scale;
+  int32_t max_blocks_per_seq;
+  int64_t q_stride, kv_block_stride, kv_head_stride;
+  int32_t lpad;
+};
+typedef void (*pa_f32_kernel_t)(const PAF32Params);
+pa_f32_kernel_t pa_v1_f32_kernel_for(int D, int BS);
+void reshape_and_cache_f32_launch(const float* key, const float* value, float* kc, float* vc, const int64_t* slots,
+                                  int64_t key_stride, int64_t value_stride, int T, int H, int D, int BS,
+                                  hipStream_t stream);
+
 // kernels for the non-core (head size, block size) combinations live in pa_variants_extra.hip
 extern Variant g_extra_variants_v1[];
 extern const int g_extra_nvariants_v1;

@@ -86,11 +86,15 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
     """Validate and flatten the 18 reference arguments into the C-ABI argument tuple."""
     if query.dim() != 3:
         raise RuntimeError(f"query must be [num_seqs, num_heads, head_size], got {tuple(query.shape)}")
-    if query.dtype not in (torch.float16, torch.bfloat16):
-        # reference dispatches float/half/bf16 (quant_utils.cuh:529-566); half and bf16 are built here
-        # (its callers only use half: gpt2.py, scheduler.py:13); fp32 has a different cache layout (x = 4)
+    if query.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        # the reference dispatches float / half / bf16 (quant_utils.cuh:529-566); its callers only use half
+        # (gpt2.py, scheduler.py:13)
         raise RuntimeError(f"Unsupported input type of paged attention: {query.dtype}")
     fp8 = _check_kv_cache_dtype(kv_cache_dtype)
+    f32 = query.dtype == torch.float32          # x = 4 cache layout, plain kernels: v1 over float32 caches only
+    if f32 and (fp8 or int(blocksparse_vert_stride) > 1):
+        raise RuntimeError("Unsupported input type of paged attention: torch.float32 is built for kv_cache_dtype='auto' "
+                           "without block-sparse attention")
     if int(blocksparse_vert_stride) > 1:          # is_block_sparse, attention_kernels.cu:822 — kernels of their own
         if fp8:
             raise RuntimeError("block-sparse paged attention (blocksparse_vert_stride > 1) is built for "
@@ -116,8 +120,9 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
         raise RuntimeError("key_cache must be [num_blocks, num_kv_heads, head_size/x, block_size, x] "
                            "and value_cache [num_blocks, num_kv_heads, head_size, block_size]")
     x = int(key_cache.shape[4])
-    if x != (16 if fp8 else 8):                                   # x = 16 / sizeof(cache_t), attention_kernels.cu:200
-        raise RuntimeError(f"key_cache innermost dimension must be {16 if fp8 else 8} (16 bytes per chunk), got {x}")
+    want_x = 16 if fp8 else (4 if f32 else 8)                     # x = 16 / sizeof(cache_t), attention_kernels.cu:200
+    if x != want_x:
+        raise RuntimeError(f"key_cache innermost dimension must be {want_x} (16 bytes per chunk), got {x}")
     if int(key_cache.shape[3]) != int(block_size) or int(value_cache.shape[3]) != int(block_size):
         raise RuntimeError(f"block_size={block_size} does not match the cache tensors "
                            f"({key_cache.shape[3]}, {value_cache.shape[3]})")
@@ -193,7 +198,11 @@ def paged_attention_v1(
                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
                       blocksparse_block_size, blocksparse_head_sliding_step)
     lib = _lib.load()
-    if int(blocksparse_vert_stride) > 1:           # block-sparse attention: its own kernels, no tuning variants
+    if query.dtype == torch.float32:               # the (float, float) dispatch branch: plain kernels, no variants
+        if _variant:
+            raise RuntimeError("_variant does not apply to float32 tensors")
+        rc = lib.vmi_paged_attention_v1_f32(*args)
+    elif int(blocksparse_vert_stride) > 1:           # block-sparse attention: its own kernels, no tuning variants
         if _variant:
             raise RuntimeError("_variant does not apply to block-sparse attention")
         rc = lib.vmi_paged_attention_v1_blocksparse(
@@ -245,6 +254,8 @@ def paged_attention_v1_append(
     """
     if _check_kv_cache_dtype(kv_cache_dtype):
         raise RuntimeError("paged_attention_v1_append is not built for an fp8 KV cache")
+    if query.dtype == torch.float32:
+        raise RuntimeError("paged_attention_v1_append is not built for float32 tensors")
     args = _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
                       seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, 0, 0, 1, 1, 0)
     num_seqs, _, head_size = (int(s) for s in query.shape)
@@ -296,6 +307,8 @@ def paged_attention_v2(
     (SURVEY.md §2 #7); it is the right operator when num_seqs*num_heads is far below the CU count.
     """
     fp8 = _check_kv_cache_dtype(kv_cache_dtype)
+    if query.dtype == torch.float32:
+        raise RuntimeError("Unsupported input type of paged attention: torch.float32 is built for paged_attention_v1 only")
     args = _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
                       seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale,
                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
@@ -348,8 +361,10 @@ def reshape_and_cache(
     fp8 = _check_kv_cache_dtype(kv_cache_dtype)
     if key.dim() != 3 or value.dim() != 3 or key.shape != value.shape:
         raise RuntimeError("key and value must both be [num_tokens, num_heads, head_size]")
-    if key.dtype not in (torch.float16, torch.bfloat16) or value.dtype != key.dtype:
+    if key.dtype not in (torch.float16, torch.bfloat16, torch.float32) or value.dtype != key.dtype:
         raise RuntimeError(f"Unsupported input type of reshape_and_cache: {key.dtype}")
+    if key.dtype == torch.float32 and fp8:
+        raise RuntimeError("Unsupported input type of reshape_and_cache: torch.float32 rows with an fp8 cache are not built")
     dev = key.device
     for name, t in (("key", key), ("value", value), ("key_cache", key_cache),
                     ("value_cache", value_cache), ("slot_mapping", slot_mapping)):
@@ -392,7 +407,8 @@ def reshape_and_cache(
         if rc != 0:
             _raise_native(rc)
         return None
-    rc = _lib.load().vmi_reshape_and_cache_f16(
+    fn16 = _lib.load().vmi_reshape_and_cache_f32 if key.dtype == torch.float32 else _lib.load().vmi_reshape_and_cache_f16
+    rc = fn16(
         key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
         slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
         int(key.stride(0)), int(value.stride(0)),                         # cache_kernels.cu:271-272
