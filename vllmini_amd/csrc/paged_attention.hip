@@ -264,8 +264,8 @@ __global__ void __launch_bounds__(256)
 // ----------------------------------------------------------------------------------------
 // reshape_and_cache, run form (calls of >= 2*block_size tokens).  A prompt's tokens arrive with consecutive slots, so
 // BS consecutive tokens usually ARE one cache block.  The per-token kernel above then writes every 32-B V row in BS
-// separate 2-byte pieces (1.0-1.2 TB/s read+write on MI355X).  Here a workgroup takes (a run of BS tokens) x (4 heads),
-// one wave per head.  Each wave checks that the run's slots are one aligned block in order and then writes the whole
+// separate 2-byte pieces (1.0-1.2 TB/s read+write on MI355X).  Here a workgroup takes (a run of BS tokens) x (4 wave
+// slices of 32 dims of a head; whole heads when the head size is not a multiple of 32).  Each wave checks that the run's slots are one aligned block in order and then writes the whole
 // (block, head) tiles: the K tile needs no transposition at all (lane chunk*BS + tok loads 16 B of row tok and owns
 // exactly that 16-B unit of the tile), the V tile is transposed through the wave's LDS slice.  A run that is not a whole
 // aligned block (prompt tails, decode batches, padding) is written token by token by the same waves.  No workgroup
@@ -278,12 +278,17 @@ __global__ void __launch_bounds__(256)
     reshape_and_cache_blocks_kernel(const h16* __restrict__ key, const h16* __restrict__ value,
                                     h16* __restrict__ kc, h16* __restrict__ vc,
                                     const int64_t* __restrict__ slot_mapping, int64_t key_stride,
-                                    int64_t value_stride, int T, int H, int D) {
+                                    int64_t value_stride, int T, int H, int D, int DW) {
+  // A wave owns DW dims of one head for a run of BS tokens (DW = 32 when D % 32 == 0 — with BS = 16 that is one
+  // 16-byte unit per lane, the same parallelism as the per-token kernel — else the whole head).  A dim range is
+  // self-contained in both layouts: chunks d/8 of the K tile, rows d of the V tile.
   constexpr int UPR = BS / 8;  // 16-B units per V dim row
   constexpr int PAD = 8;       // halves; keeps LDS rows 16-B aligned and the two 8-token halves on different banks
   extern __shared__ __attribute__((aligned(16))) char blk_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = blockIdx.y * 4 + wave;
+  const int wph = D / DW;                      // waves per head
+  const int gw = blockIdx.y * 4 + wave;
+  const int h = gw / wph, d0 = (gw % wph) * DW;
   if (h >= H) return;  // waves are independent: no workgroup barrier below
   const int t0 = blockIdx.x * BS;
   const int nt = (T - t0) < BS ? (T - t0) : BS;
@@ -291,42 +296,50 @@ __global__ void __launch_bounds__(256)
   const long long s0 = __shfl(mine, 0);
   const bool in_order = lane >= BS || mine == s0 + lane;
   const bool whole = nt == BS && s0 >= 0 && (s0 % BS) == 0 && __all(in_order);
-  const int units = D * BS / 8;  // 16-B units of one (block, head) tile, K and V alike
+  const int units = DW * BS / 8;  // 16-B units of this wave's slice of one (block, head) tile, K and V alike
   if (whole) {
     const int64_t blk = s0 / BS;
-    h16* lds = reinterpret_cast<h16*>(blk_smem) + (size_t)wave * BS * (D + PAD);
-    h16* ktile = kc + ((blk * H + h) * (int64_t)D) * BS;
-    h16* vtile = vc + ((blk * H + h) * (int64_t)D) * BS;
+    h16* lds = reinterpret_cast<h16*>(blk_smem) + (size_t)wave * BS * (DW + PAD);
+    h16* ktile = kc + ((blk * H + h) * (int64_t)D + d0) * BS;   // chunks d0/8.. of the K tile: a contiguous run
+    h16* vtile = vc + ((blk * H + h) * (int64_t)D + d0) * BS;   // rows d0.. of the V tile: a contiguous run
     for (int u = lane; u < units; u += 64) {
       const int c = u / BS, tok = u % BS;
-      const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + h * D + c * 8);
-      const u32x4 vv = *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + h * D + c * 8);
-      *reinterpret_cast<u32x4*>(ktile + (int64_t)u * 8) = kv;               // K[blk,h,c,tok,0..8)
-      *reinterpret_cast<u32x4*>(lds + tok * (D + PAD) + c * 8) = vv;        // V rows, token-major, for the transpose
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + h * D + d0 + c * 8);
+      const u32x4 vv = *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + h * D + d0 + c * 8);
+      *reinterpret_cast<u32x4*>(ktile + (int64_t)u * 8) = kv;               // K[blk,h,d0/8+c,tok,0..8)
+      *reinterpret_cast<u32x4*>(lds + tok * (DW + PAD) + c * 8) = vv;       // V rows, token-major, for the transpose
     }
     for (int u = lane; u < units; u += 64) {
       const int row = u / UPR, unit = u % UPR;
       h16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = lds[(unit * 8 + e) * (D + PAD) + row];
-      *reinterpret_cast<u32x4*>(vtile + (int64_t)u * 8) = __builtin_bit_cast(u32x4, o);  // V[blk,h,row,unit*8..+8)
+      for (int e = 0; e < 8; ++e) o[e] = lds[(unit * 8 + e) * (DW + PAD) + row];
+      *reinterpret_cast<u32x4*>(vtile + (int64_t)u * 8) = __builtin_bit_cast(u32x4, o);  // V[blk,h,d0+row,unit*8..+8)
     }
     return;
   }
-  // not a whole aligned block: token by token, as reshape_and_cache_kernel does (this wave: head h of the run's tokens)
-  const int c8 = D >> 3;
-  for (int u = lane; u < nt * c8; u += 64) {
-    const int tok = u / c8, c = u - tok * c8;
-    const int64_t slot = slot_mapping[t0 + tok];  // (not a shuffle of `mine`: the lane holding it may have left the loop)
-    if (slot < 0) continue;  // padding token (ref cache_kernels.cu:165-169)
-    const int64_t blk = slot / BS, off = slot % BS;
-    const int i = h * D + c * 8;
-    const h16x8 kv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + i));
-    const h16x8 vv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + i));
-    *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * c8 + c) * BS + off) * 8) = __builtin_bit_cast(u32x4, kv);
-    h16* vdst = vc + ((blk * H + h) * (int64_t)D + c * 8) * BS + off;
+  // not a whole aligned block: token by token, as reshape_and_cache_kernel does (this wave: dims d0.. of head h of the
+  // run's tokens).  This is the DECODE case (every token of the batch in a different block), so it is written for
+  // latency: a uniform trip count — every lane stays in the loop, so the slots come from the `mine` registers by
+  // shuffle instead of a dependent global load per trip.
+  const int c8 = DW >> 3;
+  const int total = nt * c8;
+  for (int u0 = 0; u0 < total; u0 += 64) {  // wave-uniform
+    const int u = u0 + lane;
+    const bool act = u < total;
+    const int tok = act ? u / c8 : 0, c = u - tok * c8;
+    long long slot = __shfl(mine, tok);
+    if (!act) slot = -1;
+    if (slot >= 0) {  // padding tokens (slot < 0) are skipped (ref cache_kernels.cu:165-169)
+      const int64_t blk = slot / BS, off = slot % BS;
+      const int i = h * D + d0 + c * 8;
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + i);
+      const h16x8 vv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + i));
+      *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (int64_t)(D >> 3) + (d0 >> 3) + c) * BS + off) * 8) = kv;
+      h16* vdst = vc + ((blk * H + h) * (int64_t)D + d0 + c * 8) * BS + off;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) vdst[(int64_t)e * BS] = vv[e];
+      for (int e = 0; e < 8; ++e) vdst[(int64_t)e * BS] = vv[e];
+    }
   }
 }
 
@@ -1337,22 +1350,26 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
   dim3 grid(num_tokens), block(threads);
   // prefill-sized calls with 16-B aligned rows: whole-block form (falls back per run inside the kernel)
   if (vec && num_tokens >= 2 * block_size && (block_size == 8 || block_size == 16 || block_size == 32)) {
-    typedef void (*blocks_fn)(const h16*, const h16*, h16*, h16*, const int64_t*, int64_t, int64_t, int, int, int);
+    typedef void (*blocks_fn)(const h16*, const h16*, h16*, h16*, const int64_t*, int64_t, int64_t, int, int, int, int);
+    // dims per wave: 32-dim slices while whole-head waves would not fill the chip (decode batches: cfg3 6.8 us instead
+    // of 8.5), whole heads for prompt-sized calls (16384 tokens x 32 x 128: 118 us vs 133 with slices)
+    const long whole_head_waves = (long)((num_tokens + block_size - 1) / block_size) * num_heads;
+    const int dw = (head_size % 32 == 0 && whole_head_waves < 4096) ? 32 : head_size;
     const blocks_fn fn = block_size == 8    ? (blocks_fn)reshape_and_cache_blocks_kernel<8>
                          : block_size == 16 ? (blocks_fn)reshape_and_cache_blocks_kernel<16>
                                             : (blocks_fn)reshape_and_cache_blocks_kernel<32>;
-    const size_t lds = (size_t)4 * block_size * (head_size + 8) * 2;
+    const size_t lds = (size_t)4 * block_size * (dw + 8) * 2;
     if (lds <= 160 * 1024) {
       if (lds > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(reshape_and_cache_blocks)");
       }
-      hipLaunchKernelGGL(fn, dim3((num_tokens + block_size - 1) / block_size, (num_heads + 3) / 4), dim3(256), lds,
+      hipLaunchKernelGGL(fn, dim3((num_tokens + block_size - 1) / block_size, (num_heads * (head_size / dw) + 3) / 4), dim3(256), lds,
                          static_cast<hipStream_t>(stream), static_cast<const h16*>(key),
                          static_cast<const h16*>(value), static_cast<h16*>(key_cache),
                          static_cast<h16*>(value_cache), slot_mapping, key_stride, value_stride, num_tokens,
-                         num_heads, head_size);
+                         num_heads, head_size, dw);
       e = hipGetLastError();
       if (e != hipSuccess) return hip_fail(e, "reshape_and_cache (blocks) launch");
       return VMI_OK;
