@@ -1,15 +1,18 @@
 // pa_kernel.hpp — kernel templates of the MI355X paged-attention decode path (gfx950 only).
 //
-//   device helpers        16-B loads, bf16 helpers, dot8, fp8 E4M3 decode (deq8, dot16_f8*), PV8, wave reductions
-//   PAParams              kernel argument block (v1, v2 partitions, fused append, fp8 scale)
+//   device helpers        16-B loads, bf16 helpers, dot8, fp8 E4M3 / E5M2 decode (deq8, dot16_f8*), PV8, wave reductions
+//   PAParams              kernel argument block (v1, v2 partitions, fused append, fp8 scale, block-sparse pattern)
 //   pa_v1_kernel          THE attention kernel: paged_attention_v1, the partition pass of paged_attention_v2 (PART),
-//                         the fused append (APP), fp16 / bf16 query (BF), fp16-sized or fp8 pages (F8)
+//                         the fused append (APP), fp16 / bf16 query (BF), 16-bit or fp8 pages (F8 = 1 E4M3, 2 E5M2),
+//                         grouped-query tile sharing with q.K^T on MFMA (GQS), opt-in P.V on MFMA (FPV),
+//                         block-sparse attention (SPARSE)
 //   pa_v2_reduce_kernel   merge of the 512-token partitions
 //   Variant, VMI_ROW*     one row of a kernel menu (pa_table_*.inc) and the tables' extern declarations
+//   PAF32Params           float32 tensors have kernels of their own (pa_f32.hip)
 //
-// Instantiated by eight translation units (vllmini_amd/build.py): paged_attention.hip (core menu + host code + C-ABI),
-// pa_variants_extra.hip, pa_variants_bf16.hip, pa_append_{core,extra,bf16}.hip, pa_variants_fp8.hip,
-// pa_variants_fp8_bf16.hip.
+// Instantiated by the translation units listed in vllmini_amd/build.py (they compile concurrently):
+// paged_attention.hip (core menu + host code + C-ABI), pa_variants_{extra,bf16}.hip, pa_append_{core,extra,bf16}.hip,
+// pa_variants_fp8{,_bf16,_e5m2,_e5m2_bf16}.hip, pa_variants_sparse{,_bf16}.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>
