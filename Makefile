@@ -1,0 +1,30 @@
+# Builds the C-ABI library (include/vmi_paged_attention.h) without Python: `make -j` — the same commands as
+# `python -m vllmini_amd.build` (vllmini_amd/build.py), one object per translation unit.  gfx950 only.
+HIPCC  ?= hipcc
+ARCH   ?= gfx950
+# -ffp-contract=off: the fp16 p*v products are rounded before the fp16 adds (the reference's rounding points)
+FLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -fno-gpu-rdc -Iinclude
+CSRC   := vllmini_amd/csrc
+OUTDIR := vllmini_amd/_C
+UNITS  := paged_attention pa_variants_extra pa_variants_bf16 pa_append_core pa_append_extra pa_append_bf16 \
+          pa_variants_fp8 pa_variants_fp8_bf16 pa_variants_fp8_e5m2 pa_variants_fp8_e5m2_bf16 \
+          pa_variants_sparse pa_variants_sparse_bf16 pa_f32
+OBJS   := $(UNITS:%=$(OUTDIR)/%.hip.o)
+LIB    := $(OUTDIR)/libvmi_paged_attention.so
+
+all: $(LIB) oracle
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -fno-gpu-rdc $^ -o $@
+
+$(OUTDIR)/%.hip.o: $(CSRC)/%.hip $(CSRC)/pa_kernel.hpp $(wildcard $(CSRC)/*.inc) include/vmi_paged_attention.h
+	mkdir -p $(OUTDIR)
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(OUTDIR) oracle/_build
+
+.PHONY: all oracle clean

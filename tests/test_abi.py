@@ -227,3 +227,16 @@ def test_driver_entry_points_compile_and_parse_arguments():
     assert r.returncode == 0, r.stderr[-2000:]
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in r.stdout
+
+
+def test_makefile_lists_the_same_translation_units_as_build_py():
+    """`make` and `python -m vllmini_amd.build` must produce the same library."""
+    import re
+
+    from vllmini_amd import build as b
+
+    mk = open(os.path.join(REPO, "Makefile")).read()
+    units = re.search(r"UNITS\s*:=\s*((?:.*\\\n)*.*)\n", mk).group(1).replace("\\\n", " ").split()
+    assert sorted(units) == sorted(os.path.basename(s)[: -len(".hip")] for s in b.SOURCES)
+    for flag in ("-O3", "-std=c++17", "-ffp-contract=off", "-fno-gpu-rdc"):
+        assert flag in mk and flag in b.HIPCC_FLAGS
