@@ -975,6 +975,17 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
           const int b = block_of(idx);
           const int token0 = b * BS + hf * EPU;
           const bool last = (b == nblk_seq - 1);  // last block of the SEQUENCE (:420); wave-uniform
+          // grouped-query kernels over fp8 pages: the shared tile is decoded ONCE here, not once per query head (the
+          // compiler merged only part of the per-head decodes: 40 conversions per block instead of 16)
+          constexpr bool DQ1 = GQS && F8;
+          u32x4 vdq[DQ1 ? NL : 1][2];
+          if constexpr (DQ1) {
+  #pragma unroll
+            for (int i = 0; i < NL; ++i) {
+              vdq[i][0] = deq8<S1, BF, E5>(r[j][0][i][0], r[j][0][i][1], p.kv_scale);
+              vdq[i][1] = deq8<S1, BF, E5>(r[j][0][i][2], r[j][0][i][3], p.kv_scale);
+            }
+          }
   #pragma unroll
           for (int hh = 0; hh < HPT; ++hh) {
             if (valid(hh)) {
@@ -1005,7 +1016,9 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
               pv.load(*reinterpret_cast<const u32x4_alias*>(php));
   #pragma unroll
               for (int i = 0; i < NL; ++i) {
-                if constexpr (F8)  // first 8 of the unit's 16 tokens
+                if constexpr (DQ1)
+                  acc[hh][i] += pv.template dot<MASK>(vdq[DQ1 ? i : 0][0], last, token0, L);
+                else if constexpr (F8)  // first 8 of the unit's 16 tokens
                   acc[hh][i] += pv.template dot<MASK>(deq8<S1, BF, E5>(r[j][GQS ? 0 : hh][i][0], r[j][GQS ? 0 : hh][i][1], p.kv_scale), last, token0, L);
                 else
                   acc[hh][i] += pv.template dot<MASK>(r[j][GQS ? 0 : hh][i], last, token0, L);
@@ -1014,8 +1027,12 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
                 PV8<BF> pw;
                 pw.load(*reinterpret_cast<const u32x4_alias*>(php + 8));
 #pragma unroll
-                for (int i = 0; i < NL; ++i)
-                  acc[hh][i] += pw.template dot<MASK>(deq8<S1, BF, E5>(r[j][GQS ? 0 : hh][i][2], r[j][GQS ? 0 : hh][i][3], p.kv_scale), last, token0 + 8, L);
+                for (int i = 0; i < NL; ++i) {
+                  if constexpr (DQ1)
+                    acc[hh][i] += pw.template dot<MASK>(vdq[DQ1 ? i : 0][1], last, token0 + 8, L);
+                  else
+                    acc[hh][i] += pw.template dot<MASK>(deq8<S1, BF, E5>(r[j][GQS ? 0 : hh][i][2], r[j][GQS ? 0 : hh][i][3], p.kv_scale), last, token0 + 8, L);
+                }
               }
             }
           }
