@@ -1,5 +1,5 @@
 """Diagnostic: the opt-in "_pvm" grouped-query kernels (P.V on the matrix cores) — distance from the kernel model and
-from an fp64 attention, next to the default gq kernels.  PYTHONPATH=. python scripts/pvm_probe.py"""
+from an fp64 attention, next to the default gq kernels.  PYTHONPATH=. python tests/soak/pvm_probe.py"""
 import numpy as np
 import torch
 import oracle

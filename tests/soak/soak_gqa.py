@@ -1,6 +1,6 @@
 """Soak run for the grouped-query kernels, default and opt-in (P.V on the matrix cores): random head groupings, ragged
 lengths (empty sequences, partial pairs / quads of blocks, idle waves), ALiBi, poisoned tails, fp16 / bf16 / fp8 pages,
-forced and automatic kernels, fused-append twins.  `PYTHONPATH=.:tests python scripts/soak_gqa.py [n_cases] [first_seed]`.
+forced and automatic kernels, fused-append twins.  `PYTHONPATH=.:tests python tests/soak/soak_gqa.py [n_cases] [first_seed]`.
 Bounds: the tests' tight one for the default kernels, the north-star 1e-3 * max(1, |v|max) for `_pvm` kernels."""
 import sys
 import time

@@ -1,5 +1,5 @@
 """Soak run of the randomized parity sweep (tests/test_parity_gpu.py::test_randomized_parity_sweep logic) over many
-seeds, plus random fp8 cases: `PYTHONPATH=.:tests python scripts/soak_parity.py [n_cases] [first_seed]`.
+seeds, plus random fp8 cases: `PYTHONPATH=.:tests python tests/soak/soak_parity.py [n_cases] [first_seed]`.
 Prints one line per failure and a summary; exit code 1 if anything failed."""
 import sys
 import time
@@ -38,7 +38,7 @@ for seed in range(first, first + n_cases):
         tag = (f"d{D}_" if bs == 16 else f"d{D}_bs{bs}_")
         cands = [i + 1 for i, n in enumerate(names)
                  if n.startswith(tag) and "LOADSONLY" not in n and (bs != 16 or "_bs" not in n) and
-                 "_pvm" not in n and      # opt-in kernels: scripts/soak_gqa.py, north-star bound
+                 "_pvm" not in n and      # opt-in kernels: tests/soak/soak_gqa.py, north-star bound
                  ("_gq" not in n or (H // hkv) % int(n.split("_gq")[1].split("_")[0]) == 0)]
         vid = int(rng.choice(cands)) if (cands and rng.integers(0, 2)) else 0
         msl = int(max(lens.max(), 1)) + int(rng.integers(0, 40))

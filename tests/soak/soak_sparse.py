@@ -1,6 +1,6 @@
 """Soak run for block-sparse attention (blocksparse_vert_stride > 1): random patterns (sparse block sizes that do and do not
 divide the cache block, zero / large local windows, both sliding directions, tp_rank), every head x block size, fp16 /
-bf16, v1 / v2, ragged lengths, grouped KV heads, ALiBi.  PYTHONPATH=.:tests python scripts/soak_sparse.py [n] [seed]"""
+bf16, v1 / v2, ragged lengths, grouped KV heads, ALiBi.  PYTHONPATH=.:tests python tests/soak/soak_sparse.py [n] [seed]"""
 import sys
 import time
 
