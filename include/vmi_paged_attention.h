@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 14
+#define VMI_ABI_VERSION 15
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -302,6 +302,18 @@ int vmi_paged_attention_v2_fp8_e5m2(   /* float16 query */
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     int32_t device, void* stream,
     float kv_scale, int32_t variant);
+/* paged_attention_v2, bfloat16 query / out / tmp_out over fp8 pages of either format (is_e5m2) */
+int vmi_paged_attention_v2_fp8_bf16(
+    void* out, void* exp_sums, void* max_logits, void* tmp_out,
+    const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream,
+    float kv_scale, int32_t variant, int32_t is_e5m2);
 int vmi_reshape_and_cache_fp8_e5m2(
     const void* key, const void* value, void* key_cache, void* value_cache,
     const int64_t* slot_mapping,

@@ -371,9 +371,10 @@ def paged_attention_v1_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache
 def paged_attention_v2_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache: np.ndarray, num_kv_heads: int,
                            scale: float, block_tables: np.ndarray, seq_lens: np.ndarray, block_size: int,
                            max_seq_len: int, kv_scale: float = 1.0, alibi_slopes: np.ndarray | None = None,
-                           e5m2: bool = False):
+                           e5m2: bool = False, bf16: bool = False):
     """Split-KV kernel model over an fp8 E4M3 (e5m2=True: E5M2) cache: (out, exp_sums, max_logits, tmp_out) as paged_attention_v2."""
-    assert query.dtype == np.float16 and key_cache.dtype == value_cache.dtype == np.uint8 and key_cache.shape[4] == 16
+    et = np.uint16 if bf16 else np.float16          # bf16: query / out / tmp_out are bit patterns
+    assert query.dtype == et and key_cache.dtype == value_cache.dtype == np.uint8 and key_cache.shape[4] == 16
     S, H, D = query.shape
     qs = _elem_strides(query)
     assert qs[2] == 1 and qs[1] == D
@@ -382,10 +383,10 @@ def paged_attention_v2_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache
     seq_lens = np.ascontiguousarray(seq_lens, dtype=np.int32)
     kb, kh = _elem_strides(key_cache)[:2]
     P = (int(max_seq_len) + 511) // 512
-    out = np.zeros((S, H, D), dtype=np.float16)
+    out = np.zeros((S, H, D), dtype=et)
     exp_sums = np.full((S, H, P), np.nan, dtype=np.float32)
     max_logits = np.full((S, H, P), np.nan, dtype=np.float32)
-    tmp_out = np.full((S, H, P, D), np.nan, dtype=np.float16)
+    tmp_out = np.full((S, H, P, D), 0x7FC0 if bf16 else np.nan, dtype=et)
     alibi = None if alibi_slopes is None else np.ascontiguousarray(alibi_slopes, dtype=np.float32)
     lib = _load()
     base_types = ([ctypes.c_void_p] * 7 + [ctypes.c_int32] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 +
@@ -395,10 +396,10 @@ def paged_attention_v2_fp8(query: np.ndarray, key_cache: np.ndarray, value_cache
             _base_ptr(block_tables), _base_ptr(seq_lens), int(block_size), int(max_seq_len),
             int(block_tables.shape[1]), None if alibi is None else _base_ptr(alibi), int(qs[0]), int(kb), int(kh),
             float(kv_scale))
-    if e5m2:
+    if e5m2 or bf16:
         fn = lib.vmi_oracle_paged_attention_v2_fp8x
         fn.restype, fn.argtypes = ctypes.c_int, base_types + [ctypes.c_int32] * 2
-        rc = fn(*args, 0, 2)
+        rc = fn(*args, 1 if bf16 else 0, 2 if e5m2 else 1)
     else:
         lib.vmi_oracle_paged_attention_v2_fp8.restype = ctypes.c_int
         lib.vmi_oracle_paged_attention_v2_fp8.argtypes = base_types

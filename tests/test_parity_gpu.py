@@ -1728,6 +1728,37 @@ def test_pa_fp8_e5m2_matches_kernel_model(D, bs):
             assert_close(_run_e5m2(case, 0.8, variant=vid, v2_msl=1024), r2, name, vmax=1.6)
 
 
+@pytest.mark.parametrize("D,bs", [(64, 16), (128, 16), (80, 32), (256, 16), (112, 16), (192, 32), (96, 32)])
+def test_pa_v2_bf16_query_over_fp8_pages(D, bs):
+    """Split-KV with a bfloat16 query over E4M3 and E5M2 pages: merged output against the kernel model, auto pick
+    and every kernel of this head x block size."""
+    from vllmini_amd import ops
+
+    rng = np.random.default_rng(3100 + D + bs)
+    lens = [3, 511, 513, 1100, 40]
+    for e5m2, kvd in ((False, "fp8"), (True, "fp8_e5m2")):
+        case = _e5m2_case(rng, len(lens), 4, D, lens, bs, num_kv_heads=2)      # codes 0..63 + sign are fine for both formats
+        qb = np.ascontiguousarray(oracle.f32_to_bf16_bits(case["qbuf"].astype(np.float32))[:, : 4 * D].reshape(len(lens), 4, D))
+        ref = oracle.paged_attention_v2_fp8(qb, case["kq"], case["vq"], 2, case["scale"], case["tables"], case["lens"], bs,
+                                            1536, kv_scale=0.8, e5m2=e5m2, bf16=True)[0]
+        dev = _dev()
+        S, H = len(lens), 4
+        q = _bf16_tensor(oracle.f32_to_bf16_bits(case["qbuf"].astype(np.float32)), dev)[:, : H * D].view(S, H, D)
+        pfx = "bf16_fp8e5m2_v2_" if e5m2 else "bf16_fp8_v2_"
+        vids = [0] + [i + 1 for i, n in enumerate(ops.variant_names_v2()) if n.startswith(f"{pfx}d{D}_bs{bs}_")]
+        assert len(vids) == 3, vids
+        for vid in vids:
+            out = torch.full((S, H, D), float("nan"), dtype=torch.bfloat16, device=dev)
+            es = torch.full((S, H, 3), float("nan"), dtype=torch.float32, device=dev)
+            ml = torch.full((S, H, 3), float("nan"), dtype=torch.float32, device=dev)
+            tmp = torch.full((S, H, 3, D), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.paged_attention_v2(out, es, ml, tmp, q, torch.from_numpy(case["kq"]).to(dev), torch.from_numpy(case["vq"]).to(dev),
+                                   2, case["scale"], torch.from_numpy(case["tables"]).to(dev),
+                                   torch.from_numpy(case["lens"]).to(dev), bs, 1536, None, kvd, 0.8, 0, 0, 1, 1, 0, _variant=vid)
+            torch.cuda.synchronize()
+            assert_close_bf16(out.view(torch.int16).cpu().numpy().view(np.uint16), ref, f"bf16 x {kvd} v2 D{D} bs{bs} variant {vid}", vmax=1.6)
+
+
 def test_fp8_e5m2_grouped_query_kernels_and_opt_in():
     from vllmini_amd import ops
 

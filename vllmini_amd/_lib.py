@@ -54,6 +54,7 @@ SIGNATURES = {
                                                  _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _c_void_p]),
     "vmi_convert_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _f32, _i32, _i32, _i32, _c_void_p]),
     "vmi_paged_attention_v1_fp8_e5m2": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32, _i32]),
+    "vmi_paged_attention_v2_fp8_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32, _i32]),
     "vmi_paged_attention_v2_fp8_e5m2": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32]),
     "vmi_reshape_and_cache_fp8_e5m2": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                                       _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _c_void_p, _i32]),
@@ -82,7 +83,7 @@ SIGNATURES = {
     ]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lock = threading.Lock()
 _lib = None

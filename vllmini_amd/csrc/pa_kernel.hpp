@@ -1377,6 +1377,10 @@ extern Variant g_fp8_variants_v2_e5m2[];
 extern const int g_fp8_nvariants_v2_e5m2;
 extern Variant g_fp8bf_variants_v1_e5m2[];
 extern const int g_fp8bf_nvariants_v1_e5m2;
+extern Variant g_fp8bf_variants_v2[];
+extern const int g_fp8bf_nvariants_v2;
+extern Variant g_fp8bf_variants_v2_e5m2[];
+extern const int g_fp8bf_nvariants_v2_e5m2;
 pa_reduce_t bf16_reduce_kernel(int head_size);
 
 }  // namespace vmi

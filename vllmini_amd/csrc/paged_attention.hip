@@ -886,7 +886,8 @@ static Variant g_variants_v2[] = {
 static const int g_ncore_v2 = (int)(sizeof(g_variants_v2) / sizeof(g_variants_v2[0]));
 
 static int nvariants_v2() {
-  return g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2 + g_fp8_nvariants_v2 + g_fp8_nvariants_v2_e5m2;
+  return g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2 + g_fp8_nvariants_v2 + g_fp8_nvariants_v2_e5m2 +
+         g_fp8bf_nvariants_v2 + g_fp8bf_nvariants_v2_e5m2;
 }
 static Variant& variant_v2(int id) {  // [core fp16][extra fp16][bf16][fp8 cache]
   if (id <= g_ncore_v2) return g_variants_v2[id - 1];
@@ -895,7 +896,11 @@ static Variant& variant_v2(int id) {  // [core fp16][extra fp16][bf16][fp8 cache
     return g_bf16_variants_v2[id - 1 - g_ncore_v2 - g_extra_nvariants_v2];
   const int f0 = g_ncore_v2 + g_extra_nvariants_v2 + g_bf16_nvariants_v2;
   if (id <= f0 + g_fp8_nvariants_v2) return g_fp8_variants_v2[id - 1 - f0];
-  return g_fp8_variants_v2_e5m2[id - 1 - f0 - g_fp8_nvariants_v2];
+  const int f1 = f0 + g_fp8_nvariants_v2;
+  if (id <= f1 + g_fp8_nvariants_v2_e5m2) return g_fp8_variants_v2_e5m2[id - 1 - f1];
+  const int f2 = f1 + g_fp8_nvariants_v2_e5m2;                                     // bfloat16 query over fp8 pages
+  if (id <= f2 + g_fp8bf_nvariants_v2) return g_fp8bf_variants_v2[id - 1 - f2];
+  return g_fp8bf_variants_v2_e5m2[id - 1 - f2 - g_fp8bf_nvariants_v2];
 }
 
 static int find_variant_v2(int D, int BS, int HPW, int WPH, bool bf = false, int f8 = false) {
@@ -1249,6 +1254,22 @@ int vmi_paged_attention_v2_fp8_e5m2(void* out, void* exp_sums, void* max_logits,
                            key_cache, value_cache, num_seqs, num_heads, head_size, num_kv_heads, scale,
                            block_tables, seq_lens, block_size, max_seq_len, max_num_blocks_per_seq, alibi_slopes,
                            q_stride, kv_block_stride, kv_head_stride, device, stream, variant, false, 2,
+                           kv_scale);
+}
+
+int vmi_paged_attention_v2_fp8_bf16(void* out, void* exp_sums, void* max_logits, void* tmp_out, const void* query,
+                                    const void* key_cache, const void* value_cache, int32_t num_seqs,
+                                    int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
+                                    const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
+                                    int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                                    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                    int32_t device, void* stream, float kv_scale, int32_t variant, int32_t is_e5m2) {
+  if (!(kv_scale > 0.f))
+    return vmi::fail(VMI_E_SHAPE, "paged_attention_v2 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
+  return vmi::launch_pa_v2(out, static_cast<float*>(exp_sums), static_cast<float*>(max_logits), tmp_out, query,
+                           key_cache, value_cache, num_seqs, num_heads, head_size, num_kv_heads, scale,
+                           block_tables, seq_lens, block_size, max_seq_len, max_num_blocks_per_seq, alibi_slopes,
+                           q_stride, kv_block_stride, kv_head_stride, device, stream, variant, true, is_e5m2 ? 2 : 1,
                            kv_scale);
 }
 

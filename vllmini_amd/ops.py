@@ -323,8 +323,6 @@ def paged_attention_v2(
         if t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
             raise RuntimeError(f"{name} must be a contiguous {dt} tensor of shape {shape} "
                                f"(max_num_partitions = ceil(max_seq_len/512) = {parts})")
-    if fp8 and query.dtype != torch.float16:
-        raise RuntimeError("paged_attention_v2 over an fp8 KV cache is built for float16 query/out only")
     if int(blocksparse_vert_stride) > 1:
         if _variant:
             raise RuntimeError("_variant does not apply to block-sparse attention")
@@ -332,6 +330,10 @@ def paged_attention_v2(
             args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:],
             int(query.dtype == torch.bfloat16), int(tp_rank), int(blocksparse_local_blocks),
             int(blocksparse_vert_stride), int(blocksparse_block_size), int(blocksparse_head_sliding_step))
+    elif fp8 and query.dtype == torch.bfloat16:
+        rc = _lib.load().vmi_paged_attention_v2_fp8_bf16(args[0], exp_sums.data_ptr(), max_logits.data_ptr(),
+                                                         tmp_out.data_ptr(), *args[1:], float(kv_scale), int(_variant),
+                                                         int(fp8 == 2))
     elif fp8:
         fn8 = _lib.load().vmi_paged_attention_v2_fp8_e5m2 if fp8 == 2 else _lib.load().vmi_paged_attention_v2_fp8
         rc = fn8(args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:],
