@@ -479,6 +479,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   constexpr bool APP_TILE = APP && HPT == 1;
   u32x4 klast[APP_TILE ? NL : 1], vlast[APP_TILE ? NL : 1];
   bool own_last = false;              // wave-uniform: this wave met block lbA
+  int32_t phys_last = 0;              // ... and its physical block id (the table slice in bt_reg moves on afterwards)
   const int lbA = (Lfull - 1) / BS;   // block and in-block offset of the appended token
   const int offA = (Lfull - 1) % BS;
   // The step's rows in the lane map of the K / V tiles: knew_at(hh, i) = this lane's 16-B chunk of load i,
@@ -580,9 +581,9 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   const int hf = lane % UPR;   // which 8-token group of the block this lane owns
   const int rowl = lane / UPR;  // dim row within a load
 
-  auto store_tile = [&](h16* cache, u32x4(&t)[NL], int idx) {  // APP_TILE (HPT = 1)
+  auto store_tile = [&](h16* cache, u32x4(&t)[NL]) {  // APP_TILE (HPT = 1)
     if ((head0 % qpk) == 0) {  // one writer per KV head
-      const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);  // bt_reg still holds this group's slice
+      const int64_t phys = phys_last;
       h16* dst = cache + phys * p.kv_block_stride + hoff[0];
 #pragma unroll
       for (int i = 0; i < NL; ++i)
@@ -753,6 +754,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
                     if constexpr (APP_TILE) klast[i] = r[j][GQS ? 0 : hh][i];
                   }
                   own_last = true;
+                  phys_last = __builtin_amdgcn_readlane(bt_reg, idx & 63);  // this (final) group's slice is still in bt_reg
                 }
               }
               float accv[NL];
@@ -804,8 +806,14 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       if (g < ngroups) compute_k(std::integral_constant<bool, APP>{}, ra, g);  // final group of an odd count
     }
 
-    // first V group goes out now: HBM stays busy while the softmax runs
-    if (ngroups > 1) load_v(ra, 0);
+    // first V group goes out now: HBM stays busy while the softmax runs.
+    // VREV: the V pass walks the page groups from the LAST one back to the first.  In the reference's call pair the
+    // sequence's last block has just been written by reshape_and_cache with scattered partial stores, and reading those
+    // lines is slow (profiles/r01o_call_pair_gap.md): requested here, the wait hides behind the softmax instead of
+    // standing at the very end of the wave.  (Only the order of the fp32 accumulation over blocks changes; the fused
+    // append walks the same order, so it stays bit-identical to the call pair.)
+    constexpr bool VREV = true;
+    if (ngroups > 1) load_v(ra, VREV ? ngroups - 1 : 0);
 
     if constexpr (QK_MFMA) {  // per-head maxima live in lanes (lane & 15) = head: fold the 4 row groups, then hand out
       qmaxB = fmaxf(qmaxB, __shfl_xor(qmaxB, 16));
@@ -1042,6 +1050,21 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
 
     if (single) {
       compute_v(std::true_type{}, rb, 0);
+    } else if constexpr (VREV) {
+      // processing step s handles group ngroups-1-s; step 0 (the masked "final" group) is in ra, odd steps in rb
+      const int last = ngroups - 1;
+      if (ngroups > 1) {  // (a wave without blocks — more waves than blocks — has ngroups == 0; one group is `single`)
+        load_v(rb, last - 1);
+        compute_v(std::true_type{}, ra, last);
+        int s = 1;
+        for (; s + 1 < ngroups; s += 2) {
+          load_v(ra, last - (s + 1));
+          compute_v(std::false_type{}, rb, last - s);
+          if (s + 2 < ngroups) load_v(rb, last - (s + 2));
+          compute_v(std::false_type{}, ra, last - (s + 1));
+        }
+        if (s < ngroups) compute_v(std::false_type{}, rb, last - s);
+      }
     } else {
       int g = 0;
       for (; g + 2 <= ngroups; g += 2) {
@@ -1161,8 +1184,8 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   // the read stream); here +5 us (pieces) / +3 us (whole tiles, non-temporal).
   if constexpr (APP_TILE) {
     if (own_last) {
-      store_tile(const_cast<h16*>(p.kc), klast, nmy - 1);
-      store_tile(const_cast<h16*>(p.vc), vlast, nmy - 1);
+      store_tile(const_cast<h16*>(p.kc), klast);
+      store_tile(const_cast<h16*>(p.vc), vlast);
     }
   } else if constexpr (APP) {
     if (sub == 0 && lbA < p.max_blocks_per_seq) {
