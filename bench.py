@@ -296,16 +296,16 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
 
 def run_matrix(args, base, dev):
     """Every (head size, block size, element type / cache type) the operators are built for, at base's
-    batch/heads/seq_len: fp16, bf16, and fp16 query over an fp8 E4M3 cache."""
+    batch/heads/seq_len: fp16, bf16, float32, and fp16 query over fp8 E4M3 / E5M2 caches."""
     import dataclasses
 
     global KV_DTYPE
     res = []
-    for kind in ("float16", "bfloat16", "fp8_kv"):
-        dt = torch.bfloat16 if kind == "bfloat16" else torch.float16
+    for kind in ("float16", "bfloat16", "fp8_kv", "fp8_e5m2_kv", "float32"):
+        dt = {"bfloat16": torch.bfloat16, "float32": torch.float32}.get(kind, torch.float16)
         for D in (64, 80, 96, 112, 128, 192, 256):
             for bs in (8, 16, 32):
-                if kind == "fp8_kv" and bs == 8:
+                if kind.startswith("fp8") and bs == 8:
                     continue
                 per = -(-base.seq_len // bs)
                 c = dataclasses.replace(base, name=f"m_d{D}_bs{bs}", head_size=D, block_size=bs,
@@ -314,8 +314,12 @@ def run_matrix(args, base, dev):
                 KV_DTYPE = "auto"
                 if kind == "bfloat16":
                     wl.key_cache, wl.value_cache, wl.qkv = (wl.key_cache.to(dt), wl.value_cache.to(dt), wl.qkv.to(dt))
-                elif kind == "fp8_kv":
-                    KV_DTYPE = "fp8"
+                elif kind == "float32":          # x = 4 layout: same bytes per chunk, half the elements
+                    wl.key_cache = torch.empty((c.num_blocks, c.num_heads, D // 4, bs, 4), dtype=dt, device=dev).uniform_(-1, 1)
+                    wl.value_cache = torch.empty((c.num_blocks, c.num_heads, D, bs), dtype=dt, device=dev).uniform_(-1, 1)
+                    wl.qkv = wl.qkv.to(dt)
+                elif kind.startswith("fp8"):
+                    KV_DTYPE = "fp8" if kind == "fp8_kv" else "fp8_e5m2"
                     gk = torch.Generator(device=dev).manual_seed(3)
                     ks = (c.num_blocks, c.num_heads, D // 16, bs, 16)
                     vs = (c.num_blocks, c.num_heads, D, bs)
@@ -334,10 +338,13 @@ def run_matrix(args, base, dev):
                 torch.cuda.synchronize(dev)
                 us = statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
                 vid = ops.pick_variant(c.batch, c.num_heads, D, c.seq_len, bs, bf16=kind == "bfloat16",
-                                       fp8=kind == "fp8_kv")
+                                       fp8={"fp8_kv": True, "fp8_e5m2_kv": "e5m2"}.get(kind, False))
                 nbytes = alg_bytes(c)
+                if kind == "float32":            # K and V bytes double
+                    nbytes += 2 * c.batch * c.kv_heads * c.seq_len * c.head_size * 2
                 row = {"dtype": kind, "head_size": D, "block_size": bs, "us_median": us,
-                       "gbps": nbytes / (us * 1e-6) / 1e9, "variant": ops.variant_names()[vid - 1]}
+                       "gbps": nbytes / (us * 1e-6) / 1e9,
+                       "variant": "pa_v1_f32_kernel" if kind == "float32" else ops.variant_names()[vid - 1]}
                 res.append(row)
                 print(json.dumps(row), file=sys.stderr, flush=True)
                 del wl, out
