@@ -8,7 +8,7 @@ CSRC   := vllmini_amd/csrc
 OUTDIR := vllmini_amd/_C
 UNITS  := paged_attention pa_variants_extra pa_variants_bf16 pa_append_core pa_append_extra pa_append_bf16 \
           pa_variants_fp8 pa_variants_fp8_bf16 pa_variants_fp8_e5m2 pa_variants_fp8_e5m2_bf16 \
-          pa_variants_sparse pa_variants_sparse_bf16 pa_f32
+          pa_variants_sparse pa_variants_sparse_bf16 pa_f32 pa_queue
 OBJS   := $(UNITS:%=$(OUTDIR)/%.hip.o)
 LIB    := $(OUTDIR)/libvmi_paged_attention.so
 
@@ -17,7 +17,7 @@ all: $(LIB) oracle
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -fno-gpu-rdc $^ -o $@
 
-$(OUTDIR)/%.hip.o: $(CSRC)/%.hip $(CSRC)/pa_kernel.hpp $(wildcard $(CSRC)/*.inc) include/vmi_paged_attention.h
+$(OUTDIR)/%.hip.o: $(CSRC)/%.hip $(CSRC)/pa_kernel.hpp $(CSRC)/pa_queue.hpp $(wildcard $(CSRC)/*.inc) include/vmi_paged_attention.h
 	mkdir -p $(OUTDIR)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 15
+#define VMI_ABI_VERSION 16
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -350,6 +350,14 @@ int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads,
  * No effect on multi-head attention (num_kv_heads == num_heads) or on an explicit `variant`.
  */
 int vmi_set_pv_mfma(int32_t on);
+
+/*
+ * Test / benchmark knob of the balanced ("q_*") kernels (process-wide, default 0 = automatic; returns the previous
+ * value): forces their mode, worker count or hand-out policy (bit layout: vllmini_amd/csrc/pa_queue.hpp, QF_*).
+ * Results do not depend on it — every mode computes an item with the same operations in the same order — only the
+ * schedule does; tests use it to drive every path of the kernel on small inputs.
+ */
+int vmi_debug_set_queue_flags(int32_t flags);
 
 /*
  * The same heuristic with what a caller may know on the host: the batch's mean sequence length (0 = unknown) and

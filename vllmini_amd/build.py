@@ -30,8 +30,10 @@ SRC_FP8_BF16 = os.path.join(CSRC, "pa_variants_fp8_bf16.hip")  # ... with a bflo
 SRC_SPARSE = [os.path.join(CSRC, f"pa_variants_sparse{t}.hip") for t in ("", "_bf16")]   # block-sparse attention
 SRC_FP8_E5M2 = [os.path.join(CSRC, f"pa_variants_fp8_e5m2{t}.hip") for t in ("", "_bf16")]   # ... over E5M2 bytes
 SRC_F32 = os.path.join(CSRC, "pa_f32.hip")                    # float32 tensors (x = 4)
-SOURCES = [SRC, SRC_EXTRA, SRC_BF16, *SRC_APPEND, SRC_FP8, SRC_FP8_BF16, *SRC_FP8_E5M2, *SRC_SPARSE, SRC_F32]
+SRC_QUEUE = os.path.join(CSRC, "pa_queue.hip")                # balanced (work-queue) kernels for ragged batches
+SOURCES = [SRC, SRC_EXTRA, SRC_BF16, *SRC_APPEND, SRC_FP8, SRC_FP8_BF16, *SRC_FP8_E5M2, *SRC_SPARSE, SRC_F32, SRC_QUEUE]
 HDR = os.path.join(CSRC, "pa_kernel.hpp")
+HDR_QUEUE = os.path.join(CSRC, "pa_queue.hpp")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 OUT_DIR = os.path.join(PKG_DIR, "_C")
 LIB_NAME = "libvmi_paged_attention.so"
@@ -59,7 +61,7 @@ def _hipcc() -> str:
 
 
 def _deps() -> list[str]:
-    return [*SOURCES, *TABLES, HDR, os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.abspath(__file__)]
+    return [*SOURCES, *TABLES, HDR, HDR_QUEUE, os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.abspath(__file__)]
 
 
 def is_stale() -> bool:
@@ -69,25 +71,53 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
+def _obj_of(src: str) -> str:
+    return os.path.join(OUT_DIR, os.path.basename(src) + ".o")
+
+
+def _flags_stamp() -> str:
+    return " ".join(HIPCC_FLAGS)
+
+
+def _obj_stale(src: str) -> bool:
+    """An object is rebuilt when it is missing, older than anything its depfile (hipcc -MD) lists, or was
+    compiled with other flags."""
+    obj, dep, stamp = _obj_of(src), _obj_of(src) + ".d", _obj_of(src) + ".flags"
+    if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(stamp)):
+        return True
+    if open(stamp).read() != _flags_stamp():
+        return True
+    t = os.path.getmtime(obj)
+    text = open(dep).read().replace("\\\n", " ")
+    files = text.split(":", 1)[1].split() if ":" in text else []
+    for f in [*files, os.path.abspath(__file__)]:
+        if not os.path.exists(f) or os.path.getmtime(f) > t:
+            return True
+    return False
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the library if missing or older than its sources; return its path."""
-    if not force and not is_stale():
-        return LIB_PATH
+    """Compile the translation units that are missing or stale (all of them with force=True), link; return the
+    library's path."""
     os.makedirs(OUT_DIR, exist_ok=True)
+    todo = [s for s in SOURCES if force or _obj_stale(s)]
+    if not todo and os.path.exists(LIB_PATH) and not is_stale():
+        return LIB_PATH
     tmp = LIB_PATH + ".tmp"
-    objs = []
     procs = []
-    for src in SOURCES:                               # the units compile concurrently
-        obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
-        cmd = [_hipcc(), *HIPCC_FLAGS, "-c", src, "-o", obj]
+    for src in todo:                                  # the units compile concurrently
+        obj = _obj_of(src)
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
-        objs.append(obj)
-    for cmd, proc in procs:
+        procs.append((src, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for src, cmd, proc in procs:
         out, err = proc.communicate()
         if proc.returncode != 0:
             raise RuntimeError(f"hipcc failed ({proc.returncode}): {' '.join(cmd)}\n{out}\n{err}")
+        with open(_obj_of(src) + ".flags", "w") as f:
+            f.write(_flags_stamp())
+    objs = [_obj_of(s) for s in SOURCES]
     link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *os.environ.get("VMI_EXTRA_FLAGS", "").split(), *objs, "-o", tmp]
     if verbose:
         print(" ".join(link), file=sys.stderr)

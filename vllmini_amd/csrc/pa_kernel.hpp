@@ -287,6 +287,10 @@ struct PAParams {
   // block-sparse attention (SPARSE kernels only; the operator's tp_rank + four blocksparse_* arguments,
   // attention_kernels.cu:108-110): a cache block is read when its sparse block is "remote" or "local" (:232-254)
   int32_t bs_tp_rank, bs_local_blocks, bs_vert_stride, bs_block_size, bs_head_sliding_step;
+  // balanced kernels (pa_queue.hpp) only: the grid is not (heads, seqs), so the batch size rides here;
+  // q_flags = test / experiment knobs, 0 = automatic
+  int32_t num_seqs;
+  int32_t q_flags;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -1293,6 +1297,7 @@ struct Variant {
   bool GQS;          // the HPT query heads of a wave share one KV head: num_heads / num_kv_heads % HPT == 0 required
   bool FPV;          // opt-in: probabilities x V on the matrix cores too (vmi_set_pv_mfma); north-star bound, not 1 ulp
   bool SPARSE;       // block-sparse attention (blocksparse_vert_stride > 1); menus of their own (pa_variants_sparse.hip)
+  bool QUEUE;        // balanced kernel (pa_queue.hpp): persistent grid of 3 workgroups per CU, mode chosen on the device
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
@@ -1405,5 +1410,8 @@ extern const int g_fp8bf_nvariants_v2;
 extern Variant g_fp8bf_variants_v2_e5m2[];
 extern const int g_fp8bf_nvariants_v2_e5m2;
 pa_reduce_t bf16_reduce_kernel(int head_size);
+// balanced (work-queue) kernels, pa_queue.hip: v1 ids continue after every other menu
+extern Variant g_queue_variants[];
+extern const int g_queue_nvariants;
 
 }  // namespace vmi

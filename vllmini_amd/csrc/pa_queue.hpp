@@ -1,0 +1,497 @@
+// pa_queue.hpp — the BALANCED form of paged_attention_v1 for a full chip (gfx950 only).
+//
+// pa_v1_kernel (pa_kernel.hpp) gives every (sequence, head) its own resident wave.  On equal lengths that is the
+// fastest form found (cfg3: 0.82 of the HBM roofline), on RAGGED batches nothing rebalances the chip when the short
+// sequences are done: the long ones run on alone, each limited to its own bytes in flight per memory round trip
+// (cfg3 with seq_lens ~ U{1..1024}: 0.61).  The launch geometry cannot react — the operator's argument list
+// (reference attention_kernels.cu:805-826) carries the lengths only as a DEVICE tensor.
+//
+// pa_q_kernel decides on the device.  One launch geometry — 3 workgroups of 4 waves per CU, all resident — and two
+// modes, chosen by every wave from the same seq_lens (so all waves agree without talking to each other):
+//
+//   S  (equal lengths, one item per wave)   wave w owns item w, 1 block per register group: pa_v1_kernel's best form,
+//                                           same lane maps, same order of operations.
+//   Q  (ragged, or more items than waves)   2 waves per workgroup stay as WORKERS, the rest retire.  A worker runs
+//                                           items one after the other, 2 blocks per register group, so the chip holds
+//                                           the same bytes in flight with half the waves.  Items are handed out
+//                                           longest first: the sequences are ranked by a deterministic 64-bucket
+//                                           counting sort that every workgroup repeats for itself in LDS, and worker w
+//                                           takes ranks w, 2W-1-w, 2W+w, ... (a snake over the ranks: each worker
+//                                           pairs a long item with a short one — what longest-processing-time-first
+//                                           list scheduling would hand it, without any communication).
+//                                           The table slice, length and q of the NEXT item are requested at the
+//                                           K -> V change of the current one and its first K group right after the
+//                                           softmax (third register buffer), so a worker's page stream has no bubble
+//                                           at an item boundary.
+//
+// Tried and dropped (profiles/r02a_queue_probe_cfg3_ticket_vs_static.log): handing items out through ONE device-scope
+// ticket counter (atomic add per item).  cfg3 ragged: 105 us against 73 us for the static snake, uniform 153 against
+// 129 — a single word sustains ~88 atomics/us (MI355X_MICROARCH.md, "dequeue"), 3072 pulls are 35 us of it, and vmcnt
+// retires in order, so a slow atomic also blocks every page group requested behind it.
+//
+// Arithmetic: an item is computed by ONE wave exactly as pa_v1_kernel<D, *, 1, 1, ...> computes it — K lane map
+// lane = chunk*16 + token, dot8 chains + xor butterfly, fp32 softmax, probabilities rounded once to fp16/bf16,
+// PV8 per 8-token group, fp32 accumulation over the blocks from the LAST block down to the first.  That order does
+// not depend on the group size, so S and Q results are bit-identical to each other and to the u1 kernels: what a
+// sequence gets never depends on its batch neighbours (tests/test_parity_gpu.py::test_queue_kernel_*).
+// Reference rounding points: attention_kernels.cu:115-136 (context bounds), 302-305 (masked logits), 334-342
+// (softmax), 398-430 (fp16 p, zeroed tail of V), dtype_float16.cuh:252-260, 439-457 (packed products and sums).
+//
+// No state outside the launch: no counters, no workspace, nothing to reset — safe under hipGraph replay and from any
+// number of streams and host threads.
+#pragma once
+
+#include "pa_kernel.hpp"
+
+namespace vmi {
+
+constexpr int QSORT_MAX = 2048;  // sequences ranked in LDS (2 B each); larger batches are served in index order
+
+// q_flags (PAParams): experiment / test knobs; 0 = automatic
+//   bits 0-1  mode      0 auto, 1 force S (when every item has a wave), 2 force Q
+//   bits 2-4  WQ        workers per workgroup in mode Q (0 -> 2)
+//   bit  11   no ranking (index order)
+constexpr int QF_MODE(int f) { return f & 3; }
+constexpr int QF_WQ(int f) { return (f >> 2) & 7; }
+constexpr int QF_NOSORT = 1 << 11;
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int o = __shfl_xor(v, m);
+    v = v > o ? v : o;
+  }
+  return v;
+}
+
+// grid = (G), block = 256.  LDS = 4*lpad*4 (logits / probabilities, one region per wave) + QSORT_MAX*2 (ranking)
+//                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + 4*64*8 (bucket masks).
+template <int D, bool BF, bool NT, int US, int UQ>
+// (second launch bound = minimum waves per SIMD: 3 workgroups of 4 waves per CU must all be resident in mode S, i.e.
+//  <= 168 VGPRs; the 4-blocks-per-group experiments need more and run 2 per SIMD)
+__global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel(const PAParams p) {
+  constexpr int BS = 16;
+  constexpr int NL = D * BS / 8 / 64;  // 1-KiB loads per (block, head) tile of K — and of V
+  static_assert(D % 32 == 0 && NL >= 1, "head size must fill whole 1-KiB loads");
+  constexpr int UPR = 2;   // V: 16-B units per dim row
+  constexpr int RPL = 32;  // V: rows per load
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* smem_f = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* logits = smem_f + (size_t)wave * p.lpad;
+  uint16_t* ph = reinterpret_cast<uint16_t*>(logits);  // probabilities, in place over the consumed fp32 values
+  uint16_t* order = reinterpret_cast<uint16_t*>(smem_f + (size_t)4 * p.lpad);
+
+  const int B = p.num_seqs, H = p.num_heads;
+  const int N = B * H;                    // items
+  const int nwaves = gridDim.x * 4;
+  const int w_nat = blockIdx.x * 4 + wave;  // this wave's item in mode S
+  const int qpk = H / p.num_kv_heads;
+
+  // ---- everything a wave needs to know about an item before its first page can be requested -------------------
+  struct Meta {
+    int seq, head, L;    // wave-uniform
+    int32_t bt;          // lane j: physical id of block j (first 64 blocks)
+    u32x4 q[NL];         // this lane's 8 dims of q facing each K load
+    float slope;
+  };
+  const int c4 = lane >> 4;  // K: chunk within a load
+  const int tk = lane & 15;  // K: token within the block
+  auto meta_issue = [&](Meta& m, int seq, int head) {
+    m.seq = seq;
+    m.head = head;
+    const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
+    m.bt = lane < p.max_blocks_per_seq ? bt[lane] : 0;
+    m.L = p.seq_lens[seq];
+    const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) m.q[i] = *reinterpret_cast<const u32x4*>(qp + (4 * i + c4) * 8);
+    m.slope = p.alibi ? p.alibi[head] : 0.f;
+  };
+
+  // ---- mode: every wave derives it from the same lengths ---------------------------------------------------------
+  // (the natural item's metadata is requested first, so in mode S the decision costs no extra round trip)
+  Meta cur;
+  const bool nat_ok = w_nat < N;
+  {
+    const int s0 = nat_ok ? w_nat / H : 0;
+    meta_issue(cur, s0, nat_ok ? w_nat - s0 * H : 0);
+  }
+  const int flags = p.q_flags;
+  bool queue = N > nwaves;
+  int maxL = 0;
+  // lengths of the chunks this wave ranks (chunk = 64 sequences; chunk c belongs to wave c & 3), read ONCE: the
+  // statistics and both passes of the counting sort use these registers, not three dependent trips to memory
+  constexpr int MYCH = QSORT_MAX / 256;
+  int mylen[MYCH];
+  const bool rankable = B <= QSORT_MAX && !(flags & QF_NOSORT);
+  auto clampL = [&](int l) { return l < 0 ? 0 : (l > p.lpad ? p.lpad : l); };
+  if (rankable) {
+    float sum = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < MYCH; ++cc) {
+      mylen[cc] = -1;
+      if (cc * 256 < B) {  // wave-uniform
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          const int i = (cc * 4 + w4) * 64 + lane;
+          const int l = i < B ? clampL(p.seq_lens[i]) : -1;
+          maxL = maxL > l ? maxL : l;
+          sum += l > 0 ? (float)l : 0.f;
+          mylen[cc] = w4 == wave ? l : mylen[cc];
+        }
+      }
+    }
+    maxL = wave_max_i(maxL);
+    sum = wave_sum(sum);
+    queue = queue || sum < 0.8f * (float)maxL * (float)B;
+  } else if (!queue) {  // too many sequences to rank, yet a wave for every item (few heads): statistics only
+    float sum = 0.f;
+    for (int i = lane; i < B; i += 64) {
+      const int l = clampL(p.seq_lens[i]);
+      maxL = maxL > l ? maxL : l;
+      sum += (float)l;
+    }
+    maxL = wave_max_i(maxL);
+    sum = wave_sum(sum);
+    queue = sum < 0.8f * (float)maxL * (float)B;
+  }
+  if (QF_MODE(flags) == 1 && N <= nwaves) queue = false;
+  if (QF_MODE(flags) == 2) queue = true;
+  queue = __builtin_amdgcn_readfirstlane(queue);
+  const int WQ = QF_WQ(flags) ? QF_WQ(flags) : 2;
+  const bool ranked = queue && rankable;
+  const int nworkers = queue ? gridDim.x * WQ : nwaves;
+  const int wq = queue ? blockIdx.x * WQ + wave : w_nat;  // worker index
+
+  if (queue) {
+    // ---- rank the sequences, longest first: a counting sort with 64 length buckets (bucket k in lane k), index order
+    //      inside a bucket — deterministic, so every workgroup computes the same table for itself.  The four waves
+    //      share the 64-sequence chunks; B <= QSORT_MAX. ----
+    if (ranked) {
+      uint16_t* cnt = order + QSORT_MAX;  // [chunk][bucket]: sequences of the chunk in the bucket
+      const int nch = (B + 63) >> 6;
+      const float bscale = 64.f / (float)(maxL + 1);
+      auto bucket_of = [&](int l) -> int {
+        if (l < 0) return 64;  // past the end of the batch
+        const int bk = (int)((float)(maxL - l) * bscale);  // 0 = longest
+        return bk > 63 ? 63 : bk;
+      };
+      // Per chunk: which lanes share my bucket (a 64-bit mask per bucket, built with ONE LDS atomic OR — the result of
+      // an OR does not depend on the order the lanes are served in) and how many sequences each bucket holds.
+      uint64_t* bm = reinterpret_cast<uint64_t*>(cnt + QSORT_MAX) + wave * 64;  // this wave's 64 masks
+      uint64_t same[MYCH];
+#pragma unroll
+      for (int cc = 0; cc < MYCH; ++cc) {
+        const int c = cc * 4 + wave;
+        same[cc] = 0;
+        if (c >= nch) break;
+        const int bk = bucket_of(mylen[cc]);
+        bm[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (DS operations of one wave execute in order)
+        if (bk < 64) __hip_atomic_fetch_or(&bm[bk], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        same[cc] = bm[bk & 63];
+        cnt[c * 64 + lane] = (uint16_t)__popcll(bm[lane]);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+      __syncthreads();
+      int tot = 0;
+      for (int c = 0; c < nch; ++c) tot += cnt[c * 64 + lane];
+      int incl = tot;  // inclusive scan over the buckets
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        incl += lane >= d ? o : 0;
+      }
+      int run = incl - tot;  // lane k: rank of the first sequence of bucket k in the chunk at hand
+#pragma unroll
+      for (int cq = 0; cq < MYCH * 4; ++cq) {
+        const int c = cq;
+        if (c >= nch) break;
+        if ((c & 3) == wave) {
+          const int bk = bucket_of(mylen[cq >> 2]);
+          const int pos = __shfl(run, bk & 63) + __popcll(same[cq >> 2] & ((1ull << lane) - 1ull));
+          if (bk < 64) order[pos] = (uint16_t)(c * 64 + lane);
+        }
+        run += cnt[c * 64 + lane];
+      }
+    }
+    __syncthreads();
+    if (wave >= WQ) return;  // not a worker in this mode
+  }
+  auto seq_of_rank = [&](int r) -> int {  // wave-uniform
+    return ranked ? (int)__builtin_amdgcn_readfirstlane((int)order[r]) : r;
+  };
+  // item t (0 <= t < N) in hand-out order -> (seq, head): the H heads of a rank are consecutive items
+  auto ids_of = [&](int t, int& seq, int& head) {
+    const int r = t / H;
+    head = t - r * H;
+    seq = seq_of_rank(r);
+  };
+
+  if (wq >= N) return;  // more workers than items (forced modes only)
+  if (queue) {  // first item of worker wq = rank order position wq
+    int s, h;
+    ids_of(wq, s, h);
+    meta_issue(cur, s, h);
+  }
+
+  const int hf = lane & 1;     // V: which 8-token group of the block this lane owns
+  const int rowl = lane >> 1;  // V: dim row within a load
+
+  auto run = [&](auto utag) {
+    constexpr int UU = decltype(utag)::value;
+    u32x4 rn[UU][NL], ra[UU][NL], rb[UU][NL];
+
+    // per-item state (wave-uniform unless noted)
+    int L = 0, nblk = 0;
+    int32_t bt_reg = 0;  // lane j: physical id of block bt_sg*64 + j
+    int bt_sg = 0;
+    const int32_t* bt = nullptr;
+    int64_t hoff = 0;  // this lane's element offset inside a block: kv head tile + lane*8
+    u32x4 qreg[NL];
+    float slope = 0.f;
+    uint16_t* outp = nullptr;
+
+    auto adopt = [&](const Meta& m) {  // make m the current item
+      int l = m.L;
+      l = l > p.lpad ? p.lpad : l;  // seq_len > max_seq_len: truncated to the LDS that was reserved
+      L = __builtin_amdgcn_readfirstlane(l);
+      nblk = (L + BS - 1) / BS;
+      bt = p.block_tables + (int64_t)m.seq * p.max_blocks_per_seq;
+      bt_reg = m.bt;
+      bt_sg = 0;
+      hoff = (int64_t)(m.head / qpk) * p.kv_head_stride + lane * 8;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) qreg[i] = m.q[i];
+      slope = m.slope;
+      outp = reinterpret_cast<uint16_t*>(p.out) + ((int64_t)m.seq * H + m.head) * D;
+    };
+    auto table_for = [&](int g) {
+      const int sg = (g * UU) >> 6;
+      if (sg != bt_sg) {  // once per 64 blocks
+        const int b = sg * 64 + lane;
+        bt_reg = b < p.max_blocks_per_seq ? bt[b] : 0;
+        bt_sg = sg;
+        // The wait for this load belongs INSIDE the branch.  Left to the compiler it lands at the join in front of
+        // the v_readlane — as s_waitcnt vmcnt(0) on EVERY page group, which drains the group in flight before the next
+        // one is requested, i.e. no register double buffer at all.
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bt_reg));
+      }
+    };
+    static_assert(64 % UU == 0, "a register group must not straddle two table slices");
+    auto load_group = [&](u32x4(&r)[UU][NL], const h16* cache, int g) {
+      table_for(g);
+#pragma unroll
+      for (int j = 0; j < UU; ++j) {
+        int idx = g * UU + j;
+        idx = idx < nblk ? idx : nblk - 1;  // padding slots re-read my last block (never out of bounds)
+        const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
+        const h16* blk = cache + phys * p.kv_block_stride + hoff;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(blk + i * 512);
+      }
+    };
+
+    float qk_max;
+    auto compute_k = [&](u32x4(&r)[UU][NL], int g) {
+#pragma unroll
+      for (int j = 0; j < UU; ++j) {
+        const int b = g * UU + j;
+        if (b < nblk) {  // wave-uniform
+          const int token = b * BS + tk;
+          const bool masked = token >= L;
+          float accv[NL];
+#pragma unroll
+          for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[i], r[j][i]);
+          float acc = accv[0];
+#pragma unroll
+          for (int i = 1; i < NL; ++i) acc += accv[i];
+          acc += __shfl_xor(acc, 16);
+          acc += __shfl_xor(acc, 32);
+          float qk = p.scale * acc;
+          qk += (slope != 0.f) ? slope * (float)(token - L + 1) : 0.f;
+          if (lane < BS) logits[token] = masked ? 0.f : qk;
+          qk_max = masked ? qk_max : fmaxf(qk_max, qk);
+        }
+      }
+    };
+
+    float acc[NL];
+    auto compute_v = [&](auto masked, u32x4(&r)[UU][NL], int g) {
+      constexpr bool MASK = decltype(masked)::value;
+#pragma unroll
+      for (int jj = 0; jj < UU; ++jj) {
+        const int j = UU - 1 - jj;  // blocks in descending order whatever the group size
+        const int b = g * UU + j;
+        if (b < nblk) {
+          const int token0 = b * BS + hf * 8;
+          const bool last = (b == nblk - 1);
+          PV8<BF> pv;
+          pv.load(*reinterpret_cast<const u32x4_alias*>(ph + token0));
+#pragma unroll
+          for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
+        }
+      }
+    };
+
+    // the first K group of the NEXT item (issued as soon as the current item's first V group has been consumed)
+    auto prefetch_next = [&](const Meta& m, bool has) {
+      if (!has) return;
+      int l2 = m.L;
+      l2 = l2 > p.lpad ? p.lpad : l2;
+      l2 = __builtin_amdgcn_readfirstlane(l2);
+      if (l2 <= 0) return;
+      const int nb2 = (l2 + BS - 1) / BS;
+      const int64_t hoff2 = (int64_t)(m.head / qpk) * p.kv_head_stride + lane * 8;
+#pragma unroll
+      for (int j = 0; j < UU; ++j) {
+        const int idx = j < nb2 ? j : nb2 - 1;
+        const int64_t phys = __builtin_amdgcn_readlane(m.bt, idx);
+        const h16* blk = p.kc + phys * p.kv_block_stride + hoff2;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) rn[j][i] = ld16<NT>(blk + i * 512);
+      }
+    };
+
+    // ---- first item: its metadata was requested above ----
+    adopt(cur);
+    if (L > 0) load_group(rn, p.kc, 0);
+    int round = 0;  // items this worker has finished
+
+    for (;;) {
+      Meta nxt;  // (deliberately uninitialised: a default value would become a phi, i.e. register copies that wait
+                 //  for the loads the moment they are issued)
+      bool has_next = false;
+      auto fetch_next = [&]() {  // wave-uniform decision + the requests for the next item's metadata
+        if (!queue) return;
+        const int k = round + 1;  // the snake over the ranks
+        const int64_t t64 = (int64_t)k * nworkers + ((k & 1) ? (nworkers - 1 - wq) : wq);
+        has_next = t64 < N;
+        const int t = (int)t64;
+        int s, h;
+        ids_of(has_next ? t : 0, s, h);  // requested unconditionally (item 0 when there is no next one): no phi
+        meta_issue(nxt, s, h);
+      };
+
+      if (L <= 0) {  // reference: exp_sum = 0 -> every output 0
+        for (int d = lane; d < D; d += 64) outp[d] = 0;
+        fetch_next();
+        if (!has_next) break;
+        adopt(nxt);
+        if (L > 0) load_group(rn, p.kc, 0);
+        ++round;
+        continue;
+      }
+
+      const int ngroups = (nblk + UU - 1) / UU;
+      const int lastg = ngroups - 1;
+      qk_max = -FLT_MAX;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) acc[i] = 0.f;
+
+      // =========================== K pass: logits -> LDS, running max ========================
+      // group 0 is in rn (requested during the previous item); the rest ping-pongs between ra and rb
+      if (ngroups == 1) {
+        load_group(ra, p.vc, 0);  // one group in all: K and V cost one round trip between them
+        compute_k(rn, 0);
+      } else {
+        // The V pass starts BEFORE the K pass ends: its first group (the LAST one: the block reshape_and_cache has just
+        // written is requested early, profiles/r01o_call_pair_gap.md) goes into rn — free since group 0 was consumed —
+        // ahead of the final K computation, the second one right behind it, so two groups stay in flight across the
+        // K -> V change and the softmax instead of the queue running empty there.
+        load_group(ra, p.kc, 1);
+        compute_k(rn, 0);
+        int g = 1;
+        for (; g + 2 < ngroups; g += 2) {
+          load_group(rb, p.kc, g + 1);
+          compute_k(ra, g);
+          load_group(ra, p.kc, g + 2);
+          compute_k(rb, g + 1);
+        }
+        if (g + 2 == ngroups) {
+          load_group(rb, p.kc, g + 1);
+          compute_k(ra, g);
+          load_group(rn, p.vc, lastg);
+          compute_k(rb, g + 1);
+        } else {
+          load_group(rn, p.vc, lastg);
+          compute_k(ra, g);
+        }
+        load_group(ra, p.vc, lastg - 1);
+      }
+      fetch_next();  // the next item's table slice, length and q are requested
+
+      // =========================== softmax over the logits in LDS ============================
+      float inv_sum;
+      {
+        const float m = wave_max(qk_max);
+        float e_sum = 0.f;
+        for (int i = lane; i < L; i += 64) {
+          const float e = __expf(logits[i] - m);
+          logits[i] = e;
+          e_sum += e;
+        }
+        inv_sum = __builtin_amdgcn_rcpf(wave_sum(e_sum) + 1e-6f);
+      }
+      // p = exp * inv_sum -> fp16 (bf16), once per token, in place: the 64 lanes read fp32 values [t0, t0+64) and then
+      // write bytes [2*t0, 2*t0+128), i.e. fp32 slots [t0/2, t0/2+32) — already consumed, or read by this very access
+      for (int t = lane; t < nblk * BS; t += 64) {
+        const float e = logits[t];
+        ph[t] = t < L ? to_elem<BF>(e * inv_sum) : (uint16_t)0;
+      }
+      // The next item's metadata is waited for HERE, where only the first V group (needed next anyway) is in flight
+      // with it: no later use of it can then make the compiler drain the V stream.
+      if (queue) {
+        asm volatile("" : "+v"(nxt.bt), "+v"(nxt.L), "+v"(nxt.slope));
+#pragma unroll
+        for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(nxt.q[i]));
+      }
+
+      // =========================== V pass, last group first ===================================
+      if (ngroups == 1) {
+        compute_v(std::true_type{}, ra, 0);
+        if (queue) prefetch_next(nxt, has_next);
+      } else {
+        compute_v(std::true_type{}, rn, lastg);  // the only group that can hold the sequence's last block
+        // rn is free again: the next item's first K group goes out now and has the rest of the V pass to arrive
+        if (queue) prefetch_next(nxt, has_next);
+        int s = 1;  // step s = group lastg - s; odd steps in ra, even steps in rb
+        for (; s + 2 < ngroups; s += 2) {
+          load_group(rb, p.vc, lastg - (s + 1));
+          compute_v(std::false_type{}, ra, lastg - s);
+          load_group(ra, p.vc, lastg - (s + 2));
+          compute_v(std::false_type{}, rb, lastg - (s + 1));
+        }
+        if (s + 2 == ngroups) {
+          load_group(rb, p.vc, lastg - (s + 1));
+          compute_v(std::false_type{}, ra, lastg - s);
+          compute_v(std::false_type{}, rb, lastg - (s + 1));
+        } else {
+          compute_v(std::false_type{}, ra, lastg - s);
+        }
+      }
+
+      // the two lanes of a row hold its 8-token groups
+#pragma unroll
+      for (int i = 0; i < NL; ++i) acc[i] += __shfl_xor(acc[i], 1);
+      if (hf == 0) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) outp[RPL * i + rowl] = to_elem<BF>(acc[i]);
+      }
+      if (!has_next) break;
+      adopt(nxt);  // its first K group is already in flight in rn
+      ++round;
+    }
+  };
+
+  if (queue) run(std::integral_constant<int, UQ>{});
+  else run(std::integral_constant<int, US>{});
+
+}
+
+}  // namespace vmi

@@ -34,6 +34,7 @@
 
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -477,7 +478,7 @@ static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
 static int nvariants_v1() {
   return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1 + g_fp8_nvariants_v1 + g_fp8bf_nvariants_v1 +
-         g_fp8_nvariants_v1_e5m2 + g_fp8bf_nvariants_v1_e5m2;
+         g_fp8_nvariants_v1_e5m2 + g_fp8bf_nvariants_v1_e5m2 + g_queue_nvariants;
 }
 static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf16][fp8 cache]
   if (id <= g_ncore) return g_variants[id - 1];
@@ -490,7 +491,9 @@ static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf
   if (id <= f1 + g_fp8bf_nvariants_v1) return g_fp8bf_variants_v1[id - 1 - f1];  // bf16 query over the fp8 cache
   const int f2 = f1 + g_fp8bf_nvariants_v1;                                        // ... and the E5M2 menus
   if (id <= f2 + g_fp8_nvariants_v1_e5m2) return g_fp8_variants_v1_e5m2[id - 1 - f2];
-  return g_fp8bf_variants_v1_e5m2[id - 1 - f2 - g_fp8_nvariants_v1_e5m2];
+  const int f3 = f2 + g_fp8_nvariants_v1_e5m2;
+  if (id <= f3 + g_fp8bf_nvariants_v1_e5m2) return g_fp8bf_variants_v1_e5m2[id - 1 - f3];
+  return g_queue_variants[id - 1 - f3 - g_fp8bf_nvariants_v1_e5m2];  // balanced kernels (pa_queue.hip)
 }
 
 static bool is_diag(const Variant& v) { return strstr(v.name, "LOADSONLY") != nullptr; }
@@ -501,7 +504,7 @@ static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = a
   for (int id = 1; id <= nvariants_v1(); ++id) {
     const Variant& v = variant_v1(id);
     if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
-        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0 && !v.GQS)
+        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0 && !v.GQS && !v.QUEUE)
       return id;
   }
   return 0;
@@ -627,7 +630,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
     if (wph == 1 && u == 1 && nt) {  // full chip, one wave per head: the adaptive-depth form where one is built
       for (int id = 1; id <= nvariants_v1(); ++id) {
         const Variant& c = variant_v1(id);
-        if (c.BF == bf && c.D == head_size && c.BS == 16 && c.UMAX > 0 && c.WPH == 1 && c.U == 1 &&
+        if (c.BF == bf && c.D == head_size && c.BS == 16 && c.UMAX > 0 && c.WPH == 1 && c.U == 1 && !c.QUEUE &&
             c.HPW == ((num_heads % 4 == 0) ? 4 : 1))
           return id;
       }
@@ -635,7 +638,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
     if (wph == 1 && head_size == 128 && nt && num_heads % 16 == 0 && waves_per_cu >= 12.0) {
       for (int id = 1; id <= nvariants_v1(); ++id) {  // d128_mh4_h4_u1_nt1_lock
         const Variant& c = variant_v1(id);
-        if (c.BF == bf && c.D == 128 && c.HPT == 4 && c.HPW == 4 && c.U == 1) return id;
+        if (c.BF == bf && c.D == 128 && c.HPT == 4 && c.HPW == 4 && c.U == 1 && !c.QUEUE) return id;
       }
     }
     const int hpw = (wph == 1 && num_heads % 4 == 0) ? 4 : 1;
@@ -655,6 +658,26 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   int v = find_variant(head_size, block_size, 1, wph == 1 ? 1 : 4, -1, -1, bf);
   if (!v) v = find_variant(head_size, block_size, 1, 1, -1, -1, bf);
   return v;
+}
+
+// ---- per-device facts, guarded by one mutex (several host threads may drive several GPUs through this library) ----
+constexpr int MAX_DEVICES = 64;
+struct DeviceState {
+  int cus = 0;  // CU count (hipDeviceProp), read once per device
+};
+static std::mutex g_dev_mutex;
+static DeviceState g_dev[MAX_DEVICES];
+static std::atomic<int> g_queue_flags{0};  // test / bench knob for the balanced kernels (pa_queue.hpp QF_*)
+
+static int device_cus(int device) {  // caller holds the device current
+  if (device < 0 || device >= MAX_DEVICES) return 256;
+  std::lock_guard<std::mutex> lk(g_dev_mutex);
+  if (!g_dev[device].cus) {
+    hipDeviceProp_t prop;
+    g_dev[device].cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                            ? prop.multiProcessorCount : 256;
+  }
+  return g_dev[device].cus;
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -743,6 +766,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                 "fill a 16-byte unit; block sizes 16 and 32 are built)");
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
   auto lds_of = [&](const Variant& c) {
+    if (c.QUEUE) return (size_t)4 * lpad * 4 + (size_t)2048 * 4 + 2048;  // 4 waves' logits + the ranking, its bucket counts and masks (pa_queue.hpp)
     return (size_t)c.HPW * c.HPT *
            ((size_t)lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? (size_t)lpad * 2 : 0) +
             (c.SPARSE ? (size_t)lpad / 2 : 0));  // SPARSE: the list of attended blocks, one int per block (BS >= 8)
@@ -790,6 +814,12 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (v.GQS && (num_heads / num_kv_heads) % v.HPT != 0)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s shares a KV head between %d query heads, got "
                 "num_heads / num_kv_heads = %d", v.name, v.HPT, num_heads / num_kv_heads);
+  if (v.QUEUE && (append || f8 || bsp))
+    return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (balanced kernel) is built for fp16 / bf16 caches, "
+                "without the fused append or block-sparse attention", v.name);
+  if (v.QUEUE && (int64_t)num_seqs * num_heads > 0x7fffffff)
+    return fail(VMI_E_SHAPE, "paged_attention_v1: num_seqs * num_heads = %lld items exceed 2^31",
+                (long long)num_seqs * num_heads);
 
   const size_t lds = lds_of(v);
   if (lds > 160 * 1024)
@@ -833,6 +863,23 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   p.value_stride = value_stride;
   p.kv_scale = kv_scale;
   fill_sparse(p, bsp);
+  p.num_seqs = num_seqs;
+  p.q_flags = 0;
+
+  if (v.QUEUE) {
+    // persistent geometry: as many 4-wave workgroups as stay resident (3 per CU while their LDS fits), never more than
+    // one wave per item; the kernel picks its mode from seq_lens (pa_queue.hpp)
+    const int cus = device_cus(device);
+    const int per_cu = lds * 3 <= 160 * 1024 ? 3 : (lds * 2 <= 160 * 1024 ? 2 : 1);
+    const int64_t items = (int64_t)num_seqs * num_heads;
+    int64_t g = (int64_t)cus * per_cu;
+    if (g * 4 > items) g = (items + 3) / 4;
+    p.q_flags = g_queue_flags.load(std::memory_order_relaxed);
+    hipLaunchKernelGGL(v.fn, dim3((unsigned)g), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 launch");
+    return VMI_OK;
+  }
 
   dim3 block(v.HPW * v.WPH * 64);
   // gridDim.y is limited to 65535: longer batches go out as consecutive launches over slices
@@ -1321,6 +1368,8 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
 }
 
 int vmi_set_pv_mfma(int on) { return vmi::g_pv_mfma.exchange(on ? 1 : 0); }
+
+int vmi_debug_set_queue_flags(int flags) { return vmi::g_queue_flags.exchange(flags); }
 
 int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
                                             int32_t head_size, int32_t block_size, int32_t max_seq_len,
