@@ -360,6 +360,15 @@ int vmi_set_pv_mfma(int32_t on);
 int vmi_debug_set_queue_flags(int32_t flags);
 
 /*
+ * 1 when `variant` can serve a launch with this max_seq_len (its logits rows fit the 160 KiB of LDS) and, with
+ * for_append != 0, has a fused-append twin; 0 otherwise.  For callers that pick a variant from what they know about
+ * the batch (the pick functions above take the batch's longest length) but launch with a larger max_seq_len — the
+ * capacity of the pool, as the reference's scheduler does (vllmini/scheduler.py:97): an explicit `variant` that does not
+ * fit is an error (VMI_E_MAX_SEQ_LEN), variant 0 falls back by itself.
+ */
+int vmi_paged_attention_v1_variant_fits(int32_t variant, int32_t max_seq_len, int32_t for_append);
+
+/*
  * The same heuristic with what a caller may know on the host: the batch's mean sequence length (0 = unknown) and
  * the element type.  mean_seq_len well below max_seq_len marks a ragged batch, for which a many-waves-per-head
  * decomposition is chosen (the hardware dispatcher then balances the chip).  Pass the result as `variant`.

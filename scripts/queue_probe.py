@@ -29,8 +29,8 @@ if args.batch:
 D = cfg.head_size
 
 
-def flags(mode=0, wq=0, nosort=0):
-    return mode | (wq << 2) | (nosort << 11)
+def flags(mode=0, wq=0, nosort=0, team=0):
+    return mode | (wq << 2) | (nosort << 11) | (team << 12)
 
 
 def run(wl, out, t, variant):
@@ -57,9 +57,9 @@ res = {"cfg": cfg.name, "batch": cfg.batch}
 qnames = [n for n in names if n.startswith(f"q_d{D}_")]
 ref_name = f"d{D}_h4_w1_u1_nt1"
 auto_name = None
-for ragged in (False, True):
+for ragged in (False, True, "sorted"):
     wl = make_workload(cfg, dev, seed=0, ragged=ragged)
-    tag = "ragged" if ragged else "uniform"
+    tag = "rag-sort" if ragged == "sorted" else ("ragged" if ragged else "uniform")
     kv_bytes = int(wl.seq_lens.sum().item()) * cfg.kv_heads * D * 2 * 2
     out_ref = torch.empty((cfg.batch, cfg.num_heads, D), dtype=torch.float16, device=dev)
     run(wl, out_ref, 0, names[ref_name])
@@ -74,19 +74,21 @@ for ragged in (False, True):
     run(wl, out_ref, 0, names[ref_name])
     torch.cuda.synchronize()
     for qn in qnames:
-        for label, f in [("auto", flags()), ("S", flags(1)), ("Q_wq2", flags(2, 2)), ("Q_wq2_nosort", flags(2, 2, 1)),
-                         ("Q_wq3", flags(2, 3)), ("Q_wq4", flags(2, 4))]:
+        for label, f in [("auto", flags()), ("S", flags(1)), ("Q_solo", flags(2, 2, 0, 1)), ("Q_solo_nosort", flags(2, 2, 1, 1)),
+                         ("Q_team", flags(2, 0, 0, 2)), ("Q_team_nosort", flags(2, 0, 1, 2))]:
             lib.vmi_debug_set_queue_flags(f)
             out = torch.full_like(out_ref, float("nan"))
             run(wl, out, 0, names[qn])
             torch.cuda.synchronize()
-            same = bool(torch.equal(out.view(torch.int16), out_ref.view(torch.int16)))
             maxd = float((out.float() - out_ref.float()).abs().nan_to_num(nan=1e9).max().item())
+            same = bool(torch.equal(out.view(torch.int16), out_ref.view(torch.int16)))
+            if "team" in label:   # other fp32 summation order: not bit-identical to the solo kernels by design
+                same = maxd <= 2e-3
             # a second launch straight after: the ticket slot must have been left clean
             out2 = torch.full_like(out_ref, float("nan"))
             run(wl, out2, 0, names[qn])
             torch.cuda.synchronize()
-            same2 = bool(torch.equal(out2.view(torch.int16), out_ref.view(torch.int16)))
+            same2 = bool(torch.equal(out2.view(torch.int16), out.view(torch.int16)))
             r = timeit(wl, out, names[qn], args.iters)
             r.update(bit_identical=same and same2, max_abs_diff=maxd)
             rows[f"{qn}:{label}"] = r
@@ -122,7 +124,7 @@ for dname, lens in dists.items():
                                                         int(wl.seq_lens.float().mean().item()), 0)
     rows["hint:" + lib.vmi_paged_attention_v1_variant_name(hint).decode()] = timeit(wl, out, hint, args.iters)
     qn = f"q_d{D}_s1q2"
-    for label, f in [("auto", flags()), ("S", flags(1)), ("Q", flags(2, 2))]:
+    for label, f in [("auto", flags()), ("S", flags(1)), ("Q_solo", flags(2, 2, 0, 1)), ("Q_team", flags(2, 0, 0, 2))]:
         lib.vmi_debug_set_queue_flags(f)
         rows[f"{qn}:{label}"] = timeit(wl, out, names[qn], args.iters)
     lib.vmi_debug_set_queue_flags(0)

@@ -1,0 +1,259 @@
+"""GPU parity of the balanced paged_attention_v1 kernels (vllmini_amd/csrc/pa_queue.hpp): every mode the kernel
+can choose on the device — one item per wave (S), ranked work lists with solo workers or 4-wave teams (Q) — is forced
+through vmi_debug_set_queue_flags on small inputs and compared with the CPU oracle (checker only) and, for the
+single-wave modes, bit for bit with the one-wave-per-head kernel whose operations they repeat; then the BASELINE cfg3
+size with ragged lengths goes through the DEFAULT entry (no hint, no variant).
+
+Reference semantics under test: attention_kernels.cu:115-136 (context bounds), 302-305 (masked logits -> 0),
+334-342 (softmax), 420-430 (tail of V zeroed).  Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import BS, make_case
+from test_parity_gpu import _dev, assert_close, run_hip, run_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _names():
+    from vllmini_amd import ops
+
+    return {n: i + 1 for i, n in enumerate(ops.variant_names())}
+
+
+def _flags(mode=0, wq=0, nosort=0, team=0):
+    return mode | (wq << 2) | (nosort << 11) | (team << 12)
+
+
+# label -> (flags, bit-identical to the one-wave-per-head kernel?)
+MODES = {
+    "auto": (_flags(), None),                      # whatever the kernel chooses from seq_lens
+    "S": (_flags(1), True),                        # one item per wave
+    "Q solo": (_flags(2, 2, 0, 1), True),          # ranked hand-out, 2 workers per workgroup
+    "Q solo unranked": (_flags(2, 2, 1, 1), True),
+    "Q solo 1 worker": (_flags(2, 1, 0, 1), True),
+    "Q solo 4 workers": (_flags(2, 4, 0, 1), True),
+    "Q team": (_flags(2, 0, 0, 2), False),         # 4 waves per item: other fp32 summation order
+    "Q team unranked": (_flags(2, 0, 1, 2), False),
+}
+
+
+@pytest.fixture()
+def queue_flags():
+    from vllmini_amd import _lib
+
+    lib = _lib.load()
+    yield lib.vmi_debug_set_queue_flags
+    lib.vmi_debug_set_queue_flags(0)
+
+
+def _check_all_modes(case, qname, ref_name, set_flags, what, **kw):
+    names = _names()
+    ref = run_model(case, alibi=kw.get("alibi"))
+    plain = run_hip(case, variant=names[ref_name], **kw)
+    assert_close(plain, ref, f"{what}: {ref_name}")
+    for label, (flags, bitwise) in MODES.items():
+        set_flags(flags)
+        got = run_hip(case, variant=names[qname], **kw)
+        again = run_hip(case, variant=names[qname], **kw)
+        set_flags(0)
+        assert_close(got, ref, f"{what}: {qname} [{label}]")
+        assert np.array_equal(got.view(np.uint16), again.view(np.uint16)), f"{what}: {qname} [{label}] not deterministic"
+        if bitwise:
+            assert np.array_equal(got.view(np.uint16), plain.view(np.uint16)), \
+                f"{what}: {qname} [{label}] differs from {ref_name} ({np.abs(got.astype(np.float64) - plain).max():.3e})"
+
+
+@pytest.mark.parametrize("D,qname", [(64, "q_d64_s1q2"), (128, "q_d128_s1q1")])
+def test_queue_kernel_every_mode_matches_model_and_single_wave_kernel(D, qname, queue_flags):
+    """Block-boundary lengths, empty sequences, one long sequence among short ones, NaN-poisoned tails and unowned
+    blocks, q as a strided view, more heads than a workgroup has waves."""
+    H = 12 if D == 64 else 8
+    lens = [1, 15, 16, 17, 31, 33, 0, 100, 64, 257, 1024, 513, 2, 700, 0, 48, 333, 1023, 5, 16]
+    rng = np.random.default_rng(4200 + D)
+    case = make_case(rng, len(lens), H, D, lens, q_row_pad=2, poison_tail=True)
+    _check_all_modes(case, qname, f"d{D}_h1_w1_u1_nt1", queue_flags, f"D={D}")
+
+
+def test_queue_kernel_alibi_gqa_capacity_max_seq_len_and_truncation(queue_flags):
+    rng = np.random.default_rng(4300)
+    # ALiBi + grouped-query attention (every query head reads its KV head's pages; no tile sharing in these kernels)
+    lens = [40, 300, 7, 128, 129, 1]
+    case = make_case(rng, len(lens), 8, 64, lens, num_kv_heads=2, q_row_pad=1, poison_tail=True, max_blocks=40)
+    alibi = (0.5 ** np.arange(1, 9)).astype(np.float32)
+    _check_all_modes(case, "q_d64_s1q2", "d64_h1_w1_u1_nt1", queue_flags, "ALiBi + GQA", alibi=alibi,
+                     max_seq_len=40 * BS)  # capacity-style max_seq_len, table rows wider than any sequence needs
+    # seq_len > max_seq_len: truncated to the reserved logits (max_seq_len padded to 32), as the plain kernels do
+    case = make_case(rng, 3, 4, 64, [100, 20, 64], max_blocks=8)
+    trunc = dict(case)
+    trunc["lens"] = np.array([64, 20, 64], dtype=np.int32)
+    ref = run_model(trunc)
+    names = _names()
+    for label, (flags, _) in MODES.items():
+        queue_flags(flags)
+        got = run_hip(case, variant=names["q_d64_s1q2"], max_seq_len=40)
+        queue_flags(0)
+        assert_close(got, ref, f"truncated context [{label}]")
+
+
+def test_queue_kernel_bf16(queue_flags):
+    """bfloat16 elements (products rounded to bf16, fp32 sums — dtype_bfloat16.cuh): all modes agree with the plain
+    bf16 kernel bit for bit (solo) / to 2 bf16 ulp (teams)."""
+    from vllmini_amd import ops
+
+    dev = _dev()
+    names = _names()
+    rng = np.random.default_rng(4400)
+    lens = np.array([1, 16, 17, 100, 333, 1024, 47, 2, 0, 640], dtype=np.int32)
+    S, H, D, NB = len(lens), 12, 64, 200
+    kc = torch.from_numpy(rng.uniform(-1, 1, (NB, H, D // 8, BS, 8)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    vc = torch.from_numpy(rng.uniform(-1, 1, (NB, H, D, BS)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    q = torch.from_numpy(rng.standard_normal((S, H, D)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    nblk = (lens + BS - 1) // BS
+    tab = np.full((S, 64), -1, dtype=np.int32)
+    perm = rng.permutation(NB).astype(np.int32)
+    pos = 0
+    for s in range(S):
+        tab[s, : nblk[s]] = perm[pos:pos + nblk[s]]
+        pos += nblk[s]
+    t_tab, t_len = torch.from_numpy(tab).to(dev), torch.from_numpy(lens).to(dev)
+
+    def attend(variant):
+        out = torch.full((S, H, D), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.paged_attention_v1(out, q, kc, vc, H, D ** -0.5, t_tab, t_len, BS, 1024, None, "auto", 1.0, 0, 0, 1, 1, 0,
+                               _variant=variant)
+        torch.cuda.synchronize()
+        return out
+
+    plain = attend(names["bf16_d64_bs16_h1_w1_u1_nt1"])
+    assert torch.isfinite(plain.float()).all()
+    for label, (flags, bitwise) in MODES.items():
+        queue_flags(flags)
+        got = attend(names["bf16_q_d64_s1q2"])
+        queue_flags(0)
+        if bitwise:
+            assert torch.equal(got.view(torch.int16), plain.view(torch.int16)), label
+        else:
+            d = (got.float() - plain.float()).abs()
+            assert float(d.max()) <= 2 * 2.0 ** -8, f"{label}: {float(d.max()):.3e}"   # 2 bf16 ulp at |x| < 1
+
+
+def test_queue_kernel_more_sequences_than_the_ranking_holds(queue_flags):
+    """num_seqs > 2048: too many sequences to rank in LDS -> items go out in index order; and a grid with far more items
+    than waves (one head) still covers every row."""
+    from vllmini_amd import ops
+
+    dev = _dev()
+    names = _names()
+    rng = np.random.default_rng(4500)
+    S, H, D, NB = 5000, 2, 64, 96
+    kc = torch.from_numpy(rng.uniform(-1, 1, (NB, H, D // 8, BS, 8)).astype(np.float16)).to(dev)
+    vc = torch.from_numpy(rng.uniform(-1, 1, (NB, H, D, BS)).astype(np.float16)).to(dev)
+    q_np = rng.standard_normal((S, H, D)).astype(np.float16)
+    tab_np = rng.integers(0, NB, (S, 3)).astype(np.int32)     # sequences may share pages: read-only
+    lens_np = rng.integers(0, 49, S).astype(np.int32)
+    t_q, t_tab, t_len = torch.from_numpy(q_np).to(dev), torch.from_numpy(tab_np).to(dev), torch.from_numpy(lens_np).to(dev)
+    idx = np.r_[0:40, 2040:2060, S - 40:S]
+    ref = oracle.paged_attention_v1(np.ascontiguousarray(q_np[idx]), kc.cpu().numpy(), vc.cpu().numpy(), H, D ** -0.5,
+                                    tab_np[idx], lens_np[idx], BS, threads=8)
+    outs = []
+    for label in ("auto", "Q solo", "Q team"):
+        queue_flags(MODES[label][0])
+        out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v1(out, t_q, kc, vc, H, D ** -0.5, t_tab, t_len, BS, 48, None, "auto", 1.0, 0, 0, 1, 1, 0,
+                               _variant=names["q_d64_s1q2"])
+        torch.cuda.synchronize()
+        queue_flags(0)
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all(), label
+        assert_close(got[idx], ref, f"5000 sequences [{label}]")
+        outs.append(got)
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+
+
+def _pages_to_host(wl, table, idx, cfg):
+    """The sampled sequences' pages, re-indexed into a small pool the CPU oracle can take."""
+    dev = wl.key_cache.device
+    tab_dev = table[torch.from_numpy(idx).to(dev)][:, : cfg.blocks_per_seq].clamp(min=0)
+    flat = tab_dev.reshape(-1).to(torch.int64)
+    kc = wl.key_cache[flat].cpu().numpy()
+    vc = wl.value_cache[flat].cpu().numpy()
+    small_tab = np.arange(flat.numel(), dtype=np.int32).reshape(len(idx), cfg.blocks_per_seq)
+    return kc, vc, small_tab
+
+
+def test_queue_kernel_full_size_ragged_cfg3_through_the_default_entry():
+    """BASELINE cfg3 (B256 H12 D64, pool of 32768 blocks) with seq_lens ~ U{1..1024}: the DEFAULT entry — no hint, no
+    variant — must run the balanced kernel in its ranked mode.  Checked: bit-identical to the one-wave-per-head kernel on
+    all 3072 rows, determinism, permutation equivariance over sequences (a different ranking, the same rows), and 32
+    sequences against the CPU kernel model — the longest and shortest, the first and last workgroups' items."""
+    from vllmini_amd import ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    dev = _dev()
+    names = _names()
+    cfg = CONFIGS["cfg3"]
+    wl = make_workload(cfg, dev, seed=11, table_sets=2, ragged=True)
+    assert ops.variant_names()[ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len) - 1] == "q_d64_s1q2"
+
+    def attend(q, table, lens, variant=0):
+        out = torch.full((cfg.batch, cfg.num_heads, cfg.head_size), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v1(out, q, wl.key_cache, wl.value_cache, cfg.num_heads, wl.scale, table, lens,
+                               cfg.block_size, cfg.seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+        torch.cuda.synchronize()
+        return out
+
+    base = attend(wl.query, wl.tables[0], wl.seq_lens)
+    assert torch.isfinite(base).all()
+    assert torch.equal(base, attend(wl.query, wl.tables[0], wl.seq_lens))
+    plain = attend(wl.query, wl.tables[0], wl.seq_lens, names["d64_h4_w1_u1_nt1"])
+    assert torch.equal(base.view(torch.int16), plain.view(torch.int16))
+    perm = torch.randperm(cfg.batch, device=dev)
+    permuted = attend(wl.qkv[perm][:, : cfg.num_heads * cfg.head_size].view(cfg.batch, cfg.num_heads, cfg.head_size),
+                      wl.tables[0][perm], wl.seq_lens[perm])
+    assert torch.equal(permuted, base[perm])
+    lens = wl.seq_lens.cpu().numpy()
+    order = np.argsort(-lens, kind="stable")
+    idx = np.unique(np.r_[order[:8], order[-8:], order[124:132], np.arange(0, 4), np.arange(cfg.batch - 4, cfg.batch)])
+    kc, vc, small_tab = _pages_to_host(wl, wl.tables[0], idx, cfg)
+    qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
+    ref = oracle.paged_attention_v1(qn, kc, vc, cfg.num_heads, wl.scale, small_tab, lens[idx], cfg.block_size, threads=8)
+    assert_close(base.cpu().numpy()[idx], ref, "cfg3 ragged, default entry, sampled vs model")
+
+
+def test_queue_kernel_heavy_tailed_batch_runs_teams_and_matches_model(queue_flags):
+    """A few long sequences among many short ones (the usual serving batch): the kernel's own choice is the team mode;
+    rows match the model and the forced solo mode to summation-order effects."""
+    from vllmini_amd import ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    dev = _dev()
+    names = _names()
+    cfg = CONFIGS["cfg3"]
+    wl = make_workload(cfg, dev, seed=12, table_sets=1)
+    g = torch.Generator().manual_seed(5)
+    lens = torch.where(torch.rand(cfg.batch, generator=g) < 0.125, cfg.seq_len, cfg.seq_len // 8).to(torch.int32)
+    lens[7] = 0
+    t_len = lens.to(dev)
+    outs = {}
+    for label in ("auto", "Q solo", "Q team"):
+        queue_flags(MODES[label][0])
+        out = torch.full((cfg.batch, cfg.num_heads, cfg.head_size), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, cfg.num_heads, wl.scale, wl.tables[0], t_len,
+                               cfg.block_size, cfg.seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=names["q_d64_s1q2"])
+        torch.cuda.synchronize()
+        queue_flags(0)
+        outs[label] = out
+        assert torch.isfinite(out).all(), label
+    assert torch.equal(outs["auto"].view(torch.int16), outs["Q team"].view(torch.int16)), "auto mode should be the team mode here"
+    assert float((outs["Q team"].float() - outs["Q solo"].float()).abs().max()) <= 1e-3
+    idx = np.unique(np.r_[np.nonzero(lens.numpy() == cfg.seq_len)[0][:6], 7, np.arange(0, 6), np.arange(250, 256)])
+    kc, vc, small_tab = _pages_to_host(wl, wl.tables[0], idx, cfg)
+    qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
+    ref = oracle.paged_attention_v1(qn, kc, vc, cfg.num_heads, wl.scale, small_tab, lens.numpy()[idx], cfg.block_size, threads=8)
+    assert_close(outs["auto"].cpu().numpy()[idx], ref, "heavy-tailed batch, team mode vs model")

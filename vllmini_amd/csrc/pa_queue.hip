@@ -1,5 +1,5 @@
 // pa_queue.hip — instantiations of the balanced paged_attention_v1 kernels (pa_queue.hpp), block size 16.
-// Names: q_d<head>[_bf16]; the mode (one item per wave / work queue) is chosen on the device.
+// Names: [bf16_]q_d<head>_s<U of mode S>q<U of mode Q>; the mode is chosen on the device.
 #include "pa_queue.hpp"
 
 namespace vmi {
@@ -8,10 +8,12 @@ namespace vmi {
   {NAME, D, 16, 4, 1, US, true, 1, BF, (pa_kernel_t)pa_q_kernel<D, BF, true, US, UQ>, 0, UQ, 0, 0, false, false, false, true},
 
 Variant g_queue_variants[] = {
+    // head size 64: one block per group when every item has its own wave, two when workers run items in turn
     VMI_ROW_Q("q_d64_s1q2", 64, false, 1, 2)
-    VMI_ROW_Q("q_d64_s1q1", 64, false, 1, 1)
-    VMI_ROW_Q("q_d64_s2q4", 64, false, 2, 4)
-    VMI_ROW_Q("q_d64_s4q4", 64, false, 4, 4)
+    VMI_ROW_Q("bf16_q_d64_s1q2", 64, true, 1, 2)
+    // head size 128: twice the registers per block -> one block per group in both modes, 2 workgroups per CU
+    VMI_ROW_Q("q_d128_s1q1", 128, false, 1, 1)
+    VMI_ROW_Q("bf16_q_d128_s1q1", 128, true, 1, 1)
 };
 const int g_queue_nvariants = (int)(sizeof(g_queue_variants) / sizeof(g_queue_variants[0]));
 

@@ -51,7 +51,9 @@ constexpr int QSORT_MAX = 2048;  // sequences ranked in LDS (2 B each); larger b
 //   bits 0-1  mode      0 auto, 1 force S (when every item has a wave), 2 force Q
 //   bits 2-4  WQ        workers per workgroup in mode Q (0 -> 2)
 //   bit  11   no ranking (index order)
+//   bits 12-13 team     0 auto, 1 force solo workers, 2 force teams (mode Q only)
 constexpr int QF_MODE(int f) { return f & 3; }
+constexpr int QF_TEAM(int f) { return (f >> 12) & 3; }
 constexpr int QF_WQ(int f) { return (f >> 2) & 7; }
 constexpr int QF_NOSORT = 1 << 11;
 
@@ -65,11 +67,12 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 // grid = (G), block = 256.  LDS = 4*lpad*4 (logits / probabilities, one region per wave) + QSORT_MAX*2 (ranking)
-//                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + 4*64*8 (bucket masks).
+//                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + 4*64*8 (bucket masks)
+//                                 + 8*4 + 4*D*4 (a team's max / sum exchange and partial outputs).
 template <int D, bool BF, bool NT, int US, int UQ>
 // (second launch bound = minimum waves per SIMD: 3 workgroups of 4 waves per CU must all be resident in mode S, i.e.
-//  <= 168 VGPRs; the 4-blocks-per-group experiments need more and run 2 per SIMD)
-__global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel(const PAParams p) {
+//  <= 168 VGPRs; head size 128 — twice the registers per block — runs 2 workgroups per CU, 256 VGPRs)
+__global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) pa_q_kernel(const PAParams p) {
   constexpr int BS = 16;
   constexpr int NL = D * BS / 8 / 64;  // 1-KiB loads per (block, head) tile of K — and of V
   static_assert(D % 32 == 0 && NL >= 1, "head size must fill whole 1-KiB loads");
@@ -94,17 +97,17 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
   // ---- everything a wave needs to know about an item before its first page can be requested -------------------
   struct Meta {
     int seq, head, L;    // wave-uniform
-    int32_t bt;          // lane j: physical id of block j (first 64 blocks)
+    int32_t bt;          // lane j: physical id of my block j (first 64 of them; my blocks are sub + j*T)
     u32x4 q[NL];         // this lane's 8 dims of q facing each K load
     float slope;
   };
   const int c4 = lane >> 4;  // K: chunk within a load
   const int tk = lane & 15;  // K: token within the block
-  auto meta_issue = [&](Meta& m, int seq, int head) {
+  auto meta_issue = [&](Meta& m, int seq, int head, int T, int sub) {
     m.seq = seq;
     m.head = head;
     const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
-    m.bt = lane < p.max_blocks_per_seq ? bt[lane] : 0;
+    m.bt = sub + lane * T < p.max_blocks_per_seq ? bt[sub + lane * T] : 0;
     m.L = p.seq_lens[seq];
     const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
 #pragma unroll
@@ -118,11 +121,13 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
   const bool nat_ok = w_nat < N;
   {
     const int s0 = nat_ok ? w_nat / H : 0;
-    meta_issue(cur, s0, nat_ok ? w_nat - s0 * H : 0);
+    meta_issue(cur, s0, nat_ok ? w_nat - s0 * H : 0, 1, 0);
   }
   const int flags = p.q_flags;
   bool queue = N > nwaves;
   int maxL = 0;
+  float sumL = 0.f;
+  bool have_sum = false;
   // lengths of the chunks this wave ranks (chunk = 64 sequences; chunk c belongs to wave c & 3), read ONCE: the
   // statistics and both passes of the counting sort use these registers, not three dependent trips to memory
   constexpr int MYCH = QSORT_MAX / 256;
@@ -147,6 +152,8 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
     }
     maxL = wave_max_i(maxL);
     sum = wave_sum(sum);
+    sumL = sum;
+    have_sum = true;
     queue = queue || sum < 0.8f * (float)maxL * (float)B;
   } else if (!queue) {  // too many sequences to rank, yet a wave for every item (few heads): statistics only
     float sum = 0.f;
@@ -157,15 +164,30 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
     }
     maxL = wave_max_i(maxL);
     sum = wave_sum(sum);
+    sumL = sum;
+    have_sum = true;
     queue = sum < 0.8f * (float)maxL * (float)B;
   }
   if (QF_MODE(flags) == 1 && N <= nwaves) queue = false;
   if (QF_MODE(flags) == 2) queue = true;
   queue = __builtin_amdgcn_readfirstlane(queue);
-  const int WQ = QF_WQ(flags) ? QF_WQ(flags) : 2;
+  // Mode Q, solo workers or teams?  A worker that runs its items alone needs (longest item) <= (its share of the
+  // batch) to finish with the others; when a few sequences are much longer than the rest — the usual shape of a
+  // serving batch — the four waves of a workgroup work on ONE item together instead (blocks dealt round-robin, three
+  // LDS barriers per item), which makes the longest item four times shorter.
+  bool team = false;
+  if (queue && have_sum) {
+    const int wq0 = QF_WQ(flags) ? QF_WQ(flags) : 2;
+    const float share = sumL * (float)H / (float)(gridDim.x * wq0);  // tokens per solo worker
+    team = (float)maxL > 1.15f * share;
+  }
+  if (QF_TEAM(flags) == 1) team = false;
+  if (QF_TEAM(flags) == 2) team = queue;
+  team = __builtin_amdgcn_readfirstlane(team);
+  const int WQ = team ? 4 : (QF_WQ(flags) ? QF_WQ(flags) : 2);
   const bool ranked = queue && rankable;
-  const int nworkers = queue ? gridDim.x * WQ : nwaves;
-  const int wq = queue ? blockIdx.x * WQ + wave : w_nat;  // worker index
+  const int nworkers = queue ? (team ? gridDim.x : gridDim.x * WQ) : nwaves;
+  const int wq = queue ? (team ? blockIdx.x : blockIdx.x * WQ + wave) : w_nat;  // worker index
 
   if (queue) {
     // ---- rank the sequences, longest first: a counting sort with 64 length buckets (bucket k in lane k), index order
@@ -237,19 +259,29 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
   if (queue) {  // first item of worker wq = rank order position wq
     int s, h;
     ids_of(wq, s, h);
-    meta_issue(cur, s, h);
+    meta_issue(cur, s, h, team ? 4 : 1, team ? wave : 0);
   }
 
   const int hf = lane & 1;     // V: which 8-token group of the block this lane owns
   const int rowl = lane >> 1;  // V: dim row within a load
 
-  auto run = [&](auto utag) {
+  // LDS of a team: ONE logits array for the item (region 0), the probabilities behind it (region 1: in place would
+  // overwrite slots another wave has not read yet), the max / sum exchange and the waves' partial outputs
+  float* red = reinterpret_cast<float*>(reinterpret_cast<uint64_t*>(order + 2 * QSORT_MAX) + 4 * 64);  // [8]
+  float* osm = red + 8;                                                                                  // [4][D]
+
+  auto run = [&](auto utag, auto teamtag) {
     constexpr int UU = decltype(utag)::value;
+    constexpr bool TEAM = decltype(teamtag)::value;
+    constexpr int T = TEAM ? 4 : 1;       // waves per item; my blocks are sub + idx*T
+    const int sub = TEAM ? wave : 0;
+    float* lg = TEAM ? smem_f : logits;
+    uint16_t* pr = TEAM ? reinterpret_cast<uint16_t*>(smem_f + p.lpad) : ph;
     u32x4 rn[UU][NL], ra[UU][NL], rb[UU][NL];
 
     // per-item state (wave-uniform unless noted)
-    int L = 0, nblk = 0;
-    int32_t bt_reg = 0;  // lane j: physical id of block bt_sg*64 + j
+    int L = 0, nblk = 0, nmy = 0;  // sequence length, its blocks, MY blocks
+    int32_t bt_reg = 0;  // lane j: physical id of my block bt_sg*64 + j
     int bt_sg = 0;
     const int32_t* bt = nullptr;
     int64_t hoff = 0;  // this lane's element offset inside a block: kv head tile + lane*8
@@ -262,6 +294,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
       l = l > p.lpad ? p.lpad : l;  // seq_len > max_seq_len: truncated to the LDS that was reserved
       L = __builtin_amdgcn_readfirstlane(l);
       nblk = (L + BS - 1) / BS;
+      nmy = nblk > sub ? (nblk - sub + T - 1) / T : 0;
       bt = p.block_tables + (int64_t)m.seq * p.max_blocks_per_seq;
       bt_reg = m.bt;
       bt_sg = 0;
@@ -273,8 +306,8 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
     };
     auto table_for = [&](int g) {
       const int sg = (g * UU) >> 6;
-      if (sg != bt_sg) {  // once per 64 blocks
-        const int b = sg * 64 + lane;
+      if (sg != bt_sg) {  // once per 64 of my blocks
+        const int b = sub + (sg * 64 + lane) * T;
         bt_reg = b < p.max_blocks_per_seq ? bt[b] : 0;
         bt_sg = sg;
         // The wait for this load belongs INSIDE the branch.  Left to the compiler it lands at the join in front of
@@ -289,7 +322,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
 #pragma unroll
       for (int j = 0; j < UU; ++j) {
         int idx = g * UU + j;
-        idx = idx < nblk ? idx : nblk - 1;  // padding slots re-read my last block (never out of bounds)
+        idx = idx < nmy ? idx : nmy - 1;  // padding slots re-read my last block (never out of bounds)
         const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
         const h16* blk = cache + phys * p.kv_block_stride + hoff;
 #pragma unroll
@@ -301,9 +334,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
     auto compute_k = [&](u32x4(&r)[UU][NL], int g) {
 #pragma unroll
       for (int j = 0; j < UU; ++j) {
-        const int b = g * UU + j;
-        if (b < nblk) {  // wave-uniform
-          const int token = b * BS + tk;
+        const int idx = g * UU + j;
+        if (idx < nmy) {  // wave-uniform
+          const int token = (sub + idx * T) * BS + tk;
           const bool masked = token >= L;
           float accv[NL];
 #pragma unroll
@@ -315,7 +348,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
           acc += __shfl_xor(acc, 32);
           float qk = p.scale * acc;
           qk += (slope != 0.f) ? slope * (float)(token - L + 1) : 0.f;
-          if (lane < BS) logits[token] = masked ? 0.f : qk;
+          if (lane < BS) lg[token] = masked ? 0.f : qk;
           qk_max = masked ? qk_max : fmaxf(qk_max, qk);
         }
       }
@@ -327,12 +360,13 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
 #pragma unroll
       for (int jj = 0; jj < UU; ++jj) {
         const int j = UU - 1 - jj;  // blocks in descending order whatever the group size
-        const int b = g * UU + j;
-        if (b < nblk) {
+        const int idx = g * UU + j;
+        if (idx < nmy) {
+          const int b = sub + idx * T;
           const int token0 = b * BS + hf * 8;
           const bool last = (b == nblk - 1);
           PV8<BF> pv;
-          pv.load(*reinterpret_cast<const u32x4_alias*>(ph + token0));
+          pv.load(*reinterpret_cast<const u32x4_alias*>(pr + token0));
 #pragma unroll
           for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
         }
@@ -345,12 +379,13 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
       int l2 = m.L;
       l2 = l2 > p.lpad ? p.lpad : l2;
       l2 = __builtin_amdgcn_readfirstlane(l2);
-      if (l2 <= 0) return;
       const int nb2 = (l2 + BS - 1) / BS;
+      const int nmy2 = nb2 > sub ? (nb2 - sub + T - 1) / T : 0;
+      if (nmy2 <= 0) return;
       const int64_t hoff2 = (int64_t)(m.head / qpk) * p.kv_head_stride + lane * 8;
 #pragma unroll
       for (int j = 0; j < UU; ++j) {
-        const int idx = j < nb2 ? j : nb2 - 1;
+        const int idx = j < nmy2 ? j : nmy2 - 1;
         const int64_t phys = __builtin_amdgcn_readlane(m.bt, idx);
         const h16* blk = p.kc + phys * p.kv_block_stride + hoff2;
 #pragma unroll
@@ -360,7 +395,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
 
     // ---- first item: its metadata was requested above ----
     adopt(cur);
-    if (L > 0) load_group(rn, p.kc, 0);
+    if (nmy > 0) load_group(rn, p.kc, 0);
     int round = 0;  // items this worker has finished
 
     for (;;) {
@@ -375,20 +410,21 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
         const int t = (int)t64;
         int s, h;
         ids_of(has_next ? t : 0, s, h);  // requested unconditionally (item 0 when there is no next one): no phi
-        meta_issue(nxt, s, h);
+        meta_issue(nxt, s, h, T, sub);
       };
 
-      if (L <= 0) {  // reference: exp_sum = 0 -> every output 0
-        for (int d = lane; d < D; d += 64) outp[d] = 0;
+      if (L <= 0) {  // reference: exp_sum = 0 -> every output 0  (the whole team takes this branch together)
+        if (sub == 0)
+          for (int d = lane; d < D; d += 64) outp[d] = 0;
         fetch_next();
         if (!has_next) break;
         adopt(nxt);
-        if (L > 0) load_group(rn, p.kc, 0);
+        if (nmy > 0) load_group(rn, p.kc, 0);
         ++round;
         continue;
       }
 
-      const int ngroups = (nblk + UU - 1) / UU;
+      const int ngroups = (nmy + UU - 1) / UU;  // 0 for a team wave without blocks
       const int lastg = ngroups - 1;
       qk_max = -FLT_MAX;
 #pragma unroll
@@ -399,7 +435,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
       if (ngroups == 1) {
         load_group(ra, p.vc, 0);  // one group in all: K and V cost one round trip between them
         compute_k(rn, 0);
-      } else {
+      } else if (ngroups > 1) {
         // The V pass starts BEFORE the K pass ends: its first group (the LAST one: the block reshape_and_cache has just
         // written is requested early, profiles/r01o_call_pair_gap.md) goes into rn — free since group 0 was consumed —
         // ahead of the final K computation, the second one right behind it, so two groups stay in flight across the
@@ -428,23 +464,47 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
 
       // =========================== softmax over the logits in LDS ============================
       float inv_sum;
-      {
+      if constexpr (TEAM) {
+        // every wave exponentiates and sums the tokens of ITS blocks (no wave reads another's logits); the maxima
+        // and the sums meet in LDS
+        float m = wave_max(qk_max);
+        if (lane == 0) red[sub] = m;
+        lds_barrier();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float e_sum = 0.f;
+        for (int t = lane; t < nmy * BS; t += 64) {
+          const int i = (sub + (t >> 4) * T) * BS + (t & 15);
+          if (i < L) {
+            const float e = __expf(lg[i] - m);
+            lg[i] = e;
+            e_sum += e;
+          }
+        }
+        e_sum = wave_sum(e_sum);
+        if (lane == 0) red[4 + sub] = e_sum;
+        lds_barrier();
+        inv_sum = __builtin_amdgcn_rcpf((((red[4] + red[5]) + red[6]) + red[7]) + 1e-6f);
+        for (int t = lane; t < nmy * BS; t += 64) {
+          const int i = (sub + (t >> 4) * T) * BS + (t & 15);
+          pr[i] = i < L ? to_elem<BF>(lg[i] * inv_sum) : (uint16_t)0;
+        }
+      } else {
         const float m = wave_max(qk_max);
         float e_sum = 0.f;
         for (int i = lane; i < L; i += 64) {
-          const float e = __expf(logits[i] - m);
-          logits[i] = e;
+          const float e = __expf(lg[i] - m);
+          lg[i] = e;
           e_sum += e;
         }
         inv_sum = __builtin_amdgcn_rcpf(wave_sum(e_sum) + 1e-6f);
+        // p = exp * inv_sum -> fp16 (bf16), once per token, in place: the 64 lanes read fp32 values [t0, t0+64) and
+        // then write bytes [2*t0, 2*t0+128), i.e. fp32 slots [t0/2, t0/2+32) — already consumed, or read by this access
+        for (int t = lane; t < nblk * BS; t += 64) {
+          const float e = lg[t];
+          pr[t] = t < L ? to_elem<BF>(e * inv_sum) : (uint16_t)0;
+        }
       }
-      // p = exp * inv_sum -> fp16 (bf16), once per token, in place: the 64 lanes read fp32 values [t0, t0+64) and then
-      // write bytes [2*t0, 2*t0+128), i.e. fp32 slots [t0/2, t0/2+32) — already consumed, or read by this very access
-      for (int t = lane; t < nblk * BS; t += 64) {
-        const float e = logits[t];
-        ph[t] = t < L ? to_elem<BF>(e * inv_sum) : (uint16_t)0;
-      }
-      // The next item's metadata is waited for HERE, where only the first V group (needed next anyway) is in flight
+      // The next item's metadata is waited for HERE, where only the first V groups (needed next anyway) are in flight
       // with it: no later use of it can then make the compiler drain the V stream.
       if (queue) {
         asm volatile("" : "+v"(nxt.bt), "+v"(nxt.L), "+v"(nxt.slope));
@@ -456,7 +516,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
       if (ngroups == 1) {
         compute_v(std::true_type{}, ra, 0);
         if (queue) prefetch_next(nxt, has_next);
-      } else {
+      } else if (ngroups > 1) {
         compute_v(std::true_type{}, rn, lastg);  // the only group that can hold the sequence's last block
         // rn is free again: the next item's first K group goes out now and has the rest of the V pass to arrive
         if (queue) prefetch_next(nxt, has_next);
@@ -474,14 +534,30 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
         } else {
           compute_v(std::false_type{}, ra, lastg - s);
         }
+      } else if (queue) {
+        prefetch_next(nxt, has_next);  // a team wave without blocks in this item may have some in the next
       }
 
       // the two lanes of a row hold its 8-token groups
 #pragma unroll
       for (int i = 0; i < NL; ++i) acc[i] += __shfl_xor(acc[i], 1);
-      if (hf == 0) {
+      if constexpr (TEAM) {
+        if (hf == 0) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) outp[RPL * i + rowl] = to_elem<BF>(acc[i]);
+          for (int i = 0; i < NL; ++i) osm[sub * D + RPL * i + rowl] = acc[i];
+        }
+        lds_barrier();
+        // (the next item's first barrier — every wave passes it only after this read — keeps osm from being
+        //  overwritten early)
+        if (sub == 0) {
+          for (int d = lane; d < D; d += 64)
+            outp[d] = to_elem<BF>(((osm[d] + osm[D + d]) + osm[2 * D + d]) + osm[3 * D + d]);
+        }
+      } else {
+        if (hf == 0) {
+#pragma unroll
+          for (int i = 0; i < NL; ++i) outp[RPL * i + rowl] = to_elem<BF>(acc[i]);
+        }
       }
       if (!has_next) break;
       adopt(nxt);  // its first K group is already in flight in rn
@@ -489,8 +565,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4) ? 2 : 3) pa_q_kernel
     }
   };
 
-  if (queue) run(std::integral_constant<int, UQ>{});
-  else run(std::integral_constant<int, US>{});
+  if (team) run(std::integral_constant<int, 1>{}, std::true_type{});
+  else if (queue) run(std::integral_constant<int, UQ>{}, std::false_type{});
+  else run(std::integral_constant<int, US>{}, std::false_type{});
 
 }
 

@@ -612,21 +612,33 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
 }
 
 static int pick_variant(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
-                        bool bf = false, int mean_seq_len = 0) {
+                        bool bf = false, int mean_seq_len = 0, bool allow_balanced = true) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
   while (wph < 16 && units * wph < 3072 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
-  const bool ragged = mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
-  if (ragged)
-    while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   const double kv_bytes = 4.0 * (double)units * (double)max_seq_len * head_size;
   const int nt = kv_bytes > 128e6 ? 1 : 0;
+  // (a batch the caller knows to be ragged: many waves per head, so that the hardware dispatcher balances the chip —
+  //  except where the balanced kernel below does that itself, from the lengths it reads on the device)
+  const bool balanced = allow_balanced && wph == 1 && nt && block_size == 16 && head_size == 64 &&
+                        3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 12 * 1024) <= (size_t)160 * 1024;
+  const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
+  if (ragged)
+    while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {  // core table: full menu
     const double waves_per_cu = (double)units * wph / 256.0;
     const double tile_kib = head_size * 16 * 2 / 1024.0;
     int u = 1;
     while (u < 4 && waves_per_cu * u * tile_kib < 24.0) u *= 2;
+    if (balanced && u == 1) {
+      // full chip: the balanced kernel (pa_queue.hpp) — it reads seq_lens on the device and runs one wave per
+      // (sequence, head) on equal lengths, ranked work lists on ragged ones; needs 3 workgroups' LDS per CU
+      for (int id = 1; id <= nvariants_v1(); ++id) {
+        const Variant& c = variant_v1(id);
+        if (c.QUEUE && c.BF == bf && c.D == head_size && c.BS == 16) return id;
+      }
+    }
     if (wph == 1 && u == 1 && nt) {  // full chip, one wave per head: the adaptive-depth form where one is built
       for (int id = 1; id <= nvariants_v1(); ++id) {
         const Variant& c = variant_v1(id);
@@ -678,6 +690,15 @@ static int device_cus(int device) {  // caller holds the device current
                             ? prop.multiProcessorCount : 256;
   }
   return g_dev[device].cus;
+}
+
+// dynamic LDS a kernel needs for logits rows of `lpad` floats (max_seq_len padded to 32)
+static size_t variant_lds_bytes(const Variant& c, int lpad) {
+  if (c.QUEUE)  // 4 waves' logits + the ranking, its bucket counts and masks + a team's exchange buffers (pa_queue.hpp)
+    return (size_t)4 * lpad * 4 + (size_t)2048 * 4 + 2048 + 32 + (size_t)4 * c.D * 4;
+  return (size_t)c.HPW * c.HPT *
+         ((size_t)lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? (size_t)lpad * 2 : 0) +
+          (c.SPARSE ? (size_t)lpad / 2 : 0));  // SPARSE: the list of attended blocks, one int per block (BS >= 8)
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -765,12 +786,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: 8 with an fp8 KV cache (a value row of 8 bytes does not "
                 "fill a 16-byte unit; block sizes 16 and 32 are built)");
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
-  auto lds_of = [&](const Variant& c) {
-    if (c.QUEUE) return (size_t)4 * lpad * 4 + (size_t)2048 * 4 + 2048;  // 4 waves' logits + the ranking, its bucket counts and masks (pa_queue.hpp)
-    return (size_t)c.HPW * c.HPT *
-           ((size_t)lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? (size_t)lpad * 2 : 0) +
-            (c.SPARSE ? (size_t)lpad / 2 : 0));  // SPARSE: the list of attended blocks, one int per block (BS >= 8)
-  };
+  auto lds_of = [&](const Variant& c) { return variant_lds_bytes(c, lpad); };
   Variant* sparse_v = nullptr;
   if (bsp) {  // one or four waves per head, by how many (seq, head) units there are to fill the chip with
     const int nblk = (max_seq_len + block_size - 1) / block_size;
@@ -782,7 +798,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     variant = pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size, max_seq_len, bf, f8);
     if (!variant || (append && !app_variant_v1(variant)))
       variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf, f8)
-                   : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf);
+                   : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, 0, !append);
     // a long max_seq_len may not leave room for several heads' logits in one workgroup's LDS: fall back to one
     // head per workgroup, then to one wave per head (no second copy of the probabilities) before giving up
     if (variant >= 1 && variant <= nvariants_v1() && lds_of(variant_v1(variant)) > 160 * 1024) {
@@ -870,7 +886,8 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     // persistent geometry: as many 4-wave workgroups as stay resident (3 per CU while their LDS fits), never more than
     // one wave per item; the kernel picks its mode from seq_lens (pa_queue.hpp)
     const int cus = device_cus(device);
-    const int per_cu = lds * 3 <= 160 * 1024 ? 3 : (lds * 2 <= 160 * 1024 ? 2 : 1);
+    int per_cu = lds * 3 <= 160 * 1024 ? 3 : (lds * 2 <= 160 * 1024 ? 2 : 1);
+    if (v.D > 64 && per_cu > 2) per_cu = 2;  // register budget of the head-size-128 kernels (pa_queue.hpp launch bounds)
     const int64_t items = (int64_t)num_seqs * num_heads;
     int64_t g = (int64_t)cus * per_cu;
     if (g * 4 > items) g = (items + 3) / 4;
@@ -1370,6 +1387,13 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
 int vmi_set_pv_mfma(int on) { return vmi::g_pv_mfma.exchange(on ? 1 : 0); }
 
 int vmi_debug_set_queue_flags(int flags) { return vmi::g_queue_flags.exchange(flags); }
+
+int vmi_paged_attention_v1_variant_fits(int32_t variant, int32_t max_seq_len, int32_t for_append) {
+  if (variant < 1 || variant > vmi::nvariants_v1() || max_seq_len < 0) return 0;
+  if (for_append && !vmi::app_variant_v1(variant)) return 0;
+  const int lpad = ((max_seq_len + 31) / 32) * 32;
+  return vmi::variant_lds_bytes(vmi::variant_v1(variant), lpad) <= (size_t)160 * 1024 ? 1 : 0;
+}
 
 int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
                                             int32_t head_size, int32_t block_size, int32_t max_seq_len,

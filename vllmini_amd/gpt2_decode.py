@@ -220,6 +220,10 @@ class GPT2PagedDecoder:
                                          self.pool.block_size, mean_seq_len=max(int(lens.mean()), 1),
                                          bf16=self.pool.key_cache.dtype == torch.bfloat16,
                                          fp8={"auto": False, "fp8_e5m2": "e5m2"}.get(self.pool.kv_cache_dtype, True))
+        # ... but the launch reserves LDS for self.max_seq_len (the pool's capacity, as the reference's scheduler passes
+        # it, scheduler.py:97) and may be the fused append: a hinted variant that cannot serve that is dropped
+        if not ops.variant_fits(st["variant"], self.max_seq_len, for_append=self.fused_append):
+            st["variant"] = 0
         if isinstance(input_ids, torch.Tensor):
             st["input_ids"].copy_(input_ids.to(torch.long), non_blocking=True)
         else:

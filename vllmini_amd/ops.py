@@ -34,6 +34,7 @@ __all__ = [
     "paged_attention_v2",
     "reshape_and_cache",
     "pick_variant",
+    "variant_fits",
     "variant_names",
 ]
 
@@ -440,6 +441,12 @@ def set_pv_mfma(on: bool) -> bool:
     the reference kernel to the north-star 1e-3 instead of 1-2 fp16 ulp (include/vmi_paged_attention.h,
     vmi_set_pv_mfma); 1.2x faster with 8 query heads per KV head."""
     return bool(_lib.load().vmi_set_pv_mfma(int(bool(on))))
+
+
+def variant_fits(variant: int, max_seq_len: int, for_append: bool = False) -> bool:
+    """Can `variant` (from pick_variant) serve a launch with this max_seq_len — and the fused append, if asked?
+    False -> pass `_variant=0` and let the library choose."""
+    return bool(_lib.load().vmi_paged_attention_v1_variant_fits(int(variant), int(max_seq_len), int(bool(for_append))))
 
 
 def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16,
