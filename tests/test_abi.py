@@ -195,22 +195,33 @@ def test_workload_builder_matches_survey_byte_counts():
 
 
 def test_heuristic_picks_follow_the_host_hint():
-    """vmi_paged_attention_v1_pick_variant[_hint] need no GPU: full-chip uniform batches get one (adaptive-depth)
-    wave per head, a batch whose mean length is well below its longest gets eight waves per head, small batches
-    get as many waves per head as it takes to fill the chip."""
+    """vmi_paged_attention_v1_pick_variant[_hint] need no GPU: head size 64 on a full chip gets the balanced kernel
+    (it reads the lengths on the device, so the host hint changes nothing there) — unless max_seq_len leaves no room
+    for three workgroups' logits per CU; head size 128 keeps the hint: a batch whose mean length is well below its
+    longest gets eight waves per head; small batches get as many waves per head as it takes to fill the chip."""
     from vllmini_amd import ops
 
     names = ops.variant_names()
     pick = lambda *a, **k: names[ops.pick_variant(*a, **k) - 1]          # noqa: E731
-    assert pick(256, 12, 64, 1024) == "d64_h4_w1_u1a4_nt1"
-    assert pick(256, 12, 64, 1024, mean_seq_len=1024) == "d64_h4_w1_u1a4_nt1"
-    assert pick(256, 12, 64, 1024, mean_seq_len=900) == "d64_h4_w1_u1a4_nt1"
-    assert pick(256, 12, 64, 1024, mean_seq_len=512) == "d64_h1_w8_u1_nt1"
+    assert pick(256, 12, 64, 1024) == "q_d64_s1q2"
+    assert pick(256, 12, 64, 1024, mean_seq_len=1024) == "q_d64_s1q2"
+    assert pick(256, 12, 64, 1024, mean_seq_len=512) == "q_d64_s1q2"
+    assert pick(2048, 12, 64, 1024) == "q_d64_s1q2"
+    assert pick(256, 12, 64, 8192) == "d64_h4_w1_u1a4_nt1"            # 3 x 16 x 8192 B of logits do not fit a CU
+    assert pick(256, 12, 64, 8192, mean_seq_len=2000) == "d64_h1_w8_u1_nt1"
+    lib = ops._lib.load()
+    q = names.index("q_d64_s1q2") + 1
+    assert lib.vmi_paged_attention_v1_variant_fits(q, 1024, 0) == 1
+    assert lib.vmi_paged_attention_v1_variant_fits(q, 1024, 1) == 0   # no fused-append twin
+    assert lib.vmi_paged_attention_v1_variant_fits(q, 40000, 0) == 0
+    assert lib.vmi_paged_attention_v1_variant_fits(names.index("d64_h4_w1_u1_nt1") + 1, 1024, 1) == 1
+    assert lib.vmi_paged_attention_v1_variant_fits(0, 1024, 0) == 0
     assert pick(128, 32, 128, 2048) == "d128_mh4_h4_u1_nt1_lock"
     assert pick(128, 32, 128, 2048, mean_seq_len=1000) == "d128_h1_w8_u1_nt1"
     assert "_w16_" in pick(1, 12, 64, 1024)
-    assert pick(256, 12, 64, 1024, bf16=True).startswith("bf16_d64_bs16_h4_w1")
-    assert pick(256, 12, 64, 1024, mean_seq_len=300, bf16=True) == "bf16_d64_bs16_h1_w8_u1_nt1"
+    assert pick(256, 12, 64, 1024, bf16=True) == "bf16_q_d64_s1q2"
+    assert pick(256, 12, 64, 8192, bf16=True).startswith("bf16_d64_bs16_h4_w1")
+    assert pick(256, 12, 64, 8192, mean_seq_len=300, bf16=True) == "bf16_d64_bs16_h1_w8_u1_nt1"
     assert pick(256, 5, 80, 1024, 32) == "d80_bs32_h1_w4_u1_nt1"       # 1280 (seq, head) units do not fill 256 CUs
     assert pick(1024, 5, 80, 1024, 32) == "d80_bs32_h1_w1_u1_nt1"
 
