@@ -20,8 +20,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                 (oracle/eager.py, restating vllmini/model/gpt2.py:71-78) — timed on this box's host
                 cores on the same synthetic workload (rank 0, N=1 only)
 
-Multi-GPU: sequences are sharded over ranks as independent KV pools (weak scaling: `batch`
-sequences per GPU), no data-path collective; ranks only meet at the timing barriers.
+Beside `value` (never as it): `fused_step` (the pair as one launch), `fp8_kv_step` (fp8 E4M3 pages), `ragged_step`
+(seq_lens ~ U{1..seq_len} through the same default entry: the shape a continuous-batching server produces),
+`graph_step` (the call pair replayed from one hipGraph: what is left when the host is out of the way).
+
+Multi-GPU: sequences are sharded over ranks as independent KV pools, no collective on the data
+path.  --scaling weak (default): 256 sequences per GPU, pool of 65536 blocks (BASELINE configs[4]); --scaling strong:
+2048 sequences in all, 2048/N per GPU, pool = max(65536, what the batch needs).  For N > 1 every timed step ends
+with the one exchange a decode loop has — the all_gather of the step's sampled token ids (8 B per sequence, RCCL
+over xGMI; vllmini_amd/shard.py:gather_token_ids) — and its share of the step is reported as `token_exchange_us`.
 """
 from __future__ import annotations
 
@@ -60,6 +67,7 @@ def parse_args():
     ap.add_argument("--op", default="v1", choices=["v1", "v2", "fused"],
                     help="attention operator in the step: paged_attention_v1 (headline) or the split-KV paged_attention_v2")
     ap.add_argument("--variant", type=int, default=0, help="force a kernel work decomposition (0 = heuristic)")
+    ap.add_argument("--variant-name", default="", help="the same by kernel name (ops.variant_names())")
     ap.add_argument("--sweep", action="store_true", help="time every kernel variant, write gpurun_out/sweep.json")
     ap.add_argument("--diag", action="store_true",
                     help="report the plain 16-B/lane read bandwidth of this box over the K pool (stderr + gpurun_out/diag.json)")
@@ -71,6 +79,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-step measurement")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-KV-cache measurement")
+    ap.add_argument("--noop-instead-of-reshape", action="store_true",
+                    help="diagnostic: a 4-byte fill kernel takes reshape_and_cache's place in the step")
+    ap.add_argument("--reshape-other-set", action="store_true",
+                    help="diagnostic: reshape_and_cache writes the OTHER table set's blocks (no freshly written lines are read)")
     ap.add_argument("--skip-reshape", action="store_true",
                     help="DIAGNOSTIC (invalid as a bench line): attention launches back to back, no reshape_and_cache")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -86,6 +98,10 @@ def parse_args():
                          "this config's batch/heads/seq_len, fp16 and bf16 -> gpurun_out/matrix.json (diagnostic)")
     ap.add_argument("--hint-mean", action="store_true",
                     help="pass the batch's mean length to the heuristic (what a host-side scheduler can do)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = 256 sequences per GPU (default), strong = 2048 sequences in all")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the extra ragged-batch measurement")
+    ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
     return ap.parse_args()
 
 
@@ -161,12 +177,36 @@ def attend(wl, out, t, variant, op="v1"):
                            0, 0, 1, 1, 0, _variant=variant)
 
 
+RESHAPE_OTHER = False
+NOOP_RESHAPE = None
+
+
 def one_step(wl, out, i, variant, op="v1"):
     """The reference's per-layer decode call pair, in its call order (gpt2.py:44, :62)."""
     t = i % len(wl.tables)
-    if op != "fused" and not SKIP_RESHAPE:
-        cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], KV_DTYPE, 1.0)
+    if NOOP_RESHAPE is not None:
+        NOOP_RESHAPE.fill_(1.0)
+    elif op != "fused" and not SKIP_RESHAPE:
+        cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache,
+                                    wl.slots[(t + 1) % len(wl.tables) if RESHAPE_OTHER else t], KV_DTYPE, 1.0)
     attend(wl, out, t, variant, op)
+
+
+_EXCHANGE = {}     # per-run state of the N > 1 token exchange: ids tensor, global batch, per-step event pairs
+
+
+def exchange_tokens(dist, i=None):
+    """The decode loop's only collective: every rank hands the ids it sampled for its sequences to
+    all ranks.  Synthetic ids here; the all_gather is the real one."""
+    if dist is None:
+        return
+    ev = _EXCHANGE.get("events")
+    if ev is not None and i is not None:
+        ev[i][0].record()
+    _EXCHANGE["gathered"] = shard.gather_token_ids(_EXCHANGE["ids"], _EXCHANGE["global_batch"], dist,
+                                                   out=_EXCHANGE["out"])
+    if ev is not None and i is not None:
+        ev[i][1].record()
 
 
 def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
@@ -174,19 +214,65 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
     (vllmini_amd/shard.py:timed_steps — the same code the 2-rank gloo test exercises)."""
     c = wl.cfg
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if dist is not None:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        _EXCHANGE["global_batch"] = c.batch * world
+        _EXCHANGE["ids"] = torch.arange(rank * c.batch, (rank + 1) * c.batch, dtype=torch.int64, device=dev)
+        _EXCHANGE["out"] = torch.empty(c.batch * world, dtype=torch.int64, device=dev)
+        _EXCHANGE["events"] = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                               for _ in range(steps)]
+
+    def step(i):
+        one_step(wl, out, i, variant, op)
+        exchange_tokens(dist)
 
     def timed(i):
         t = i % len(wl.tables)
-        if op != "fused" and not SKIP_RESHAPE:
-            cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], KV_DTYPE, 1.0)
+        if NOOP_RESHAPE is not None:
+            NOOP_RESHAPE.fill_(1.0)
+        elif op != "fused" and not SKIP_RESHAPE:
+            cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache,
+                                        wl.slots[(t + 1) % len(wl.tables) if RESHAPE_OTHER else t], KV_DTYPE, 1.0)
         ev[i][0].record()  # HIP events on the launch stream (torch's current stream)
         attend(wl, out, t, variant, op)
         ev[i][1].record()
+        exchange_tokens(dist, i)
 
-    elapsed = shard.timed_steps(lambda i: one_step(wl, out, i, variant, op), steps, warmup, dist,
+    elapsed = shard.timed_steps(step, steps, warmup, dist,
                                 sync=lambda: torch.cuda.synchronize(dev), timed_step=timed)
     kern_ms = [a.elapsed_time(b) for a, b in ev]
+    if dist is not None:
+        _EXCHANGE["us"] = statistics.mean(a.elapsed_time(b) for a, b in _EXCHANGE["events"]) * 1e3
+        g = _EXCHANGE["gathered"]
+        assert g.numel() == _EXCHANGE["global_batch"] and int(g[0]) == 0 and int(g[-1]) == g.numel() - 1
+        _EXCHANGE["events"] = None
     return elapsed, kern_ms
+
+
+def graph_steps(wl, out, steps, variant, dev):
+    """The reference's call pair captured ONCE into a hipGraph (one graph per table set) and replayed: the launch
+    work the host does per step is one graph launch, so this is the step the GPU can do when the host is out of
+    the way.  Returns seconds for `steps` replays."""
+    graphs = []
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for t in range(len(wl.tables)):
+            one_step(wl, out, t, variant)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for t in range(len(wl.tables)):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one_step(wl, out, t, variant)
+        graphs.append(g)
+    for i in range(10):
+        graphs[i % len(graphs)].replay()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        graphs[i % len(graphs)].replay()
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
 
 
 def pmc_traffic(cfg_name: str, kernel_variant: str):
@@ -356,17 +442,32 @@ def run_matrix(args, base, dev):
 
 
 def main():
-    global KV_DTYPE, SKIP_RESHAPE
+    global KV_DTYPE, SKIP_RESHAPE, RESHAPE_OTHER, NOOP_RESHAPE
     args = parse_args()
+    RESHAPE_OTHER = args.reshape_other_set
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists for the product kernels)")
     dist, rank, world, local_rank = init_dist(args.gpus)
     dev = torch.device("cuda", local_rank)
+    if args.noop_instead_of_reshape:
+        NOOP_RESHAPE = torch.zeros(1, device=dev)
     cfg = CONFIGS[args.config]
-    if world > 1 and args.config == "cfg3":
+    if (world > 1 or dist is not None) and args.config == "cfg3":
         # BASELINE.json configs[4]: batch 2048 over 8 GPUs = 256 sequences per GPU (the cfg3 shape) with a
         # per-GPU KV pool of 65536 blocks.  Same kernel work per GPU as N=1; only the pool is larger.
         cfg = CONFIGS["cfg5"]
+        if args.scaling == "strong":
+            # total batch 2048 whatever N; N = 1 needs 2 x 131072 blocks for two disjoint table sets,
+            # more than the stated 65536 -> the pool is max(65536, needed)
+            import dataclasses
+            total = 2048
+            if total % world:
+                raise SystemExit(f"--scaling strong: {total} sequences do not divide over {world} GPUs")
+            b_ = total // world
+            cfg = dataclasses.replace(cfg, name="cfg5_strong", batch=b_,
+                                      num_blocks=max(cfg.num_blocks, 2 * b_ * cfg.blocks_per_seq))
+    if args.variant_name:
+        args.variant = ops.variant_names().index(args.variant_name) + 1
     if args.pv_mfma:
         ops.set_pv_mfma(True)
     if args.kv_heads:
@@ -510,7 +611,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
@@ -526,7 +627,8 @@ def main():
                         + (" (DIAGNOSTIC: reshape_and_cache skipped)" if args.skip_reshape else ""),
             "global_batch": cfg.batch * world,
             "seq_len": cfg.seq_len,
-            "parallelism": f"dp{world} (independent KV pools, no data-path collective)",
+            "parallelism": f"dp{world} (independent KV pools, no data-path collective"
+                           + ("; per-step all_gather of the sampled token ids over RCCL)" if dist is not None else ")"),
             "kernel_variant": vname, "op": args.op,
         },
         "paged_attention_v1_us_per_step": kern_mean_ms * 1e3,
@@ -540,7 +642,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "kernel": "pa_v1_kernel",
+            "kernel": "pa_q_kernel" if vname.startswith(("q_d", "bf16_q_d")) else "pa_v1_kernel",
             "algorithmic_bytes_per_launch": alg_bytes(cfg),
         },
     }
@@ -579,6 +681,34 @@ def main():
                                "ms_per_step": q_elapsed / args.steps * 1e3, "kernel_us_mean": q_us,
                                "achieved_GBps": q_bytes / (q_us * 1e-6) / 1e9,
                                "frac_of_hbm_peak": q_bytes / (q_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+    if dist is not None:
+        line["token_exchange_us"] = shard.max_over_ranks(_EXCHANGE["us"], dist, dev)
+        line["token_exchange"] = f"all_gather of {cfg.batch} int64 ids per rank ({cfg.batch * world * 8} B in all), backend nccl (RCCL)"
+    if args.op == "v1" and args.kv == "auto" and not args.no_graph and not args.ragged and not args.ragged_sorted and \
+            dist is None and not args.skip_reshape:
+        g_elapsed = graph_steps(wl, out, args.steps, args.variant, dev)
+        line["graph_step"] = {"op": "reshape_and_cache + paged_attention_v1 replayed from one hipGraph per table set",
+                              "value": cfg.batch * args.steps / g_elapsed, "unit": "tokens/s",
+                              "ms_per_step": g_elapsed / args.steps * 1e3}
+    if args.op == "v1" and args.kv == "auto" and not args.no_ragged and not args.ragged and not args.ragged_sorted and \
+            not args.variant and not args.sequential_tables:
+        # the same call pair, same default entry (no hint, no variant), on a RAGGED batch: seq_lens ~ U{1..seq_len}
+        pools = (wl.key_cache, wl.value_cache)
+        rwl = make_workload(cfg, dev, seed=4321 + rank, table_sets=2, ragged=True)
+        del rwl.key_cache, rwl.value_cache
+        rwl.key_cache, rwl.value_cache = pools          # same pools: only tables, lengths and slots differ
+        r_elapsed, r_kern = time_steps(rwl, out, args.steps, args.warmup, 0, dist, dev, op="v1")
+        r_elapsed = shard.max_over_ranks(r_elapsed, dist, dev)
+        r_us = shard.max_over_ranks(statistics.mean(r_kern), dist, dev) * 1e3
+        tok = int(rwl.seq_lens.sum().item())
+        r_bytes = 2 * tok * cfg.kv_heads * cfg.head_size * 2 + 2 * cfg.batch * cfg.num_heads * cfg.head_size * 2 + \
+            int(((rwl.seq_lens + cfg.block_size - 1) // cfg.block_size).sum().item()) * 4 + cfg.batch * 4
+        line["ragged_step"] = {"op": "reshape_and_cache + paged_attention_v1, default entry, seq_lens ~ U{1..%d}" % cfg.seq_len,
+                               "value": tokens / r_elapsed, "unit": "tokens/s",
+                               "ms_per_step": r_elapsed / args.steps * 1e3, "kernel_us_mean": r_us,
+                               "algorithmic_bytes_per_launch": r_bytes,
+                               "achieved_GBps": r_bytes / (r_us * 1e-6) / 1e9,
+                               "frac_of_hbm_peak": r_bytes / (r_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps)
     elif rank == 0:

@@ -56,6 +56,7 @@ constexpr int QF_MODE(int f) { return f & 3; }
 constexpr int QF_TEAM(int f) { return (f >> 12) & 3; }
 constexpr int QF_WQ(int f) { return (f >> 2) & 7; }
 constexpr int QF_NOSORT = 1 << 11;
+constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at all (with a forced mode)
 
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
@@ -67,7 +68,8 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 // grid = (G), block = 256.  LDS = 4*lpad*4 (logits / probabilities, one region per wave) + QSORT_MAX*2 (ranking)
-//                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + 4*64*8 (bucket masks)
+//                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + QSORT_MAX*2 (the
+//                                 clamped lengths) + 4*64*8 (bucket masks)
 //                                 + 8*4 + 4*D*4 (a team's max / sum exchange and partial outputs).
 template <int D, bool BF, bool NT, int US, int UQ>
 // (second launch bound = minimum waves per SIMD: 3 workgroups of 4 waves per CU must all be resident in mode S, i.e.
@@ -128,25 +130,29 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
   int maxL = 0;
   float sumL = 0.f;
   bool have_sum = false;
-  // lengths of the chunks this wave ranks (chunk = 64 sequences; chunk c belongs to wave c & 3), read ONCE: the
-  // statistics and both passes of the counting sort use these registers, not three dependent trips to memory
-  constexpr int MYCH = QSORT_MAX / 256;
-  int mylen[MYCH];
-  const bool rankable = B <= QSORT_MAX && !(flags & QF_NOSORT);
+  // Statistics: every wave reads ALL the lengths once (8 loads in flight per trip of the loop) and leaves them, clamped,
+  // in LDS for the counting sort below — the passes of the sort must not go back to memory (three dependent round
+  // trips in front of the first page).
+  uint16_t* len16 = order + 2 * QSORT_MAX;
+  const bool rankable = B <= QSORT_MAX && !(flags & QF_NOSORT) && !(flags & QF_NOSTATS);
   auto clampL = [&](int l) { return l < 0 ? 0 : (l > p.lpad ? p.lpad : l); };
-  if (rankable) {
+  if ((rankable || !queue) && !(flags & QF_NOSTATS)) {
     float sum = 0.f;
+    for (int base = 0; base < B; base += 512) {
+      int l[8];
 #pragma unroll
-    for (int cc = 0; cc < MYCH; ++cc) {
-      mylen[cc] = -1;
-      if (cc * 256 < B) {  // wave-uniform
+      for (int k = 0; k < 8; ++k) {
+        const int i = base + k * 64 + lane;
+        l[k] = i < B ? p.seq_lens[i] : -1;
+      }
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) {
-          const int i = (cc * 4 + w4) * 64 + lane;
-          const int l = i < B ? clampL(p.seq_lens[i]) : -1;
-          maxL = maxL > l ? maxL : l;
-          sum += l > 0 ? (float)l : 0.f;
-          mylen[cc] = w4 == wave ? l : mylen[cc];
+      for (int k = 0; k < 8; ++k) {
+        const int i = base + k * 64 + lane;
+        const int c = clampL(l[k]);
+        if (i < B) {
+          maxL = maxL > c ? maxL : c;
+          sum += (float)c;
+          if (rankable) len16[i] = (uint16_t)c;  // (all four waves write the same values)
         }
       }
     }
@@ -155,18 +161,6 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
     sumL = sum;
     have_sum = true;
     queue = queue || sum < 0.8f * (float)maxL * (float)B;
-  } else if (!queue) {  // too many sequences to rank, yet a wave for every item (few heads): statistics only
-    float sum = 0.f;
-    for (int i = lane; i < B; i += 64) {
-      const int l = clampL(p.seq_lens[i]);
-      maxL = maxL > l ? maxL : l;
-      sum += (float)l;
-    }
-    maxL = wave_max_i(maxL);
-    sum = wave_sum(sum);
-    sumL = sum;
-    have_sum = true;
-    queue = sum < 0.8f * (float)maxL * (float)B;
   }
   if (QF_MODE(flags) == 1 && N <= nwaves) queue = false;
   if (QF_MODE(flags) == 2) queue = true;
@@ -197,26 +191,22 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
       uint16_t* cnt = order + QSORT_MAX;  // [chunk][bucket]: sequences of the chunk in the bucket
       const int nch = (B + 63) >> 6;
       const float bscale = 64.f / (float)(maxL + 1);
-      auto bucket_of = [&](int l) -> int {
-        if (l < 0) return 64;  // past the end of the batch
-        const int bk = (int)((float)(maxL - l) * bscale);  // 0 = longest
+      auto bucket_of = [&](int i) -> int {  // bucket of sequence i (64 = past the end of the batch)
+        if (i >= B) return 64;
+        const int bk = (int)((float)(maxL - (int)len16[i]) * bscale);  // 0 = longest
         return bk > 63 ? 63 : bk;
       };
       // Per chunk: which lanes share my bucket (a 64-bit mask per bucket, built with ONE LDS atomic OR — the result of
       // an OR does not depend on the order the lanes are served in) and how many sequences each bucket holds.
-      uint64_t* bm = reinterpret_cast<uint64_t*>(cnt + QSORT_MAX) + wave * 64;  // this wave's 64 masks
-      uint64_t same[MYCH];
-#pragma unroll
-      for (int cc = 0; cc < MYCH; ++cc) {
-        const int c = cc * 4 + wave;
-        same[cc] = 0;
-        if (c >= nch) break;
-        const int bk = bucket_of(mylen[cc]);
+      uint64_t* bm = reinterpret_cast<uint64_t*>(order + 3 * QSORT_MAX) + wave * 64;  // this wave's 64 masks
+      auto masks_of = [&](int bk) {
         bm[lane] = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (DS operations of one wave execute in order)
         if (bk < 64) __hip_atomic_fetch_or(&bm[bk], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        same[cc] = bm[bk & 63];
+      };
+      for (int c = wave; c < nch; c += 4) {
+        masks_of(bucket_of(c * 64 + lane));
         cnt[c * 64 + lane] = (uint16_t)__popcll(bm[lane]);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       }
@@ -230,14 +220,14 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
         incl += lane >= d ? o : 0;
       }
       int run = incl - tot;  // lane k: rank of the first sequence of bucket k in the chunk at hand
-#pragma unroll
-      for (int cq = 0; cq < MYCH * 4; ++cq) {
-        const int c = cq;
-        if (c >= nch) break;
+      for (int c = 0; c < nch; ++c) {
         if ((c & 3) == wave) {
-          const int bk = bucket_of(mylen[cq >> 2]);
-          const int pos = __shfl(run, bk & 63) + __popcll(same[cq >> 2] & ((1ull << lane) - 1ull));
+          const int bk = bucket_of(c * 64 + lane);
+          masks_of(bk);
+          const uint64_t same = bm[bk & 63];
+          const int pos = __shfl(run, bk & 63) + __popcll(same & ((1ull << lane) - 1ull));
           if (bk < 64) order[pos] = (uint16_t)(c * 64 + lane);
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
         run += cnt[c * 64 + lane];
       }
@@ -267,12 +257,14 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
 
   // LDS of a team: ONE logits array for the item (region 0), the probabilities behind it (region 1: in place would
   // overwrite slots another wave has not read yet), the max / sum exchange and the waves' partial outputs
-  float* red = reinterpret_cast<float*>(reinterpret_cast<uint64_t*>(order + 2 * QSORT_MAX) + 4 * 64);  // [8]
+  float* red = reinterpret_cast<float*>(reinterpret_cast<uint64_t*>(order + 3 * QSORT_MAX) + 4 * 64);  // [8]
   float* osm = red + 8;                                                                                  // [4][D]
 
-  auto run = [&](auto utag, auto teamtag) {
+  // QMODE = false is mode S: one item, nothing to hand out or to prefetch — compiled without any of that.
+  auto run = [&](auto utag, auto teamtag, auto qtag) {
     constexpr int UU = decltype(utag)::value;
     constexpr bool TEAM = decltype(teamtag)::value;
+    constexpr bool QMODE = decltype(qtag)::value;
     constexpr int T = TEAM ? 4 : 1;       // waves per item; my blocks are sub + idx*T
     const int sub = TEAM ? wave : 0;
     float* lg = TEAM ? smem_f : logits;
@@ -403,14 +395,15 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
                  //  for the loads the moment they are issued)
       bool has_next = false;
       auto fetch_next = [&]() {  // wave-uniform decision + the requests for the next item's metadata
-        if (!queue) return;
-        const int k = round + 1;  // the snake over the ranks
-        const int64_t t64 = (int64_t)k * nworkers + ((k & 1) ? (nworkers - 1 - wq) : wq);
-        has_next = t64 < N;
-        const int t = (int)t64;
-        int s, h;
-        ids_of(has_next ? t : 0, s, h);  // requested unconditionally (item 0 when there is no next one): no phi
-        meta_issue(nxt, s, h, T, sub);
+        if constexpr (QMODE) {
+          const int k = round + 1;  // the snake over the ranks
+          const int64_t t64 = (int64_t)k * nworkers + ((k & 1) ? (nworkers - 1 - wq) : wq);
+          has_next = t64 < N;
+          const int t = (int)t64;
+          int s, h;
+          ids_of(has_next ? t : 0, s, h);  // requested unconditionally (item 0 when there is no next one): no phi
+          meta_issue(nxt, s, h, T, sub);
+        }
       };
 
       if (L <= 0) {  // reference: exp_sum = 0 -> every output 0  (the whole team takes this branch together)
@@ -418,9 +411,11 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
           for (int d = lane; d < D; d += 64) outp[d] = 0;
         fetch_next();
         if (!has_next) break;
-        adopt(nxt);
-        if (nmy > 0) load_group(rn, p.kc, 0);
-        ++round;
+        if constexpr (QMODE) {
+          adopt(nxt);
+          if (nmy > 0) load_group(rn, p.kc, 0);
+          ++round;
+        }
         continue;
       }
 
@@ -442,6 +437,8 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
         // K -> V change and the softmax instead of the queue running empty there.
         load_group(ra, p.kc, 1);
         compute_k(rn, 0);
+        // (written out as a two-step loop plus its two possible tails: folding the tails into the loop with
+        //  conditional loads was tried for code size and made the register allocator spill 600 bytes per lane)
         int g = 1;
         for (; g + 2 < ngroups; g += 2) {
           load_group(rb, p.kc, g + 1);
@@ -506,7 +503,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
       }
       // The next item's metadata is waited for HERE, where only the first V groups (needed next anyway) are in flight
       // with it: no later use of it can then make the compiler drain the V stream.
-      if (queue) {
+      if constexpr (QMODE) {
         asm volatile("" : "+v"(nxt.bt), "+v"(nxt.L), "+v"(nxt.slope));
 #pragma unroll
         for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(nxt.q[i]));
@@ -515,11 +512,11 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
       // =========================== V pass, last group first ===================================
       if (ngroups == 1) {
         compute_v(std::true_type{}, ra, 0);
-        if (queue) prefetch_next(nxt, has_next);
+        if constexpr (QMODE) prefetch_next(nxt, has_next);
       } else if (ngroups > 1) {
         compute_v(std::true_type{}, rn, lastg);  // the only group that can hold the sequence's last block
         // rn is free again: the next item's first K group goes out now and has the rest of the V pass to arrive
-        if (queue) prefetch_next(nxt, has_next);
+        if constexpr (QMODE) prefetch_next(nxt, has_next);
         int s = 1;  // step s = group lastg - s; odd steps in ra, even steps in rb
         for (; s + 2 < ngroups; s += 2) {
           load_group(rb, p.vc, lastg - (s + 1));
@@ -534,8 +531,8 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
         } else {
           compute_v(std::false_type{}, ra, lastg - s);
         }
-      } else if (queue) {
-        prefetch_next(nxt, has_next);  // a team wave without blocks in this item may have some in the next
+      } else {
+        if constexpr (QMODE) prefetch_next(nxt, has_next);  // a team wave without blocks in this item may have some in the next
       }
 
       // the two lanes of a row hold its 8-token groups
@@ -560,14 +557,16 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
         }
       }
       if (!has_next) break;
-      adopt(nxt);  // its first K group is already in flight in rn
-      ++round;
+      if constexpr (QMODE) {
+        adopt(nxt);  // its first K group is already in flight in rn
+        ++round;
+      }
     }
   };
 
-  if (team) run(std::integral_constant<int, 1>{}, std::true_type{});
-  else if (queue) run(std::integral_constant<int, UQ>{}, std::false_type{});
-  else run(std::integral_constant<int, US>{}, std::false_type{});
+  if (team) run(std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{});
+  else if (queue) run(std::integral_constant<int, UQ>{}, std::false_type{}, std::true_type{});
+  else run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{});
 
 }
 

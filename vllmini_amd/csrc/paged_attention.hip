@@ -37,6 +37,7 @@
 #include <mutex>
 #include <stdint.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <float.h>
@@ -336,10 +337,17 @@ __global__ void __launch_bounds__(256)
       const int i = h * D + d0 + c * 8;
       const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + i);
       const h16x8 vv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + i));
-      *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (int64_t)(D >> 3) + (d0 >> 3) + c) * BS + off) * 8) = kv;
+      h16* kdst = kc + (((blk * H + h) * (int64_t)(D >> 3) + (d0 >> 3) + c) * BS + off) * 8;
       h16* vdst = vc + ((blk * H + h) * (int64_t)D + d0 + c * 8) * BS + off;
+      // NON-TEMPORAL stores.  A decode batch writes 16-byte and 2-byte pieces into 24 different cache lines per
+      // (token, head); left dirty in L2 by plain stores they are evicted piecemeal by the attention launch that follows
+      // and cost THAT kernel 4-7 us (cfg3: 75.9 -> 68.6 us on ragged lengths, 123.1 -> 118.8 us on equal ones; a no-op
+      // kernel in between costs nothing, so it is these lines, not the launch).  Streamed out here they cost this
+      // kernel 3 us (6.9 -> 10.0) — the pair is 4 us faster on ragged batches and no slower on equal ones.  Write-
+      // through (sc1) stores and touching the lines first were measured too: profiles/r02b_call_pair_aftermath.md.
+      __builtin_nontemporal_store(kv, reinterpret_cast<u32x4*>(kdst));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) vdst[(int64_t)e * BS] = vv[e];
+      for (int e = 0; e < 8; ++e) __builtin_nontemporal_store(vv[e], vdst + (int64_t)e * BS);
     }
   }
 }
@@ -622,7 +630,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   // (a batch the caller knows to be ragged: many waves per head, so that the hardware dispatcher balances the chip —
   //  except where the balanced kernel below does that itself, from the lengths it reads on the device)
   const bool balanced = allow_balanced && wph == 1 && nt && block_size == 16 && head_size == 64 &&
-                        3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 12 * 1024) <= (size_t)160 * 1024;
+                        3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
   const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
   if (ragged)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
@@ -679,7 +687,12 @@ struct DeviceState {
 };
 static std::mutex g_dev_mutex;
 static DeviceState g_dev[MAX_DEVICES];
-static std::atomic<int> g_queue_flags{0};  // test / bench knob for the balanced kernels (pa_queue.hpp QF_*)
+static int env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+// test / bench knob for the balanced kernels (pa_queue.hpp QF_*); initial value from VMI_QUEUE_FLAGS
+static std::atomic<int> g_queue_flags{env_int("VMI_QUEUE_FLAGS")};
 
 static int device_cus(int device) {  // caller holds the device current
   if (device < 0 || device >= MAX_DEVICES) return 256;
@@ -695,7 +708,7 @@ static int device_cus(int device) {  // caller holds the device current
 // dynamic LDS a kernel needs for logits rows of `lpad` floats (max_seq_len padded to 32)
 static size_t variant_lds_bytes(const Variant& c, int lpad) {
   if (c.QUEUE)  // 4 waves' logits + the ranking, its bucket counts and masks + a team's exchange buffers (pa_queue.hpp)
-    return (size_t)4 * lpad * 4 + (size_t)2048 * 4 + 2048 + 32 + (size_t)4 * c.D * 4;
+    return (size_t)4 * lpad * 4 + (size_t)2048 * 6 + 2048 + 32 + (size_t)4 * c.D * 4;
   return (size_t)c.HPW * c.HPT *
          ((size_t)lpad * 4 + 2 * c.WPH * 4 + (size_t)c.WPH * c.D * 4 + (c.WPH > 1 ? (size_t)lpad * 2 : 0) +
           (c.SPARSE ? (size_t)lpad / 2 : 0));  // SPARSE: the list of attended blocks, one int per block (BS >= 8)

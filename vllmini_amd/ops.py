@@ -80,72 +80,111 @@ def _raise_native(code: int) -> None:
     raise RuntimeError(f"{_lib.last_error()} (vmi code {code})")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_of(index: int) -> int:
+    """The current HIP stream of device `index` as an integer handle (what the C-ABI takes)."""
+    if _raw_stream is not None:
+        return _raw_stream(index)
+    return torch.cuda.current_stream(index).cuda_stream
+
+
+def _on(name: str, t: torch.Tensor, index: int, dev) -> None:
+    """`t` lives on HIP device `index` (there is no CPU path)."""
+    if t.get_device() != index:
+        _check_device(name, t, dev)      # raises with the full message
+
+
 def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables, seq_lens,
                block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
                blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
                blocksparse_head_sliding_step):
-    """Validate and flatten the 18 reference arguments into the C-ABI argument tuple."""
-    if query.dim() != 3:
-        raise RuntimeError(f"query must be [num_seqs, num_heads, head_size], got {tuple(query.shape)}")
-    if query.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+    """Validate and flatten the 18 reference arguments into the C-ABI argument tuple.
+
+    Runs on every call (a decode loop hands in fresh views each step, so nothing about a tensor can be remembered
+    safely); written to touch each tensor as few times as possible — shape and stride tuples are fetched once and
+    compared as tuples: 11.7 -> about 5 us per call on the GPU box's host (profiles/r02_host_overhead.md)."""
+    qs = query.shape
+    if len(qs) != 3:
+        raise RuntimeError(f"query must be [num_seqs, num_heads, head_size], got {tuple(qs)}")
+    qdt = query.dtype
+    if qdt not in (torch.float16, torch.bfloat16, torch.float32):
         # the reference dispatches float / half / bf16 (quant_utils.cuh:529-566); its callers only use half
         # (gpt2.py, scheduler.py:13)
-        raise RuntimeError(f"Unsupported input type of paged attention: {query.dtype}")
+        raise RuntimeError(f"Unsupported input type of paged attention: {qdt}")
     fp8 = _check_kv_cache_dtype(kv_cache_dtype)
-    f32 = query.dtype == torch.float32          # x = 4 cache layout, plain kernels: v1 over float32 caches only
-    if f32 and (fp8 or int(blocksparse_vert_stride) > 1):
+    f32 = qdt == torch.float32          # x = 4 cache layout, plain kernels: v1 over float32 caches only
+    sparse = int(blocksparse_vert_stride) > 1
+    if f32 and (fp8 or sparse):
         raise RuntimeError("Unsupported input type of paged attention: torch.float32 is built for kv_cache_dtype='auto' "
                            "without block-sparse attention")
-    if int(blocksparse_vert_stride) > 1:          # is_block_sparse, attention_kernels.cu:822 — kernels of their own
+    if sparse:          # is_block_sparse, attention_kernels.cu:822 — kernels of their own
         if fp8:
             raise RuntimeError("block-sparse paged attention (blocksparse_vert_stride > 1) is built for "
                                "kv_cache_dtype='auto' (fp16 / bf16 caches) only")
         if int(blocksparse_block_size) <= 0:
             raise RuntimeError(f"blocksparse_block_size must be positive, got {blocksparse_block_size}")
+    index = query.get_device()
     dev = query.device
-    _check_device("query", query, dev)
-    for name, t in (("out", out), ("key_cache", key_cache), ("value_cache", value_cache),
-                    ("block_tables", block_tables), ("seq_lens", seq_lens)):
-        _check_device(name, t, dev)
+    if index < 0:
+        _check_device("query", query, dev)
+    _on("out", out, index, dev)
+    _on("key_cache", key_cache, index, dev)
+    _on("value_cache", value_cache, index, dev)
+    _on("block_tables", block_tables, index, dev)
+    _on("seq_lens", seq_lens, index, dev)
+    kdt, vdt = key_cache.dtype, value_cache.dtype
     if fp8:
         _check_fp8_cache_dtype(fp8, key_cache, value_cache, kv_cache_dtype)
-    elif key_cache.dtype != query.dtype or value_cache.dtype != query.dtype:
-        raise RuntimeError(f"key_cache/value_cache must be {query.dtype} for kv_cache_dtype='auto'")
-    if out.dtype != query.dtype:
-        raise RuntimeError(f"out must be {query.dtype}, got {out.dtype}")
+    elif kdt != qdt or vdt != qdt:
+        raise RuntimeError(f"key_cache/value_cache must be {qdt} for kv_cache_dtype='auto'")
+    if out.dtype != qdt:
+        raise RuntimeError(f"out must be {qdt}, got {out.dtype}")
     if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
         raise RuntimeError("block_tables and seq_lens must be int32")
 
-    num_seqs, num_heads, head_size = (int(s) for s in query.shape)  # attention_kernels.cu:701-703
-    if key_cache.dim() != 5 or value_cache.dim() != 4:
+    num_seqs, num_heads, head_size = qs  # attention_kernels.cu:701-703
+    ks, vs = key_cache.shape, value_cache.shape
+    if len(ks) != 5 or len(vs) != 4:
         raise RuntimeError("key_cache must be [num_blocks, num_kv_heads, head_size/x, block_size, x] "
                            "and value_cache [num_blocks, num_kv_heads, head_size, block_size]")
-    x = int(key_cache.shape[4])
+    x = ks[4]
     want_x = 16 if fp8 else (4 if f32 else 8)                     # x = 16 / sizeof(cache_t), attention_kernels.cu:200
     if x != want_x:
         raise RuntimeError(f"key_cache innermost dimension must be {want_x} (16 bytes per chunk), got {x}")
-    if int(key_cache.shape[3]) != int(block_size) or int(value_cache.shape[3]) != int(block_size):
+    block_size = int(block_size)
+    if ks[3] != block_size or vs[3] != block_size:
         raise RuntimeError(f"block_size={block_size} does not match the cache tensors "
-                           f"({key_cache.shape[3]}, {value_cache.shape[3]})")
-    if int(key_cache.shape[2]) * x != head_size or int(value_cache.shape[2]) != head_size:
+                           f"({ks[3]}, {vs[3]})")
+    if ks[2] * x != head_size or vs[2] != head_size:
         raise RuntimeError("cache head_size does not match query head_size")
-    if int(key_cache.shape[1]) != int(num_kv_heads) or int(value_cache.shape[1]) != int(num_kv_heads):
+    num_kv_heads = int(num_kv_heads)
+    if ks[1] != num_kv_heads or vs[1] != num_kv_heads:
         raise RuntimeError("cache num_kv_heads does not match num_kv_heads argument")
-    if query.stride(2) != 1 or query.stride(1) != head_size:
+    qst = query.stride()
+    if qst[2] != 1 or qst[1] != head_size:
         raise RuntimeError("query must be contiguous in its last two dimensions")
-    if not key_cache[0].is_contiguous() or not value_cache[0].is_contiguous():
+    kst, vst = key_cache.stride(), value_cache.stride()
+    tile = head_size * block_size
+    # every (block, head) tile dense; blocks and heads may be strided (size-1 dimensions carry no layout)
+    if (kst[4] != 1 and x != 1) or (kst[3] != x and block_size != 1) or (kst[2] != block_size * x and ks[2] != 1) or \
+            (kst[1] != tile and ks[1] != 1) or (vst[3] != 1 and block_size != 1) or \
+            (vst[2] != block_size and head_size != 1) or (vst[1] != tile and vs[1] != 1):
         raise RuntimeError("each cache block must be dense")
-    if value_cache.stride(0) != key_cache.stride(0) or value_cache.stride(1) != key_cache.stride(1):
+    if vst[0] != kst[0] or vst[1] != kst[1]:
         # the reference applies key_cache's strides to both tensors (attention_kernels.cu:706-707)
         raise RuntimeError("key_cache and value_cache must have identical block/head strides")
     if not out.is_contiguous() or out.numel() != num_seqs * num_heads * head_size:
         # reference tests pass out as [S, H, 1, D] (tests/kernels/paged_attention.py:114)
         raise RuntimeError("out must be contiguous with num_seqs*num_heads*head_size elements")
-    if block_tables.dim() != 2 or int(block_tables.shape[0]) != num_seqs or block_tables.stride(1) != 1:
+    ts, tst = block_tables.shape, block_tables.stride()
+    if len(ts) != 2 or ts[0] != num_seqs or tst[1] != 1:
         raise RuntimeError("block_tables must be [num_seqs, max_num_blocks_per_seq] with unit inner stride")
-    if block_tables.stride(0) != block_tables.shape[1] and num_seqs > 1:
+    if tst[0] != ts[1] and num_seqs > 1:
         raise RuntimeError("block_tables must be row-contiguous")
-    if seq_lens.dim() != 1 or int(seq_lens.shape[0]) != num_seqs or not seq_lens.is_contiguous():
+    ls = seq_lens.shape
+    if len(ls) != 1 or ls[0] != num_seqs or not seq_lens.is_contiguous():
         raise RuntimeError("seq_lens must be a contiguous [num_seqs] tensor")
     alibi_ptr = None
     if alibi_slopes is not None:
@@ -155,15 +194,14 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
             raise RuntimeError("alibi_slopes must be a contiguous float32 [num_heads] tensor")
         alibi_ptr = alibi_slopes.data_ptr()
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
     return (
         out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
-        num_seqs, num_heads, head_size, int(num_kv_heads), float(scale),
+        num_seqs, num_heads, head_size, num_kv_heads, float(scale),
         block_tables.data_ptr(), seq_lens.data_ptr(),
-        int(block_size), int(max_seq_len), int(block_tables.shape[1]),   # attention_kernels.cu:704
+        block_size, int(max_seq_len), ts[1],   # attention_kernels.cu:704
         alibi_ptr,
-        int(query.stride(0)), int(key_cache.stride(0)), int(key_cache.stride(1)),  # :705-707
-        dev.index if dev.index is not None else torch.cuda.current_device(), stream,
+        qst[0], kst[0], kst[1],  # :705-707
+        index, _stream_of(index),
     )
 
 
@@ -362,60 +400,65 @@ def reshape_and_cache(
     Reference: cache_kernels.cu:256-281 (host), :152-207 (kernel).
     """
     fp8 = _check_kv_cache_dtype(kv_cache_dtype)
-    if key.dim() != 3 or value.dim() != 3 or key.shape != value.shape:
+    kshape = key.shape
+    if len(kshape) != 3 or kshape != value.shape:
         raise RuntimeError("key and value must both be [num_tokens, num_heads, head_size]")
-    if key.dtype not in (torch.float16, torch.bfloat16, torch.float32) or value.dtype != key.dtype:
-        raise RuntimeError(f"Unsupported input type of reshape_and_cache: {key.dtype}")
-    if key.dtype == torch.float32 and fp8:
+    kdt = key.dtype
+    if kdt not in (torch.float16, torch.bfloat16, torch.float32) or value.dtype != kdt:
+        raise RuntimeError(f"Unsupported input type of reshape_and_cache: {kdt}")
+    if kdt == torch.float32 and fp8:
         raise RuntimeError("Unsupported input type of reshape_and_cache: torch.float32 rows with an fp8 cache are not built")
+    index = key.get_device()
     dev = key.device
-    for name, t in (("key", key), ("value", value), ("key_cache", key_cache),
-                    ("value_cache", value_cache), ("slot_mapping", slot_mapping)):
-        _check_device(name, t, dev)
+    if index < 0:
+        _check_device("key", key, dev)
+    _on("value", value, index, dev)
+    _on("key_cache", key_cache, index, dev)
+    _on("value_cache", value_cache, index, dev)
+    _on("slot_mapping", slot_mapping, index, dev)
     if fp8:
         _check_fp8_cache_dtype(fp8, key_cache, value_cache, kv_cache_dtype)
-    elif key_cache.dtype != key.dtype or value_cache.dtype != key.dtype:
-        raise RuntimeError(f"key_cache/value_cache must be {key.dtype} for kv_cache_dtype='auto'")
+    elif key_cache.dtype != kdt or value_cache.dtype != kdt:
+        raise RuntimeError(f"key_cache/value_cache must be {kdt} for kv_cache_dtype='auto'")
     if slot_mapping.dtype != torch.int64:
         raise RuntimeError("slot_mapping must be int64")
-    num_tokens, num_heads, head_size = (int(s) for s in key.shape)       # cache_kernels.cu:265-267
-    if key_cache.dim() != 5 or value_cache.dim() != 4:
+    num_tokens, num_heads, head_size = kshape       # cache_kernels.cu:265-267
+    ks, vs = key_cache.shape, value_cache.shape
+    if len(ks) != 5 or len(vs) != 4:
         raise RuntimeError("key_cache must be [num_blocks, num_heads, head_size/x, block_size, x] "
                            "and value_cache [num_blocks, num_heads, head_size, block_size]")
-    block_size = int(key_cache.shape[3])                                  # cache_kernels.cu:268
-    x = int(key_cache.shape[4])                                           # cache_kernels.cu:269
+    block_size = ks[3]                                  # cache_kernels.cu:268
+    x = ks[4]                                           # cache_kernels.cu:269
     if not key_cache.is_contiguous() or not value_cache.is_contiguous():
         # the reference computes dense offsets (cache_kernels.cu:187-194)
         raise RuntimeError("key_cache and value_cache must be contiguous")
-    if int(key_cache.shape[1]) != num_heads or int(key_cache.shape[2]) * x != head_size or \
-            tuple(value_cache.shape[1:]) != (num_heads, head_size, block_size):
+    if ks[1] != num_heads or ks[2] * x != head_size or tuple(vs[1:]) != (num_heads, head_size, block_size):
         raise RuntimeError("cache shapes do not match key/value shapes")
-    if key.stride(2) != 1 or key.stride(1) != head_size or value.stride(2) != 1 or \
-            value.stride(1) != head_size:
+    kst, vst = key.stride(), value.stride()
+    if kst[2] != 1 or kst[1] != head_size or vst[2] != 1 or vst[1] != head_size:
         raise RuntimeError("key/value must be contiguous in their last two dimensions")
     if slot_mapping.numel() != num_tokens or not slot_mapping.is_contiguous():
         raise RuntimeError("slot_mapping must be a contiguous [num_tokens] tensor")
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _stream_of(index)
     if fp8:                                                               # cache_kernels.cu:200-205
         a8 = (key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
               slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
-              int(key.stride(0)), int(value.stride(0)), float(kv_scale),
-              dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+              kst[0], vst[0], float(kv_scale), index, stream)
         if fp8 == 2:
-            rc = _lib.load().vmi_reshape_and_cache_fp8_e5m2(*a8, int(key.dtype == torch.bfloat16))
+            rc = _lib.load().vmi_reshape_and_cache_fp8_e5m2(*a8, int(kdt == torch.bfloat16))
         else:
-            fn = _lib.load().vmi_reshape_and_cache_fp8_bf16 if key.dtype == torch.bfloat16 else \
+            fn = _lib.load().vmi_reshape_and_cache_fp8_bf16 if kdt == torch.bfloat16 else \
                 _lib.load().vmi_reshape_and_cache_fp8
             rc = fn(*a8)
         if rc != 0:
             _raise_native(rc)
         return None
-    fn16 = _lib.load().vmi_reshape_and_cache_f32 if key.dtype == torch.float32 else _lib.load().vmi_reshape_and_cache_f16
+    fn16 = _lib.load().vmi_reshape_and_cache_f32 if kdt == torch.float32 else _lib.load().vmi_reshape_and_cache_f16
     rc = fn16(
         key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
         slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
-        int(key.stride(0)), int(value.stride(0)),                         # cache_kernels.cu:271-272
-        dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+        kst[0], vst[0],                                                   # cache_kernels.cu:271-272
+        index, stream)
     if rc != 0:
         _raise_native(rc)
     return None

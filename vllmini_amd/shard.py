@@ -71,24 +71,31 @@ def max_over_ranks(value: float, dist=None, device: torch.device | str = "cpu") 
     return float(t.item())
 
 
-def gather_token_ids(local_ids: torch.Tensor, global_batch: int, dist=None) -> torch.Tensor:
-    """all_gather the int64 ids each rank sampled for its slice into the global [B] order.
-    Slices may differ by one element, so every rank pads to the largest slice (8 bytes/sequence:
-    latency-bound, nowhere near a 153 GB/s xGMI link)."""
+def gather_token_ids(local_ids: torch.Tensor, global_batch: int, dist=None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """all_gather the int64 ids each rank sampled for its slice into the global [B] order (8 bytes per sequence:
+    latency-bound, nowhere near a 153 GB/s xGMI link).  When the batch divides evenly over the ranks — the bench's
+    and the scheduler's normal case — it is ONE collective into `out` (a preallocated [global_batch] int64 tensor,
+    optional); otherwise slices differ by one element and every rank pads to the largest."""
     if dist is None:
         return local_ids
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_range(global_batch, rank, world)
     assert local_ids.dtype == torch.int64 and local_ids.numel() == hi - lo
+    if global_batch % world == 0:
+        if out is None:
+            out = torch.empty(global_batch, dtype=torch.int64, device=local_ids.device)
+        dist.all_gather_into_tensor(out, local_ids)
+        return out
     width = -(-global_batch // world)
     padded = torch.zeros(width, dtype=torch.int64, device=local_ids.device)
     padded[: hi - lo] = local_ids
-    out = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(out, padded)
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded)
     parts = []
     for r in range(world):
         a, b = shard_range(global_batch, r, world)
-        parts.append(out[r][: b - a])
+        parts.append(gathered[r][: b - a])
     return torch.cat(parts)
 
 
