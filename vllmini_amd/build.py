@@ -111,12 +111,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    failed = None
     for src, cmd, proc in procs:
         out, err = proc.communicate()
         if proc.returncode != 0:
-            raise RuntimeError(f"hipcc failed ({proc.returncode}): {' '.join(cmd)}\n{out}\n{err}")
+            failed = failed or RuntimeError(f"hipcc failed ({proc.returncode}): {' '.join(cmd)}\n{out}\n{err}")
+            continue                                   # (let the other units finish: their objects stay valid)
         with open(_obj_of(src) + ".flags", "w") as f:
             f.write(_flags_stamp())
+    if failed:
+        raise failed
     objs = [_obj_of(s) for s in SOURCES]
     link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *os.environ.get("VMI_EXTRA_FLAGS", "").split(), *objs, "-o", tmp]
     if verbose:

@@ -247,6 +247,52 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int o = __shfl_xor(v, m);
+    v = v > o ? v : o;
+  }
+  return v;
+}
+
+// Batch statistics that every wave of a launch computes for itself from the same seq_lens (clamped to [0, lpad]), in
+// the same order of operations — so all waves, and the two kernels of a gated double launch (launch_pa_v1), reach
+// the same verdict without talking to each other.  8 loads in flight per trip; each(i, clamped_len) sees every
+// sequence once per wave.
+template <typename F>
+__device__ __forceinline__ void batch_stats(const int32_t* __restrict__ seq_lens, int B, int lpad, int lane, int& maxL,
+                                            float& sum, F&& each) {
+  maxL = 0;
+  sum = 0.f;
+  for (int base = 0; base < B; base += 512) {
+    int l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + k * 64 + lane;
+      l[k] = i < B ? seq_lens[i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + k * 64 + lane;
+      const int c = l[k] < 0 ? 0 : (l[k] > lpad ? lpad : l[k]);
+      if (i < B) {
+        maxL = maxL > c ? maxL : c;
+        sum += (float)c;
+        each(i, c);
+      }
+    }
+  }
+  maxL = wave_max_i(maxL);
+  sum = wave_sum(sum);
+}
+// a batch is RAGGED when its mean length is below 0.8 of its longest
+__device__ __forceinline__ bool batch_is_ragged(int maxL, float sum, int B) { return sum < 0.8f * (float)maxL * (float)B; }
+// q_flags bits shared by pa_v1_kernel and pa_q_kernel: a gated double launch runs the kernel built for equal lengths
+// and the balanced kernel back to back, and each leaves at once unless the batch is its kind
+constexpr int QF_GATE_UNIFORM = 1 << 16;  // pa_v1_kernel: leave unless the batch has (nearly) equal lengths
+constexpr int QF_GATE_RAGGED = 1 << 17;   // pa_q_kernel: leave unless the batch is ragged
+
 // Workgroup barrier for waves that exchange data through LDS only.  __syncthreads() is a release/acquire fence at
 // workgroup scope plus s_barrier, and the fence makes every wave wait for ALL its outstanding global loads
 // (s_waitcnt vmcnt(0)) — here that would be the V pages requested just before the softmax, i.e. the prefetch would
@@ -398,6 +444,14 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   int samp = 0;
   if constexpr (UMAX >= 2 * U && !PART) samp = p.seq_lens[(int)(((int64_t)lane * gridDim.y) >> 6)];
   if constexpr (!PART) L = L > p.lpad ? p.lpad : L;
+  if constexpr (!PART && !APP && !SPARSE) {
+    if (p.q_flags & QF_GATE_UNIFORM) {  // gated double launch: a ragged batch belongs to the balanced kernel behind me
+      int mx;
+      float sm;
+      batch_stats(p.seq_lens, p.num_seqs, p.lpad, lane, mx, sm, [](int, int) {});
+      if (batch_is_ragged(mx, sm, p.num_seqs)) return;  // the same verdict in every wave of the launch
+    }
+  }
   const int nblk_seq = (L + BS - 1) / BS;                                     // :121
   const int blk_hi = PART ? (blk_lo + PBLK < nblk_seq ? blk_lo + PBLK : nblk_seq) : nblk_seq;  // :128-129
   if (PART && blk_lo * BS >= L) return;  // nothing in this partition (:116-119); uniform per workgroup
@@ -1290,9 +1344,9 @@ struct Variant {
   int HPT;  // heads per wave (1 except for the multi-head kernel)
   bool BF;  // element type: false = fp16, true = bfloat16
   pa_kernel_t fn;
-  int lds_attr_set;  // largest dynamic-LDS size already granted through hipFuncSetAttribute
+  int reserved0;     // (was a cache of the granted dynamic-LDS size: process-global mutable state, removed)
   int UMAX;          // adaptive queue depth limit (0 = fixed U)
-  int lds_attr_dev;  // device that grant was made on (the attribute is per device)
+  int reserved1;
   int F8;            // caches hold fp8 bytes: 1 = E4M3 (kv_cache_dtype "fp8" / "fp8_e4m3"), 2 = E5M2 ("fp8_e5m2"); 0 = 16-bit
   bool GQS;          // the HPT query heads of a wave share one KV head: num_heads / num_kv_heads % HPT == 0 required
   bool FPV;          // opt-in: probabilities x V on the matrix cores too (vmi_set_pv_mfma); north-star bound, not 1 ulp

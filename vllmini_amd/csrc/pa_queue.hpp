@@ -58,15 +58,6 @@ constexpr int QF_WQ(int f) { return (f >> 2) & 7; }
 constexpr int QF_NOSORT = 1 << 11;
 constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at all (with a forced mode)
 
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const int o = __shfl_xor(v, m);
-    v = v > o ? v : o;
-  }
-  return v;
-}
-
 // grid = (G), block = 256.  LDS = 4*lpad*4 (logits / probabilities, one region per wave) + QSORT_MAX*2 (ranking)
 //                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + QSORT_MAX*2 (the
 //                                 clamped lengths) + 4*64*8 (bucket masks)
@@ -135,32 +126,16 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
   // trips in front of the first page).
   uint16_t* len16 = order + 2 * QSORT_MAX;
   const bool rankable = B <= QSORT_MAX && !(flags & QF_NOSORT) && !(flags & QF_NOSTATS);
-  auto clampL = [&](int l) { return l < 0 ? 0 : (l > p.lpad ? p.lpad : l); };
-  if ((rankable || !queue) && !(flags & QF_NOSTATS)) {
-    float sum = 0.f;
-    for (int base = 0; base < B; base += 512) {
-      int l[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = base + k * 64 + lane;
-        l[k] = i < B ? p.seq_lens[i] : -1;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = base + k * 64 + lane;
-        const int c = clampL(l[k]);
-        if (i < B) {
-          maxL = maxL > c ? maxL : c;
-          sum += (float)c;
-          if (rankable) len16[i] = (uint16_t)c;  // (all four waves write the same values)
-        }
-      }
-    }
-    maxL = wave_max_i(maxL);
-    sum = wave_sum(sum);
+  if ((rankable || !queue || (flags & QF_GATE_RAGGED)) && !(flags & QF_NOSTATS)) {
+    float sum;
+    batch_stats(p.seq_lens, B, p.lpad, lane, maxL, sum, [&](int i, int c) {
+      if (rankable) len16[i] = (uint16_t)c;  // (all four waves write the same values)
+    });
     sumL = sum;
     have_sum = true;
-    queue = queue || sum < 0.8f * (float)maxL * (float)B;
+    const bool ragged = batch_is_ragged(maxL, sum, B);
+    if ((flags & QF_GATE_RAGGED) && !ragged) return;  // gated double launch: the kernel in front of me did this batch
+    queue = queue || ragged;
   }
   if (QF_MODE(flags) == 1 && N <= nwaves) queue = false;
   if (QF_MODE(flags) == 2) queue = true;

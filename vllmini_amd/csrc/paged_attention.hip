@@ -800,6 +800,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                 "fill a 16-byte unit; block sizes 16 and 32 are built)");
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
   auto lds_of = [&](const Variant& c) { return variant_lds_bytes(c, lpad); };
+  const bool gate_ok = variant == 0 && !append && !bsp && !f8;  // an explicit variant is run as asked
   Variant* sparse_v = nullptr;
   if (bsp) {  // one or four waves per head, by how many (seq, head) units there are to fill the chip with
     const int nblk = (max_seq_len + block_size - 1) / block_size;
@@ -859,12 +860,12 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   DeviceGuard guard(device);
   hipError_t e = guard.err;
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  if (lds > 48 * 1024 && ((int)lds > v.lds_attr_set || device != v.lds_attr_dev)) {
+  if (lds > 48 * 1024) {
+    // (set on every such launch: the attribute is per device and the library may be driven from several host threads —
+    //  remembering "already granted" in the variant table was a data race; the call costs about a microsecond)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    v.lds_attr_set = (int)lds;
-    v.lds_attr_dev = device;
   }
 
   PAParams p;
@@ -895,21 +896,44 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   p.num_seqs = num_seqs;
   p.q_flags = 0;
 
-  if (v.QUEUE) {
-    // persistent geometry: as many 4-wave workgroups as stay resident (3 per CU while their LDS fits), never more than
-    // one wave per item; the kernel picks its mode from seq_lens (pa_queue.hpp)
+  // the balanced kernel's launch: persistent geometry — as many 4-wave workgroups as stay resident (3 per CU while their
+  // LDS fits, 2 for head size 128), never more than one wave per item; the kernel picks its mode from seq_lens
+  auto launch_balanced = [&](Variant& q, int gate) -> int {
+    const size_t qlds = variant_lds_bytes(q, lpad);
+    if (qlds > 48 * 1024) {
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(q.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
+      if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
     const int cus = device_cus(device);
-    int per_cu = lds * 3 <= 160 * 1024 ? 3 : (lds * 2 <= 160 * 1024 ? 2 : 1);
-    if (v.D > 64 && per_cu > 2) per_cu = 2;  // register budget of the head-size-128 kernels (pa_queue.hpp launch bounds)
+    int per_cu = qlds * 3 <= 160 * 1024 ? 3 : (qlds * 2 <= 160 * 1024 ? 2 : 1);
+    if (q.D > 64 && per_cu > 2) per_cu = 2;  // register budget of the head-size-128 kernels (pa_queue.hpp launch bounds)
     const int64_t items = (int64_t)num_seqs * num_heads;
     int64_t g = (int64_t)cus * per_cu;
     if (g * 4 > items) g = (items + 3) / 4;
-    p.q_flags = g_queue_flags.load(std::memory_order_relaxed);
-    hipLaunchKernelGGL(v.fn, dim3((unsigned)g), dim3(256), lds, static_cast<hipStream_t>(stream), p);
-    e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 launch");
+    PAParams pq = p;
+    pq.q_flags = g_queue_flags.load(std::memory_order_relaxed) | gate;
+    hipLaunchKernelGGL(q.fn, dim3((unsigned)g), dim3(256), qlds, static_cast<hipStream_t>(stream), pq);
+    hipError_t el = hipGetLastError();
+    if (el != hipSuccess) return hip_fail(el, "paged_attention_v1 launch");
     return VMI_OK;
+  };
+  if (v.QUEUE) return launch_balanced(v, 0);
+
+  // Head size 128 on a full chip: the fastest kernel for equal lengths reads 4 adjacent heads per wave in lockstep
+  // (d128_mh4_*_lock, 0.87 of the roofline) and is the slowest on ragged ones (cfg4 U{1..2048}: 469 us against 325 us
+  // for the balanced kernel, which in turn is 4 % behind on equal lengths).  Only the device knows which batch this
+  // is, and the two kernels have different launch geometries — so BOTH are launched, each told to leave at once
+  // unless the batch is its kind (same statistics, same arithmetic in both: pa_kernel.hpp batch_stats).  The kernel
+  // that leaves costs a launch boundary, about 2 us of a 300-600 us call.
+  Variant* partner = nullptr;
+  if (gate_ok && v.D == 128 && v.BS == 16 && v.WPH == 1 && !v.GQS && !v.F8 && !v.SPARSE &&
+      num_seqs <= 65535 && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
+    for (int i = 0; i < g_queue_nvariants; ++i)
+      if (g_queue_variants[i].D == v.D && g_queue_variants[i].BF == v.BF && g_queue_variants[i].BS == v.BS &&
+          2 * variant_lds_bytes(g_queue_variants[i], lpad) <= (size_t)160 * 1024)
+        partner = &g_queue_variants[i];
   }
+  if (partner) p.q_flags |= QF_GATE_UNIFORM;
 
   dim3 block(v.HPW * v.WPH * 64);
   // gridDim.y is limited to 65535: longer batches go out as consecutive launches over slices
@@ -930,6 +954,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 launch");
   }
+  if (partner) return launch_balanced(*partner, QF_GATE_RAGGED);
   return VMI_OK;
 }
 
@@ -1114,6 +1139,8 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   p.value = nullptr;
   p.key_stride = 0;
   p.value_stride = 0;
+  p.num_seqs = num_seqs;
+  p.q_flags = 0;
   p.kv_scale = kv_scale;
   fill_sparse(p, bsp);
   dim3 grid((num_heads + v.HPW * v.HPT - 1) / (v.HPW * v.HPT), num_seqs, parts);  // :890
