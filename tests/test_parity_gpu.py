@@ -434,7 +434,11 @@ def _full_size_checks(cfg_name, sample_seqs):
     assert float((dominated.float() - 0.5).abs().max()) <= 2e-3
     # (6) sampled sequences against the kernel model (CPU, seconds): only the sampled sequences'
     #     pages are brought to the host, re-indexed into a small pool
-    idx = np.linspace(0, cfg.batch - 1, sample_seqs).astype(int)
+    #     — the sequences of the first and the last workgroups (workgroup b runs on XCD b % 8: the first and last eight
+    #     workgroups cover every XCD) plus an even spread in between
+    edge = max(2, min(4, sample_seqs // 4))
+    idx = np.unique(np.r_[np.arange(edge), np.arange(cfg.batch - edge, cfg.batch),
+                          np.linspace(edge, cfg.batch - edge - 1, max(sample_seqs - 2 * edge, 1)).astype(int)])
     for which, got in ((0, base), (t, dominated)) if t != 0 else ((t, dominated),):
         tab_dev = wl.tables[which][torch.from_numpy(idx).to(dev)][:, : cfg.blocks_per_seq]
         flat = tab_dev.reshape(-1).to(torch.int64)
@@ -452,11 +456,17 @@ def test_full_size_cfg2_properties():
 
 
 def test_full_size_cfg3_roofline_config_properties():
-    _full_size_checks("cfg3", sample_seqs=3)
+    _full_size_checks("cfg3", sample_seqs=20)
 
 
 def test_full_size_cfg4_properties():
-    _full_size_checks("cfg4", sample_seqs=2)
+    _full_size_checks("cfg4", sample_seqs=10)
+
+
+def test_full_size_cfg5_per_gpu_workload_properties():
+    """BASELINE configs[4] as ONE GPU sees it: the cfg3 batch over a pool of 65536 blocks (3.2 GB of K and of V).
+    Physical block ids reach 65535: block offsets are 64-bit in every kernel (attention_kernels.cu:229-231)."""
+    _full_size_checks("cfg5", sample_seqs=12)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -257,3 +257,45 @@ def test_queue_kernel_heavy_tailed_batch_runs_teams_and_matches_model(queue_flag
     qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
     ref = oracle.paged_attention_v1(qn, kc, vc, cfg.num_heads, wl.scale, small_tab, lens.numpy()[idx], cfg.block_size, threads=8)
     assert_close(outs["auto"].cpu().numpy()[idx], ref, "heavy-tailed batch, team mode vs model")
+
+
+def test_head_128_default_entry_is_a_gated_double_launch():
+    """BASELINE cfg4 (B128 H32 D128 L2048): the default entry launches the lockstep multi-head kernel AND the balanced
+    kernel; each decides on the device, from the same statistics, whether the batch is its kind.  Equal lengths: rows
+    bit-identical to the multi-head kernel alone.  Ragged lengths: rows bit-identical to the balanced kernel alone,
+    every row written exactly once (the output starts as NaN), sampled sequences match the CPU kernel model."""
+    from vllmini_amd import ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    dev = _dev()
+    names = _names()
+    cfg = CONFIGS["cfg4"]
+    wl = make_workload(cfg, dev, seed=21, table_sets=1)
+
+    def attend(lens, variant=0):
+        out = torch.full((cfg.batch, cfg.num_heads, cfg.head_size), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, cfg.num_heads, wl.scale, wl.tables[0], lens,
+                               cfg.block_size, cfg.seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+        torch.cuda.synchronize()
+        return out
+
+    uniform = attend(wl.seq_lens)
+    assert torch.isfinite(uniform).all()
+    assert torch.equal(uniform.view(torch.int16), attend(wl.seq_lens, names["d128_mh4_h4_u1_nt1_lock"]).view(torch.int16))
+    g = torch.Generator().manual_seed(3)
+    for what, lens in (("U{1..2048}", torch.randint(1, cfg.seq_len + 1, (cfg.batch,), generator=g)),
+                       ("just ragged enough", torch.full((cfg.batch,), int(0.79 * cfg.seq_len)).index_fill_(0, torch.tensor([5]), cfg.seq_len)),
+                       ("just not ragged", torch.full((cfg.batch,), int(0.81 * cfg.seq_len)).index_fill_(0, torch.tensor([5]), cfg.seq_len))):
+        t_len = lens.to(torch.int32).to(dev)
+        got = attend(t_len)
+        assert torch.isfinite(got).all(), f"{what}: a row was written by neither kernel"
+        alone = attend(t_len, names["d128_mh4_h4_u1_nt1_lock" if what == "just not ragged" else "q_d128_s1q1"])
+        assert torch.equal(got.view(torch.int16), alone.view(torch.int16)), what
+    lens = torch.randint(1, cfg.seq_len + 1, (cfg.batch,), generator=g).to(torch.int32)
+    got = attend(lens.to(dev))
+    order = np.argsort(-lens.numpy(), kind="stable")
+    idx = np.unique(np.r_[order[:3], order[-3:], 0, cfg.batch - 1])
+    kc, vc, small_tab = _pages_to_host(wl, wl.tables[0], idx, cfg)
+    qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
+    ref = oracle.paged_attention_v1(qn, kc, vc, cfg.num_heads, wl.scale, small_tab, lens.numpy()[idx], cfg.block_size, threads=8)
+    assert_close(got.cpu().numpy()[idx], ref, "cfg4 ragged, default entry, sampled vs model")
