@@ -118,24 +118,34 @@ def init_dist(n_gpus: int):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
-        # RCCL prints a banner on STDOUT when the communicator is created; stdout must carry exactly one
-        # JSON line, so fd 1 points at stderr until the first collective has run.
+        # RCCL prints a banner on STDOUT — when the communicator is created and again, with the lazily created
+        # communicator of the first all_gather, later on.  stdout must carry exactly ONE JSON line, so fd 1 points at
+        # stderr for the whole run and the line goes to the saved descriptor (emit_line).
+        global _REAL_STDOUT
         sys.stdout.flush()
-        saved = os.dup(1)
+        _REAL_STDOUT = os.dup(1)
         os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world,  # "nccl" IS RCCL on ROCm
-                                    device_id=torch.device("cuda", local_rank))
-            warm = torch.zeros(1, device=torch.device("cuda", local_rank))
-            dist.all_reduce(warm)
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        dist.init_process_group("nccl", rank=rank, world_size=world,  # "nccl" IS RCCL on ROCm
+                                device_id=torch.device("cuda", local_rank))
+        warm = torch.zeros(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
         return dist, rank, world, local_rank
     torch.cuda.set_device(0)
     return None, 0, 1, 0
+
+
+_REAL_STDOUT = None
+
+
+def emit_line(line: dict) -> None:
+    text = json.dumps(line) + "\n"
+    if _REAL_STDOUT is None:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, text.encode())
 
 
 _V2_SCRATCH = {}
@@ -611,7 +621,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": args.scaling if world > 1 else "weak",
+        "scaling": args.scaling if dist is not None else "weak",
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
@@ -714,7 +724,7 @@ def main():
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     if dist is not None:
         dist.destroy_process_group()
 

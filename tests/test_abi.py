@@ -251,3 +251,44 @@ def test_makefile_lists_the_same_translation_units_as_build_py():
     assert sorted(units) == sorted(os.path.basename(s)[: -len(".hip")] for s in b.SOURCES)
     for flag in ("-O3", "-std=c++17", "-ffp-contract=off", "-fno-gpu-rdc"):
         assert flag in mk and flag in b.HIPCC_FLAGS
+
+
+def test_c_abi_is_callable_from_several_host_threads():
+    """Error strings and the opt-in switches are per thread: two threads that fail differently each read their own
+    message, and one thread's vmi_set_pv_mfma / vmi_debug_set_queue_flags does not leak into the other's calls."""
+    import threading
+
+    from vllmini_amd import _lib
+
+    lib = _lib.load()
+    buf = (ctypes.c_char * 4096)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+
+    def args(hs=64, bs=16):
+        return (p16, p16, p16, p16, 2, 4, hs, 4, 0.125, p16, p16, bs, 64, 4, None, 256, 4096, 1024, 0, None)
+
+    errors, barrier = [], threading.Barrier(2)
+
+    def worker(kind):
+        try:
+            barrier.wait()
+            for _ in range(300):
+                if kind == 0:
+                    assert lib.vmi_paged_attention_v1_f16(*args(hs=72)) == 2
+                    assert b"head size: 72" in lib.vmi_last_error_string()
+                    assert lib.vmi_set_pv_mfma(1) in (0, 1)
+                    assert lib.vmi_debug_set_queue_flags(5) in (0, 5)
+                else:
+                    assert lib.vmi_paged_attention_v1_f16(*args(bs=64)) == 3
+                    assert b"block size: 64" in lib.vmi_last_error_string()
+                    assert lib.vmi_set_pv_mfma(0) == 0                  # never sees thread 0's opt-in
+                    assert lib.vmi_debug_set_queue_flags(0) == 0
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors

@@ -299,3 +299,45 @@ def test_head_128_default_entry_is_a_gated_double_launch():
     qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
     ref = oracle.paged_attention_v1(qn, kc, vc, cfg.num_heads, wl.scale, small_tab, lens.numpy()[idx], cfg.block_size, threads=8)
     assert_close(got.cpu().numpy()[idx], ref, "cfg4 ragged, default entry, sampled vs model")
+
+
+def test_two_host_threads_alternate_large_max_seq_len_launches():
+    """Two host threads (each on its own stream) alternate launches whose logits need more than 48 KiB of LDS with two
+    different max_seq_len values: the dynamic-LDS attribute is granted per launch, not remembered in a shared table
+    (round 1 kept a per-process cache there: a data race), so no launch may fail or use a stale grant."""
+    import threading
+
+    from vllmini_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(4700)
+    lens = [1500, 40, 13000, 7]
+    case = make_case(rng, len(lens), 4, 64, lens, max_blocks=1024)
+    ref = run_model(case)
+    S, H, D = case["q"].shape
+    kc, vc = torch.from_numpy(case["kc"]).to(dev), torch.from_numpy(case["vc"]).to(dev)
+    q = torch.from_numpy(case["q"].copy()).to(dev)
+    tab, ln = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
+    errors, results = [], {}
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(stream):
+                for i in range(40):
+                    msl = (13056, 16384)[(i + k) % 2]
+                    out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=dev)
+                    ops.paged_attention_v1(out, q, kc, vc, H, case["scale"], tab, ln, BS, msl, None, "auto", 1.0, 0, 0, 1, 1, 0)
+                stream.synchronize()
+                results[k] = out.cpu().numpy()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for k in (0, 1):
+        assert_close(results[k], ref, f"thread {k}")

@@ -167,3 +167,15 @@ def test_two_rank_sharded_scheduling_gloo(tmp_path):
     mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(2))
     assert deal_requests(5, 0, 2) == [0, 2, 4] and deal_requests(5, 1, 2) == [1, 3]
+
+
+def test_max_length_beyond_the_block_table_is_refused_up_front():
+    """One sequence that outgrows its block table would abort the decode step of every sequence batched with it
+    (the reference crashes there too, block_manager.py:36-39): the scheduler checks the capacity when it is built."""
+    import types
+
+    dec = FakeDecoder()
+    dec.pool = types.SimpleNamespace(max_blocks_per_seq=4, block_size=16)
+    BatchScheduler(dec, max_length=48, eos_token_id=EOS)                 # (4 - 1) * 16 tokens: fits
+    with pytest.raises(ValueError, match="does not fit"):
+        BatchScheduler(dec, max_length=49, eos_token_id=EOS)

@@ -1288,7 +1288,10 @@ __global__ void __launch_bounds__(128)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int L = seq_lens[seq];
+  // seq_len > max_seq_len is undefined behaviour in the reference (its logits buffer overflows); the partition kernels
+  // here truncate the context to the partitions that exist, so the merge does too
+  const int Lraw = seq_lens[seq];
+  const int L = Lraw > max_num_partitions * 512 ? max_num_partitions * 512 : Lraw;
   const int np = (L + 511) / 512;  // :581
   const int64_t sh = ((int64_t)seq * num_heads + head) * max_num_partitions;
   uint16_t* outp = reinterpret_cast<uint16_t*>(out_) + ((int64_t)seq * num_heads + head) * D;

@@ -311,6 +311,11 @@ __global__ void __launch_bounds__(256)
       *reinterpret_cast<u32x4*>(ktile + (int64_t)u * 8) = kv;               // K[blk,h,d0/8+c,tok,0..8)
       *reinterpret_cast<u32x4*>(lds + tok * (DW + PAD) + c * 8) = vv;       // V rows, token-major, for the transpose
     }
+    // the lanes now read what OTHER lanes of this wave wrote: make the order explicit instead of leaning on in-order
+    // LDS execution and on the compiler keeping the two loops apart
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int u = lane; u < units; u += 64) {
       const int row = u / UPR, unit = u % UPR;
       h16x8 o;
@@ -542,13 +547,18 @@ static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }
 // Opt-in (vmi_set_pv_mfma): let the grouped-query picks use the "_pvm" kernels, which run probabilities x V on the
 // matrix cores as well.  Off by default: those results are within the north-star 1e-3 of the reference kernel, not
 // within an ulp of it (pa_kernel.hpp, FPV).
-static std::atomic<int> g_pv_mfma{0};
+// (thread-local: one host thread opting in must not change another thread's numerics)
+static thread_local int g_pv_mfma = 0;
+// CU count the heuristics below size their launches for: the launch paths set it from hipDeviceProp (device_cus),
+// the pick queries of the C-ABI, which name no device, use the MI355X's 256
+static thread_local int g_cus = 256;
+static inline long full_chip_waves() { return 12L * g_cus; }  // 12 waves per CU: one (sequence, head) each
 
 static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
                                bool bf, int f8, bool fpv);
 static int pick_variant_gqa(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
                             bool bf, int f8) {
-  if (g_pv_mfma.load(std::memory_order_relaxed)) {
+  if (g_pv_mfma) {
     const int v = pick_variant_gqa_of(num_seqs, num_heads, qpk, head_size, block_size, max_seq_len, bf, f8, true);
     if (v) return v;
   }
@@ -602,7 +612,7 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
-  while (wph < 16 && units * wph < 3072 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  while (wph < 16 && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   if (mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   int v = 0;
@@ -624,7 +634,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
-  while (wph < 16 && units * wph < 3072 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  while (wph < 16 && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   const double kv_bytes = 4.0 * (double)units * (double)max_seq_len * head_size;
   const int nt = kv_bytes > 128e6 ? 1 : 0;
   // (a batch the caller knows to be ragged: many waves per head, so that the hardware dispatcher balances the chip —
@@ -635,7 +645,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   if (ragged)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {  // core table: full menu
-    const double waves_per_cu = (double)units * wph / 256.0;
+    const double waves_per_cu = (double)units * wph / (double)g_cus;
     const double tile_kib = head_size * 16 * 2 / 1024.0;
     int u = 1;
     while (u < 4 && waves_per_cu * u * tile_kib < 24.0) u *= 2;
@@ -692,7 +702,7 @@ static int env_int(const char* name) {
   return v ? atoi(v) : 0;
 }
 // test / bench knob for the balanced kernels (pa_queue.hpp QF_*); initial value from VMI_QUEUE_FLAGS
-static std::atomic<int> g_queue_flags{env_int("VMI_QUEUE_FLAGS")};
+static thread_local int g_queue_flags = env_int("VMI_QUEUE_FLAGS");
 
 static int device_cus(int device) {  // caller holds the device current
   if (device < 0 || device >= MAX_DEVICES) return 256;
@@ -801,10 +811,11 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
   auto lds_of = [&](const Variant& c) { return variant_lds_bytes(c, lpad); };
   const bool gate_ok = variant == 0 && !append && !bsp && !f8;  // an explicit variant is run as asked
+  g_cus = device_cus(device);  // the heuristics size the launch for THIS device
   Variant* sparse_v = nullptr;
   if (bsp) {  // one or four waves per head, by how many (seq, head) units there are to fill the chip with
     const int nblk = (max_seq_len + block_size - 1) / block_size;
-    const bool many = (long)num_seqs * num_heads >= 3072 || nblk < 4;
+    const bool many = (long)num_seqs * num_heads >= full_chip_waves() || nblk < 4;
     sparse_v = find_sparse(head_size, block_size, many ? 1 : 4, bf, false);
     if (sparse_v && lds_of(*sparse_v) > 160 * 1024) sparse_v = find_sparse(head_size, block_size, 1, bf, false);
     if (!sparse_v) return fail(VMI_E_VARIANT, "paged_attention_v1: no block-sparse kernel for head size %d / block size %d", head_size, block_size);
@@ -911,7 +922,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     int64_t g = (int64_t)cus * per_cu;
     if (g * 4 > items) g = (items + 3) / 4;
     PAParams pq = p;
-    pq.q_flags = g_queue_flags.load(std::memory_order_relaxed) | gate;
+    pq.q_flags = g_queue_flags | gate;
     hipLaunchKernelGGL(q.fn, dim3((unsigned)g), dim3(256), qlds, static_cast<hipStream_t>(stream), pq);
     hipError_t el = hipGetLastError();
     if (el != hipSuccess) return hip_fail(el, "paged_attention_v1 launch");
@@ -1085,9 +1096,10 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   const int parts = (max_seq_len + 511) / 512;  // attention_kernels.cu:885
   if (num_seqs == 0 || parts == 0) return VMI_OK;
   if (parts > 65535) return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v2: too many partitions");
+  g_cus = device_cus(device);
   Variant* sparse_v = nullptr;
   if (bsp) {
-    sparse_v = find_sparse(head_size, block_size, (long)num_seqs * num_heads * parts >= 3072 ? 1 : 4, bf, true);
+    sparse_v = find_sparse(head_size, block_size, (long)num_seqs * num_heads * parts >= full_chip_waves() ? 1 : 4, bf, true);
     if (!sparse_v) return fail(VMI_E_VARIANT, "paged_attention_v2: no block-sparse kernel for head size %d / block size %d", head_size, block_size);
   } else if (variant == 0) {
     variant = pick_variant_v2(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, f8, num_heads / num_kv_heads);
@@ -1424,9 +1436,17 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
   return vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len);
 }
 
-int vmi_set_pv_mfma(int on) { return vmi::g_pv_mfma.exchange(on ? 1 : 0); }
+int vmi_set_pv_mfma(int on) {
+  const int prev = vmi::g_pv_mfma;
+  vmi::g_pv_mfma = on ? 1 : 0;
+  return prev;
+}
 
-int vmi_debug_set_queue_flags(int flags) { return vmi::g_queue_flags.exchange(flags); }
+int vmi_debug_set_queue_flags(int flags) {
+  const int prev = vmi::g_queue_flags;
+  vmi::g_queue_flags = flags;
+  return prev;
+}
 
 int vmi_paged_attention_v1_variant_fits(int32_t variant, int32_t max_seq_len, int32_t for_append) {
   if (variant < 1 || variant > vmi::nvariants_v1() || max_seq_len < 0) return 0;

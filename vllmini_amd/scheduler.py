@@ -51,6 +51,13 @@ class BatchScheduler:
                  sampler: Callable[..., torch.Tensor] = sample_top_k, use_graph: bool = False,
                  generator: Optional[torch.Generator] = None):
         self.decoder = decoder
+        # a sequence may grow to max_length tokens; the pool's table must hold them (the reference crashes at that
+        # point, block_manager.py:41-63 — here ONE such sequence would abort the step of every sequence in its batch)
+        pool = getattr(decoder, "pool", None)
+        if pool is not None and max_length > (pool.max_blocks_per_seq - 1) * pool.block_size:
+            # (the table keeps a trailing -1, as the reference's last-block search needs it: block_manager.py:36-39)
+            raise ValueError(f"max_length={max_length} does not fit (max_blocks_per_seq - 1) x block_size = "
+                             f"{(pool.max_blocks_per_seq - 1) * pool.block_size} tokens")
         self.max_length = max_length                         # scheduler.py:15
         self.eos_token_id = eos_token_id
         self.max_batch = max_batch
