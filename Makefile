@@ -8,7 +8,7 @@ CSRC   := vllmini_amd/csrc
 OUTDIR := vllmini_amd/_C
 UNITS  := paged_attention pa_variants_extra pa_variants_bf16 pa_append_core pa_append_extra pa_append_bf16 \
           pa_variants_fp8 pa_variants_fp8_bf16 pa_variants_fp8_e5m2 pa_variants_fp8_e5m2_bf16 \
-          pa_variants_sparse pa_variants_sparse_bf16 pa_f32 pa_queue
+          pa_variants_sparse pa_variants_sparse_bf16 pa_f32 pa_queue pa_stage
 OBJS   := $(UNITS:%=$(OUTDIR)/%.hip.o)
 LIB    := $(OUTDIR)/libvmi_paged_attention.so
 

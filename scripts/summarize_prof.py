@@ -16,7 +16,7 @@ for f in find("trace/**/*kernel_stats.csv"):
         for r in rows[:8]]
 # per-dispatch durations of the attention kernel (skip warm-up dispatches)
 for f in find("trace/**/*kernel_trace.csv"):
-    rows = [r for r in csv.DictReader(open(f)) if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_"))]
+    rows = [r for r in csv.DictReader(open(f)) if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_", "pa_stage_"))]
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     if d:
         tail = d[10:] if len(d) > 20 else d
@@ -30,7 +30,7 @@ for f in find("trace/**/*kernel_trace.csv"):
 for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     for f in find(f"{sub}/**/*counter_collection.csv"):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_")) and r.get("Counter_Name") == name]
+                if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_", "pa_stage_")) and r.get("Counter_Name") == name]
         if vals:
             tail = vals[10:] if len(vals) > 20 else vals
             res[name] = {"n": len(vals), "mean_raw_KiB_units": statistics.mean(tail),
@@ -40,7 +40,7 @@ for sub in ("pmc_sq", "pmc_mfma"):
     for f in find(f"{sub}/**/*counter_collection.csv"):
         acc = {}
         for r in csv.DictReader(open(f)):
-            if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_")):
+            if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_", "pa_stage_")):
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in acc.items():
             tail = v[10:] if len(v) > 20 else v

@@ -31,7 +31,9 @@ SRC_SPARSE = [os.path.join(CSRC, f"pa_variants_sparse{t}.hip") for t in ("", "_b
 SRC_FP8_E5M2 = [os.path.join(CSRC, f"pa_variants_fp8_e5m2{t}.hip") for t in ("", "_bf16")]   # ... over E5M2 bytes
 SRC_F32 = os.path.join(CSRC, "pa_f32.hip")                    # float32 tensors (x = 4)
 SRC_QUEUE = os.path.join(CSRC, "pa_queue.hip")                # balanced (work-queue) kernels for ragged batches
-SOURCES = [SRC, SRC_EXTRA, SRC_BF16, *SRC_APPEND, SRC_FP8, SRC_FP8_BF16, *SRC_FP8_E5M2, *SRC_SPARSE, SRC_F32, SRC_QUEUE]
+SRC_STAGE = os.path.join(CSRC, "pa_stage.hip")                # experiment: pages staged through LDS (global_load_lds)
+SOURCES = [SRC, SRC_EXTRA, SRC_BF16, *SRC_APPEND, SRC_FP8, SRC_FP8_BF16, *SRC_FP8_E5M2, *SRC_SPARSE, SRC_F32, SRC_QUEUE,
+           SRC_STAGE]
 HDR = os.path.join(CSRC, "pa_kernel.hpp")
 HDR_QUEUE = os.path.join(CSRC, "pa_queue.hpp")
 INCLUDE = os.path.join(REPO_ROOT, "include")

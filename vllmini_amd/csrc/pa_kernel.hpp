@@ -1355,6 +1355,7 @@ struct Variant {
   bool FPV;          // opt-in: probabilities x V on the matrix cores too (vmi_set_pv_mfma); north-star bound, not 1 ulp
   bool SPARSE;       // block-sparse attention (blocksparse_vert_stride > 1); menus of their own (pa_variants_sparse.hip)
   bool QUEUE;        // balanced kernel (pa_queue.hpp): persistent grid of 3 workgroups per CU, mode chosen on the device
+  bool STAGE;        // experiment (pa_stage.hip): pages staged through an LDS ring of U slots by global_load_lds
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
@@ -1470,5 +1471,8 @@ pa_reduce_t bf16_reduce_kernel(int head_size);
 // balanced (work-queue) kernels, pa_queue.hip: v1 ids continue after every other menu
 extern Variant g_queue_variants[];
 extern const int g_queue_nvariants;
+// LDS-staged experiment kernels, pa_stage.hip: the last ids of all; never picked by a heuristic
+extern Variant g_stage_variants[];
+extern const int g_stage_nvariants;
 
 }  // namespace vmi

@@ -491,7 +491,7 @@ static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
 static int nvariants_v1() {
   return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1 + g_fp8_nvariants_v1 + g_fp8bf_nvariants_v1 +
-         g_fp8_nvariants_v1_e5m2 + g_fp8bf_nvariants_v1_e5m2 + g_queue_nvariants;
+         g_fp8_nvariants_v1_e5m2 + g_fp8bf_nvariants_v1_e5m2 + g_queue_nvariants + g_stage_nvariants;
 }
 static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf16][fp8 cache]
   if (id <= g_ncore) return g_variants[id - 1];
@@ -506,7 +506,9 @@ static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf
   if (id <= f2 + g_fp8_nvariants_v1_e5m2) return g_fp8_variants_v1_e5m2[id - 1 - f2];
   const int f3 = f2 + g_fp8_nvariants_v1_e5m2;
   if (id <= f3 + g_fp8bf_nvariants_v1_e5m2) return g_fp8bf_variants_v1_e5m2[id - 1 - f3];
-  return g_queue_variants[id - 1 - f3 - g_fp8bf_nvariants_v1_e5m2];  // balanced kernels (pa_queue.hip)
+  const int f4 = f3 + g_fp8bf_nvariants_v1_e5m2;
+  if (id <= f4 + g_queue_nvariants) return g_queue_variants[id - 1 - f4];  // balanced kernels (pa_queue.hip)
+  return g_stage_variants[id - 1 - f4 - g_queue_nvariants];                 // LDS-staged experiment (pa_stage.hip)
 }
 
 static bool is_diag(const Variant& v) { return strstr(v.name, "LOADSONLY") != nullptr; }
@@ -517,7 +519,7 @@ static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = a
   for (int id = 1; id <= nvariants_v1(); ++id) {
     const Variant& v = variant_v1(id);
     if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
-        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0 && !v.GQS && !v.QUEUE)
+        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0 && !v.GQS && !v.QUEUE && !v.STAGE)
       return id;
   }
   return 0;
@@ -717,6 +719,8 @@ static int device_cus(int device) {  // caller holds the device current
 
 // dynamic LDS a kernel needs for logits rows of `lpad` floats (max_seq_len padded to 32)
 static size_t variant_lds_bytes(const Variant& c, int lpad) {
+  if (c.STAGE)  // per wave: the logits + a ring of U slots, each one (block, head) tile
+    return (size_t)4 * ((size_t)lpad * 4 + (size_t)c.U * (c.D * 16 * (c.F8 ? 1 : 2)));
   if (c.QUEUE)  // 4 waves' logits + the ranking, its bucket counts and masks + a team's exchange buffers (pa_queue.hpp)
     return (size_t)4 * lpad * 4 + (size_t)2048 * 6 + 2048 + 32 + (size_t)4 * c.D * 4;
   return (size_t)c.HPW * c.HPT *
@@ -855,6 +859,9 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (v.GQS && (num_heads / num_kv_heads) % v.HPT != 0)
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s shares a KV head between %d query heads, got "
                 "num_heads / num_kv_heads = %d", v.name, v.HPT, num_heads / num_kv_heads);
+  if (v.STAGE && (append || bsp || (f8 && kv_scale != 1.0f)))
+    return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (LDS-staging experiment) takes fp16 pages or fp8 E4M3 "
+                "pages with kv_scale 1, without the fused append or block-sparse attention", v.name);
   if (v.QUEUE && (append || f8 || bsp))
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (balanced kernel) is built for fp16 / bf16 caches, "
                 "without the fused append or block-sparse attention", v.name);
