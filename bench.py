@@ -610,6 +610,8 @@ def main():
     vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len,
                                            fp8=FP8_ARG[args.kv], num_kv_heads=cfg.kv_heads)
     vname = ops.variant_names()[vid - 1] if args.op in ("v1", "fused") else f"paged_attention_v2 variant {args.variant or 'auto'}"
+    if args.op == "fused" and not args.variant and not ops.variant_fits(vid, cfg.seq_len, for_append=True):
+        vname = "fused-append twin chosen by the library (the balanced kernels have none)"
     traffic, traffic_src = (pmc_traffic(cfg.name + {"auto": "", "fp8": "_fp8", "fp8_e5m2": "_fp8_e5m2"}[args.kv], vname) if args.op == "v1" else
                             pmc_traffic(cfg.name + "_fused", vname) if args.op == "fused" else (None, None))
     line = {

@@ -680,6 +680,11 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
         }
         bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
         bt_sg = sg;
+        // The wait for this load belongs INSIDE the branch.  Left to the compiler it lands at the join in front of
+        // the v_readlane that follows — as s_waitcnt vmcnt(0) on EVERY page group: the group in flight was drained
+        // before the next one was requested, i.e. the "register double buffer" of round 1 never had two groups in
+        // flight (found in the ISA this round; profiles/r02b_call_pair_aftermath.md, r02f_fp8.md).
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bt_reg));
       }
     };
 
