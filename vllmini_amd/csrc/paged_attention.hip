@@ -341,18 +341,30 @@ __global__ void __launch_bounds__(256)
       const int64_t blk = slot / BS, off = slot % BS;
       const int i = h * D + d0 + c * 8;
       const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + i);
-      const h16x8 vv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + i));
       h16* kdst = kc + (((blk * H + h) * (int64_t)(D >> 3) + (d0 >> 3) + c) * BS + off) * 8;
-      h16* vdst = vc + ((blk * H + h) * (int64_t)D + d0 + c * 8) * BS + off;
       // NON-TEMPORAL stores.  A decode batch writes 16-byte and 2-byte pieces into 24 different cache lines per
       // (token, head); left dirty in L2 by plain stores they are evicted piecemeal by the attention launch that follows
       // and cost THAT kernel 4-7 us (cfg3: 75.9 -> 68.6 us on ragged lengths, 123.1 -> 118.8 us on equal ones; a no-op
       // kernel in between costs nothing, so it is these lines, not the launch).  Streamed out here they cost this
-      // kernel 3 us (6.9 -> 10.0) — the pair is 4 us faster on ragged batches and no slower on equal ones.  Write-
+      // kernel some of that back — the pair is 4 us faster on ragged batches and no slower on equal ones.  Write-
       // through (sc1) stores and touching the lines first were measured too: profiles/r02b_call_pair_aftermath.md.
       __builtin_nontemporal_store(kv, reinterpret_cast<u32x4*>(kdst));
+      if (c8 == 4) {
+        // V: the 4 lanes of a token take the rows 4e + c (not 8c + e): in store instruction e they write 4 CONSECUTIVE
+        // rows of the tile = one 128-byte line, which leaves the wave as one request instead of four
+        const h16* vsrc = value + (int64_t)(t0 + tok) * value_stride + h * D + d0 + c;
+        h16 ve[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) __builtin_nontemporal_store(vv[e], vdst + (int64_t)e * BS);
+        for (int e = 0; e < 8; ++e) ve[e] = vsrc[4 * e];
+        h16* vdst = vc + ((blk * H + h) * (int64_t)D + d0 + c) * BS + off;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) __builtin_nontemporal_store(ve[e], vdst + (int64_t)(4 * e) * BS);
+      } else {
+        const h16x8 vv = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride + i));
+        h16* vdst = vc + ((blk * H + h) * (int64_t)D + d0 + c * 8) * BS + off;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) __builtin_nontemporal_store(vv[e], vdst + (int64_t)e * BS);
+      }
     }
   }
 }
