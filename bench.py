@@ -76,6 +76,7 @@ def parse_args():
                          "extra JSON line on stderr + gpurun_out/e2e.json")
     ap.add_argument("--e2e-fused", action="store_true", help="e2e with one fused append+attention launch per layer")
     ap.add_argument("--e2e-context", type=int, default=1008, help="context length the e2e sequences start at")
+    ap.add_argument("--e2e-ragged", action="store_true", help="e2e with contexts ~ U{16..e2e-context} instead of equal ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-step measurement")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-KV-cache measurement")
@@ -361,8 +362,9 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
     # shuffle the free list so pages are scattered like a long-running pool's
     perm = np.random.default_rng(rank).permutation(pool.num_blocks)
     pool.free_blocks = perm.tolist()
+    ctxs = np.random.default_rng(100 + rank).integers(16, ctx0 + 1, cfg.batch) if args.e2e_ragged else [ctx0] * cfg.batch
     for s in range(cfg.batch):
-        pool.allocate_for_prefill(s, ctx0)           # bookkeeping only: the pages already hold synthetic KV
+        pool.allocate_for_prefill(s, int(ctxs[s]))   # bookkeeping only: the pages already hold synthetic KV
     dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, fused_append=args.e2e_fused)
     ids = list(range(cfg.batch))
     tok = torch.randint(0, dims.vocab_size, (cfg.batch,), device=dev, generator=g)
@@ -376,7 +378,8 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     res = {"metric": "gpt2_small_decode_tokens_per_sec_end_to_end", "value": cfg.batch * world * args.steps / elapsed,
            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": elapsed / args.steps * 1e3, "context": ctx0, "batch_per_gpu": cfg.batch,
+           "ms_per_step": elapsed / args.steps * 1e3,
+           "context": f"U{{16..{ctx0}}} (mean {float(np.mean(ctxs)):.0f})" if args.e2e_ragged else ctx0, "batch_per_gpu": cfg.batch,
            "data": "synthetic KV + random-init GPT-2 small weights", "dtype": "f16",
            "note": ("12 x (c_attn, paged_attention_v1_append [fused], c_proj, MLP) + lm_head, hipGraph replay, greedy"
                     if args.e2e_fused else
@@ -385,7 +388,7 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
         print(json.dumps(res), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
         res["kv_cache_dtype"] = args.kv
-        with open(os.path.join(REPO, "gpurun_out", "e2e_fused.json" if args.e2e_fused else
+        with open(os.path.join(REPO, "gpurun_out", "e2e_ragged.json" if args.e2e_ragged else "e2e_fused.json" if args.e2e_fused else
                                ("e2e_fp8.json" if args.kv == "fp8" else ("e2e_fp8_e5m2.json" if args.kv == "fp8_e5m2" else "e2e.json"))), "w") as f:
             json.dump(res, f, indent=1)
 
