@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cfg", default="cfg3")
 ap.add_argument("--iters", type=int, default=60)
 ap.add_argument("--batch", type=int, default=0)
+ap.add_argument("--kv", default="auto", choices=["auto", "fp8"])
 args = ap.parse_args()
 
 lib = _lib.load()
@@ -33,10 +34,22 @@ def flags(mode=0, wq=0, nosort=0, team=0):
     return mode | (wq << 2) | (nosort << 11) | (team << 12)
 
 
+def to_fp8(wl):
+    c = wl.cfg
+    g = torch.Generator(device=dev).manual_seed(9)
+    kshape = (c.num_blocks, c.kv_heads, c.head_size // 16, 16, 16)
+    vshape = (c.num_blocks, c.kv_heads, c.head_size, 16)
+    wl.key_cache = (torch.randint(0, 64, kshape, dtype=torch.uint8, device=dev, generator=g)
+                    | (torch.randint(0, 2, kshape, dtype=torch.uint8, device=dev, generator=g) << 7))
+    wl.value_cache = (torch.randint(0, 64, vshape, dtype=torch.uint8, device=dev, generator=g)
+                      | (torch.randint(0, 2, vshape, dtype=torch.uint8, device=dev, generator=g) << 7))
+    return wl
+
+
 def run(wl, out, t, variant):
     c = wl.cfg
     ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.kv_heads, wl.scale, wl.tables[t],
-                           wl.seq_lens, c.block_size, c.seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+                           wl.seq_lens, c.block_size, c.seq_len, None, args.kv, 1.0, 0, 0, 1, 1, 0, _variant=variant)
 
 
 def timeit(wl, out, variant, iters):
@@ -54,13 +67,16 @@ def timeit(wl, out, variant, iters):
 
 
 res = {"cfg": cfg.name, "batch": cfg.batch}
-qnames = [n for n in names if n.startswith(f"q_d{D}_")]
-ref_name = f"d{D}_h4_w1_u1_nt1"
+PRE = "fp8_" if args.kv == "fp8" else ""
+qnames = [n for n in names if n.startswith(f"{PRE}q_d{D}_")]
+ref_name = f"fp8_d{D}_bs16_h4_w1_u1_nt1" if args.kv == "fp8" else f"d{D}_h4_w1_u1_nt1"
 auto_name = None
 for ragged in (False, True, "sorted"):
     wl = make_workload(cfg, dev, seed=0, ragged=ragged)
+    if args.kv == "fp8":
+        to_fp8(wl)
     tag = "rag-sort" if ragged == "sorted" else ("ragged" if ragged else "uniform")
-    kv_bytes = int(wl.seq_lens.sum().item()) * cfg.kv_heads * D * 2 * 2
+    kv_bytes = int(wl.seq_lens.sum().item()) * cfg.kv_heads * D * 2 * (1 if args.kv == "fp8" else 2)
     out_ref = torch.empty((cfg.batch, cfg.num_heads, D), dtype=torch.float16, device=dev)
     run(wl, out_ref, 0, names[ref_name])
     torch.cuda.synchronize()
@@ -68,8 +84,12 @@ for ragged in (False, True, "sorted"):
     rows[ref_name] = timeit(wl, out_ref, names[ref_name], args.iters)
     lib.vmi_debug_set_queue_flags(0)
     rows["default_entry"] = timeit(wl, out_ref, 0, args.iters)
-    hint = lib.vmi_paged_attention_v1_pick_variant_hint(cfg.batch, cfg.num_heads, D, 16, cfg.seq_len,
-                                                        int(wl.seq_lens.float().mean().item()), 0)
+    if args.kv == "fp8":
+        hint = lib.vmi_paged_attention_v1_pick_variant_fp8(cfg.batch, cfg.num_heads, D, 16, cfg.seq_len,
+                                                           int(wl.seq_lens.float().mean().item()))
+    else:
+        hint = lib.vmi_paged_attention_v1_pick_variant_hint(cfg.batch, cfg.num_heads, D, 16, cfg.seq_len,
+                                                            int(wl.seq_lens.float().mean().item()), 0)
     rows["hint:" + lib.vmi_paged_attention_v1_variant_name(hint).decode()] = timeit(wl, out_ref, hint, args.iters)
     run(wl, out_ref, 0, names[ref_name])
     torch.cuda.synchronize()
@@ -99,6 +119,10 @@ for ragged in (False, True, "sorted"):
               f"{r['TBps']:.2f} TB/s  {'' if 'bit_identical' not in r else ('BIT-IDENTICAL' if r['bit_identical'] else 'DIFFERS max|d|=%g' % r['max_abs_diff'])}",
               flush=True)
     res[tag] = {"kv_bytes": kv_bytes, "rows": rows}
+if args.kv == "fp8":
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(res, open(f"gpurun_out/queue_probe_{cfg.name}_b{cfg.batch}_fp8.json", "w"), indent=1)
+    sys.exit(0)
 # ---- where does mode Q start to pay?  other length distributions, full tables (lengths overwritten) ----
 wl = make_workload(cfg, dev, seed=0, ragged=False)
 g = torch.Generator().manual_seed(1)

@@ -341,3 +341,51 @@ def test_two_host_threads_alternate_large_max_seq_len_launches():
     assert not errors, errors
     for k in (0, 1):
         assert_close(results[k], ref, f"thread {k}")
+
+
+@pytest.mark.parametrize("qname,kvd", [("fp8_q_d64_s2q4", "fp8"), ("fp8_q_d64_s1q2", "fp8"), ("fp8e5m2_q_d64_s2q4", "fp8_e5m2"),
+                                       ("fp8_q_d128_s1q2", "fp8")])
+def test_queue_kernel_over_fp8_pages_every_mode(qname, kvd, queue_flags):
+    """fp8 pages (kv_scale 1: every cache element is half(float(fp8)), quant_utils.cuh:295-300) through every mode of the
+    balanced kernel, against the CPU kernel model; single-wave modes agree with each other bit for bit; any other
+    kv_scale is refused for these kernels (the operator's automatic choice then stays with pa_v1_kernel)."""
+    from test_parity_gpu import _fp8_case
+    from vllmini_amd import ops
+
+    dev = _dev()
+    names = _names()
+    D = 128 if "d128" in qname else 64
+    H = 8
+    lens = [1, 16, 17, 100, 333, 47, 700, 2, 0, 1024, 513, 31]
+    rng = np.random.default_rng(4800 + D + len(kvd))
+    case = _fp8_case(rng, len(lens), H, D, lens, 16, num_kv_heads=4)
+    if kvd == "fp8_e5m2":   # E5M2 bytes: keep exponent field <= 15 (|x| < 2) and drop the Inf / NaN codes
+        for key in ("kq", "vq"):
+            a = case[key]
+            case[key] = np.where((a & 0x7f) >= 0x40, (a & 0x80) | 0x38 | (a & 3), a).astype(np.uint8)
+    ref = oracle.paged_attention_v1_fp8(case["q"], case["kq"], case["vq"], 4, case["scale"], case["tables"], case["lens"],
+                                        16, kv_scale=1.0, threads=8, e5m2=kvd == "fp8_e5m2")
+    S = len(lens)
+    q = torch.from_numpy(case["qbuf"]).to(dev)[:, : H * D].view(S, H, D)
+    kq, vq = torch.from_numpy(case["kq"]).to(dev), torch.from_numpy(case["vq"]).to(dev)
+    tab, ln = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
+
+    def attend(variant, kv_scale=1.0):
+        out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v1(out, q, kq, vq, 4, case["scale"], tab, ln, 16, 1024, None, kvd, kv_scale, 0, 0, 1, 1, 0,
+                               _variant=variant)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    solo = None
+    for label, (flags, bitwise) in MODES.items():
+        queue_flags(flags)
+        got = attend(names[qname])
+        queue_flags(0)
+        assert_close(got, ref, f"{qname} [{label}]", vmax=2.0)
+        if bitwise:
+            solo = got if solo is None else solo
+            assert np.array_equal(got.view(np.uint16), solo.view(np.uint16)), f"{qname} [{label}] differs from mode S"
+    with pytest.raises(RuntimeError, match="kv_scale 1"):
+        attend(names[qname], kv_scale=0.5)
+    assert_close(attend(0), ref, "default entry, kv_scale 1", vmax=2.0)

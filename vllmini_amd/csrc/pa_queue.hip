@@ -5,7 +5,9 @@
 namespace vmi {
 
 #define VMI_ROW_Q(NAME, D, BF, US, UQ)                                                                           \
-  {NAME, D, 16, 4, 1, US, true, 1, BF, (pa_kernel_t)pa_q_kernel<D, BF, true, US, UQ>, 0, UQ, 0, 0, false, false, false, true},
+  {NAME, D, 16, 4, 1, US, true, 1, BF, (pa_kernel_t)pa_q_kernel<D, BF, true, US, UQ>, 0, 0, 0, 0, false, false, false, true},
+#define VMI_ROW_Q8(NAME, D, US, UQ, F8) /* fp8 pages (1 = E4M3, 2 = E5M2), float16 query, kv_scale 1 */            \
+  {NAME, D, 16, 4, 1, US, true, 1, false, (pa_kernel_t)pa_q_kernel<D, false, true, US, UQ, F8>, 0, 0, 0, F8, false, false, false, true},
 
 Variant g_queue_variants[] = {
     // head size 64: one block per group when every item has its own wave, two when workers run items in turn
@@ -14,6 +16,12 @@ Variant g_queue_variants[] = {
     // head size 128: twice the registers per block -> one block per group in both modes, 2 workgroups per CU
     VMI_ROW_Q("q_d128_s1q1", 128, false, 1, 1)
     VMI_ROW_Q("bf16_q_d128_s1q1", 128, true, 1, 1)
+    // fp8 pages, kv_scale == 1 (any other scale stays with pa_v1_kernel): a tile is half the bytes, so twice the blocks
+    // per register group keep the bytes in flight where the 16-bit kernels have them
+    VMI_ROW_Q8("fp8_q_d64_s2q4", 64, 2, 4, 1)
+    VMI_ROW_Q8("fp8_q_d64_s1q2", 64, 1, 2, 1)
+    VMI_ROW_Q8("fp8e5m2_q_d64_s2q4", 64, 2, 4, 2)
+    VMI_ROW_Q8("fp8_q_d128_s1q2", 128, 1, 2, 1)
 };
 const int g_queue_nvariants = (int)(sizeof(g_queue_variants) / sizeof(g_queue_variants[0]));
 

@@ -62,15 +62,23 @@ constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at a
 //                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + QSORT_MAX*2 (the
 //                                 clamped lengths) + 4*64*8 (bucket masks)
 //                                 + 8*4 + 4*D*4 (a team's max / sum exchange and partial outputs).
-template <int D, bool BF, bool NT, int US, int UQ>
+template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0>
 // (second launch bound = minimum waves per SIMD: 3 workgroups of 4 waves per CU must all be resident in mode S, i.e.
 //  <= 168 VGPRs; head size 128 — twice the registers per block — runs 2 workgroups per CU, 256 VGPRs)
-__global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) pa_q_kernel(const PAParams p) {
+__global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ? 2 : 3) pa_q_kernel(const PAParams p) {
   constexpr int BS = 16;
-  constexpr int NL = D * BS / 8 / 64;  // 1-KiB loads per (block, head) tile of K — and of V
-  static_assert(D % 32 == 0 && NL >= 1, "head size must fill whole 1-KiB loads");
-  constexpr int UPR = 2;   // V: 16-B units per dim row
-  constexpr int RPL = 32;  // V: rows per load
+  // F8: the pages hold fp8 bytes (1 = E4M3, 2 = E5M2; kv_scale == 1 only — the launcher sends any other scale to
+  // pa_v1_kernel): a 16-byte unit carries 16 elements, a (block, head) tile is D*16 BYTES; every element becomes
+  // half(float(fp8)) first (reference quant_utils.cuh:295-300) — with kv_scale 1 that is the byte's own value
+  constexpr bool E5 = F8 == 2;
+  constexpr int EPU = F8 ? 16 : 8;       // cache elements per 16-byte unit
+  constexpr int ES = F8 ? 1 : 2;         // bytes per cache element
+  constexpr int NL = D * BS / EPU / 64;  // 1-KiB loads per (block, head) tile of K — and of V
+  static_assert((D * BS / EPU) % 64 == 0 && NL >= 1, "a tile must fill whole 1-KiB loads");
+  static_assert(!(F8 && BF), "fp8 pages: float16 query only in these kernels");
+  constexpr int UPR = BS / EPU;  // V: 16-B units per dim row
+  constexpr int RPL = 64 / UPR;  // V: rows per load
+  constexpr int QW = F8 ? 2 : 1;  // 16-byte pieces of q facing one K unit
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* smem_f = reinterpret_cast<float*>(smem);
@@ -91,7 +99,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
   struct Meta {
     int seq, head, L;    // wave-uniform
     int32_t bt;          // lane j: physical id of my block j (first 64 of them; my blocks are sub + j*T)
-    u32x4 q[NL];         // this lane's 8 dims of q facing each K load
+    u32x4 q[NL][QW];     // this lane's EPU dims of q facing each K load
     float slope;
   };
   const int c4 = lane >> 4;  // K: chunk within a load
@@ -104,7 +112,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
     m.L = p.seq_lens[seq];
     const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) m.q[i] = *reinterpret_cast<const u32x4*>(qp + (4 * i + c4) * 8);
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+      for (int w = 0; w < QW; ++w) m.q[i][w] = *reinterpret_cast<const u32x4*>(qp + (4 * i + c4) * EPU + 8 * w);
     m.slope = p.alibi ? p.alibi[head] : 0.f;
   };
 
@@ -227,8 +237,8 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
     meta_issue(cur, s, h, team ? 4 : 1, team ? wave : 0);
   }
 
-  const int hf = lane & 1;     // V: which 8-token group of the block this lane owns
-  const int rowl = lane >> 1;  // V: dim row within a load
+  const int hf = lane % UPR;    // V: which 16-byte unit of the dim row this lane owns
+  const int rowl = lane / UPR;  // V: dim row within a load
 
   // LDS of a team: ONE logits array for the item (region 0), the probabilities behind it (region 1: in place would
   // overwrite slots another wave has not read yet), the max / sum exchange and the waves' partial outputs
@@ -251,8 +261,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
     int32_t bt_reg = 0;  // lane j: physical id of my block bt_sg*64 + j
     int bt_sg = 0;
     const int32_t* bt = nullptr;
-    int64_t hoff = 0;  // this lane's element offset inside a block: kv head tile + lane*8
-    u32x4 qreg[NL];
+    int64_t hoff = 0;  // this lane's BYTE offset inside a block: kv head tile + its 16-byte unit
+    u32x4 qreg[NL][QW];
+    f32x2_t qf[F8 ? NL : 1][8];  // fp8 pages: q as fp32 pairs (v_pk_fma_f32 against the decoded bytes)
     float slope = 0.f;
     uint16_t* outp = nullptr;
 
@@ -265,9 +276,21 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
       bt = p.block_tables + (int64_t)m.seq * p.max_blocks_per_seq;
       bt_reg = m.bt;
       bt_sg = 0;
-      hoff = (int64_t)(m.head / qpk) * p.kv_head_stride + lane * 8;
+      hoff = ((int64_t)(m.head / qpk) * p.kv_head_stride + lane * EPU) * ES;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) qreg[i] = m.q[i];
+      for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int w = 0; w < QW; ++w) qreg[i][w] = m.q[i][w];
+      if constexpr (F8) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const h16x8 qh = __builtin_bit_cast(h16x8, qreg[i][w]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qf[i][4 * w + e] = f32x2_t{(float)qh[2 * e], (float)qh[2 * e + 1]};
+          }
+      }
       slope = m.slope;
       outp = reinterpret_cast<uint16_t*>(p.out) + ((int64_t)m.seq * H + m.head) * D;
     };
@@ -284,16 +307,17 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
       }
     };
     static_assert(64 % UU == 0, "a register group must not straddle two table slices");
-    auto load_group = [&](u32x4(&r)[UU][NL], const h16* cache, int g) {
+    auto load_group = [&](u32x4(&r)[UU][NL], const h16* cache_, int g) {
+      const char* cache = reinterpret_cast<const char*>(cache_);
       table_for(g);
 #pragma unroll
       for (int j = 0; j < UU; ++j) {
         int idx = g * UU + j;
         idx = idx < nmy ? idx : nmy - 1;  // padding slots re-read my last block (never out of bounds)
         const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
-        const h16* blk = cache + phys * p.kv_block_stride + hoff;
+        const char* blk = cache + phys * p.kv_block_stride * ES + hoff;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(blk + i * 512);
+        for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(blk + i * 1024);
       }
     };
 
@@ -307,7 +331,10 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
           const bool masked = token >= L;
           float accv[NL];
 #pragma unroll
-          for (int i = 0; i < NL; ++i) accv[i] = dot8<BF>(qreg[i], r[j][i]);
+          for (int i = 0; i < NL; ++i) {
+            if constexpr (F8) accv[i] = dot16_f8_s1<E5>(qf[i], r[j][i]);
+            else accv[i] = dot8<BF>(qreg[i][0], r[j][i]);
+          }
           float acc = accv[0];
 #pragma unroll
           for (int i = 1; i < NL; ++i) acc += accv[i];
@@ -330,12 +357,23 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
         const int idx = g * UU + j;
         if (idx < nmy) {
           const int b = sub + idx * T;
-          const int token0 = b * BS + hf * 8;
+          const int token0 = b * BS + hf * EPU;
           const bool last = (b == nblk - 1);
           PV8<BF> pv;
           pv.load(*reinterpret_cast<const u32x4_alias*>(pr + token0));
+          if constexpr (F8) {  // a unit is 16 tokens: two 8-token groups, each with its own probability vector
+            PV8<BF> pw;
+            pw.load(*reinterpret_cast<const u32x4_alias*>(pr + token0 + 8));
 #pragma unroll
-          for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
+            for (int i = 0; i < NL; ++i)
+              acc[i] += pv.template dot<MASK>(deq8<true, false, E5>(r[j][i][0], r[j][i][1], 1.f), last, token0, L);
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+              acc[i] += pw.template dot<MASK>(deq8<true, false, E5>(r[j][i][2], r[j][i][3], 1.f), last, token0 + 8, L);
+          } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
+          }
         }
       }
     };
@@ -349,14 +387,14 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
       const int nb2 = (l2 + BS - 1) / BS;
       const int nmy2 = nb2 > sub ? (nb2 - sub + T - 1) / T : 0;
       if (nmy2 <= 0) return;
-      const int64_t hoff2 = (int64_t)(m.head / qpk) * p.kv_head_stride + lane * 8;
+      const int64_t hoff2 = ((int64_t)(m.head / qpk) * p.kv_head_stride + lane * EPU) * ES;
 #pragma unroll
       for (int j = 0; j < UU; ++j) {
         const int idx = j < nmy2 ? j : nmy2 - 1;
         const int64_t phys = __builtin_amdgcn_readlane(m.bt, idx);
-        const h16* blk = p.kc + phys * p.kv_block_stride + hoff2;
+        const char* blk = reinterpret_cast<const char*>(p.kc) + phys * p.kv_block_stride * ES + hoff2;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) rn[j][i] = ld16<NT>(blk + i * 512);
+        for (int i = 0; i < NL; ++i) rn[j][i] = ld16<NT>(blk + i * 1024);
       }
     };
 
@@ -481,7 +519,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
       if constexpr (QMODE) {
         asm volatile("" : "+v"(nxt.bt), "+v"(nxt.L), "+v"(nxt.slope));
 #pragma unroll
-        for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(nxt.q[i]));
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+          for (int w = 0; w < QW; ++w) asm volatile("" : "+v"(nxt.q[i][w]));
       }
 
       // =========================== V pass, last group first ===================================
@@ -512,7 +552,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || UQ >= 4 || D > 64) ? 2 : 3) p
 
       // the two lanes of a row hold its 8-token groups
 #pragma unroll
-      for (int i = 0; i < NL; ++i) acc[i] += __shfl_xor(acc[i], 1);
+      for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int mm = 1; mm < UPR; mm <<= 1) acc[i] += __shfl_xor(acc[i], mm);
       if constexpr (TEAM) {
         if (hf == 0) {
 #pragma unroll

@@ -621,12 +621,23 @@ static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_si
 }
 
 // fp8 cache: a (block, head) tile is half the bytes; measured picks in profiles/r01h_fp8_kv.md
+// unit_scale: the caller's kv_scale is 1 (the balanced fp8 kernels are built for that case only; the pick queries of
+// the C-ABI, which carry no scale, describe the general case)
 static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
-                            int mean_seq_len, bool bf = false, int fmt = 1) {
+                            int mean_seq_len, bool bf = false, int fmt = 1, bool unit_scale = false) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
   while (wph < 16 && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  if (unit_scale && wph == 1 && !bf && block_size == 16 && head_size == 64 &&
+      4.0 * (double)units * max_seq_len * head_size > 256e6 &&  // (2 bytes per token and dim: past the Infinity Cache)
+      3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024) {
+    // full chip, head size 64: the balanced kernel over fp8 pages (pa_queue.hpp) — ragged batches without a hint
+    for (int id = 1; id <= nvariants_v1(); ++id) {
+      const Variant& c = variant_v1(id);
+      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == 2) return id;
+    }
+  }
   if (mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   int v = 0;
@@ -838,7 +849,8 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   } else if (variant == 0) {
     variant = pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size, max_seq_len, bf, f8);
     if (!variant || (append && !app_variant_v1(variant)))
-      variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf, f8)
+      variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf, f8,
+                                      kv_scale == 1.0f && !append)
                    : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, 0, !append);
     // a long max_seq_len may not leave room for several heads' logits in one workgroup's LDS: fall back to one
     // head per workgroup, then to one wave per head (no second copy of the probabilities) before giving up
@@ -874,9 +886,9 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (v.STAGE && (append || bsp || (f8 && kv_scale != 1.0f)))
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (LDS-staging experiment) takes fp16 pages or fp8 E4M3 "
                 "pages with kv_scale 1, without the fused append or block-sparse attention", v.name);
-  if (v.QUEUE && (append || f8 || bsp))
-    return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (balanced kernel) is built for fp16 / bf16 caches, "
-                "without the fused append or block-sparse attention", v.name);
+  if (v.QUEUE && (append || bsp || (f8 && kv_scale != 1.0f)))
+    return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (balanced kernel) takes fp16 / bf16 pages, or fp8 pages "
+                "with kv_scale 1, without the fused append or block-sparse attention", v.name);
   if (v.QUEUE && (int64_t)num_seqs * num_heads > 0x7fffffff)
     return fail(VMI_E_SHAPE, "paged_attention_v1: num_seqs * num_heads = %lld items exceed 2^31",
                 (long long)num_seqs * num_heads);
@@ -960,6 +972,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
       num_seqs <= 65535 && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
     for (int i = 0; i < g_queue_nvariants; ++i)
       if (g_queue_variants[i].D == v.D && g_queue_variants[i].BF == v.BF && g_queue_variants[i].BS == v.BS &&
+          g_queue_variants[i].F8 == v.F8 &&
           2 * variant_lds_bytes(g_queue_variants[i], lpad) <= (size_t)160 * 1024)
         partner = &g_queue_variants[i];
   }
