@@ -191,38 +191,41 @@ __global__ void __launch_bounds__(256)
   const h16* ksrc = key + token * key_stride;
   const h16* vsrc = value + token * value_stride;
   const int n16 = (H * D) >> 4;
+  const int cph = D >> 4;  // 16-dim chunks (lanes) per head
   for (int c = threadIdx.x; c < n16; c += blockDim.x) {
     const int i = c << 4, h = i / D, d = i - h * D;
+    const int cc = d >> 4;  // this lane's chunk within its head
+    // K: the lane's 16 consecutive dims are one 16-byte unit of the tile.
+    // V: the lanes of a head take the rows e*cph + cc (not 16*cc + e), so that store instruction e writes cph CONSECUTIVE
+    // rows of the tile — one 64- or 128-byte piece of a line per token instead of cph pieces of cph lines; and both are
+    // stored NON-TEMPORALLY: dirty partial lines left in L2 are paid for by the attention launch behind this one
+    // (profiles/r02b_call_pair_aftermath.md).
     h16 kv[16], vv[16];
     if constexpr (VEC) {
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
         const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(ksrc + i + 8 * w));
-        const h16x8 b = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(vsrc + i + 8 * w));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          kv[8 * w + e] = a[e];
-          vv[8 * w + e] = b[e];
-        }
+        for (int e = 0; e < 8; ++e) kv[8 * w + e] = a[e];
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        kv[e] = ksrc[i + e];
-        vv[e] = vsrc[i + e];
-      }
+      for (int e = 0; e < 16; ++e) kv[e] = ksrc[i + e];
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) vv[e] = vsrc[h * D + e * cph + cc];
     u32x4 kq = {0u, 0u, 0u, 0u};
-    uint8_t* vdst = vc + ((blk * H + h) * (int64_t)D + d) * BS + off;
+    uint8_t* vdst = vc + ((blk * H + h) * (int64_t)D + cc) * BS + off;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       // bfloat16 rows (quant_utils.cuh:468-478) widen by a 16-bit shift; float16 rows by v_cvt_f32_f16
       const float kf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, kv[e]) << 16) : (float)kv[e];
       const float vf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, vv[e]) << 16) : (float)vv[e];
       kq[e >> 2] |= (E5 ? f32_to_fp8e5m2_satfinite(kf / kv_scale) : f32_to_fp8e4m3_satfinite(kf / kv_scale)) << (8 * (e & 3));
-      vdst[(int64_t)e * BS] = (uint8_t)(E5 ? f32_to_fp8e5m2_satfinite(vf / kv_scale) : f32_to_fp8e4m3_satfinite(vf / kv_scale));
+      __builtin_nontemporal_store((uint8_t)(E5 ? f32_to_fp8e5m2_satfinite(vf / kv_scale) : f32_to_fp8e4m3_satfinite(vf / kv_scale)),
+                                  vdst + (int64_t)(e * cph) * BS);
     }
-    *reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (D >> 4) + (d >> 4)) * BS + off) * 16) = kq;
+    __builtin_nontemporal_store(kq, reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (D >> 4) + (d >> 4)) * BS + off) * 16));
   }
 }
 
