@@ -135,6 +135,9 @@ dists = {
     "half full, half 1/16": torch.where(torch.rand(cfg.batch, generator=g) < 0.5, Lm, Lm // 16),
     "1/8 full, rest 1/8": torch.where(torch.rand(cfg.batch, generator=g) < 0.125, Lm, Lm // 8),
     "exponential mean 1/4": torch.clamp((torch.empty(cfg.batch).exponential_(1.0, generator=g) * Lm / 4).long() + 1, max=Lm),
+    "exponential mean 1/8": torch.clamp((torch.empty(cfg.batch).exponential_(1.0, generator=g) * Lm / 8).long() + 1, max=Lm),
+    "lognormal(5, 1)": torch.clamp(torch.empty(cfg.batch).log_normal_(5.0, 1.0, generator=g).long() + 1, max=Lm),
+    "one full, rest 1/16": torch.where(torch.arange(cfg.batch) < 1, Lm, Lm // 16),
 }
 res["distributions"] = {}
 for dname, lens in dists.items():
