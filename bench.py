@@ -14,8 +14,10 @@ batch 256, seq 1024, block 16, num_blocks 32768), the configuration the metric i
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      achieved = algorithmic bytes of paged_attention_v1 / mean kernel
-                duration from HIP events recorded around every attention launch inside the timed
-                region, on the launch stream; peak = 8000 GB/s (MI355X HBM3E spec)
+                duration from HIP events recorded around the attention launch on every n-th step of the
+                timed region (--event-stride, default: every 4th, at least 5 samples), on the launch
+                stream: an event pair costs the stream 6.5 us (profiles/r02k_event_cost.md), so probing
+                every step would put 5 % of instrumentation into `value`; peak = 8000 GB/s (HBM3E spec)
   cpu_baseline  the reference's CPU fallback — PyTorch eager attention over the gathered pages
                 (oracle/eager.py, restating vllmini/model/gpt2.py:71-78) — timed on this box's host
                 cores on the same synthetic workload (rank 0, N=1 only)
@@ -103,6 +105,10 @@ def parse_args():
                     help="N > 1: weak = 256 sequences per GPU (default), strong = 2048 sequences in all")
     ap.add_argument("--no-ragged", action="store_true", help="skip the extra ragged-batch measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="record the HIP event pair around the attention launch on every n-th timed step (1 = every "
+                         "step; the records are measurement and cost the stream 6.5 us a pair); lowered so that at "
+                         "least 5 launches are probed")
     return ap.parse_args()
 
 
@@ -220,6 +226,9 @@ def exchange_tokens(dist, i=None):
         ev[i][1].record()
 
 
+EVENT_STRIDE = 1
+
+
 def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
     """W untimed steps, then EXACTLY K timed steps between barrier+synchronize pairs
     (vllmini_amd/shard.py:timed_steps — the same code the 2-rank gloo test exercises)."""
@@ -244,14 +253,17 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
         elif op != "fused" and not SKIP_RESHAPE:
             cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache,
                                         wl.slots[(t + 1) % len(wl.tables) if RESHAPE_OTHER else t], KV_DTYPE, 1.0)
-        ev[i][0].record()  # HIP events on the launch stream (torch's current stream)
+        probe = i % EVENT_STRIDE == 0
+        if probe:
+            ev[i][0].record()  # HIP events on the launch stream (torch's current stream)
         attend(wl, out, t, variant, op)
-        ev[i][1].record()
+        if probe:
+            ev[i][1].record()
         exchange_tokens(dist, i)
 
     elapsed = shard.timed_steps(step, steps, warmup, dist,
                                 sync=lambda: torch.cuda.synchronize(dev), timed_step=timed)
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = [a.elapsed_time(b) for i, (a, b) in enumerate(ev) if i % EVENT_STRIDE == 0]
     if dist is not None:
         _EXCHANGE["us"] = statistics.mean(a.elapsed_time(b) for a, b in _EXCHANGE["events"]) * 1e3
         g = _EXCHANGE["gathered"]
@@ -260,7 +272,7 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
     return elapsed, kern_ms
 
 
-def graph_steps(wl, out, steps, variant, dev):
+def graph_steps(wl, out, steps, variant, dev, per_graph=1):
     """The reference's call pair captured ONCE into a hipGraph (one graph per table set) and replayed: the launch
     work the host does per step is one graph launch, so this is the step the GPU can do when the host is out of
     the way.  Returns seconds for `steps` replays."""
@@ -271,19 +283,28 @@ def graph_steps(wl, out, steps, variant, dev):
         for t in range(len(wl.tables)):
             one_step(wl, out, t, variant)
     torch.cuda.current_stream(dev).wait_stream(side)
-    for t in range(len(wl.tables)):
+    if per_graph <= 1:
+        for t in range(len(wl.tables)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step(wl, out, t, variant)
+            graphs.append(g)
+        per_graph = 1
+    else:   # `per_graph` consecutive steps (table sets in the loop's order) in ONE graph
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            one_step(wl, out, t, variant)
+            for t in range(per_graph):
+                one_step(wl, out, t, variant)
         graphs.append(g)
-    for i in range(10):
+    replays = -(-steps // per_graph)
+    for i in range(max(2, 10 // per_graph)):
         graphs[i % len(graphs)].replay()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(replays):
         graphs[i % len(graphs)].replay()
     torch.cuda.synchronize(dev)
-    return time.perf_counter() - t0
+    return (time.perf_counter() - t0) * steps / (replays * per_graph)
 
 
 def pmc_traffic(cfg_name: str, kernel_variant: str):
@@ -455,7 +476,7 @@ def run_matrix(args, base, dev):
 
 
 def main():
-    global KV_DTYPE, SKIP_RESHAPE, RESHAPE_OTHER, NOOP_RESHAPE
+    global KV_DTYPE, SKIP_RESHAPE, RESHAPE_OTHER, NOOP_RESHAPE, EVENT_STRIDE
     args = parse_args()
     RESHAPE_OTHER = args.reshape_other_set
     if not torch.cuda.is_available():
@@ -599,6 +620,7 @@ def main():
         return
 
     SKIP_RESHAPE = args.skip_reshape
+    EVENT_STRIDE = max(1, min(args.event_stride, args.steps // 5))
     if args.hint_mean and not args.variant and args.op in ("v1", "fused"):
         lens_h = wl.seq_lens.cpu()
         args.variant = ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, int(lens_h.max()), cfg.block_size,
@@ -649,6 +671,7 @@ def main():
         "paged_attention_v1_us_per_step": kern_mean_ms * 1e3,
         "paged_attention_v1_us_median": statistics.median(kern_ms) * 1e3,
         "paged_attention_v1_us_min": min(kern_ms) * 1e3,
+        "kernel_event_stride": EVENT_STRIDE, "kernel_event_samples": len(kern_ms),
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,
@@ -705,6 +728,10 @@ def main():
         line["graph_step"] = {"op": "reshape_and_cache + paged_attention_v1 replayed from one hipGraph per table set",
                               "value": cfg.batch * args.steps / g_elapsed, "unit": "tokens/s",
                               "ms_per_step": g_elapsed / args.steps * 1e3}
+        n_sets = len(wl.tables)
+        g_elapsed = graph_steps(wl, out, args.steps, args.variant, dev, per_graph=n_sets)
+        line["graph_step"]["steps_per_graph"] = {"steps": n_sets, "ms_per_step": g_elapsed / args.steps * 1e3,
+                                                 "value": cfg.batch * args.steps / g_elapsed}
     if args.op == "v1" and args.kv == "auto" and not args.no_ragged and not args.ragged and not args.ragged_sorted and \
             not args.variant and not args.sequential_tables:
         # the same call pair, same default entry (no hint, no variant), on a RAGGED batch: seq_lens ~ U{1..seq_len}
