@@ -151,7 +151,8 @@ for dname, lens in dists.items():
                                                         int(wl.seq_lens.float().mean().item()), 0)
     rows["hint:" + lib.vmi_paged_attention_v1_variant_name(hint).decode()] = timeit(wl, out, hint, args.iters)
     qn = f"q_d{D}_s1q2"
-    for label, f in [("auto", flags()), ("S", flags(1)), ("Q_solo", flags(2, 2, 0, 1)), ("Q_team", flags(2, 0, 0, 2))]:
+    for label, f in [("auto", flags()), ("S", flags(1)), ("Q_solo", flags(2, 2, 0, 1)), ("Q_solo_w4", flags(2, 4, 0, 1)),
+                     ("Q_team", flags(2, 0, 0, 2))]:
         lib.vmi_debug_set_queue_flags(f)
         rows[f"{qn}:{label}"] = timeit(wl, out, names[qn], args.iters)
     lib.vmi_debug_set_queue_flags(0)
