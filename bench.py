@@ -632,11 +632,9 @@ def main():
     tokens = cfg.batch * world * args.steps          # one new token per sequence per step
     ms_per_step = elapsed / args.steps * 1e3
     achieved = alg_bytes(cfg) / (kern_mean_ms * 1e-3) / 1e9
-    vid = args.variant or ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len,
-                                           fp8=FP8_ARG[args.kv], num_kv_heads=cfg.kv_heads)
-    vname = ops.variant_names()[vid - 1] if args.op in ("v1", "fused") else f"paged_attention_v2 variant {args.variant or 'auto'}"
-    if args.op == "fused" and not args.variant and not ops.variant_fits(vid, cfg.seq_len, for_append=True):
-        vname = "fused-append twin chosen by the library (the balanced kernels have none)"
+    # the variant the library actually launched (it knows the launch's kv_scale, the pick queries do not)
+    vid = args.variant or (ops.last_variant() if args.op in ("v1", "fused") else 0)
+    vname = ops.variant_names()[vid - 1] if vid else f"paged_attention_v2 variant {args.variant or 'auto'}"
     traffic, traffic_src = (pmc_traffic(cfg.name + {"auto": "", "fp8": "_fp8", "fp8_e5m2": "_fp8_e5m2"}[args.kv], vname) if args.op == "v1" else
                             pmc_traffic(cfg.name + "_fused", vname) if args.op == "fused" else (None, None))
     line = {

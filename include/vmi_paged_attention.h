@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 16
+#define VMI_ABI_VERSION 17
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -352,7 +352,14 @@ int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads,
 int vmi_set_pv_mfma(int32_t on);
 
 /*
- * Test / benchmark knob of the balanced ("q_*") kernels (process-wide, default 0 = automatic; returns the previous
+ * The variant id the calling thread's last paged_attention_v1 launch ran (what `variant == 0` resolved to, or the
+ * explicit one; 0 before the first launch and after a block-sparse one).  For benchmarks and tests that label a
+ * measurement with the kernel that produced it; the pick functions above answer without the launch's kv_scale.
+ */
+int vmi_paged_attention_v1_last_variant(void);
+
+/*
+ * Test / benchmark knob of the balanced ("q_*") kernels (per host thread, default 0 = automatic; returns the previous
  * value): forces their mode, worker count or hand-out policy (bit layout: vllmini_amd/csrc/pa_queue.hpp, QF_*).
  * Results do not depend on it — every mode computes an item with the same operations in the same order — only the
  * schedule does; tests use it to drive every path of the kernel on small inputs.

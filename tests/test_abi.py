@@ -40,7 +40,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 16
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 17
     assert typed.vmi_target_arch() == b"gfx950"
 
 

@@ -209,9 +209,11 @@ def test_queue_kernel_full_size_ragged_cfg3_through_the_default_entry():
         return out
 
     base = attend(wl.query, wl.tables[0], wl.seq_lens)
+    assert ops.variant_names()[ops.last_variant() - 1] == "q_d64_s1q2"     # what the launch really ran
     assert torch.isfinite(base).all()
     assert torch.equal(base, attend(wl.query, wl.tables[0], wl.seq_lens))
     plain = attend(wl.query, wl.tables[0], wl.seq_lens, names["d64_h4_w1_u1_nt1"])
+    assert ops.last_variant() == names["d64_h4_w1_u1_nt1"]
     assert torch.equal(base.view(torch.int16), plain.view(torch.int16))
     perm = torch.randperm(cfg.batch, device=dev)
     permuted = attend(wl.qkv[perm][:, : cfg.num_heads * cfg.head_size].view(cfg.batch, cfg.num_heads, cfg.head_size),

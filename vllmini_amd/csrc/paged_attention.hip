@@ -731,6 +731,7 @@ static int env_int(const char* name) {
 }
 // test / bench knob for the balanced kernels (pa_queue.hpp QF_*); initial value from VMI_QUEUE_FLAGS
 static thread_local int g_queue_flags = env_int("VMI_QUEUE_FLAGS");
+static thread_local int g_last_variant = 0;  // what this thread's last paged_attention_v1 launch ran (0: none yet / block-sparse)
 
 static int device_cus(int device) {  // caller holds the device current
   if (device < 0 || device >= MAX_DEVICES) return 256;
@@ -940,6 +941,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   fill_sparse(p, bsp);
   p.num_seqs = num_seqs;
   p.q_flags = 0;
+  g_last_variant = sparse_v ? 0 : variant;
 
   // the balanced kernel's launch: persistent geometry — as many 4-wave workgroups as stay resident (3 per CU while their
   // LDS fits, 2 for head size 128), never more than one wave per item; the kernel picks its mode from seq_lens
@@ -1476,6 +1478,8 @@ int vmi_set_pv_mfma(int on) {
   vmi::g_pv_mfma = on ? 1 : 0;
   return prev;
 }
+
+int vmi_paged_attention_v1_last_variant(void) { return vmi::g_last_variant; }
 
 int vmi_debug_set_queue_flags(int flags) {
   const int prev = vmi::g_queue_flags;

@@ -492,6 +492,11 @@ def variant_fits(variant: int, max_seq_len: int, for_append: bool = False) -> bo
     return bool(_lib.load().vmi_paged_attention_v1_variant_fits(int(variant), int(max_seq_len), int(bool(for_append))))
 
 
+def last_variant() -> int:
+    """Id of the variant the calling thread's last paged_attention_v1 launch ran (0: none yet / block-sparse)."""
+    return int(_lib.load().vmi_paged_attention_v1_last_variant())
+
+
 def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16,
                  mean_seq_len: int = 0, bf16: bool = False, fp8=False, num_kv_heads: int = 0) -> int:
     """The library's work-decomposition heuristic (what `_variant=0` runs).  A caller that knows the batch's
