@@ -1,0 +1,41 @@
+"""Same-box A/B of two builds of the library: `python scripts/ab_lib_probe.py <path/to/lib.so> [--cfg cfg3]` times the
+default entry on equal and on ragged lengths (HIP events, launches back to back).  Run it alternately with each build."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllmini_amd import build as _build  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("lib")
+ap.add_argument("--cfg", default="cfg3")
+ap.add_argument("--iters", type=int, default=300)
+ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
+args = ap.parse_args()
+_build.LIB_PATH = os.path.abspath(args.lib)
+from vllmini_amd import _lib, ops  # noqa: E402
+from vllmini_amd.workload import CONFIGS, make_workload  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+cfg = CONFIGS[args.cfg]
+lib.vmi_debug_set_queue_flags(args.flags)
+for ragged in (False, True):
+    wl = make_workload(cfg, dev, seed=0, ragged=ragged)
+    out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
+    for i in range(args.iters + 10):
+        if i >= 10:
+            ev[i - 10][0].record()
+        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, cfg.kv_heads, wl.scale,
+                               wl.tables[i % len(wl.tables)], wl.seq_lens, cfg.block_size, cfg.seq_len, None, "auto", 1.0,
+                               0, 0, 1, 1, 0)
+        if i >= 10:
+            ev[i - 10][1].record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    print(f"{os.path.basename(args.lib):32s} flags {args.flags:#x} {'ragged ' if ragged else 'uniform'} mean {sum(ts) / len(ts):7.1f} us  "
+          f"median {ts[len(ts) // 2]:7.1f}  min {ts[0]:7.1f}", flush=True)

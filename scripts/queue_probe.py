@@ -94,7 +94,8 @@ for ragged in (False, True, "sorted"):
     run(wl, out_ref, 0, names[ref_name])
     torch.cuda.synchronize()
     for qn in qnames:
-        for label, f in [("auto", flags()), ("S", flags(1)), ("Q_solo", flags(2, 2, 0, 1)), ("Q_solo_nosort", flags(2, 2, 1, 1)),
+        for label, f in [("auto", flags()), ("S", flags(1)), ("S_earlysort", flags(1) | (1 << 15)), ("Q_solo", flags(2, 2, 0, 1)),
+                         ("Q_solo_earlysort", flags(2, 2, 0, 1) | (1 << 15)), ("Q_solo_nosort", flags(2, 2, 1, 1)),
                          ("Q_team", flags(2, 0, 0, 2)), ("Q_team_nosort", flags(2, 0, 1, 2))]:
             lib.vmi_debug_set_queue_flags(f)
             out = torch.full_like(out_ref, float("nan"))
@@ -151,8 +152,8 @@ for dname, lens in dists.items():
                                                         int(wl.seq_lens.float().mean().item()), 0)
     rows["hint:" + lib.vmi_paged_attention_v1_variant_name(hint).decode()] = timeit(wl, out, hint, args.iters)
     qn = f"q_d{D}_s1q2"
-    for label, f in [("auto", flags()), ("S", flags(1)), ("Q_solo", flags(2, 2, 0, 1)), ("Q_solo_w4", flags(2, 4, 0, 1)),
-                     ("Q_team", flags(2, 0, 0, 2))]:
+    for label, f in [("auto", flags()), ("S", flags(1)), ("Q_solo", flags(2, 2, 0, 1)),
+                     ("Q_solo_earlysort", flags(2, 2, 0, 1) | (1 << 15)), ("Q_team", flags(2, 0, 0, 2))]:
         lib.vmi_debug_set_queue_flags(f)
         rows[f"{qn}:{label}"] = timeit(wl, out, names[qn], args.iters)
     lib.vmi_debug_set_queue_flags(0)

@@ -34,7 +34,8 @@ def _flags(mode=0, wq=0, nosort=0, team=0):
 MODES = {
     "auto": (_flags(), None),                      # whatever the kernel chooses from seq_lens
     "S": (_flags(1), True),                        # one item per wave
-    "Q solo": (_flags(2, 2, 0, 1), True),          # ranked hand-out, 2 workers per workgroup
+    "Q solo": (_flags(2, 2, 0, 1), True),          # first round in index order, the rest ranked; 2 workers per workgroup
+    "Q solo early sort": (_flags(2, 2, 0, 1) | (1 << 15), True),   # everything ranked before the first item
     "Q solo unranked": (_flags(2, 2, 1, 1), True),
     "Q solo 1 worker": (_flags(2, 1, 0, 1), True),
     "Q solo 4 workers": (_flags(2, 4, 0, 1), True),

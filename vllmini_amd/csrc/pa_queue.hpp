@@ -46,6 +46,7 @@
 namespace vmi {
 
 constexpr int QSORT_MAX = 2048;  // sequences ranked in LDS (2 B each); larger batches are served in index order
+constexpr int QLATE_MAX = 512;   // ... ranked by ONE retired wave beside the workers' first items (else by all four, up front)
 
 // q_flags (PAParams): experiment / test knobs; 0 = automatic
 //   bits 0-1  mode      0 auto, 1 force S (when every item has a wave), 2 force Q
@@ -56,6 +57,7 @@ constexpr int QF_MODE(int f) { return f & 3; }
 constexpr int QF_TEAM(int f) { return (f >> 12) & 3; }
 constexpr int QF_WQ(int f) { return (f >> 2) & 7; }
 constexpr int QF_NOSORT = 1 << 11;
+constexpr int QF_EARLYSORT = 1 << 15;  // rank every sequence before the first item (no first round in index order)
 constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at all (with a forced mode)
 
 // grid = (G), block = 256.  LDS = 4*lpad*4 (logits / probabilities, one region per wave) + QSORT_MAX*2 (ranking)
@@ -127,6 +129,12 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     meta_issue(cur, s0, nat_ok ? w_nat - s0 * H : 0, 1, 0);
   }
   const int flags = p.q_flags;
+  // ... and so is the item that would be this wave's FIRST as a solo worker of mode Q: item <worker index>, in INDEX order
+  // (see "first round" below) — two waves per workgroup ask for a table slice and a q they may not need.
+  const int WQd = QF_WQ(flags) ? QF_WQ(flags) : 2;        // solo workers per workgroup
+  const int wq_solo = blockIdx.x * WQd + wave;
+  const int sq0 = wq_solo < N ? wq_solo / H : 0;          // its sequence and head
+  const int hq0 = wq_solo < N ? wq_solo - sq0 * H : 0;
   bool queue = N > nwaves;
   int maxL = 0;
   float sumL = 0.f;
@@ -168,58 +176,71 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   const int nworkers = queue ? (team ? gridDim.x : gridDim.x * WQ) : nwaves;
   const int wq = queue ? (team ? blockIdx.x : blockIdx.x * WQ + wave) : w_nat;  // worker index
 
-  if (queue) {
-    // ---- rank the sequences, longest first: a counting sort with 64 length buckets (bucket k in lane k), index order
-    //      inside a bucket — deterministic, so every workgroup computes the same table for itself.  The four waves
-    //      share the 64-sequence chunks; B <= QSORT_MAX. ----
-    if (ranked) {
-      uint16_t* cnt = order + QSORT_MAX;  // [chunk][bucket]: sequences of the chunk in the bucket
-      const int nch = (B + 63) >> 6;
-      const float bscale = 64.f / (float)(maxL + 1);
-      auto bucket_of = [&](int i) -> int {  // bucket of sequence i (64 = past the end of the batch)
-        if (i >= B) return 64;
-        const int bk = (int)((float)(maxL - (int)len16[i]) * bscale);  // 0 = longest
-        return bk > 63 ? 63 : bk;
-      };
-      // Per chunk: which lanes share my bucket (a 64-bit mask per bucket, built with ONE LDS atomic OR — the result of
-      // an OR does not depend on the order the lanes are served in) and how many sequences each bucket holds.
-      uint64_t* bm = reinterpret_cast<uint64_t*>(order + 3 * QSORT_MAX) + wave * 64;  // this wave's 64 masks
-      auto masks_of = [&](int bk) {
-        bm[lane] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (DS operations of one wave execute in order)
-        if (bk < 64) __hip_atomic_fetch_or(&bm[bk], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      };
-      for (int c = wave; c < nch; c += 4) {
-        masks_of(bucket_of(c * 64 + lane));
-        cnt[c * 64 + lane] = (uint16_t)__popcll(bm[lane]);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      }
-      __syncthreads();
-      int tot = 0;
-      for (int c = 0; c < nch; ++c) tot += cnt[c * 64 + lane];
-      int incl = tot;  // inclusive scan over the buckets
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        incl += lane >= d ? o : 0;
-      }
-      int run = incl - tot;  // lane k: rank of the first sequence of bucket k in the chunk at hand
-      for (int c = 0; c < nch; ++c) {
-        if ((c & 3) == wave) {
-          const int bk = bucket_of(c * 64 + lane);
-          masks_of(bk);
-          const uint64_t same = bm[bk & 63];
-          const int pos = __shfl(run, bk & 63) + __popcll(same & ((1ull << lane) - 1ull));
-          if (bk < 64) order[pos] = (uint16_t)(c * 64 + lane);
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        }
-        run += cnt[c * 64 + lane];
-      }
+  // ---- rank the sequences from index `lo` on, longest first: a counting sort with 64 length buckets (bucket k in lane
+  //      k), index order inside a bucket — deterministic, so every workgroup computes the same table for itself.
+  //      `nsw` waves share the 64-sequence chunks (this one is number `me` of them): all four with a workgroup barrier
+  //      between the passes, or ONE wave on its own, without any barrier.  B <= QSORT_MAX. ----
+  auto rank_sequences = [&](int lo, int me, int nsw) {
+    uint16_t* cnt = order + QSORT_MAX;  // [chunk][bucket]: sequences of the chunk in the bucket
+    const int nch = (B + 63) >> 6;
+    const float bscale = 64.f / (float)(maxL + 1);
+    auto bucket_of = [&](int i) -> int {  // bucket of sequence i (64 = not ranked: before lo or past the end of the batch)
+      if (i >= B || i < lo) return 64;
+      const int bk = (int)((float)(maxL - (int)len16[i]) * bscale);  // 0 = longest
+      return bk > 63 ? 63 : bk;
+    };
+    // Per chunk: which lanes share my bucket (a 64-bit mask per bucket, built with ONE LDS atomic OR — the result of
+    // an OR does not depend on the order the lanes are served in) and how many sequences each bucket holds.
+    uint64_t* bm = reinterpret_cast<uint64_t*>(order + 3 * QSORT_MAX) + wave * 64;  // this wave's 64 masks
+    auto masks_of = [&](int bk) {
+      bm[lane] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (DS operations of one wave execute in order)
+      if (bk < 64) __hip_atomic_fetch_or(&bm[bk], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    };
+    for (int c = me; c < nch; c += nsw) {
+      masks_of(bucket_of(c * 64 + lane));
+      cnt[c * 64 + lane] = (uint16_t)__popcll(bm[lane]);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
-    __syncthreads();
-    if (wave >= WQ) return;  // not a worker in this mode
-  }
+    if (nsw > 1) __syncthreads();
+    int tot = 0;
+    for (int c = 0; c < nch; ++c) tot += cnt[c * 64 + lane];
+    int incl = tot;  // inclusive scan over the buckets
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      incl += lane >= d ? o : 0;
+    }
+    int run = incl - tot;  // lane k: rank of the first sequence of bucket k in the chunk at hand
+    for (int c = 0; c < nch; ++c) {
+      if (c % nsw == me) {
+        const int bk = bucket_of(c * 64 + lane);
+        masks_of(bk);
+        const uint64_t same = bm[bk & 63];
+        const int pos = __shfl(run, bk & 63) + __popcll(same & ((1ull << lane) - 1ull));
+        if (bk < 64) order[pos] = (uint16_t)(c * 64 + lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+      run += cnt[c * 64 + lane];
+    }
+  };
+
+  // ---- solo workers, FIRST ROUND IN INDEX ORDER ("late" ranking).  Ranking everything first puts the sort and one more
+  //      round trip (the ranked first item's table slice and q) in front of a worker's first page.  Instead worker w
+  //      starts with item w as the batch lists them — requested above, before the lengths were even read — and the
+  //      sequences the first round does NOT cover (index >= R0) are ranked meanwhile by one of the waves that retire in
+  //      this mode; the workers look at its table for the first time when their first item's K pass is over (a flag in
+  //      LDS says it is complete).  What the snake needs from the first round is only each worker's place among its
+  //      peers: v = (how many first-round sequences are longer than mine) * H + head.  Round k of the rest then goes by
+  //      v exactly as the snake goes by w: the worker that started with the longest item gets the shortest of the next
+  //      W, and so on.  Needs every first-round sequence to be wholly inside the round (W a multiple of H). ----
+  const int R0 = nworkers / H;
+  const bool late = queue && !team && ranked && WQ < 4 && nworkers % H == 0 && B <= QLATE_MAX && !(flags & QF_EARLYSORT);
+  const bool more = N > nworkers;  // there are rounds after the first
+  volatile uint32_t* sorted = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint64_t*>(order + 3 * QSORT_MAX) + 4 * 64);
+  int vrank = 0;
+
   auto seq_of_rank = [&](int r) -> int {  // wave-uniform
     return ranked ? (int)__builtin_amdgcn_readfirstlane((int)order[r]) : r;
   };
@@ -230,13 +251,6 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     seq = seq_of_rank(r);
   };
 
-  if (wq >= N) return;  // more workers than items (forced modes only)
-  if (queue) {  // first item of worker wq = rank order position wq
-    int s, h;
-    ids_of(wq, s, h);
-    meta_issue(cur, s, h, team ? 4 : 1, team ? wave : 0);
-  }
-
   const int hf = lane % UPR;    // V: which 16-byte unit of the dim row this lane owns
   const int rowl = lane / UPR;  // V: dim row within a load
 
@@ -246,7 +260,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   float* osm = red + 8;                                                                                  // [4][D]
 
   // QMODE = false is mode S: one item, nothing to hand out or to prefetch — compiled without any of that.
-  auto run = [&](auto utag, auto teamtag, auto qtag) {
+  auto run = [&](auto utag, auto teamtag, auto qtag, const Meta& first) {
     constexpr int UU = decltype(utag)::value;
     constexpr bool TEAM = decltype(teamtag)::value;
     constexpr bool QMODE = decltype(qtag)::value;
@@ -268,9 +282,8 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     uint16_t* outp = nullptr;
 
     auto adopt = [&](const Meta& m) {  // make m the current item
-      int l = m.L;
-      l = l > p.lpad ? p.lpad : l;  // seq_len > max_seq_len: truncated to the LDS that was reserved
-      L = __builtin_amdgcn_readfirstlane(l);
+      L = __builtin_amdgcn_readfirstlane(m.L);
+      L = L > p.lpad ? p.lpad : L;  // seq_len > max_seq_len: truncated to the LDS that was reserved
       nblk = (L + BS - 1) / BS;
       nmy = nblk > sub ? (nblk - sub + T - 1) / T : 0;
       bt = p.block_tables + (int64_t)m.seq * p.max_blocks_per_seq;
@@ -399,7 +412,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     };
 
     // ---- first item: its metadata was requested above ----
-    adopt(cur);
+    adopt(first);
     if (nmy > 0) load_group(rn, p.kc, 0);
     int round = 0;  // items this worker has finished
 
@@ -409,13 +422,23 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       bool has_next = false;
       auto fetch_next = [&]() {  // wave-uniform decision + the requests for the next item's metadata
         if constexpr (QMODE) {
-          const int k = round + 1;  // the snake over the ranks
-          const int64_t t64 = (int64_t)k * nworkers + ((k & 1) ? (nworkers - 1 - wq) : wq);
-          has_next = t64 < N;
-          const int t = (int)t64;
           int s, h;
-          ids_of(has_next ? t : 0, s, h);  // requested unconditionally (item 0 when there is no next one): no phi
-          meta_issue(nxt, s, h, T, sub);
+          if (!TEAM && late) {  // the snake over the ranks of the sequences behind the first round, by my place v in it
+            const int64_t t64 = (int64_t)round * nworkers + ((round & 1) ? vrank : nworkers - 1 - vrank);
+            has_next = t64 < N - nworkers;
+            if (has_next && round == 0)  // the retired wave's ranking must be complete before its first use
+              while (*sorted != 1) __builtin_amdgcn_s_sleep(1);
+            const int t = has_next ? (int)t64 : 0;
+            const int r = t / H;
+            h = t - r * H;
+            s = has_next ? (int)__builtin_amdgcn_readfirstlane((int)order[r]) : 0;
+          } else {
+            const int k = round + 1;  // the snake over the ranks
+            const int64_t t64 = (int64_t)k * nworkers + ((k & 1) ? (nworkers - 1 - wq) : wq);
+            has_next = t64 < N;
+            ids_of(has_next ? (int)t64 : 0, s, h);
+          }
+          meta_issue(nxt, s, h, T, sub);  // requested unconditionally (item 0 when there is no next one): no phi
         }
       };
 
@@ -581,9 +604,53 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     }
   };
 
-  if (team) run(std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{});
-  else if (queue) run(std::integral_constant<int, UQ>{}, std::false_type{}, std::true_type{});
-  else run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{});
+  // Mode S goes first, before any of mode Q's preparation: the metadata of its item (requested at the very top) then
+  // lives only as far as here — kept across the ranking code below, the register allocator spilled it, and a kernel with
+  // a private segment is several microseconds slower to DISPATCH (profiles/r02m_scratch_and_dispatch.md).
+  if (!queue) {
+    if (wq >= N) return;
+    run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{}, cur);
+    return;
+  }
+
+  if (queue) {
+    if (!late) {
+      if (ranked) rank_sequences(0, wave, 4);
+      __syncthreads();
+    } else if (more) {
+      if (tid == 0) *sorted = 0;
+      lds_barrier();
+    }
+    if (wave >= WQ) {  // not a worker in this mode
+      if (late && more && wave == WQ) {
+        rank_sequences(R0, 0, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *sorted = 1;
+      }
+      return;
+    }
+  }
+  if (wq >= N) return;  // more workers than items (forced modes only)
+  Meta first;  // (a variable of its own: sharing `cur` with mode S made the two paths' values one register, spilled)
+  if (late) {
+    meta_issue(first, sq0, hq0, 1, 0);  // first item = item wq in index order
+    const int myL = (int)len16[sq0];  // (every wave staged all the lengths itself: no barrier needed)
+    int a = 0;
+    for (int j0 = 0; j0 < R0; j0 += 64) {
+      const int j = j0 + lane;
+      const int lj = j < R0 ? (int)len16[j] : -1;
+      a += (int)__popcll(__ballot(lj > myL || (lj == myL && j < sq0)));
+    }
+    vrank = a * H + hq0;
+  } else if (queue) {  // first item of worker wq = rank order position wq
+    int s, h;
+    ids_of(wq, s, h);
+    meta_issue(first, s, h, team ? 4 : 1, team ? wave : 0);
+  }
+
+
+  if (team) run(std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{}, first);
+  else run(std::integral_constant<int, UQ>{}, std::false_type{}, std::true_type{}, first);
 
 }
 
