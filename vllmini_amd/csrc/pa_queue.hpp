@@ -135,6 +135,8 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   const int wq_solo = blockIdx.x * WQd + wave;
   const int sq0 = wq_solo < N ? wq_solo / H : 0;          // its sequence and head
   const int hq0 = wq_solo < N ? wq_solo - sq0 * H : 0;
+  Meta firstq;
+  if (wave < WQd && !(flags & QF_EARLYSORT)) meta_issue(firstq, sq0, hq0, 1, 0);
   bool queue = N > nwaves;
   int maxL = 0;
   float sumL = 0.f;
@@ -633,7 +635,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   if (wq >= N) return;  // more workers than items (forced modes only)
   Meta first;  // (a variable of its own: sharing `cur` with mode S made the two paths' values one register, spilled)
   if (late) {
-    meta_issue(first, sq0, hq0, 1, 0);  // first item = item wq in index order
+    first = firstq;  // first item = item wq in index order: asked for at the top of the kernel
     const int myL = (int)len16[sq0];  // (every wave staged all the lengths itself: no barrier needed)
     int a = 0;
     for (int j0 = 0; j0 < R0; j0 += 64) {
