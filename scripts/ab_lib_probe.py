@@ -23,8 +23,21 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 cfg = CONFIGS[args.cfg]
 lib.vmi_debug_set_queue_flags(args.flags)
-for ragged in (False, True):
+g = torch.Generator().manual_seed(1)
+Lm = cfg.seq_len
+cases = [("uniform", False, None), ("ragged", True, None),
+         ("1/8 full, rest 1/8", False, torch.where(torch.rand(cfg.batch, generator=g) < 0.125, Lm, Lm // 8)),
+         ("exponential mean 1/4", False,
+          torch.clamp((torch.empty(cfg.batch).exponential_(1.0, generator=g) * Lm / 4).long() + 1, max=Lm)),
+         ("exponential mean 1/8", False,
+          torch.clamp((torch.empty(cfg.batch).exponential_(1.0, generator=g) * Lm / 8).long() + 1, max=Lm)),
+         ("lognormal(5, 1)", False, torch.clamp(torch.empty(cfg.batch).log_normal_(5.0, 1.0, generator=g).long() + 1, max=Lm)),
+         ("lognormal(5.5, 0.7)", False, torch.clamp(torch.empty(cfg.batch).log_normal_(5.5, 0.7, generator=g).long() + 1, max=Lm)),
+         ("one full, rest 1/16", False, torch.where(torch.arange(cfg.batch) < 1, Lm, Lm // 16))]
+for tag, ragged, lens in cases:
     wl = make_workload(cfg, dev, seed=0, ragged=ragged)
+    if lens is not None:
+        wl.seq_lens = lens.to(torch.int32).to(dev)
     out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
     for i in range(args.iters + 10):
@@ -37,5 +50,5 @@ for ragged in (False, True):
             ev[i - 10][1].record()
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
-    print(f"{os.path.basename(args.lib):32s} flags {args.flags:#x} {'ragged ' if ragged else 'uniform'} mean {sum(ts) / len(ts):7.1f} us  "
+    print(f"{os.path.basename(args.lib):32s} flags {args.flags:#x} {tag:22s} mean {sum(ts) / len(ts):7.1f} us  "
           f"median {ts[len(ts) // 2]:7.1f}  min {ts[0]:7.1f}", flush=True)

@@ -236,7 +236,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   //      LDS says it is complete).  What the snake needs from the first round is only each worker's place among its
   //      peers: v = (how many first-round sequences are longer than mine) * H + head.  Round k of the rest then goes by
   //      v exactly as the snake goes by w: the worker that started with the longest item gets the shortest of the next
-  //      W, and so on.  Needs every first-round sequence to be wholly inside the round (W a multiple of H). ----
+  //      W, and so on.  Needs every first-round sequence to be wholly inside the round (W a multiple of H).
+  //      Teams keep the full ranking up front: tried with the team ranking the rest itself under its first pages'
+  //      flight, bimodal batches gained 1.5-2 us and exponential / lognormal ones lost 1-2 (r02m_late_ranking.md). ----
   const int R0 = nworkers / H;
   const bool late = queue && !team && ranked && WQ < 4 && nworkers % H == 0 && B <= QLATE_MAX && !(flags & QF_EARLYSORT);
   const bool more = N > nworkers;  // there are rounds after the first
@@ -607,8 +609,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   };
 
   // Mode S goes first, before any of mode Q's preparation: the metadata of its item (requested at the very top) then
-  // lives only as far as here — kept across the ranking code below, the register allocator spilled it, and a kernel with
-  // a private segment is several microseconds slower to DISPATCH (profiles/r02m_scratch_and_dispatch.md).
+  // lives only as far as here.  Kept across the ranking code below it was spilled and reloaded on the way into the
+  // item, and equal lengths ran 2.7 us slower than in pa_v1_kernel (124.5 -> 121.8 us by HIP events, same box, with
+  // identical hot loops and identical rocprofv3 kernel time: profiles/r02m_late_ranking.md).
   if (!queue) {
     if (wq >= N) return;
     run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{}, cur);
