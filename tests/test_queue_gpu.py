@@ -81,6 +81,30 @@ def test_queue_kernel_every_mode_matches_model_and_single_wave_kernel(D, qname, 
     _check_all_modes(case, qname, f"d{D}_h1_w1_u1_nt1", queue_flags, f"D={D}")
 
 
+@pytest.mark.parametrize("B,H", [(96, 12), (100, 7), (77, 5), (160, 12), (600, 4)])
+def test_queue_kernel_several_rounds_of_solo_workers(B, H, queue_flags):
+    """More items than solo workers, so the hand-out beyond the first round really runs: with a worker count that is a
+    multiple of the head count (first round in index order, the rest ranked by a retired wave: 96x12, 100x7, 160x12 =
+    three rounds and a part), with one that is not (77x5: everything ranked up front), and with more sequences than the
+    late ranking takes (600).  Every row against the kernel model and bit for bit against the one-wave-per-head kernel."""
+    rng = np.random.default_rng(4400 + B)
+    lens = rng.integers(0, 97, B).tolist()
+    lens[3], lens[B // 2] = 200, 0
+    case = make_case(rng, B, H, 64, lens, poison_tail=True)
+    names = _names()
+    ref = run_model(case)
+    plain = run_hip(case, variant=names["d64_h1_w1_u1_nt1"])
+    assert_close(plain, ref, f"B={B} H={H}: plain kernel")
+    for label in ("auto", "Q solo", "Q solo early sort", "Q solo 1 worker", "Q team"):
+        flags, bitwise = MODES[label]
+        queue_flags(flags)
+        got = run_hip(case, variant=names["q_d64_s1q2"])
+        queue_flags(0)
+        assert_close(got, ref, f"B={B} H={H} [{label}]")
+        if bitwise:
+            assert np.array_equal(got.view(np.uint16), plain.view(np.uint16)), f"B={B} H={H} [{label}] differs from the plain kernel"
+
+
 def test_queue_kernel_alibi_gqa_capacity_max_seq_len_and_truncation(queue_flags):
     rng = np.random.default_rng(4300)
     # ALiBi + grouped-query attention (every query head reads its KV head's pages; no tile sharing in these kernels)
