@@ -34,7 +34,7 @@ for batch in (256, 512):
     out = torch.empty((cfg.batch, cfg.num_heads, D), dtype=torch.float16, device=dev)
     variant = names[f"q_d{D}_s1q2"]
     N = batch * cfg.num_heads
-    for label, f, W in (("solo", flags(2, 2, 0, 1), 1536), ("team", flags(2, 0, 0, 2), 768)):
+    for label, f, W in (("solo", flags(2, 2, 0, 1), 1536), ("solo4", flags(2, 4, 0, 1), 3072), ("team", flags(2, 0, 0, 2), 768)):
         lib.vmi_debug_set_queue_flags(f)
         xs, ys = [], []
         for L in (16, 32, 64, 128, 256, 384, 512, 768, 1024):

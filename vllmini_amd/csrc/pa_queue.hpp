@@ -23,6 +23,12 @@
 //                                           K -> V change of the current one and its first K group right after the
 //                                           softmax (third register buffer), so a worker's page stream has no bubble
 //                                           at an item boundary.
+//                                           Solo workers take their FIRST item in index order (requested at the top of
+//                                           the kernel) while a retired wave ranks the rest; 4-wave TEAMS (heavy-tailed
+//                                           batches) rank everything up front.  Both are described where they are coded.
+//
+// Mode S is entered before any of mode Q's preparation code (see the end of the kernel): what lies between the top of
+// the kernel and a mode's first page request is paid by every launch (profiles/r02m_late_ranking.md).
 //
 // Tried and dropped (profiles/r02a_queue_probe_cfg3_ticket_vs_static.log): handing items out through ONE device-scope
 // ticket counter (atomic add per item).  cfg3 ragged: 105 us against 73 us for the static snake, uniform 153 against
@@ -53,6 +59,7 @@ constexpr int QLATE_MAX = 512;   // ... ranked by ONE retired wave beside the wo
 //   bits 2-4  WQ        workers per workgroup in mode Q (0 -> 2)
 //   bit  11   no ranking (index order)
 //   bits 12-13 team     0 auto, 1 force solo workers, 2 force teams (mode Q only)
+//   bit  14   no statistics (with a forced mode)      bit 15   rank everything up front (solo workers too)
 constexpr int QF_MODE(int f) { return f & 3; }
 constexpr int QF_TEAM(int f) { return (f >> 12) & 3; }
 constexpr int QF_WQ(int f) { return (f >> 2) & 7; }
