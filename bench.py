@@ -457,14 +457,13 @@ def run_matrix(args, base, dev):
                         ev[k][1].record()
                 torch.cuda.synchronize(dev)
                 us = statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
-                vid = ops.pick_variant(c.batch, c.num_heads, D, c.seq_len, bs, bf16=kind == "bfloat16",
-                                       fp8={"fp8_kv": True, "fp8_e5m2_kv": "e5m2"}.get(kind, False))
+                vid = ops.last_variant()      # what the launches really ran (0 for the float32 kernels)
                 nbytes = alg_bytes(c)
                 if kind == "float32":            # K and V bytes double
                     nbytes += 2 * c.batch * c.kv_heads * c.seq_len * c.head_size * 2
                 row = {"dtype": kind, "head_size": D, "block_size": bs, "us_median": us,
                        "gbps": nbytes / (us * 1e-6) / 1e9,
-                       "variant": "pa_v1_f32_kernel" if kind == "float32" else ops.variant_names()[vid - 1]}
+                       "variant": "pa_v1_f32_kernel" if kind == "float32" or not vid else ops.variant_names()[vid - 1]}
                 res.append(row)
                 print(json.dumps(row), file=sys.stderr, flush=True)
                 del wl, out
