@@ -96,6 +96,7 @@ for ragged in (False, True, "sorted"):
     for qn in qnames:
         for label, f in [("auto", flags()), ("S", flags(1)), ("S_earlysort", flags(1) | (1 << 15)), ("Q_solo", flags(2, 2, 0, 1)),
                          ("Q_solo_earlysort", flags(2, 2, 0, 1) | (1 << 15)), ("Q_solo_nosort", flags(2, 2, 1, 1)),
+                         ("Q_solo_w4", flags(2, 4, 0, 1)), ("Q_solo_w4_nosort", flags(2, 4, 1, 1)),
                          ("Q_team", flags(2, 0, 0, 2)), ("Q_team_nosort", flags(2, 0, 1, 2))]:
             lib.vmi_debug_set_queue_flags(f)
             out = torch.full_like(out_ref, float("nan"))
