@@ -105,6 +105,7 @@ def parse_args():
                     help="N > 1: weak = 256 sequences per GPU (default), strong = 2048 sequences in all")
     ap.add_argument("--no-ragged", action="store_true", help="skip the extra ragged-batch measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
+    ap.add_argument("--e2e-eager", action="store_true", help="e2e: plain launches instead of hipGraph replay")
     ap.add_argument("--event-stride", type=int, default=4,
                     help="record the HIP event pair around the attention launch on every n-th timed step (1 = every "
                          "step; the records are measurement and cost the stream 6.5 us a pair); lowered so that at "
@@ -392,7 +393,7 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
 
     def step(i):
         nonlocal tok
-        logits = dec.decode(ids, tok, use_graph=True)
+        logits = dec.decode(ids, tok, use_graph=not args.e2e_eager)
         tok = logits.argmax(-1)                       # greedy: stays on the device, no host sync
 
     elapsed = shard.timed_steps(step, args.steps, args.warmup, dist, sync=lambda: torch.cuda.synchronize(dev))
@@ -404,7 +405,8 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
            "data": "synthetic KV + random-init GPT-2 small weights", "dtype": "f16",
            "note": ("12 x (c_attn, paged_attention_v1_append [fused], c_proj, MLP) + lm_head, hipGraph replay, greedy"
                     if args.e2e_fused else
-                    "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy")}
+                    "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy")
+                   .replace("hipGraph replay", "plain launches" if args.e2e_eager else "hipGraph replay")}
     if rank == 0:
         print(json.dumps(res), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
