@@ -2,7 +2,7 @@
 over persistent workers really runs (several rounds, late and early ranking, teams), random length distributions, every
 forced mode and the kernel's own choice.  Each case: all rows bit for bit against the one-wave-per-head kernel (solo
 modes) or within the team tolerance, determinism, and a sample of sequences against the CPU kernel model (checker only).
-`PYTHONPATH=.:tests python tests/soak/soak_queue.py [n_cases] [first_seed]`; exit code 1 if anything failed."""
+`PYTHONPATH=.:tests python tests/soak/soak_queue.py [n_cases] [first_seed] [auto|fp8|mix]`; exit code 1 if anything failed."""
 import sys
 import time
 
@@ -15,6 +15,7 @@ from vllmini_amd import _lib, ops  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
+KV = sys.argv[3] if len(sys.argv) > 3 else "mix"   # "auto" (16-bit pages), "fp8" (E4M3 pages), "mix" (a third fp8)
 dev = torch.device("cuda:0")
 lib = _lib.load()
 names = {n: i + 1 for i, n in enumerate(ops.variant_names())}
@@ -32,7 +33,8 @@ fails = 0
 t0 = time.time()
 for seed in range(first, first + n_cases):
     rng = np.random.default_rng(seed)
-    D = int(rng.choice([64, 64, 128]))
+    f8 = KV == "fp8" or (KV == "mix" and seed % 3 == 0)
+    D = 64 if f8 else int(rng.choice([64, 64, 128]))
     H = int(rng.choice([4, 5, 7, 8, 12, 16] if D == 64 else [4, 8, 12]))
     B = int(rng.integers(40, 700 if D == 64 else 300))
     top = int(rng.choice([48, 130, 300, 520]))
@@ -54,8 +56,14 @@ for seed in range(first, first + n_cases):
     MB = max(int(nblk.max()), 1)
     g = torch.Generator(device=dev).manual_seed(seed)
     NB = need + 5
-    kc = (torch.rand((NB, H, D // 8, BS, 8), device=dev, generator=g) * 2 - 1).to(torch.float16)
-    vc = (torch.rand((NB, H, D, BS), device=dev, generator=g) * 2 - 1).to(torch.float16)
+    if f8:   # E4M3 codes of magnitude < 2, either sign (no NaN codes)
+        kc = (torch.randint(0, 64, (NB, H, D // 16, BS, 16), dtype=torch.uint8, device=dev, generator=g)
+              | (torch.randint(0, 2, (NB, H, D // 16, BS, 16), dtype=torch.uint8, device=dev, generator=g) << 7))
+        vc = (torch.randint(0, 64, (NB, H, D, BS), dtype=torch.uint8, device=dev, generator=g)
+              | (torch.randint(0, 2, (NB, H, D, BS), dtype=torch.uint8, device=dev, generator=g) << 7))
+    else:
+        kc = (torch.rand((NB, H, D // 8, BS, 8), device=dev, generator=g) * 2 - 1).to(torch.float16)
+        vc = (torch.rand((NB, H, D, BS), device=dev, generator=g) * 2 - 1).to(torch.float16)
     q = torch.randn((B, H, D), device=dev, generator=g).to(torch.float16)
     perm = rng.permutation(NB)[:need].astype(np.int32)
     tables = np.full((B, MB), -1, dtype=np.int32)
@@ -71,15 +79,15 @@ for seed in range(first, first + n_cases):
     def attend(variant, fl):
         lib.vmi_debug_set_queue_flags(fl)
         out = torch.full((B, H, D), float("nan"), dtype=torch.float16, device=dev)
-        ops.paged_attention_v1(out, q, kc, vc, H, scale, tab, lens_d, BS, top, None, "auto", 1.0, 0, 0, 1, 1, 0,
-                               _variant=variant)
+        ops.paged_attention_v1(out, q, kc, vc, H, scale, tab, lens_d, BS, top, None, "fp8" if f8 else "auto", 1.0, 0, 0, 1, 1,
+                               0, _variant=variant)
         torch.cuda.synchronize()
         lib.vmi_debug_set_queue_flags(0)
         return out
 
-    plain = attend(names[f"d{D}_h1_w1_u1_nt1"], 0)
-    qn = names[f"q_d{D}_s1q2" if D == 64 else f"q_d{D}_s1q1"]
-    what = f"seed {seed}: B{B} H{H} D{D} top {top} kind {kind}"
+    plain = attend(names["fp8_d64_bs16_h1_w1_u1_nt1" if f8 else f"d{D}_h1_w1_u1_nt1"], 0)
+    qn = names[("fp8_q_d64_s2q4" if seed % 2 else "fp8_q_d64_s1q2") if f8 else (f"q_d{D}_s1q2" if D == 64 else f"q_d{D}_s1q1")]
+    what = f"seed {seed}: B{B} H{H} D{D} top {top} kind {kind}{' fp8' if f8 else ''}"
     ok = bool(torch.isfinite(plain).all())
     nwaves = torch.cuda.get_device_properties(dev).multi_processor_count * (3 if D == 64 else 2) * 4
     for label, fl, bitwise in MODES:
@@ -107,8 +115,9 @@ for seed in range(first, first + n_cases):
     for r, i in enumerate(idx):
         small[r, : nblk[i]] = [remap[int(b)] for b in tables[i, : nblk[i]]]
     bsel = torch.from_numpy(blocks.astype(np.int64)).to(dev)
-    ref = oracle.paged_attention_v1(q[torch.from_numpy(idx).to(dev)].cpu().numpy(), kc[bsel].cpu().numpy(), vc[bsel].cpu().numpy(),
-                                    H, scale, small, lens[idx], BS, threads=8)
+    qs, ks, vs = q[torch.from_numpy(idx).to(dev)].cpu().numpy(), kc[bsel].cpu().numpy(), vc[bsel].cpu().numpy()
+    ref = (oracle.paged_attention_v1_fp8(qs, ks, vs, H, scale, small, lens[idx], BS, kv_scale=1.0) if f8 else
+           oracle.paged_attention_v1(qs, ks, vs, H, scale, small, lens[idx], BS, threads=8))
     d = np.abs(plain.cpu().numpy()[idx].astype(np.float64) - ref.astype(np.float64)).max()
     if not d <= 1e-3:
         print(f"FAIL {what}: plain kernel vs model {d:.3e}")
