@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — decode-step throughput of the MI355X paged-attention hot path.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1: plain python;
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   for N>1)
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 with no WORLD_SIZE in the environment LAUNCHES ITSELF: this process starts N
+ranks of this same file (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_ADDR=127.0.0.1 set), waits for them and
+exits with their status; rank 0 prints the line.  Under `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N ...` the ranks already exist and each simply runs.
 
 One "step" = one decode step of ONE transformer layer's attention over one batch of synthetic
 input, i.e. the reference's per-layer call pair (vllmini/model/gpt2.py:44 then :62):
@@ -12,32 +16,43 @@ through the drop-in Python surface -> C-ABI -> HIP kernels.  Inputs are resident
 the timed region.  Default workload = BASELINE.json configs[2] ("cfg3": GPT-2 small heads,
 batch 256, seq 1024, block 16, num_blocks 32768), the configuration the metric is quoted on.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      achieved = algorithmic bytes of paged_attention_v1 / mean kernel
-                duration from HIP events recorded around the attention launch on every n-th step of the
-                timed region (--event-stride, default: every 4th, at least 5 samples), on the launch
-                stream: an event pair costs the stream 6.5 us (profiles/r02k_event_cost.md), so probing
-                every step would put 5 % of instrumentation into `value`; peak = 8000 GB/s (HBM3E spec)
+Prints ONE JSON line on rank 0 (contract in the task statement).  `value` comes from a timed region that holds
+nothing but the K steps (no event records).  Two extra objects:
+  roofline      achieved = algorithmic bytes of paged_attention_v1 / MEDIAN kernel duration from a
+                separate pass of >= 50 call pairs with a HIP event pair around every attention launch, on the launch
+                stream (--kernel-samples; mean and min are on the line too); for N > 1 the slowest rank's median;
+                peak = 8000 GB/s (HBM3E spec)
   cpu_baseline  the reference's CPU fallback — PyTorch eager attention over the gathered pages
                 (oracle/eager.py, restating vllmini/model/gpt2.py:71-78) — timed on this box's host
-                cores on the same synthetic workload (rank 0, N=1 only)
+                cores on the same synthetic workload (rank 0, after the GPU work), at several thread counts;
+                the best one is `value`, all of them are listed
 
-Beside `value` (never as it): `fused_step` (the pair as one launch), `fp8_kv_step` (fp8 E4M3 pages), `ragged_step`
-(seq_lens ~ U{1..seq_len} through the same default entry: the shape a continuous-batching server produces),
-`graph_step` (the call pair replayed from one hipGraph: what is left when the host is out of the way).
+Beside `value` (never as it), each a sub-record of the same line:
+  fused_step    the call pair as one launch (extension)
+  fp8_kv_step   the call pair over fp8 E4M3 pages
+  ragged_step   seq_lens ~ U{1..seq_len} through the same default entry: what a continuous-batching server produces
+  graph_step    the call pair replayed from one hipGraph (N = 1)
+  cfg4_step     the call pair on BASELINE configs[3] (32 heads x 128, batch 128, seq 2048): ms/step, kernel us, frac
+  e2e_step      GPT-2 small end to end (12 layers + lm_head, random weights, batch 256/GPU, context ~1008) through
+                vllmini_amd.gpt2_decode + kv_pool: decode tokens/s — BASELINE's first metric — and the share of the
+                step spent in the two operators
 
 Multi-GPU: sequences are sharded over ranks as independent KV pools, no collective on the data
 path.  --scaling weak (default): 256 sequences per GPU, pool of 65536 blocks (BASELINE configs[4]); --scaling strong:
 2048 sequences in all, 2048/N per GPU, pool = max(65536, what the batch needs).  For N > 1 every timed step ends
 with the one exchange a decode loop has — the all_gather of the step's sampled token ids (8 B per sequence, RCCL
 over xGMI; vllmini_amd/shard.py:gather_token_ids) — and its share of the step is reported as `token_exchange_us`.
+
+Diagnostic modes (--sweep, --diag, --matrix) live in scripts/bench_diag.py.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -47,13 +62,13 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from vllmini_amd import cache_ops, ops, shard  # noqa: E402
+from vllmini_amd import shard  # noqa: E402
 from vllmini_amd.workload import CONFIGS, make_workload  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def parse_args():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -70,25 +85,29 @@ def parse_args():
                     help="attention operator in the step: paged_attention_v1 (headline) or the split-KV paged_attention_v2")
     ap.add_argument("--variant", type=int, default=0, help="force a kernel work decomposition (0 = heuristic)")
     ap.add_argument("--variant-name", default="", help="the same by kernel name (ops.variant_names())")
-    ap.add_argument("--sweep", action="store_true", help="time every kernel variant, write gpurun_out/sweep.json")
-    ap.add_argument("--diag", action="store_true",
-                    help="report the plain 16-B/lane read bandwidth of this box over the K pool (stderr + gpurun_out/diag.json)")
     ap.add_argument("--e2e", action="store_true",
-                    help="end-to-end GPT-2 small decode (12 layers, random weights) on the batched harness: "
-                         "extra JSON line on stderr + gpurun_out/e2e.json")
+                    help="ONLY the end-to-end GPT-2 small decode (12 layers, random weights) on the batched harness: "
+                         "JSON on stderr + gpurun_out/e2e*.json")
     ap.add_argument("--e2e-fused", action="store_true", help="e2e with one fused append+attention launch per layer")
     ap.add_argument("--e2e-context", type=int, default=1008, help="context length the e2e sequences start at")
     ap.add_argument("--e2e-ragged", action="store_true", help="e2e with contexts ~ U{16..e2e-context} instead of equal ones")
+    ap.add_argument("--e2e-eager", action="store_true", help="e2e: plain launches instead of hipGraph replay")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline call pair: no sub-records, no CPU baseline (what the rocprofv3 passes run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-step measurement")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-KV-cache measurement")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the extra ragged-batch measurement")
+    ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the extra BASELINE configs[3] measurement")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the extra end-to-end GPT-2 measurement")
     ap.add_argument("--noop-instead-of-reshape", action="store_true",
                     help="diagnostic: a 4-byte fill kernel takes reshape_and_cache's place in the step")
     ap.add_argument("--reshape-other-set", action="store_true",
                     help="diagnostic: reshape_and_cache writes the OTHER table set's blocks (no freshly written lines are read)")
     ap.add_argument("--skip-reshape", action="store_true",
                     help="DIAGNOSTIC (invalid as a bench line): attention launches back to back, no reshape_and_cache")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline's thread-count sweep")
     ap.add_argument("--sequential-tables", action="store_true",
                     help="physically sequential pages instead of a random permutation (diagnostic)")
     ap.add_argument("--ragged", action="store_true", help="seq_lens ~ U{1..L} (diagnostic)")
@@ -96,36 +115,90 @@ def parse_args():
     ap.add_argument("--kv", default="auto", choices=["auto", "fp8", "fp8_e5m2"],
                     help="KV cache element type: auto = fp16 (the BASELINE metric); fp8 = E4M3 bytes (diagnostic line, "
                          "SURVEY row f-4)")
-    ap.add_argument("--matrix", action="store_true",
-                    help="attention kernel time for every (head size, block size) of the reference's dispatch set at "
-                         "this config's batch/heads/seq_len, fp16 and bf16 -> gpurun_out/matrix.json (diagnostic)")
     ap.add_argument("--hint-mean", action="store_true",
                     help="pass the batch's mean length to the heuristic (what a host-side scheduler can do)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = 256 sequences per GPU (default), strong = 2048 sequences in all")
-    ap.add_argument("--no-ragged", action="store_true", help="skip the extra ragged-batch measurement")
-    ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
-    ap.add_argument("--e2e-eager", action="store_true", help="e2e: plain launches instead of hipGraph replay")
-    ap.add_argument("--event-stride", type=int, default=4,
-                    help="record the HIP event pair around the attention launch on every n-th timed step (1 = every "
-                         "step; the records are measurement and cost the stream 6.5 us a pair); lowered so that at "
-                         "least 5 launches are probed")
-    return ap.parse_args()
+    ap.add_argument("--kernel-samples", type=int, default=60,
+                    help="launches in the separate kernel-timing pass (HIP event pair around each attention launch); "
+                         "at least 50")
+    ap.add_argument("--standin-cpu", action="store_true",
+                    help="TEST ONLY: run the launch / rendezvous / timing / JSON plumbing on CPU over gloo with a "
+                         "stand-in step (no product kernel runs; the line says so and is not a measurement)")
+    return ap
 
 
-def init_dist(n_gpus: int):
+def parse_args(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_fused = args.no_fp8 = args.no_ragged = args.no_graph = True
+        args.no_cfg4 = args.no_e2e = True
+    args.kernel_samples = max(50, args.kernel_samples)
+    return args
+
+
+# ---- launching N ranks from a plain `python bench.py --gpus N` ------------------------------------------------------
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def needs_self_launch(args, env=os.environ) -> bool:
+    """`--gpus N > 1` started without a launcher: no rank environment exists, so this process becomes the launcher."""
+    return args.gpus > 1 and "WORLD_SIZE" not in env and "RANK" not in env
+
+
+def self_launch(args, argv) -> int:
+    """Start args.gpus ranks of this file, one per GPU index, on 127.0.0.1; rank 0 inherits stdout (the ONE JSON
+    line), the other ranks' stdout goes to stderr.  Returns the first non-zero exit status (0 if all succeed)."""
+    n = args.gpus
+    if not args.standin_cpu:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} but this node shows {have} HIP device(s)", file=sys.stderr)
+            return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VMI_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else sys.stderr.fileno()))
+    status = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0 and status == 0:
+                status = rc
+                for q in alive:            # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+    return status
+
+
+def init_dist(args):
+    """-> (dist or None, rank, world, local_rank, device)."""
+    n_gpus = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu = args.standin_cpu
     if n_gpus > 1 or world > 1 or os.environ.get("VMI_FORCE_DIST") == "1":   # VMI_FORCE_DIST: 1-GPU smoke of the RCCL path
         import torch.distributed as dist
 
         if world != n_gpus:
-            raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                             f"--nproc-per-node {n_gpus}")
+            raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
         # RCCL prints a banner on STDOUT — when the communicator is created and again, with the lazily created
         # communicator of the first all_gather, later on.  stdout must carry exactly ONE JSON line, so fd 1 points at
         # stderr for the whole run and the line goes to the saved descriptor (emit_line).
@@ -133,14 +206,20 @@ def init_dist(n_gpus: int):
         sys.stdout.flush()
         _REAL_STDOUT = os.dup(1)
         os.dup2(2, 1)
+        if cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            return dist, rank, world, local_rank, torch.device("cpu")
+        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,  # "nccl" IS RCCL on ROCm
                                 device_id=torch.device("cuda", local_rank))
         warm = torch.zeros(1, device=torch.device("cuda", local_rank))
         dist.all_reduce(warm)
         torch.cuda.synchronize()
-        return dist, rank, world, local_rank
+        return dist, rank, world, local_rank, torch.device("cuda", local_rank)
+    if cpu:
+        return None, 0, 1, 0, torch.device("cpu")
     torch.cuda.set_device(0)
-    return None, 0, 1, 0
+    return None, 0, 1, 0, torch.device("cuda", 0)
 
 
 _REAL_STDOUT = None
@@ -156,23 +235,29 @@ def emit_line(line: dict) -> None:
         os.write(_REAL_STDOUT, text.encode())
 
 
+# ---- the step ---------------------------------------------------------------------------------------------------------
+
 _V2_SCRATCH = {}
 SKIP_RESHAPE = False
 KV_DTYPE = "auto"      # "fp8" / "fp8_e5m2": byte caches in the x = 16 layout (--kv)
 KV_PREFIX = {"auto": "", "fp8": "fp8_", "fp8_e5m2": "fp8e5m2_"}          # variant-name prefixes
 FP8_ARG = {"auto": False, "fp8": True, "fp8_e5m2": "e5m2"}               # ops.pick_variant(fp8=...)
 KV_LABEL = {"auto": "fp16", "fp8": "fp8 E4M3", "fp8_e5m2": "fp8 E5M2"}
+RESHAPE_OTHER = False
+NOOP_RESHAPE = None
 
 
-def alg_bytes(cfg):
+def alg_bytes(cfg, kv=None):
     """Algorithmic bytes per attention launch; an fp8 cache halves the K/V term."""
     b = cfg.algorithmic_bytes()
-    if KV_DTYPE.startswith("fp8"):
+    if (kv or KV_DTYPE).startswith("fp8"):
         b -= 2 * cfg.batch * cfg.kv_heads * cfg.seq_len * cfg.head_size
     return b
 
 
 def attend(wl, out, t, variant, op="v1"):
+    from vllmini_amd import ops
+
     c = wl.cfg
     if op == "fused":   # reshape_and_cache + paged_attention_v1 in one launch (extension, include/vmi_paged_attention.h)
         ops.paged_attention_v1_append(out, wl.query, wl.key, wl.value, wl.key_cache, wl.value_cache, c.kv_heads,
@@ -195,18 +280,21 @@ def attend(wl, out, t, variant, op="v1"):
                            0, 0, 1, 1, 0, _variant=variant)
 
 
-RESHAPE_OTHER = False
-NOOP_RESHAPE = None
+def scatter(wl, t, op="v1"):
+    """reshape_and_cache of the step (gpt2.py:44) — or its diagnostic stand-ins."""
+    from vllmini_amd import cache_ops
 
-
-def one_step(wl, out, i, variant, op="v1"):
-    """The reference's per-layer decode call pair, in its call order (gpt2.py:44, :62)."""
-    t = i % len(wl.tables)
     if NOOP_RESHAPE is not None:
         NOOP_RESHAPE.fill_(1.0)
     elif op != "fused" and not SKIP_RESHAPE:
         cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache,
                                     wl.slots[(t + 1) % len(wl.tables) if RESHAPE_OTHER else t], KV_DTYPE, 1.0)
+
+
+def one_step(wl, out, i, variant, op="v1"):
+    """The reference's per-layer decode call pair, in its call order (gpt2.py:44, :62)."""
+    t = i % len(wl.tables)
+    scatter(wl, t, op)
     attend(wl, out, t, variant, op)
 
 
@@ -218,59 +306,71 @@ def exchange_tokens(dist, i=None):
     all ranks.  Synthetic ids here; the all_gather is the real one."""
     if dist is None:
         return
-    ev = _EXCHANGE.get("events")
-    if ev is not None and i is not None:
-        ev[i][0].record()
     _EXCHANGE["gathered"] = shard.gather_token_ids(_EXCHANGE["ids"], _EXCHANGE["global_batch"], dist,
                                                    out=_EXCHANGE["out"])
-    if ev is not None and i is not None:
-        ev[i][1].record()
 
 
-EVENT_STRIDE = 1
+def setup_exchange(batch, dist, dev):
+    if dist is None:
+        return
+    world, rank = dist.get_world_size(), dist.get_rank()
+    _EXCHANGE["global_batch"] = batch * world
+    _EXCHANGE["ids"] = torch.arange(rank * batch, (rank + 1) * batch, dtype=torch.int64, device=dev)
+    _EXCHANGE["out"] = torch.empty(batch * world, dtype=torch.int64, device=dev)
+
+
+def device_sync(dev):
+    return (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else None
 
 
 def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
     """W untimed steps, then EXACTLY K timed steps between barrier+synchronize pairs
-    (vllmini_amd/shard.py:timed_steps — the same code the 2-rank gloo test exercises)."""
-    c = wl.cfg
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    if dist is not None:
-        world, rank = dist.get_world_size(), dist.get_rank()
-        _EXCHANGE["global_batch"] = c.batch * world
-        _EXCHANGE["ids"] = torch.arange(rank * c.batch, (rank + 1) * c.batch, dtype=torch.int64, device=dev)
-        _EXCHANGE["out"] = torch.empty(c.batch * world, dtype=torch.int64, device=dev)
-        _EXCHANGE["events"] = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                               for _ in range(steps)]
+    (vllmini_amd/shard.py:timed_steps — the same code the 2-rank gloo test exercises).  The timed region holds the
+    steps and, for N > 1, the per-step token exchange: no event records, no host reads."""
+    setup_exchange(wl.cfg.batch, dist, dev)
 
     def step(i):
         one_step(wl, out, i, variant, op)
         exchange_tokens(dist)
 
-    def timed(i):
-        t = i % len(wl.tables)
-        if NOOP_RESHAPE is not None:
-            NOOP_RESHAPE.fill_(1.0)
-        elif op != "fused" and not SKIP_RESHAPE:
-            cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache,
-                                        wl.slots[(t + 1) % len(wl.tables) if RESHAPE_OTHER else t], KV_DTYPE, 1.0)
-        probe = i % EVENT_STRIDE == 0
-        if probe:
-            ev[i][0].record()  # HIP events on the launch stream (torch's current stream)
-        attend(wl, out, t, variant, op)
-        if probe:
-            ev[i][1].record()
-        exchange_tokens(dist, i)
-
-    elapsed = shard.timed_steps(step, steps, warmup, dist,
-                                sync=lambda: torch.cuda.synchronize(dev), timed_step=timed)
-    kern_ms = [a.elapsed_time(b) for i, (a, b) in enumerate(ev) if i % EVENT_STRIDE == 0]
+    elapsed = shard.timed_steps(step, steps, warmup, dist, sync=device_sync(dev))
     if dist is not None:
-        _EXCHANGE["us"] = statistics.mean(a.elapsed_time(b) for a, b in _EXCHANGE["events"]) * 1e3
         g = _EXCHANGE["gathered"]
         assert g.numel() == _EXCHANGE["global_batch"] and int(g[0]) == 0 and int(g[-1]) == g.numel() - 1
-        _EXCHANGE["events"] = None
-    return elapsed, kern_ms
+    return elapsed
+
+
+def kernel_pass(wl, out, n, variant, dev, op="v1", warm=5):
+    """Separate measurement pass: n call pairs with a HIP event pair around every attention launch, on the launch
+    stream (torch's current stream is the one ops.py launches on).  -> list of n durations in ms."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i in range(warm):
+        one_step(wl, out, i, variant, op)
+    for i in range(n):
+        t = i % len(wl.tables)
+        scatter(wl, t, op)
+        ev[i][0].record()
+        attend(wl, out, t, variant, op)
+        ev[i][1].record()
+    torch.cuda.synchronize(dev)
+    return [a.elapsed_time(b) for a, b in ev]
+
+
+def exchange_pass(n, dist, dev):
+    """Median duration of the token all_gather alone (event pair around each of n exchanges), us."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        exchange_tokens(dist)
+        b.record()
+    torch.cuda.synchronize(dev)
+    return statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
+
+
+def kernel_stats(kern_ms, dist, dev):
+    """mean / median / min of one rank's samples; for N > 1 the slowest rank's figure of each."""
+    return {k: shard.max_over_ranks(f(kern_ms), dist, dev) * 1e3
+            for k, f in (("mean", statistics.mean), ("median", statistics.median), ("min", min))}
 
 
 def graph_steps(wl, out, steps, variant, dev, per_graph=1):
@@ -325,56 +425,90 @@ def pmc_traffic(cfg_name: str, kernel_variant: str):
         return None, None
 
 
-def cpu_baseline(wl, steps):
-    """Reference CPU fallback: eager attention (gather by block_tables -> matmul/softmax/matmul)."""
+# ---- the CPU baseline -------------------------------------------------------------------------------------------------
+
+def physical_cores() -> int:
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_thread_candidates(logical: int, physical: int) -> list:
+    """Thread counts the baseline tries: 8 (what BASELINE.md §3 was measured on), a quarter / half / all of the
+    physical cores, and every logical CPU (round 2's only setting)."""
+    cand = {8, 16, physical // 4, physical // 2, physical, logical}
+    return sorted(c for c in cand if 1 <= c <= logical)
+
+
+def cpu_baseline(wl, budget_s: float):
+    """Reference CPU fallback: eager attention (gather by block_tables -> matmul/softmax/matmul), fp32, on the host
+    cores.  One warm-up + timed steps at each thread count; `value` is the best count's median."""
     from oracle.eager import torch_eager_decode  # checker/baseline only; never on the product path
 
     c = wl.cfg
-    torch.set_num_threads(os.cpu_count() or 1)
     kc, vc = wl.key_cache.cpu(), wl.value_cache.cpu()
     q = wl.query.cpu().contiguous()
     tab = wl.tables[0].cpu()
-    # bound the sample to ~10-30 s of CPU work: time one step, then decide how many to run
-    t0 = time.perf_counter()
-    torch_eager_decode(q, kc, vc, wl.scale, tab, c.seq_len, dtype=torch.float32)
-    first = time.perf_counter() - t0
-    n = max(1, min(steps, int(20.0 / max(first, 1e-3))))
-    ts = []
-    for _ in range(n):
+    logical, physical = os.cpu_count() or 1, physical_cores()
+
+    def run():
         t0 = time.perf_counter()
         torch_eager_decode(q, kc, vc, wl.scale, tab, c.seq_len, dtype=torch.float32)
-        ts.append(time.perf_counter() - t0)
-    med = statistics.median(ts)
+        return time.perf_counter() - t0
+
+    tried = {}
+    cands = cpu_thread_candidates(logical, physical)
+    per = budget_s * 0.6 / len(cands)
+    for n in cands:
+        torch.set_num_threads(n)
+        first = run()                                           # warm-up (page faults, thread pool start)
+        reps = max(1, min(3, int((per - first) / max(first, 1e-3))))
+        tried[n] = statistics.median(run() for _ in range(reps))
+    best = min(tried, key=tried.get)
+    torch.set_num_threads(best)
+    reps = max(3, min(7, int(budget_s * 0.4 / max(tried[best], 1e-3))))
+    ts = [run() for _ in range(reps)]
+    med = min(statistics.median(ts), tried[best])
     return {
-        "value": c.batch / med, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "value": c.batch / med, "unit": "tokens/s", "cores": best, "kind": "port",
         "ms_per_step": med * 1e3,
+        "threads_tried": {str(n): round(t * 1e3, 1) for n, t in tried.items()},
+        "host": {"logical_cpus": logical, "physical_cores": physical},
+        "ms_per_step_all_logical_cpus": tried.get(logical, float("nan")) * 1e3,
         "sample": f"full {c.name} batch ({c.batch} seqs x {c.seq_len} tokens, H{c.num_heads} D{c.head_size}), "
-                  f"fp32 torch eager incl. page gather, median of {n} steps after 1 warm-up, "
-                  f"{torch.get_num_threads()} threads",
+                  f"fp32 torch eager incl. page gather, median of {reps} steps at the best of {len(cands)} thread "
+                  f"counts ({best} threads); every count: 1 warm-up + up to 3 steps",
     }
 
 
-def run_e2e(args, dist, rank, world, local_rank, dev):
+# ---- end to end (GPT-2 small over the batched harness) ----------------------------------------------------------------
+
+def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragged=False, eager=False,
+                ctx0=1008, operator_share=True):
     """GPT-2 small, `batch` sequences per GPU at ~seq_len context, one token per sequence per step,
     through vllmini_amd.gpt2_decode (hipGraph replay of the whole step).  KV is synthetic: pages are
     filled with random fp16 and sequences are registered at the target context length."""
     import numpy as np
 
+    from vllmini_amd import cache_ops, ops
     from vllmini_amd.gpt2_decode import GPT2Dims, GPT2PagedDecoder, random_state_dict
     from vllmini_amd.kv_pool import PagedKVPool
 
-    cfg = CONFIGS[args.config]
     # GPT-2 small with the position table extended past 1024 so contexts can cross seq_len 1024
     dims = GPT2Dims(n_positions=2048)
     assert (cfg.num_heads, cfg.head_size) == (dims.n_head, dims.head_size)
-    ctx0 = args.e2e_context
     total_steps = args.warmup + args.steps + 2
     mb = -(-(ctx0 + total_steps) // cfg.block_size) + 1
     blocks_needed = cfg.batch * dims.n_layer * (mb - 1)
     pool = PagedKVPool(blocks_needed + 64, dims.n_head, dims.head_size, cfg.block_size, mb, dims.n_layer, device=dev,
-                       max_seqs=cfg.batch, multi_block_prefill=True, kv_cache_dtype=args.kv)
+                       max_seqs=cfg.batch, multi_block_prefill=True, kv_cache_dtype=kv)
     g = torch.Generator(device=dev).manual_seed(7 + rank)
-    if args.kv.startswith("fp8"):      # random E4M3 / E5M2 codes of magnitude < 2 (codes 0..63 in either format)
+    if kv.startswith("fp8"):      # random E4M3 / E5M2 codes of magnitude < 2 (codes 0..63 in either format)
         for c in (pool.key_cache, pool.value_cache):
             c.copy_(torch.randint(0, 64, c.shape, dtype=torch.uint8, device=dev, generator=g)
                     | (torch.randint(0, 2, c.shape, dtype=torch.uint8, device=dev, generator=g) << 7))
@@ -384,109 +518,142 @@ def run_e2e(args, dist, rank, world, local_rank, dev):
     # shuffle the free list so pages are scattered like a long-running pool's
     perm = np.random.default_rng(rank).permutation(pool.num_blocks)
     pool.free_blocks = perm.tolist()
-    ctxs = np.random.default_rng(100 + rank).integers(16, ctx0 + 1, cfg.batch) if args.e2e_ragged else [ctx0] * cfg.batch
+    ctxs = np.random.default_rng(100 + rank).integers(16, ctx0 + 1, cfg.batch) if ragged else [ctx0] * cfg.batch
     for s in range(cfg.batch):
         pool.allocate_for_prefill(s, int(ctxs[s]))   # bookkeeping only: the pages already hold synthetic KV
-    dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, fused_append=args.e2e_fused)
+    dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, fused_append=fused)
     ids = list(range(cfg.batch))
     tok = torch.randint(0, dims.vocab_size, (cfg.batch,), device=dev, generator=g)
 
     def step(i):
         nonlocal tok
-        logits = dec.decode(ids, tok, use_graph=not args.e2e_eager)
+        logits = dec.decode(ids, tok, use_graph=not eager)
         tok = logits.argmax(-1)                       # greedy: stays on the device, no host sync
 
-    elapsed = shard.timed_steps(step, args.steps, args.warmup, dist, sync=lambda: torch.cuda.synchronize(dev))
+    elapsed = shard.timed_steps(step, args.steps, args.warmup, dist, sync=device_sync(dev))
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    note = ("12 x (c_attn, paged_attention_v1_append [fused], c_proj, MLP) + lm_head, hipGraph replay, greedy" if fused else
+            "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy")
     res = {"metric": "gpt2_small_decode_tokens_per_sec_end_to_end", "value": cfg.batch * world * args.steps / elapsed,
            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3,
-           "context": f"U{{16..{ctx0}}} (mean {float(np.mean(ctxs)):.0f})" if args.e2e_ragged else ctx0, "batch_per_gpu": cfg.batch,
-           "data": "synthetic KV + random-init GPT-2 small weights", "dtype": "f16",
-           "note": ("12 x (c_attn, paged_attention_v1_append [fused], c_proj, MLP) + lm_head, hipGraph replay, greedy"
-                    if args.e2e_fused else
-                    "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy")
-                   .replace("hipGraph replay", "plain launches" if args.e2e_eager else "hipGraph replay")}
+           "context": f"U{{16..{ctx0}}} (mean {float(np.mean(ctxs)):.0f})" if ragged else ctx0, "batch_per_gpu": cfg.batch,
+           "data": "synthetic KV + random-init GPT-2 small weights", "dtype": "f16", "kv_cache_dtype": kv,
+           "note": note.replace("hipGraph replay", "plain launches" if eager else "hipGraph replay")}
+    if operator_share and not fused:
+        # the two operators alone on the decoder's own buffers: the 12 layers' call pairs back to back (the tables,
+        # slots and lengths of the last step, a [B, 3E] projection output as q/k/v), one event pair around the chain
+        st = dec._static
+        E, H, D = dims.n_embd, dims.n_head, dims.head_size
+        qkv = torch.randn((cfg.batch, 3 * E), dtype=torch.float16, device=dev, generator=g)
+        q, k, v = (qkv[:, i * E:(i + 1) * E].view(cfg.batch, H, D) for i in range(3))
+        out = torch.empty((cfg.batch, H, D), dtype=torch.float16, device=dev)
+        var = st.get("variant", 0)
+        n = 24
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for j in range(n + 2):
+            if j >= 2:
+                ev[j - 2][0].record()
+            for i in range(dims.n_layer):
+                cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i], kv, pool.kv_scale)
+                ops.paged_attention_v1(out, q, pool.key_cache, pool.value_cache, H, dec.scale, st["tables"][i],
+                                       st["seq_lens"], pool.block_size, dec.max_seq_len, None, kv, pool.kv_scale,
+                                       0, 0, 1, 1, 0, _variant=var)
+            if j >= 2:
+                ev[j - 2][1].record()
+        torch.cuda.synchronize(dev)
+        chain_ms = shard.max_over_ranks(statistics.median(a.elapsed_time(b) for a, b in ev), dist, dev)
+        res["operators_ms_per_step"] = chain_ms
+        res["operators_share_of_step"] = chain_ms / res["ms_per_step"]
+        res["operators_note"] = (f"{dims.n_layer} x (reshape_and_cache + paged_attention_v1) on the decoder's own pool, "
+                                 f"tables and lengths, launched back to back; median of {n} chains by HIP events")
+    del dec, pool
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_e2e(args, cfg, dist, rank, world, dev):
+    res = e2e_measure(args, cfg, dist, rank, world, dev, kv=args.kv, fused=args.e2e_fused, ragged=args.e2e_ragged,
+                      eager=args.e2e_eager, ctx0=args.e2e_context)
     if rank == 0:
         print(json.dumps(res), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-        res["kv_cache_dtype"] = args.kv
-        with open(os.path.join(REPO, "gpurun_out", "e2e_ragged.json" if args.e2e_ragged else "e2e_fused.json" if args.e2e_fused else
-                               ("e2e_fp8.json" if args.kv == "fp8" else ("e2e_fp8_e5m2.json" if args.kv == "fp8_e5m2" else "e2e.json"))), "w") as f:
+        name = "e2e_ragged.json" if args.e2e_ragged else "e2e_fused.json" if args.e2e_fused else \
+            {"fp8": "e2e_fp8.json", "fp8_e5m2": "e2e_fp8_e5m2.json"}.get(args.kv, "e2e.json")
+        with open(os.path.join(REPO, "gpurun_out", name), "w") as f:
             json.dump(res, f, indent=1)
 
 
-def run_matrix(args, base, dev):
-    """Every (head size, block size, element type / cache type) the operators are built for, at base's
-    batch/heads/seq_len: fp16, bf16, float32, and fp16 query over fp8 E4M3 / E5M2 caches."""
-    import dataclasses
+# ---- the stand-in (tests of the launch path on CPU) -------------------------------------------------------------------
 
-    global KV_DTYPE
-    res = []
-    for kind in ("float16", "bfloat16", "fp8_kv", "fp8_e5m2_kv", "float32"):
-        dt = {"bfloat16": torch.bfloat16, "float32": torch.float32}.get(kind, torch.float16)
-        for D in (64, 80, 96, 112, 128, 192, 256):
-            for bs in (8, 16, 32):
-                if kind.startswith("fp8") and bs == 8:
-                    continue
-                per = -(-base.seq_len // bs)
-                c = dataclasses.replace(base, name=f"m_d{D}_bs{bs}", head_size=D, block_size=bs,
-                                        num_blocks=2 * base.batch * per + 8)
-                wl = make_workload(c, dev, seed=5, table_sets=2)
-                KV_DTYPE = "auto"
-                if kind == "bfloat16":
-                    wl.key_cache, wl.value_cache, wl.qkv = (wl.key_cache.to(dt), wl.value_cache.to(dt), wl.qkv.to(dt))
-                elif kind == "float32":          # x = 4 layout: same bytes per chunk, half the elements
-                    wl.key_cache = torch.empty((c.num_blocks, c.num_heads, D // 4, bs, 4), dtype=dt, device=dev).uniform_(-1, 1)
-                    wl.value_cache = torch.empty((c.num_blocks, c.num_heads, D, bs), dtype=dt, device=dev).uniform_(-1, 1)
-                    wl.qkv = wl.qkv.to(dt)
-                elif kind.startswith("fp8"):
-                    KV_DTYPE = "fp8" if kind == "fp8_kv" else "fp8_e5m2"
-                    gk = torch.Generator(device=dev).manual_seed(3)
-                    ks = (c.num_blocks, c.num_heads, D // 16, bs, 16)
-                    vs = (c.num_blocks, c.num_heads, D, bs)
-                    wl.key_cache = torch.randint(0, 64, ks, dtype=torch.uint8, device=dev, generator=gk)
-                    wl.value_cache = torch.randint(0, 64, vs, dtype=torch.uint8, device=dev, generator=gk)
-                out = torch.empty((c.batch, c.num_heads, D), dtype=dt, device=dev)
-                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-                for i in range(args.warmup + args.steps):
-                    t = i % len(wl.tables)
-                    k = i - args.warmup
-                    if k >= 0:
-                        ev[k][0].record()
-                    attend(wl, out, t, 0)
-                    if k >= 0:
-                        ev[k][1].record()
-                torch.cuda.synchronize(dev)
-                us = statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
-                vid = ops.last_variant()      # what the launches really ran (0 for the float32 kernels)
-                nbytes = alg_bytes(c)
-                if kind == "float32":            # K and V bytes double
-                    nbytes += 2 * c.batch * c.kv_heads * c.seq_len * c.head_size * 2
-                row = {"dtype": kind, "head_size": D, "block_size": bs, "us_median": us,
-                       "gbps": nbytes / (us * 1e-6) / 1e9,
-                       "variant": "pa_v1_f32_kernel" if kind == "float32" or not vid else ops.variant_names()[vid - 1]}
-                res.append(row)
-                print(json.dumps(row), file=sys.stderr, flush=True)
-                del wl, out
-                torch.cuda.empty_cache()
-    KV_DTYPE = "auto"
-    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(REPO, "gpurun_out", "matrix.json"), "w") as f:
-        json.dump({"batch": base.batch, "num_heads": base.num_heads, "seq_len": base.seq_len, "rows": res}, f, indent=1)
+def standin_main(args, dist, rank, world, dev):
+    """--standin-cpu: everything around the kernels — self-launch, rendezvous, barrier-bracketed timing, max over ranks,
+    token exchange, one JSON line on rank 0's stdout — with a stand-in step on CPU tensors over gloo.  No product
+    kernel runs and the line says so: it exists for tests/test_bench_launch.py, never as a measurement."""
+    batch = 8
+    x = torch.ones(batch, 64)
+    setup_exchange(batch, dist, dev)
+
+    def step(i):
+        x.mul_(1.0)
+        exchange_tokens(dist)
+
+    elapsed = shard.max_over_ranks(shard.timed_steps(step, args.steps, args.warmup, dist), dist, dev)
+    if dist is not None:
+        g = _EXCHANGE["gathered"]
+        assert g.numel() == batch * world and int(g[-1]) == g.numel() - 1
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        emit_line({"metric": "STAND-IN (launch-path test, not a measurement)", "value": batch * world * args.steps / elapsed,
+                   "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+                   "vs_baseline": None, "dtype": "f32", "data": "stand-in",
+                   "config": {"workload": "stand-in step on CPU over gloo", "global_batch": batch * world},
+                   "roofline": None, "cpu_baseline": None,
+                   "self_launched": os.environ.get("VMI_BENCH_SELF_LAUNCHED") == "1"})
 
 
-def main():
-    global KV_DTYPE, SKIP_RESHAPE, RESHAPE_OTHER, NOOP_RESHAPE, EVENT_STRIDE
-    args = parse_args()
+# ---- sub-records ------------------------------------------------------------------------------------------------------
+
+def pair_record(wl, out, args, variant, dist, dev, tokens, nbytes, op="v1"):
+    """Timed region + kernel pass for one workload through the default entry -> (record, kernel stats)."""
+    elapsed = shard.max_over_ranks(time_steps(wl, out, args.steps, args.warmup, variant, dist, dev, op=op), dist, dev)
+    ks = kernel_stats(kernel_pass(wl, out, args.kernel_samples, variant, dev, op=op), dist, dev)
+    rec = {"value": tokens / elapsed, "unit": "tokens/s", "ms_per_step": elapsed / args.steps * 1e3,
+           "kernel_us_median": ks["median"], "kernel_us_mean": ks["mean"], "kernel_us_min": ks["min"],
+           "kernel_event_samples": args.kernel_samples}
+    if nbytes:
+        gbps = nbytes / (ks["median"] * 1e-6) / 1e9
+        rec.update({"algorithmic_bytes_per_launch": nbytes, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS})
+    return rec, ks
+
+
+def random_fp8_codes(shape, dev, gen):
+    """Random E4M3 / E5M2 codes 0..63 + sign: magnitude < 2 in E4M3 (exponent field <= 7) and in E5M2 (<= 15), no NaNs."""
+    return (torch.randint(0, 64, shape, dtype=torch.uint8, device=dev, generator=gen)
+            | (torch.randint(0, 2, shape, dtype=torch.uint8, device=dev, generator=gen) << 7))
+
+
+def main(argv=None):
+    global KV_DTYPE, SKIP_RESHAPE, RESHAPE_OTHER, NOOP_RESHAPE
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if needs_self_launch(args):
+        sys.exit(self_launch(args, argv))
     RESHAPE_OTHER = args.reshape_other_set
-    if not torch.cuda.is_available():
+    if not args.standin_cpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists for the product kernels)")
-    dist, rank, world, local_rank = init_dist(args.gpus)
-    dev = torch.device("cuda", local_rank)
+    dist, rank, world, local_rank, dev = init_dist(args)
+    if args.standin_cpu:
+        standin_main(args, dist, rank, world, dev)
+        return
+    from vllmini_amd import ops
+
     if args.noop_instead_of_reshape:
         NOOP_RESHAPE = torch.zeros(1, device=dev)
     cfg = CONFIGS[args.config]
+    e2e_cfg = CONFIGS["cfg3"]
     if (world > 1 or dist is not None) and args.config == "cfg3":
         # BASELINE.json configs[4]: batch 2048 over 8 GPUs = 256 sequences per GPU (the cfg3 shape) with a
         # per-GPU KV pool of 65536 blocks.  Same kernel work per GPU as N=1; only the pool is larger.
@@ -501,6 +668,7 @@ def main():
             b_ = total // world
             cfg = dataclasses.replace(cfg, name="cfg5_strong", batch=b_,
                                       num_blocks=max(cfg.num_blocks, 2 * b_ * cfg.blocks_per_seq))
+            e2e_cfg = dataclasses.replace(e2e_cfg, batch=b_)
     if args.variant_name:
         args.variant = ops.variant_names().index(args.variant_name) + 1
     if args.pv_mfma:
@@ -516,11 +684,8 @@ def main():
         per = -(-l_ // cfg.block_size)
         cfg = dataclasses.replace(cfg, name=f"{cfg.name}_b{b_}_l{l_}", batch=b_, seq_len=l_,
                                   num_blocks=max(2 * b_ * per, 64))
-    if args.matrix:
-        run_matrix(args, cfg, dev)
-        return
     if args.e2e:
-        run_e2e(args, dist, rank, world, local_rank, dev)
+        run_e2e(args, cfg, dist, rank, world, dev)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -535,104 +700,29 @@ def main():
         KV_DTYPE = args.kv
         if args.op != "v1":
             raise SystemExit("--kv fp8 is built for --op v1")
-        args.no_fused = True
-        args.no_cpu_baseline = True
+        args.no_fused = args.no_cpu_baseline = args.no_cfg4 = args.no_e2e = True
         gk = torch.Generator(device=dev).manual_seed(99 + rank)
         kshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size // 16, cfg.block_size, 16)
         vshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size, cfg.block_size)
         del wl.key_cache, wl.value_cache
         torch.cuda.empty_cache()
-        # random codes 0..63 + sign: magnitude < 2 in E4M3 (exponent field <= 7) and in E5M2 (<= 15), no NaN codes
-        wl.key_cache = (torch.randint(0, 64, kshape, dtype=torch.uint8, device=dev, generator=gk)
-                        | (torch.randint(0, 2, kshape, dtype=torch.uint8, device=dev, generator=gk) << 7))
-        wl.value_cache = (torch.randint(0, 64, vshape, dtype=torch.uint8, device=dev, generator=gk)
-                          | (torch.randint(0, 2, vshape, dtype=torch.uint8, device=dev, generator=gk) << 7))
-
-    if args.diag:
-        from vllmini_amd import _lib
-        lib = _lib.load()
-        sink = torch.zeros(1, dtype=torch.int32, device=dev)
-        src = wl.key_cache
-        nbytes = src.numel() * 2
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        res = []
-        for nt in (0, 1):
-            for blocks in (1024, 2048, 4096, 8192, 16384):
-                for _ in range(3):
-                    lib.vmi_diag_stream_read(src.data_ptr(), nbytes, sink.data_ptr(), blocks, nt, local_rank, stream)
-                evs = []
-                for i in range(20):
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    s_ = wl.value_cache if i % 2 else wl.key_cache   # alternate pools: defeat the 256 MiB MALL
-                    a.record()
-                    lib.vmi_diag_stream_read(s_.data_ptr(), nbytes, sink.data_ptr(), blocks, nt, local_rank, stream)
-                    b.record()
-                    evs.append((a, b))
-                torch.cuda.synchronize(dev)
-                ms = statistics.median(a.elapsed_time(b) for a, b in evs)
-                res.append({"nt": nt, "blocks": blocks, "bytes": nbytes, "us": ms * 1e3, "gbps": nbytes / (ms * 1e-3) / 1e9})
-                print(json.dumps(res[-1]), file=sys.stderr, flush=True)
-        # gather reads: contiguous chunk size x KiB in flight per wave x waves (768 blocks of 256 = 3072 waves = cfg3)
-        for blocks in (768, 384, 192):
-            for kb in (2, 4, 8, 16):
-                for infl in (1, 2, 4, 8, 16):
-                    evs = []
-                    for i in range(16):
-                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        s_ = wl.value_cache if i % 2 else wl.key_cache
-                        a.record()
-                        rc = lib.vmi_diag_gather_read(s_.data_ptr(), nbytes, sink.data_ptr(), kb, infl, blocks, 1, local_rank, stream)
-                        b.record()
-                        assert rc == 0, _lib.last_error()
-                        evs.append((a, b))
-                    torch.cuda.synchronize(dev)
-                    ms = statistics.median(a.elapsed_time(b) for a, b in evs[4:])
-                    res.append({"kind": "gather", "chunk_kb": kb, "inflight_kb_per_wave": infl, "waves": blocks * 4,
-                                "inflight_kb_per_cu": infl * blocks * 4 / 256, "bytes": nbytes,
-                                "us": ms * 1e3, "gbps": nbytes / (ms * 1e-3) / 1e9})
-                    print(json.dumps(res[-1]), file=sys.stderr, flush=True)
-        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(REPO, "gpurun_out", "diag.json"), "w") as f:
-            json.dump(res, f, indent=1)
-        return
-
-    if args.sweep:
-        names = ops.variant_names()
-        res = []
-        for vid, name in enumerate(names, start=1):
-            if not name.startswith(f"{KV_PREFIX[args.kv]}d{cfg.head_size}_") or "_gq" in name:
-                continue            # (gq kernels need num_heads / num_kv_heads > 1: scripts/gqa_probe.py)
-            try:
-                _, kern_ms = time_steps(wl, out, args.steps, args.warmup, vid, dist, dev)
-            except RuntimeError as e:
-                res.append({"variant": vid, "name": name, "error": str(e)})
-                continue
-            us = statistics.mean(kern_ms) * 1e3
-            res.append({"variant": vid, "name": name, "us_mean": us, "us_median": statistics.median(kern_ms) * 1e3,
-                        "us_min": min(kern_ms) * 1e3, "gbps": alg_bytes(cfg) / (us * 1e-6) / 1e9})
-            if rank == 0:
-                print(json.dumps(res[-1]), file=sys.stderr, flush=True)
-        if rank == 0:
-            os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(REPO, "gpurun_out", f"sweep_{cfg.name}.json"), "w") as f:
-                json.dump({"config": cfg.name, "kv": args.kv,
-                           "picked": ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, cfg.seq_len,
-                                                      fp8=FP8_ARG[args.kv]), "results": res}, f, indent=1)
-        return
+        wl.key_cache = random_fp8_codes(kshape, dev, gk)
+        wl.value_cache = random_fp8_codes(vshape, dev, gk)
 
     SKIP_RESHAPE = args.skip_reshape
-    EVENT_STRIDE = max(1, min(args.event_stride, args.steps // 5))
+    plain = args.op == "v1" and args.kv == "auto" and not args.ragged and not args.ragged_sorted   # the BASELINE line
     if args.hint_mean and not args.variant and args.op in ("v1", "fused"):
         lens_h = wl.seq_lens.cpu()
         args.variant = ops.pick_variant(cfg.batch, cfg.num_heads, cfg.head_size, int(lens_h.max()), cfg.block_size,
                                         mean_seq_len=int(lens_h.float().mean()), fp8=FP8_ARG[args.kv])
-    elapsed, kern_ms = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op)
-    elapsed = shard.max_over_ranks(elapsed, dist, dev)
-    kern_mean_ms = shard.max_over_ranks(statistics.mean(kern_ms), dist, dev)
 
+    # ---- the headline: K steps, nothing else in the timed region -------------------------------------------------------
+    elapsed = shard.max_over_ranks(time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op), dist, dev)
     tokens = cfg.batch * world * args.steps          # one new token per sequence per step
     ms_per_step = elapsed / args.steps * 1e3
-    achieved = alg_bytes(cfg) / (kern_mean_ms * 1e-3) / 1e9
+    # ---- the attention kernel's duration: its own pass ------------------------------------------------------------------
+    ks = kernel_stats(kernel_pass(wl, out, args.kernel_samples, args.variant, dev, op=args.op), dist, dev)
+    achieved = alg_bytes(cfg) / (ks["median"] * 1e-6) / 1e9
     # the variant the library actually launched (it knows the launch's kv_scale, the pick queries do not)
     vid = args.variant or (ops.last_variant() if args.op in ("v1", "fused") else 0)
     vname = ops.variant_names()[vid - 1] if vid else f"paged_attention_v2 variant {args.variant or 'auto'}"
@@ -666,11 +756,16 @@ def main():
             "parallelism": f"dp{world} (independent KV pools, no data-path collective"
                            + ("; per-step all_gather of the sampled token ids over RCCL)" if dist is not None else ")"),
             "kernel_variant": vname, "op": args.op,
+            "launch": "self-launched ranks" if os.environ.get("VMI_BENCH_SELF_LAUNCHED") == "1" else
+                      ("external launcher" if dist is not None else "single process"),
         },
-        "paged_attention_v1_us_per_step": kern_mean_ms * 1e3,
-        "paged_attention_v1_us_median": statistics.median(kern_ms) * 1e3,
-        "paged_attention_v1_us_min": min(kern_ms) * 1e3,
-        "kernel_event_stride": EVENT_STRIDE, "kernel_event_samples": len(kern_ms),
+        "paged_attention_v1_us_per_step": ks["median"],
+        "paged_attention_v1_us_median": ks["median"],
+        "paged_attention_v1_us_mean": ks["mean"],
+        "paged_attention_v1_us_min": ks["min"],
+        "kernel_event_samples": args.kernel_samples,
+        "kernel_event_pass": "separate from the timed region: one HIP event pair around every attention launch of "
+                             f"{args.kernel_samples} call pairs; roofline.achieved uses the median",
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,
@@ -679,50 +774,37 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "kernel": "pa_q_kernel" if vname.startswith(("q_d", "bf16_q_d")) else "pa_v1_kernel",
+            "kernel": "pa_q_kernel" if vname.startswith(("q_d", "bf16_q_d", "fp8_q_d")) else "pa_v1_kernel",
             "algorithmic_bytes_per_launch": alg_bytes(cfg),
+            "mfma": 0, "mfma_note": "multi-head decode is M = 1 per KV head: both contractions are GEMVs, the kernel "
+                                    "issues no MFMA (SQ_INSTS_MFMA = 0, profiles/pmc_cfg3_latest.json)",
         },
     }
+    if dist is not None:
+        line["token_exchange_us"] = shard.max_over_ranks(exchange_pass(args.kernel_samples, dist, dev), dist, dev)
+        line["token_exchange"] = f"all_gather of {cfg.batch} int64 ids per rank ({cfg.batch * world * 8} B in all), backend nccl (RCCL)"
     if args.op == "v1" and not args.no_fused:
         # the same step as ONE launch (vmi_paged_attention_v1_append_f16: bit-identical caches and out,
         # tests/test_parity_gpu.py); reported beside `value`, which stays the reference's two-op call pair
-        f_elapsed, f_kern = time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op="fused")
-        f_elapsed = shard.max_over_ranks(f_elapsed, dist, dev)
-        line["fused_step"] = {"op": "paged_attention_v1_append (reshape_and_cache + paged_attention_v1, one launch)",
-                              "value": tokens / f_elapsed, "unit": "tokens/s",
-                              "ms_per_step": f_elapsed / args.steps * 1e3,
-                              "kernel_us_mean": statistics.mean(f_kern) * 1e3}
-    if args.op == "v1" and args.kv == "auto" and not args.no_fp8 and not args.ragged and not args.ragged_sorted:
+        rec, _ = pair_record(wl, out, args, args.variant, dist, dev, tokens, alg_bytes(cfg), op="fused")
+        line["fused_step"] = {"op": "paged_attention_v1_append (reshape_and_cache + paged_attention_v1, one launch)", **rec}
+    if plain and not args.no_fp8:
         # the same step over an fp8 E4M3 KV cache (kv_cache_dtype "fp8"): half the K/V bytes.
         # A different data format, so it is reported beside `value`, never as it.
         k16, v16 = wl.key_cache, wl.value_cache
         gk = torch.Generator(device=dev).manual_seed(99 + rank)
         kshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size // 16, cfg.block_size, 16)
-        wl.key_cache = (torch.randint(0, 64, kshape, dtype=torch.uint8, device=dev, generator=gk)
-                        | (torch.randint(0, 2, kshape, dtype=torch.uint8, device=dev, generator=gk) << 7))
-        wl.value_cache = (torch.randint(0, 64, v16.shape, dtype=torch.uint8, device=dev, generator=gk)
-                          | (torch.randint(0, 2, v16.shape, dtype=torch.uint8, device=dev, generator=gk) << 7))
+        wl.key_cache = random_fp8_codes(kshape, dev, gk)
+        wl.value_cache = random_fp8_codes(v16.shape, dev, gk)
         KV_DTYPE = "fp8"
         try:
-            q_elapsed, q_kern = time_steps(wl, out, args.steps, args.warmup, 0, dist, dev, op="v1")
+            rec, _ = pair_record(wl, out, args, 0, dist, dev, tokens, alg_bytes(cfg, "fp8"))
+            rec["kernel_variant"] = ops.variant_names()[ops.last_variant() - 1]
         finally:
             KV_DTYPE = "auto"
             wl.key_cache, wl.value_cache = k16, v16
-        q_elapsed = shard.max_over_ranks(q_elapsed, dist, dev)
-        q_us = statistics.mean(q_kern) * 1e3
-        KV_DTYPE = "fp8"
-        q_bytes = alg_bytes(cfg)
-        KV_DTYPE = "auto"
-        line["fp8_kv_step"] = {"op": "reshape_and_cache + paged_attention_v1, kv_cache_dtype='fp8' (E4M3), kv_scale 1.0",
-                               "value": tokens / q_elapsed, "unit": "tokens/s",
-                               "ms_per_step": q_elapsed / args.steps * 1e3, "kernel_us_mean": q_us,
-                               "achieved_GBps": q_bytes / (q_us * 1e-6) / 1e9,
-                               "frac_of_hbm_peak": q_bytes / (q_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
-    if dist is not None:
-        line["token_exchange_us"] = shard.max_over_ranks(_EXCHANGE["us"], dist, dev)
-        line["token_exchange"] = f"all_gather of {cfg.batch} int64 ids per rank ({cfg.batch * world * 8} B in all), backend nccl (RCCL)"
-    if args.op == "v1" and args.kv == "auto" and not args.no_graph and not args.ragged and not args.ragged_sorted and \
-            dist is None and not args.skip_reshape:
+        line["fp8_kv_step"] = {"op": "reshape_and_cache + paged_attention_v1, kv_cache_dtype='fp8' (E4M3), kv_scale 1.0", **rec}
+    if plain and not args.no_graph and dist is None and not args.skip_reshape:
         g_elapsed = graph_steps(wl, out, args.steps, args.variant, dev)
         line["graph_step"] = {"op": "reshape_and_cache + paged_attention_v1 replayed from one hipGraph per table set",
                               "value": cfg.batch * args.steps / g_elapsed, "unit": "tokens/s",
@@ -731,33 +813,53 @@ def main():
         g_elapsed = graph_steps(wl, out, args.steps, args.variant, dev, per_graph=n_sets)
         line["graph_step"]["steps_per_graph"] = {"steps": n_sets, "ms_per_step": g_elapsed / args.steps * 1e3,
                                                  "value": cfg.batch * args.steps / g_elapsed}
-    if args.op == "v1" and args.kv == "auto" and not args.no_ragged and not args.ragged and not args.ragged_sorted and \
-            not args.variant and not args.sequential_tables:
+    if plain and not args.no_ragged and not args.variant and not args.sequential_tables:
         # the same call pair, same default entry (no hint, no variant), on a RAGGED batch: seq_lens ~ U{1..seq_len}
         pools = (wl.key_cache, wl.value_cache)
         rwl = make_workload(cfg, dev, seed=4321 + rank, table_sets=2, ragged=True)
         del rwl.key_cache, rwl.value_cache
         rwl.key_cache, rwl.value_cache = pools          # same pools: only tables, lengths and slots differ
-        r_elapsed, r_kern = time_steps(rwl, out, args.steps, args.warmup, 0, dist, dev, op="v1")
-        r_elapsed = shard.max_over_ranks(r_elapsed, dist, dev)
-        r_us = shard.max_over_ranks(statistics.mean(r_kern), dist, dev) * 1e3
         tok = int(rwl.seq_lens.sum().item())
         r_bytes = 2 * tok * cfg.kv_heads * cfg.head_size * 2 + 2 * cfg.batch * cfg.num_heads * cfg.head_size * 2 + \
             int(((rwl.seq_lens + cfg.block_size - 1) // cfg.block_size).sum().item()) * 4 + cfg.batch * 4
-        line["ragged_step"] = {"op": "reshape_and_cache + paged_attention_v1, default entry, seq_lens ~ U{1..%d}" % cfg.seq_len,
-                               "value": tokens / r_elapsed, "unit": "tokens/s",
-                               "ms_per_step": r_elapsed / args.steps * 1e3, "kernel_us_mean": r_us,
-                               "algorithmic_bytes_per_launch": r_bytes,
-                               "achieved_GBps": r_bytes / (r_us * 1e-6) / 1e9,
-                               "frac_of_hbm_peak": r_bytes / (r_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps)
-    elif rank == 0:
-        line["cpu_baseline"] = None
-    if rank == 0:
-        emit_line(line)
+        rec, _ = pair_record(rwl, out, args, 0, dist, dev, tokens, r_bytes)
+        rec["kernel_variant"] = ops.variant_names()[ops.last_variant() - 1]
+        line["ragged_step"] = {"op": "reshape_and_cache + paged_attention_v1, default entry, seq_lens ~ U{1..%d}" % cfg.seq_len, **rec}
+        del rwl
+    cpu_wl = None if (args.no_cpu_baseline or rank != 0) else wl
+    if cpu_wl is not None:   # host copies now: the device pools are released before the larger sub-records allocate theirs
+        cpu_wl = type("HostWorkload", (), {"cfg": cfg, "key_cache": wl.key_cache.cpu(), "value_cache": wl.value_cache.cpu(),
+                                           "query": wl.query.cpu(), "tables": [wl.tables[0].cpu()], "scale": wl.scale})()
+    del wl
+    torch.cuda.empty_cache()
+    if plain and not args.no_cfg4 and args.config == "cfg3" and not args.variant:
+        # BASELINE configs[3]: 32 heads x 128, batch 128, seq 2048 — the same call pair through the same default entry
+        c4 = CONFIGS["cfg4"]
+        wl4 = make_workload(c4, dev, seed=77 + rank, table_sets=2)
+        out4 = torch.empty((c4.batch, c4.num_heads, c4.head_size), dtype=torch.float16, device=dev)
+        rec, _ = pair_record(wl4, out4, args, 0, dist, dev, c4.batch * world * args.steps, alg_bytes(c4, "auto"))
+        v4 = ops.variant_names()[ops.last_variant() - 1]
+        t4, t4src = pmc_traffic("cfg4", v4)
+        line["cfg4_step"] = {"op": "reshape_and_cache + paged_attention_v1, BASELINE configs[3]: batch 128/GPU, seq_len 2048, "
+                                   "32 heads x 128, block_size 16, num_blocks 32768, fp16", **rec,
+                             "kernel_variant": v4, "traffic": t4, "traffic_source": t4src, "mfma": 0,
+                             "note": "kernel_us covers the gated double launch (lockstep 4-heads-per-wave kernel + balanced "
+                                     "kernel; one of them leaves at once, DESIGN.md §3.7).  BASELINE.json labels this config "
+                                     "'MFMA QK^T path': with one query row per KV head the contraction is a GEMV and the "
+                                     "kernel issues NO MFMA; the matrix cores are used by the grouped-query kernels only"}
+        del wl4, out4
+        torch.cuda.empty_cache()
+    if plain and not args.no_e2e and args.config == "cfg3" and not args.variant:
+        res = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context)
+        line["e2e_step"] = {k: res[k] for k in ("metric", "value", "unit", "ms_per_step", "context", "batch_per_gpu", "note",
+                                                "operators_ms_per_step", "operators_share_of_step", "operators_note")}
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # after the GPU work and after the process group is gone: the other ranks have exited, the host is this rank's
+        line["cpu_baseline"] = None if cpu_wl is None else cpu_baseline(cpu_wl, args.cpu_seconds)
+        emit_line(line)
 
 
 if __name__ == "__main__":

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 17
+#define VMI_ABI_VERSION 18
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -359,14 +359,6 @@ int vmi_set_pv_mfma(int32_t on);
 int vmi_paged_attention_v1_last_variant(void);
 
 /*
- * Test / benchmark knob of the balanced ("q_*") kernels (per host thread, default 0 = automatic; returns the previous
- * value): forces their mode, worker count or hand-out policy (bit layout: vllmini_amd/csrc/pa_queue.hpp, QF_*).
- * Results do not depend on it — every mode computes an item with the same operations in the same order — only the
- * schedule does; tests use it to drive every path of the kernel on small inputs.
- */
-int vmi_debug_set_queue_flags(int32_t flags);
-
-/*
  * 1 when `variant` can serve a launch with this max_seq_len (its logits rows fit the 160 KiB of LDS) and, with
  * for_append != 0, has a fused-append twin; 0 otherwise.  For callers that pick a variant from what they know about
  * the batch (the pick functions above take the batch's longest length) but launch with a larger max_seq_len — the
@@ -493,22 +485,10 @@ int vmi_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_hos
                     int64_t block_bytes, int32_t kind, int32_t device, void* stream);
 
 /*
- * Diagnostic (no reference counterpart): plain coalesced 16-B/lane read of `bytes` from `src`
- * with `blocks` workgroups of 256 threads; nt != 0 uses non-temporal loads.  `sink` is a 4-byte
- * device word that is (practically) never written.  bench.py --diag uses it to report the read
- * bandwidth this box sustains, next to the attention kernel's achieved figure.
+ * 0 for the product library, 1 for the diagnostic build (-DVMI_DIAG: adds the entries of vmi_paged_attention_diag.h, the
+ * "loads only" and LDS-staging experiment kernels; same sources otherwise).
  */
-int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blocks, int32_t nt,
-                         int32_t device, void* stream);
-
-/*
- * Diagnostic: read `bytes` from `src` as pseudo-randomly ordered contiguous chunks of chunk_kb KiB
- * (1..64, power of two), one chunk stream per wave, inflight_kb KiB (1,2,4,8,16) requested per wave before
- * anything is consumed — the attention kernel's access pattern without the math, with the contiguous-chunk
- * size and the queue depth as the variables.
- */
-int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chunk_kb, int32_t inflight_kb,
-                         int32_t blocks, int32_t nt, int32_t device, void* stream);
+int vmi_is_diag_build(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,47 @@
+/*
+ * vmi_paged_attention_diag.h — entries that exist ONLY in the diagnostic build of the library
+ * (vllmini_amd/_C/libvmi_paged_attention_diag.so: the product sources compiled with -DVMI_DIAG; `python -m
+ * vllmini_amd.build --diag`).  None of them has a reference counterpart and none is exported by the product library
+ * (tests/test_abi.py checks that with the dynamic symbol table).  The diagnostic build also carries kernels the product
+ * does not: the "LOADSONLY" variants (the page gather with the math removed — wrong results by design) and the
+ * LDS-staging experiment ("stage_*", vllmini_amd/csrc/pa_stage.hip).
+ */
+#ifndef VMI_PAGED_ATTENTION_DIAG_H
+#define VMI_PAGED_ATTENTION_DIAG_H
+
+#include "vmi_paged_attention.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * Test / benchmark knob of the balanced ("q_*") kernels (per host thread, default 0 = automatic; returns the previous
+ * value): forces their mode, worker count or hand-out policy (bit layout: vllmini_amd/csrc/pa_queue.hpp, QF_*).
+ * Results do not depend on it — every mode computes an item with the same operations in the same order — only the
+ * schedule does; tests use it to drive every path of the kernel on small inputs.
+ */
+int vmi_debug_set_queue_flags(int32_t flags);
+
+/*
+ * Diagnostic (no reference counterpart): plain coalesced 16-B/lane read of `bytes` from `src`
+ * with `blocks` workgroups of 256 threads; nt != 0 uses non-temporal loads.  `sink` is a 4-byte
+ * device word that is (practically) never written.  scripts/bench_diag.py --diag uses it to report the read
+ * bandwidth this box sustains, next to the attention kernel's achieved figure.
+ */
+int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blocks, int32_t nt,
+                         int32_t device, void* stream);
+
+/*
+ * Diagnostic: read `bytes` from `src` as pseudo-randomly ordered contiguous chunks of chunk_kb KiB
+ * (1..64, power of two), one chunk stream per wave, inflight_kb KiB (1,2,4,8,16) requested per wave before
+ * anything is consumed — the attention kernel's access pattern without the math, with the contiguous-chunk
+ * size and the queue depth as the variables.
+ */
+int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chunk_kb, int32_t inflight_kb,
+                         int32_t blocks, int32_t nt, int32_t device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMI_PAGED_ATTENTION_DIAG_H */

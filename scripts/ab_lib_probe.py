@@ -13,16 +13,21 @@ ap = argparse.ArgumentParser()
 ap.add_argument("lib")
 ap.add_argument("--cfg", default="cfg3")
 ap.add_argument("--iters", type=int, default=300)
-ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
+ap.add_argument("--flags", type=lambda x: int(x, 0), default=0, help="queue flags; needs a -DVMI_DIAG build")
 args = ap.parse_args()
 _build.LIB_PATH = os.path.abspath(args.lib)
 from vllmini_amd import _lib, ops  # noqa: E402
 from vllmini_amd.workload import CONFIGS, make_workload  # noqa: E402
 
-lib = _lib.load()
+if args.flags:        # the mode knob exists in a diagnostic build only: the path must name such a library
+    _build.DIAG_LIB_PATH = _build.LIB_PATH
+    _build.LIB_PATH = os.path.join(_build.OUT_DIR, _build.LIB_NAME)
+    lib = _lib.use_diag().__enter__()
+    lib.vmi_debug_set_queue_flags(args.flags)
+else:
+    lib = _lib.load()     # the product build at the given path
 dev = torch.device("cuda:0")
 cfg = CONFIGS[args.cfg]
-lib.vmi_debug_set_queue_flags(args.flags)
 g = torch.Generator().manual_seed(1)
 Lm = cfg.seq_len
 cases = [("uniform", False, None), ("ragged", True, None),

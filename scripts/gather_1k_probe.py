@@ -4,7 +4,7 @@ import json, os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllmini_amd import _lib
-lib = _lib.load()
+lib = _lib.use_diag().__enter__()   # the diagnostic build for the whole process (python -m vllmini_amd.build --diag)
 dev = torch.device("cuda:0")
 bufs = [torch.empty(768 * 1024 * 1024, dtype=torch.uint8, device=dev).random_() for _ in range(2)]
 sink = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -10,7 +10,7 @@ TAG=${1:-r01}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 10 --no-cpu-baseline --no-fused --no-fp8 --no-ragged --no-graph $*"   # one attention kernel per run: plain, or --op fused
+ARGS="--steps 50 --warmup 10 --headline-only $*"   # one attention kernel per run: plain, or --op fused
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python bench.py $ARGS > "$OUT/bench_under_trace.json" 2> "$OUT/trace.stderr"
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python bench.py $ARGS > "$OUT/bench_under_pmc_fetch.json" 2> "$OUT/pmc_fetch.stderr"
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python bench.py $ARGS > "$OUT/bench_under_pmc_write.json" 2> "$OUT/pmc_write.stderr"

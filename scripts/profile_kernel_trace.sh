@@ -7,7 +7,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- \
-  python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-fused --no-fp8 --no-graph "$@" > "$OUT/bench_under_trace.json" 2> "$OUT/trace.stderr"
+  python bench.py --steps 60 --warmup 10 --headline-only "$@" > "$OUT/bench_under_trace.json" 2> "$OUT/trace.stderr"
 python scripts/summarize_prof.py "$OUT" > "$OUT/summary.json" 2> "$OUT/summary.stderr"
 python - "$OUT" <<'PY'
 import json, sys

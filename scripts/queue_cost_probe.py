@@ -17,7 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cfg", default="cfg3")
 ap.add_argument("--iters", type=int, default=100)
 args = ap.parse_args()
-lib = _lib.load()
+lib = _lib.use_diag().__enter__()   # the diagnostic build for the whole process (python -m vllmini_amd.build --diag)
 names = {lib.vmi_paged_attention_v1_variant_name(i).decode(): i
          for i in range(1, lib.vmi_paged_attention_v1_variant_count() + 1)}
 dev = torch.device("cuda:0")

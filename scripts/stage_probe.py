@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllmini_amd import _lib, ops  # noqa: E402
 from vllmini_amd.workload import CONFIGS, make_workload  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.use_diag().__enter__()   # the diagnostic build for the whole process (python -m vllmini_amd.build --diag)
 names = {n: i + 1 for i, n in enumerate(ops.variant_names())}
 dev = torch.device("cuda:0")
 res = {}

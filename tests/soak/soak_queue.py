@@ -17,7 +17,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
 KV = sys.argv[3] if len(sys.argv) > 3 else "mix"   # "auto" (16-bit pages), "fp8" (E4M3 pages), "mix" (a third fp8)
 dev = torch.device("cuda:0")
-lib = _lib.load()
+lib = _lib.use_diag().__enter__()   # the diagnostic build for the whole process (python -m vllmini_amd.build --diag)
 names = {n: i + 1 for i, n in enumerate(ops.variant_names())}
 BS = 16
 

@@ -17,13 +17,16 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    names = []
-    for h in glob.glob(os.path.join(REPO, "include", "*.h")):
-        src = open(h).read()
-        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        names += re.findall(r"\b(vmi_[a-z0-9_]+)\s*\(", src)
-    return sorted(set(names))
+def _declared_symbols(header="vmi_paged_attention.h"):
+    src = open(os.path.join(REPO, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vmi_[a-z0-9_]+)\s*\(", src)))
+
+
+def _exported(path):
+    """Dynamic symbol table of a shared library (defined symbols only)."""
+    r = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True)
+    return {ln.split()[-1] for ln in r.stdout.splitlines() if ln.strip()}
 
 
 def test_library_builds_loads_and_exports_every_declared_symbol():
@@ -32,6 +35,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     path = build.build()
     assert os.path.exists(path)
     lib = ctypes.CDLL(path)
+    assert sorted(os.path.basename(h) for h in glob.glob(os.path.join(REPO, "include", "*.h"))) == \
+        ["vmi_paged_attention.h", "vmi_paged_attention_diag.h"]
     declared = _declared_symbols()
     assert {"vmi_paged_attention_v1_f16", "vmi_reshape_and_cache_f16", "vmi_last_error_string",
             "vmi_abi_version"} <= set(declared)
@@ -40,8 +45,46 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 17
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 18
     assert typed.vmi_target_arch() == b"gfx950"
+    assert typed.vmi_is_diag_build() == 0
+
+
+def test_product_library_exports_no_diagnostic_symbol_and_no_diagnostic_kernel():
+    """The product .so carries nothing that is wrong by design or untested: no vmi_diag_* / vmi_debug_* entry, no
+    "loads only" variant, no LDS-staging experiment kernel — in its C-ABI, in its variant names and in its dynamic
+    symbol table (kernel stubs included).  The diagnostic build (-DVMI_DIAG) is where those live."""
+    from vllmini_amd import _lib, build, ops
+
+    path = build.build()
+    syms = _exported(path)
+    vmi = {s for s in syms if s.startswith("vmi_")}
+    assert vmi == set(_declared_symbols()), vmi ^ set(_declared_symbols())
+    diag_only = set(_declared_symbols("vmi_paged_attention_diag.h")) - set(_declared_symbols())
+    assert diag_only == set(_lib.DIAG_SIGNATURES) and diag_only
+    assert not (diag_only & syms)
+    bad = [s for s in syms - {"vmi_is_diag_build"} if re.search(r"diag|debug|stage|gather_read|stream_read|LOADSONLY", s, re.I)]
+    assert not bad, bad[:5]
+    names = ops.variant_names() + ops.variant_names_v2()
+    assert not [n for n in names if "LOADSONLY" in n or n.startswith("stage_")]
+
+
+def test_diagnostic_library_is_the_product_plus_the_diagnostics():
+    from vllmini_amd import _lib, build, ops
+
+    path = build.build(diag=True)
+    assert path.endswith("libvmi_paged_attention_diag.so") and os.path.exists(build.LIB_PATH)
+    syms = _exported(path)
+    for name in [*_declared_symbols(), *_declared_symbols("vmi_paged_attention_diag.h")]:
+        assert name in syms, name
+    product_names = ops.variant_names()
+    with _lib.use_diag() as lib:
+        assert lib.vmi_is_diag_build() == 1 and _lib.load() is lib
+        diag_names = ops.variant_names()
+    assert _lib.load().vmi_is_diag_build() == 0            # the switch ends with the context
+    extra = [n for n in diag_names if n not in product_names]
+    assert extra and all("LOADSONLY" in n or n.startswith("stage_") for n in extra), extra
+    assert [n for n in diag_names if n in product_names] == product_names     # same kernels, same order
 
 
 def test_library_is_gfx950_only_and_has_no_torch_dependency(tmp_path):
@@ -134,9 +177,15 @@ def test_native_library_missing_is_a_loud_error(tmp_path, monkeypatch):
     from vllmini_amd import _lib, build
 
     monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "nope.so"))
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_active", None)
+    monkeypatch.setattr(_lib, "_product", None)
     with pytest.raises(_lib.NativeLibraryError, match="no CPU/torch fallback"):
         _lib.load()
+    import paged_attention_cuda as ext                      # the operators do not route around it either
+
+    x = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        ext.paged_attention_v1(x, x, x, x, 1, 1.0, x, x, 16, 16, None, "auto", 1.0, 0, 0, 1, 1, 0)
 
 
 def test_c_abi_validation_codes_without_gpu():
@@ -249,18 +298,21 @@ def test_makefile_lists_the_same_translation_units_as_build_py():
     mk = open(os.path.join(REPO, "Makefile")).read()
     units = re.search(r"UNITS\s*:=\s*((?:.*\\\n)*.*)\n", mk).group(1).replace("\\\n", " ").split()
     assert sorted(units) == sorted(os.path.basename(s)[: -len(".hip")] for s in b.SOURCES)
+    diag_units = re.search(r"DIAG_UNITS\s*:=\s*(.*)\n", mk).group(1).split()
+    assert sorted(diag_units) == sorted(os.path.basename(s)[: -len(".hip")] for s in [*b.DIAG_UNITS, *b.DIAG_ONLY])
     for flag in ("-O3", "-std=c++17", "-ffp-contract=off", "-fno-gpu-rdc"):
         assert flag in mk and flag in b.HIPCC_FLAGS
 
 
 def test_c_abi_is_callable_from_several_host_threads():
     """Error strings and the opt-in switches are per thread: two threads that fail differently each read their own
-    message, and one thread's vmi_set_pv_mfma / vmi_debug_set_queue_flags does not leak into the other's calls."""
+    message, and one thread's vmi_set_pv_mfma (and, in the diagnostic build, vmi_debug_set_queue_flags) does not leak
+    into the other's calls."""
     import threading
 
     from vllmini_amd import _lib
 
-    lib = _lib.load()
+    lib = _lib.load_diag()          # a superset of the product's entries: the same host code with the mode knob
     buf = (ctypes.c_char * 4096)()
     p16 = (ctypes.addressof(buf) + 15) & ~15
 

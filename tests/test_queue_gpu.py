@@ -1,6 +1,6 @@
 """GPU parity of the balanced paged_attention_v1 kernels (vllmini_amd/csrc/pa_queue.hpp): every mode the kernel
 can choose on the device — one item per wave (S), ranked work lists with solo workers or 4-wave teams (Q) — is forced
-through vmi_debug_set_queue_flags on small inputs and compared with the CPU oracle (checker only) and, for the
+through vmi_debug_set_queue_flags (diagnostic build of the library) on small inputs and compared with the CPU oracle (checker only) and, for the
 single-wave modes, bit for bit with the one-wave-per-head kernel whose operations they repeat; then the BASELINE cfg3
 size with ragged lengths goes through the DEFAULT entry (no hint, no variant).
 
@@ -46,11 +46,14 @@ MODES = {
 
 @pytest.fixture()
 def queue_flags():
+    """The mode knob exists in the DIAGNOSTIC build only (include/vmi_paged_attention_diag.h): tests that force a mode
+    run the operators on that library — the product's sources with -DVMI_DIAG, same kernels — for their duration.
+    The natural-trigger tests below (no fixture) drive the same modes in the product library through seq_lens."""
     from vllmini_amd import _lib
 
-    lib = _lib.load()
-    yield lib.vmi_debug_set_queue_flags
-    lib.vmi_debug_set_queue_flags(0)
+    with _lib.use_diag() as lib:
+        yield lib.vmi_debug_set_queue_flags
+        lib.vmi_debug_set_queue_flags(0)
 
 
 def _check_all_modes(case, qname, ref_name, set_flags, what, **kw):

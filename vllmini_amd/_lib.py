@@ -64,7 +64,6 @@ SIGNATURES = {
     "vmi_paged_attention_v1_pick_variant": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v1_pick_variant_gqa": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "vmi_set_pv_mfma": (ctypes.c_int, [_i32]),
-    "vmi_debug_set_queue_flags": (ctypes.c_int, [_i32]),
     "vmi_paged_attention_v1_last_variant": (ctypes.c_int, []),
     "vmi_paged_attention_v1_variant_fits": (ctypes.c_int, [_i32, _i32, _i32]),
     "vmi_paged_attention_v1_pick_variant_hint": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
@@ -75,8 +74,7 @@ SIGNATURES = {
                                                       _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _c_void_p]),
     "vmi_copy_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _i32, _c_void_p, _i32, _i64, _i32, _c_void_p]),
     "vmi_swap_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i32, _i64, _i32, _i32, _c_void_p]),
-    "vmi_diag_gather_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _i32, _i32, _c_void_p]),
-    "vmi_diag_stream_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _c_void_p]),
+    "vmi_is_diag_build": (ctypes.c_int, []),
     "vmi_reshape_and_cache_f16": (ctypes.c_int, [
         _c_void_p, _c_void_p, _c_void_p, _c_void_p,  # key, value, key_cache, value_cache
         _c_void_p,                                   # slot_mapping
@@ -86,10 +84,19 @@ SIGNATURES = {
     ]),
 }
 
-ABI_VERSION = 17
+# entries of include/vmi_paged_attention_diag.h: exported by the diagnostic build only
+DIAG_SIGNATURES = {
+    "vmi_debug_set_queue_flags": (ctypes.c_int, [_i32]),
+    "vmi_diag_gather_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _i32, _i32, _c_void_p]),
+    "vmi_diag_stream_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _c_void_p]),
+}
+
+ABI_VERSION = 18
 
 _lock = threading.Lock()
-_lib = None
+_product = None      # libvmi_paged_attention.so
+_diag = None         # libvmi_paged_attention_diag.so (tests / probes only)
+_active = None       # what load() hands to the operators: the product library unless a test switched (use_diag)
 
 
 class NativeLibraryError(RuntimeError):
@@ -100,38 +107,72 @@ def lib_path() -> str:
     return _build.LIB_PATH
 
 
-def load(build_if_missing: bool = False) -> ctypes.CDLL:
-    """Load (once) and type the shared library.  Raises NativeLibraryError if unavailable."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    with _lock:
-        if _lib is not None:
-            return _lib
-        path = _build.LIB_PATH
-        if not os.path.exists(path):
-            if build_if_missing:
-                _build.build()
-            else:
-                raise NativeLibraryError(
-                    f"{path} not found: build it with `python -m vllmini_amd.build` "
-                    "(or __graft_entry__.build()). There is no CPU/torch fallback for these ops.")
+def _open(path: str, signatures: dict, want_diag: int) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            f"{path} not found: build it with `python -m vllmini_amd.build{' --diag' if want_diag else ''}` "
+            "(or __graft_entry__.build()). There is no CPU/torch fallback for these ops.")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise NativeLibraryError(f"cannot load {path}: {e}") from e
+    for name, (restype, argtypes) in signatures.items():
         try:
-            lib = ctypes.CDLL(path)
-        except OSError as e:  # missing libamdhip64 etc.
-            raise NativeLibraryError(f"cannot load {path}: {e}") from e
-        for name, (restype, argtypes) in SIGNATURES.items():
-            try:
-                fn = getattr(lib, name)
-            except AttributeError as e:
-                raise NativeLibraryError(f"{path} does not export {name}") from e
-            fn.restype = restype
-            fn.argtypes = argtypes
-        got = lib.vmi_abi_version()
-        if got != ABI_VERSION:
-            raise NativeLibraryError(f"{path}: ABI version {got}, Python side expects {ABI_VERSION}")
-        _lib = lib
-        return _lib
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{path} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.vmi_abi_version()
+    if got != ABI_VERSION:
+        raise NativeLibraryError(f"{path}: ABI version {got}, Python side expects {ABI_VERSION}")
+    if lib.vmi_is_diag_build() != want_diag:
+        raise NativeLibraryError(f"{path}: vmi_is_diag_build() = {lib.vmi_is_diag_build()}, expected {want_diag}")
+    return lib
+
+
+def load(build_if_missing: bool = False) -> ctypes.CDLL:
+    """The library the operators call: the PRODUCT library (loaded and typed once), unless a test or probe switched
+    this process to the diagnostic build with use_diag().  Raises NativeLibraryError if unavailable."""
+    global _product, _active
+    if _active is not None:
+        return _active
+    with _lock:
+        if _active is None:
+            if not os.path.exists(_build.LIB_PATH) and build_if_missing:
+                _build.build()
+            _product = _open(_build.LIB_PATH, SIGNATURES, 0)
+            _active = _product
+        return _active
+
+
+def load_diag() -> ctypes.CDLL:
+    """The diagnostic build (include/vmi_paged_attention_diag.h): the product's entries plus the probes and knobs.
+    Loading it does not change what the operators call; use_diag() does."""
+    global _diag
+    with _lock:
+        if _diag is None:
+            _diag = _open(_build.DIAG_LIB_PATH, {**SIGNATURES, **DIAG_SIGNATURES}, 1)
+        return _diag
+
+
+class use_diag:
+    """Context manager for tests and probes: inside it the operators of this process run on the diagnostic library
+    (same sources, -DVMI_DIAG), so that kernel modes can be forced and the experiment kernels selected by variant id.
+    Variant ids differ between the two libraries (the diagnostic one has more rows): resolve names inside."""
+
+    def __enter__(self):
+        global _active
+        load()
+        self._prev = _active
+        lib = load_diag()
+        _active = lib
+        return lib
+
+    def __exit__(self, *exc):
+        global _active
+        _active = self._prev
+        return False
 
 
 def last_error() -> str:

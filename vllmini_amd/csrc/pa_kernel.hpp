@@ -1476,8 +1476,10 @@ pa_reduce_t bf16_reduce_kernel(int head_size);
 // balanced (work-queue) kernels, pa_queue.hip: v1 ids continue after every other menu
 extern Variant g_queue_variants[];
 extern const int g_queue_nvariants;
-// LDS-staged experiment kernels, pa_stage.hip: the last ids of all; never picked by a heuristic
+#ifdef VMI_DIAG
+// LDS-staged experiment kernels, pa_stage.hip (diagnostic library only): the last ids of all; never picked by a heuristic
 extern Variant g_stage_variants[];
 extern const int g_stage_nvariants;
+#endif
 
 }  // namespace vmi

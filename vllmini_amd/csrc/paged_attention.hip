@@ -43,6 +43,9 @@
 #include <float.h>
 
 #include "vmi_paged_attention.h"
+#ifdef VMI_DIAG
+#include "vmi_paged_attention_diag.h"
+#endif
 #include "pa_kernel.hpp"
 
 namespace vmi {
@@ -431,6 +434,7 @@ __global__ void __launch_bounds__(256)
   for (int64_t i = threadIdx.x; i < n16; i += 256) vd[i] = vs[i];  // :87-91
 }
 
+#ifdef VMI_DIAG   // the diagnostic library only (build.py --diag): not in the product .so
 // ----------------------------------------------------------------------------------------
 // diagnostics (not part of the reference surface): what read bandwidth does this box give a
 // plain coalesced 16-B/lane stream?  Used by bench.py --diag to state the achievable ceiling
@@ -494,6 +498,8 @@ __global__ void __launch_bounds__(256) gather_read_kernel(const u32x4* __restric
   if (x == 0x9e3779b9u) sink[0] = x;
 }
 
+#endif  // VMI_DIAG
+
 // ----------------------------------------------------------------------------------------
 // host side: variant table, validation, launch
 // ----------------------------------------------------------------------------------------
@@ -504,6 +510,10 @@ static Variant g_variants[] = {
 };
 static const int g_ncore = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
+#ifndef VMI_DIAG   // the LDS-staging experiment (pa_stage.hip) is linked into the diagnostic library only
+static Variant* const g_stage_variants = nullptr;
+static const int g_stage_nvariants = 0;
+#endif
 static int nvariants_v1() {
   return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1 + g_fp8_nvariants_v1 + g_fp8bf_nvariants_v1 +
          g_fp8_nvariants_v1_e5m2 + g_fp8bf_nvariants_v1_e5m2 + g_queue_nvariants + g_stage_nvariants;
@@ -725,12 +735,20 @@ struct DeviceState {
 };
 static std::mutex g_dev_mutex;
 static DeviceState g_dev[MAX_DEVICES];
+#ifdef VMI_DIAG
 static int env_int(const char* name) {
   const char* v = getenv(name);
   return v ? atoi(v) : 0;
 }
-// test / bench knob for the balanced kernels (pa_queue.hpp QF_*); initial value from VMI_QUEUE_FLAGS
-static thread_local int g_queue_flags = env_int("VMI_QUEUE_FLAGS");
+// q_flags bits 2-4 (QF_WQ, pa_queue.hpp) = solo workers per workgroup: a workgroup has 4 waves, so only 0 (default) .. 4 name workers that
+// exist — a larger count would hand items to waves that are not there and leave their outputs unwritten
+static int clamp_queue_flags(int flags) { return ((flags >> 2) & 7) > 4 ? (flags & ~(7 << 2)) | (4 << 2) : flags; }
+// test / bench knob for the balanced kernels (pa_queue.hpp QF_*), diagnostic library only; initial value from
+// VMI_QUEUE_FLAGS.  The product library always passes 0: the kernel decides everything from seq_lens.
+static thread_local int g_queue_flags = clamp_queue_flags(env_int("VMI_QUEUE_FLAGS"));
+#else
+static constexpr int g_queue_flags = 0;
+#endif
 static thread_local int g_last_variant = 0;  // what this thread's last paged_attention_v1 launch ran (0: none yet / block-sparse)
 
 static int device_cus(int device) {  // caller holds the device current
@@ -1481,10 +1499,20 @@ int vmi_set_pv_mfma(int on) {
 
 int vmi_paged_attention_v1_last_variant(void) { return vmi::g_last_variant; }
 
+#ifdef VMI_DIAG
 int vmi_debug_set_queue_flags(int flags) {
   const int prev = vmi::g_queue_flags;
-  vmi::g_queue_flags = flags;
+  vmi::g_queue_flags = vmi::clamp_queue_flags(flags);
   return prev;
+}
+#endif
+
+int vmi_is_diag_build(void) {
+#ifdef VMI_DIAG
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 int vmi_paged_attention_v1_variant_fits(int32_t variant, int32_t max_seq_len, int32_t for_append) {
@@ -1870,6 +1898,7 @@ int vmi_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_hos
   return VMI_OK;
 }
 
+#ifdef VMI_DIAG
 int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blocks, int32_t nt,
                          int32_t device, void* stream) {
   using namespace vmi;
@@ -1920,5 +1949,7 @@ int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chu
   if (e != hipSuccess) return hip_fail(e, "diag_gather_read launch");
   return VMI_OK;
 }
+
+#endif  // VMI_DIAG
 
 }  // extern "C"
