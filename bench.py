@@ -39,9 +39,10 @@ Beside `value` (never as it), each a sub-record of the same line:
 
 Multi-GPU: sequences are sharded over ranks as independent KV pools, no collective on the data
 path.  --scaling weak (default): 256 sequences per GPU, pool of 65536 blocks (BASELINE configs[4]); --scaling strong:
-2048 sequences in all, 2048/N per GPU, pool = max(65536, what the batch needs).  For N > 1 every timed step ends
-with the one exchange a decode loop has — the all_gather of the step's sampled token ids (8 B per sequence, RCCL
-over xGMI; vllmini_amd/shard.py:gather_token_ids) — and its share of the step is reported as `token_exchange_us`.
+2048 sequences in all, 2048/N per GPU, pool = max(65536, what the batch needs).  For N > 1 the timed region also holds
+the one exchange a decode loop has — the all_gather of the sampled token ids (8 B per sequence, RCCL over xGMI;
+vllmini_amd/shard.py:gather_token_ids) — once per TOKEN, i.e. on every 12th layer step (GPT-2 small has 12 layers and a
+step here is one layer's call pair); its duration alone is reported as `token_exchange_us`.
 
 Diagnostic modes (--sweep, --diag, --matrix) live in scripts/bench_diag.py.
 """
@@ -301,10 +302,15 @@ def one_step(wl, out, i, variant, op="v1"):
 _EXCHANGE = {}     # per-run state of the N > 1 token exchange: ids tensor, global batch, per-step event pairs
 
 
+EXCHANGE_EVERY = 12    # layer steps per token: GPT-2 small's n_layer (the model BASELINE's configs name)
+
+
 def exchange_tokens(dist, i=None):
     """The decode loop's only collective: every rank hands the ids it sampled for its sequences to
-    all ranks.  Synthetic ids here; the all_gather is the real one."""
-    if dist is None:
+    all ranks.  Synthetic ids here; the all_gather is the real one.  A decode loop samples once per TOKEN, i.e. once
+    per n_layer of this bench's steps (a step is ONE layer's call pair), so inside the timed region the exchange runs
+    on every EXCHANGE_EVERY-th step, starting with the first (i = None: unconditionally)."""
+    if dist is None or (i is not None and i % EXCHANGE_EVERY):
         return
     _EXCHANGE["gathered"] = shard.gather_token_ids(_EXCHANGE["ids"], _EXCHANGE["global_batch"], dist,
                                                    out=_EXCHANGE["out"])
@@ -331,7 +337,7 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
 
     def step(i):
         one_step(wl, out, i, variant, op)
-        exchange_tokens(dist)
+        exchange_tokens(dist, i)
 
     elapsed = shard.timed_steps(step, steps, warmup, dist, sync=device_sync(dev))
     if dist is not None:
@@ -596,7 +602,7 @@ def standin_main(args, dist, rank, world, dev):
 
     def step(i):
         x.mul_(1.0)
-        exchange_tokens(dist)
+        exchange_tokens(dist, i)
 
     elapsed = shard.max_over_ranks(shard.timed_steps(step, args.steps, args.warmup, dist), dist, dev)
     if dist is not None:
@@ -782,7 +788,11 @@ def main(argv=None):
     }
     if dist is not None:
         line["token_exchange_us"] = shard.max_over_ranks(exchange_pass(args.kernel_samples, dist, dev), dist, dev)
-        line["token_exchange"] = f"all_gather of {cfg.batch} int64 ids per rank ({cfg.batch * world * 8} B in all), backend nccl (RCCL)"
+        line["token_exchange"] = (f"all_gather of {cfg.batch} int64 ids per rank ({cfg.batch * world * 8} B in all), backend nccl "
+                                  f"(RCCL); inside the timed region once per token = on every {EXCHANGE_EVERY}th layer step "
+                                  f"(steps 0, {EXCHANGE_EVERY}, ...); token_exchange_us = median of {args.kernel_samples} "
+                                  "exchanges alone, by HIP events")
+        line["token_exchange_every_steps"] = EXCHANGE_EVERY
     if args.op == "v1" and not args.no_fused:
         # the same step as ONE launch (vmi_paged_attention_v1_append_f16: bit-identical caches and out,
         # tests/test_parity_gpu.py); reported beside `value`, which stays the reference's two-op call pair
