@@ -86,7 +86,11 @@ for seed in range(first, first + n_cases):
         return out
 
     plain = attend(names["fp8_d64_bs16_h1_w1_u1_nt1" if f8 else f"d{D}_h1_w1_u1_nt1"], 0)
-    qn = names[("fp8_q_d64_s2q4" if seed % 2 else "fp8_q_d64_s1q2") if f8 else (f"q_d{D}_s1q2" if D == 64 else f"q_d{D}_s1q1")]
+    # ((seed // 3) % 3 == 0: the default fp8 kernel, K pass on the matrix cores — single-wave modes bit-identical to EACH OTHER, all
+    #  modes within the tolerance of the plain kernel; the VALU forms are bit-identical to the plain kernel as well)
+    qn = names[("fp8_q_d64_s2q4m", "fp8_q_d64_s2q4", "fp8_q_d64_s1q2")[(seed // 3) % 3] if f8 else (f"q_d{D}_s1q2" if D == 64 else f"q_d{D}_s1q1")]
+    km = f8 and (seed // 3) % 3 == 0
+    base = None if km else plain
     what = f"seed {seed}: B{B} H{H} D{D} top {top} kind {kind}{' fp8' if f8 else ''}"
     ok = bool(torch.isfinite(plain).all())
     nwaves = torch.cuda.get_device_properties(dev).multi_processor_count * (3 if D == 64 else 2) * 4
@@ -98,11 +102,13 @@ for seed in range(first, first + n_cases):
         if not torch.equal(got.view(torch.int16), again.view(torch.int16)):
             print(f"FAIL {what} [{label}]: not deterministic")
             ok = False
+        if bitwise and base is None:
+            base = got
         if bitwise:
-            if not torch.equal(got.view(torch.int16), plain.view(torch.int16)):
+            if not torch.equal(got.view(torch.int16), base.view(torch.int16)):
                 print(f"FAIL {what} [{label}]: differs from the plain kernel, max {(got.float() - plain.float()).abs().max().item():.3e}")
                 ok = False
-        else:
+        if not bitwise or km:
             d = (got.float() - plain.float()).abs().max().item()
             if not (d <= 1e-3) or not bool(torch.isfinite(got).all()):
                 print(f"FAIL {what} [{label}]: max|d| vs the plain kernel {d:.3e}")

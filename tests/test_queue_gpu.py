@@ -374,7 +374,7 @@ def test_two_host_threads_alternate_large_max_seq_len_launches():
 
 
 @pytest.mark.parametrize("qname,kvd", [("fp8_q_d64_s2q4", "fp8"), ("fp8_q_d64_s1q2", "fp8"), ("fp8e5m2_q_d64_s2q4", "fp8_e5m2"),
-                                       ("fp8_q_d128_s1q2", "fp8")])
+                                       ("fp8_q_d128_s1q2", "fp8"), ("fp8_q_d64_s2q4m", "fp8"), ("fp8_q_d128_s1q2m", "fp8")])
 def test_queue_kernel_over_fp8_pages_every_mode(qname, kvd, queue_flags):
     """fp8 pages (kv_scale 1: every cache element is half(float(fp8)), quant_utils.cuh:295-300) through every mode of the
     balanced kernel, against the CPU kernel model; single-wave modes agree with each other bit for bit; any other

@@ -1361,6 +1361,7 @@ struct Variant {
   bool SPARSE;       // block-sparse attention (blocksparse_vert_stride > 1); menus of their own (pa_variants_sparse.hip)
   bool QUEUE;        // balanced kernel (pa_queue.hpp): persistent grid of 3 workgroups per CU, mode chosen on the device
   bool STAGE;        // experiment (pa_stage.hip): pages staged through an LDS ring of U slots by global_load_lds
+  bool KM;           // balanced kernels: q.K^T of the K pass on the matrix cores (pa_queue.hpp); "m" names
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);

@@ -1,5 +1,5 @@
 // pa_queue.hip — instantiations of the balanced paged_attention_v1 kernels (pa_queue.hpp), block size 16.
-// Names: [bf16_]q_d<head>_s<U of mode S>q<U of mode Q>; the mode is chosen on the device.
+// Names: [bf16_|fp8_]q_d<head>_s<U of mode S>q<U of mode Q>[m]; the mode is chosen on the device; m = K pass on MFMA.
 #include "pa_queue.hpp"
 
 namespace vmi {
@@ -8,6 +8,9 @@ namespace vmi {
   {NAME, D, 16, 4, 1, US, true, 1, BF, (pa_kernel_t)pa_q_kernel<D, BF, true, US, UQ>, 0, 0, 0, 0, false, false, false, true},
 #define VMI_ROW_Q8(NAME, D, US, UQ, F8) /* fp8 pages (1 = E4M3, 2 = E5M2), float16 query, kv_scale 1 */            \
   {NAME, D, 16, 4, 1, US, true, 1, false, (pa_kernel_t)pa_q_kernel<D, false, true, US, UQ, F8>, 0, 0, 0, F8, false, false, false, true},
+
+#define VMI_ROW_Q8M(NAME, D, US, UQ, F8) /* ... with q.K^T of the K pass on the matrix cores (pa_queue.hpp, KM) */  \
+  {NAME, D, 16, 4, 1, US, true, 1, false, (pa_kernel_t)pa_q_kernel<D, false, true, US, UQ, F8, true>, 0, 0, 0, F8, false, false, false, true, false, true},
 
 Variant g_queue_variants[] = {
     // head size 64: one block per group when every item has its own wave, two when workers run items in turn
@@ -22,6 +25,12 @@ Variant g_queue_variants[] = {
     VMI_ROW_Q8("fp8_q_d64_s1q2", 64, 1, 2, 1)
     VMI_ROW_Q8("fp8e5m2_q_d64_s2q4", 64, 2, 4, 2)
     VMI_ROW_Q8("fp8_q_d128_s1q2", 128, 1, 2, 1)
+    // the same with q.K^T of the K pass on the matrix cores ("m", pa_queue.hpp KM): the default over fp8 pages — equal
+    // lengths unchanged (the 1-KiB tile request pattern is the bound there), ragged batches 47.8 -> 45.1 us on cfg3
+    // (mode Q runs half the waves, each with twice the VALU work), head size 128 370.8 -> 360.5 / 205.5 -> 197.5 us;
+    // over fp16 pages the same change is neutral and is not built (profiles/r03b_k_pass_on_mfma.md)
+    VMI_ROW_Q8M("fp8_q_d64_s2q4m", 64, 2, 4, 1)
+    VMI_ROW_Q8M("fp8_q_d128_s1q2m", 128, 1, 2, 1)
 };
 const int g_queue_nvariants = (int)(sizeof(g_queue_variants) / sizeof(g_queue_variants[0]));
 

@@ -71,7 +71,15 @@ constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at a
 //                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + QSORT_MAX*2 (the
 //                                 clamped lengths) + 4*64*8 (bucket masks)
 //                                 + 8*4 + 4*D*4 (a team's max / sum exchange and partial outputs).
-template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0>
+// KM: q.K^T of the K pass on the matrix cores.  The K tile as loaded IS the B operand of v_mfma_f32_16x16x32_f16 (lane =
+//     chunk*16 + token holds 8 dims of one token = B[k = 8*chunk ..][n = token]); A is q with every row the same (lane
+//     (chunk, m) holds the q dims of k-group `chunk`), so every row of the 16x16 result is the block's 16 logits and
+//     register 0 of lane l is the logit of token l & 15 — exactly what the fp32 FMA chain + xor butterfly leaves there.
+//     Products of 16-bit operands are exact in fp32 and the accumulation is fp32: the reference's arithmetic up to
+//     summation order (dtype_float16.cuh:292-298); the V pass keeps its fp16 rounding points on the VALU.  Built for the
+//     fp8 kernels, whose K pass is VALU-pressed (16 decodes + 8 packed FMAs + the butterfly per 16 dims): the decode to
+//     half pairs feeds the MFMA directly.  M = 1 of 16 rows is useful work — the matrix pipe is idle otherwise.
+template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false>
 // (second launch bound = minimum waves per SIMD: 3 workgroups of 4 waves per CU must all be resident in mode S, i.e.
 //  <= 168 VGPRs; head size 128 — twice the registers per block — runs 2 workgroups per CU, 256 VGPRs)
 __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ? 2 : 3) pa_q_kernel(const PAParams p) {
@@ -85,6 +93,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   constexpr int NL = D * BS / EPU / 64;  // 1-KiB loads per (block, head) tile of K — and of V
   static_assert((D * BS / EPU) % 64 == 0 && NL >= 1, "a tile must fill whole 1-KiB loads");
   static_assert(!(F8 && BF), "fp8 pages: float16 query only in these kernels");
+  static_assert(!(KM && BF), "KM is built for float16 operands");
   constexpr int UPR = BS / EPU;  // V: 16-B units per dim row
   constexpr int RPL = 64 / UPR;  // V: rows per load
   constexpr int QW = F8 ? 2 : 1;  // 16-byte pieces of q facing one K unit
@@ -288,7 +297,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     const int32_t* bt = nullptr;
     int64_t hoff = 0;  // this lane's BYTE offset inside a block: kv head tile + its 16-byte unit
     u32x4 qreg[NL][QW];
-    f32x2_t qf[F8 ? NL : 1][8];  // fp8 pages: q as fp32 pairs (v_pk_fma_f32 against the decoded bytes)
+    f32x2_t qf[(F8 && !KM) ? NL : 1][8];  // fp8 pages: q as fp32 pairs (v_pk_fma_f32 against the decoded bytes)
     float slope = 0.f;
     uint16_t* outp = nullptr;
 
@@ -305,7 +314,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       for (int i = 0; i < NL; ++i)
 #pragma unroll
         for (int w = 0; w < QW; ++w) qreg[i][w] = m.q[i][w];
-      if constexpr (F8) {
+      if constexpr (F8 && !KM) {
 #pragma unroll
         for (int i = 0; i < NL; ++i)
 #pragma unroll
@@ -353,17 +362,32 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
         if (idx < nmy) {  // wave-uniform
           const int token = (sub + idx * T) * BS + tk;
           const bool masked = token >= L;
-          float accv[NL];
+          float acc;
+          if constexpr (KM) {
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int i = 0; i < NL; ++i) {
-            if constexpr (F8) accv[i] = dot16_f8_s1<E5>(qf[i], r[j][i]);
-            else accv[i] = dot8<BF>(qreg[i][0], r[j][i]);
+            for (int i = 0; i < NL; ++i)
+#pragma unroll
+              for (int w = 0; w < QW; ++w) {
+                u32x4 kb = r[j][i];
+                if constexpr (F8) kb = deq8<true, false, E5>(r[j][i][2 * w], r[j][i][2 * w + 1], 1.f);
+                d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, qreg[i][w]),
+                                                            __builtin_bit_cast(h16x8, kb), d4, 0, 0, 0);
+              }
+            acc = d4[0];  // (all 16 rows are the same product: any register of any lane group holds token lane & 15)
+          } else {
+            float accv[NL];
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+              if constexpr (F8) accv[i] = dot16_f8_s1<E5>(qf[i], r[j][i]);
+              else accv[i] = dot8<BF>(qreg[i][0], r[j][i]);
+            }
+            acc = accv[0];
+#pragma unroll
+            for (int i = 1; i < NL; ++i) acc += accv[i];
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
           }
-          float acc = accv[0];
-#pragma unroll
-          for (int i = 1; i < NL; ++i) acc += accv[i];
-          acc += __shfl_xor(acc, 16);
-          acc += __shfl_xor(acc, 32);
           float qk = p.scale * acc;
           qk += (slope != 0.f) ? slope * (float)(token - L + 1) : 0.f;
           if (lane < BS) lg[token] = masked ? 0.f : qk;

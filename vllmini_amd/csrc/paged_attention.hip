@@ -648,6 +648,10 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
     // full chip, head size 64: the balanced kernel over fp8 pages (pa_queue.hpp) — ragged batches without a hint
     for (int id = 1; id <= nvariants_v1(); ++id) {
       const Variant& c = variant_v1(id);
+      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == 2 && c.KM) return id;  // K pass on MFMA
+    }
+    for (int id = 1; id <= nvariants_v1(); ++id) {  // (formats without an "m" kernel: E5M2)
+      const Variant& c = variant_v1(id);
       if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == 2) return id;
     }
   }
@@ -692,7 +696,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
       // (sequence, head) on equal lengths, ranked work lists on ragged ones; needs 3 workgroups' LDS per CU
       for (int id = 1; id <= nvariants_v1(); ++id) {
         const Variant& c = variant_v1(id);
-        if (c.QUEUE && c.BF == bf && c.D == head_size && c.BS == 16) return id;
+        if (c.QUEUE && c.BF == bf && c.D == head_size && c.BS == 16 && !c.F8 && !c.KM) return id;
       }
     }
     if (wph == 1 && u == 1 && nt) {  // full chip, one wave per head: the adaptive-depth form where one is built
@@ -995,7 +999,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
       num_seqs <= 65535 && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
     for (int i = 0; i < g_queue_nvariants; ++i)
       if (g_queue_variants[i].D == v.D && g_queue_variants[i].BF == v.BF && g_queue_variants[i].BS == v.BS &&
-          g_queue_variants[i].F8 == v.F8 &&
+          g_queue_variants[i].F8 == v.F8 && !g_queue_variants[i].KM &&
           2 * variant_lds_bytes(g_queue_variants[i], lpad) <= (size_t)160 * 1024)
         partner = &g_queue_variants[i];
   }
