@@ -22,13 +22,13 @@ names = {n: i + 1 for i, n in enumerate(ops.variant_names())}
 BS = 16
 
 
-def flags(mode=0, wq=0, nosort=0, team=0, early=0):
-    return mode | (wq << 2) | (nosort << 11) | (team << 12) | (early << 15)
+def flags(mode=0, wq=0, nosort=0, team=0, early=0, nohybrid=0):
+    return mode | (wq << 2) | (nohybrid << 10) | (nosort << 11) | (team << 12) | (early << 15)
 
 
 MODES = [("auto", flags(), None), ("S", flags(1), True), ("solo", flags(2, 2, 0, 1), True),
          ("solo early sort", flags(2, 2, 0, 1, 1), True), ("solo 1 worker", flags(2, 1, 0, 1), True),
-         ("solo unranked", flags(2, 2, 1, 1), True), ("team", flags(2, 0, 0, 2), False)]
+         ("solo unranked", flags(2, 2, 1, 1), True), ("team + solo quads", flags(2, 0, 0, 2), False), ("team only", flags(2, 0, 0, 2, 0, 1), False)]
 fails = 0
 t0 = time.time()
 for seed in range(first, first + n_cases):

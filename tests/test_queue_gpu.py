@@ -26,8 +26,8 @@ def _names():
     return {n: i + 1 for i, n in enumerate(ops.variant_names())}
 
 
-def _flags(mode=0, wq=0, nosort=0, team=0):
-    return mode | (wq << 2) | (nosort << 11) | (team << 12)
+def _flags(mode=0, wq=0, nosort=0, team=0, nohybrid=0):
+    return mode | (wq << 2) | (nohybrid << 10) | (nosort << 11) | (team << 12)
 
 
 # label -> (flags, bit-identical to the one-wave-per-head kernel?)
@@ -39,7 +39,8 @@ MODES = {
     "Q solo unranked": (_flags(2, 2, 1, 1), True),
     "Q solo 1 worker": (_flags(2, 1, 0, 1), True),
     "Q solo 4 workers": (_flags(2, 4, 0, 1), True),
-    "Q team": (_flags(2, 0, 0, 2), False),         # 4 waves per item: other fp32 summation order
+    "Q team": (_flags(2, 0, 0, 2), False),         # long items by 4 waves (other fp32 summation order), short ones in solo quads
+    "Q team only": (_flags(2, 0, 0, 2, 1), False),  # every item by 4 waves (what an unranked batch gets)
     "Q team unranked": (_flags(2, 0, 1, 2), False),
 }
 
@@ -98,7 +99,7 @@ def test_queue_kernel_several_rounds_of_solo_workers(B, H, queue_flags):
     ref = run_model(case)
     plain = run_hip(case, variant=names["d64_h1_w1_u1_nt1"])
     assert_close(plain, ref, f"B={B} H={H}: plain kernel")
-    for label in ("auto", "Q solo", "Q solo early sort", "Q solo 1 worker", "Q team"):
+    for label in ("auto", "Q solo", "Q solo early sort", "Q solo 1 worker", "Q team", "Q team only"):
         flags, bitwise = MODES[label]
         queue_flags(flags)
         got = run_hip(case, variant=names["q_d64_s1q2"])
@@ -271,7 +272,7 @@ def test_queue_kernel_heavy_tailed_batch_runs_teams_and_matches_model(queue_flag
     lens[7] = 0
     t_len = lens.to(dev)
     outs = {}
-    for label in ("auto", "Q solo", "Q team"):
+    for label in ("auto", "Q solo", "Q team", "Q team only"):
         queue_flags(MODES[label][0])
         out = torch.full((cfg.batch, cfg.num_heads, cfg.head_size), float("nan"), dtype=torch.float16, device=dev)
         ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, cfg.num_heads, wl.scale, wl.tables[0], t_len,
@@ -287,6 +288,64 @@ def test_queue_kernel_heavy_tailed_batch_runs_teams_and_matches_model(queue_flag
     qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
     ref = oracle.paged_attention_v1(qn, kc, vc, cfg.num_heads, wl.scale, small_tab, lens.numpy()[idx], cfg.block_size, threads=8)
     assert_close(outs["auto"].cpu().numpy()[idx], ref, "heavy-tailed batch, team mode vs model")
+
+
+@pytest.mark.parametrize("kind", ["heavy tail", "bimodal", "exponential"])
+def test_default_entry_on_heavy_tailed_batches_product_library(kind):
+    """PRODUCT library, no knob: BASELINE cfg3 with a few long sequences among many short ones / half long half short /
+    exponential lengths.  The kernel's own choice is teams for the long items (more than a quarter of the longest) and
+    solo quads for the short ones.  Every short row is bit-identical to the one-wave-per-head kernel (a wave on its own
+    repeats its operations), every long row is within the team tolerance of it, every row was written, and a sample of
+    long and short sequences matches the CPU kernel model."""
+    from vllmini_amd import _lib, ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    assert _lib.load().vmi_is_diag_build() == 0
+    dev = _dev()
+    names = _names()
+    cfg = CONFIGS["cfg3"]
+    wl = make_workload(cfg, dev, seed=13, table_sets=1)
+    g = torch.Generator().manual_seed(6)
+    Lm = cfg.seq_len
+    if kind == "heavy tail":
+        lens = torch.where(torch.rand(cfg.batch, generator=g) < 0.0625, Lm, Lm // 16)
+        lens[3] = 1000
+    elif kind == "bimodal":
+        lens = torch.where(torch.rand(cfg.batch, generator=g) < 0.5, Lm, Lm // 16)
+    else:
+        lens = torch.clamp((torch.empty(cfg.batch).exponential_(1.0, generator=g) * Lm / 8).long() + 1, max=Lm)
+        lens[0] = Lm
+    lens[9] = 0
+    lens = lens.to(torch.int32)
+    t_len = lens.to(dev)
+
+    def attend(variant=0):
+        out = torch.full((cfg.batch, cfg.num_heads, cfg.head_size), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, cfg.num_heads, wl.scale, wl.tables[0], t_len,
+                               cfg.block_size, cfg.seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+        torch.cuda.synchronize()
+        return out
+
+    got = attend()
+    assert ops.variant_names()[ops.last_variant() - 1] == "q_d64_s1q2"
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, attend())                                  # deterministic
+    plain = attend(names["d64_h4_w1_u1_nt1"])
+    maxL = int(lens.max())
+    short = (lens * 4 < maxL - 4)                                      # clearly below the long/short boundary
+    long_ = (lens * 4 > maxL + 4)
+    assert int(short.sum()) > 20 and int(long_.sum()) >= 4
+    sd, ld = short.to(dev), long_.to(dev)
+    assert torch.equal(got[sd].view(torch.int16), plain[sd].view(torch.int16)), "a short row differs from the one-wave kernel"
+    assert float((got[ld].float() - plain[ld].float()).abs().max()) <= 5e-4
+    if kind != "exponential":                                           # long rows really went through the 4-wave path
+        assert not torch.equal(got[ld].view(torch.int16), plain[ld].view(torch.int16))
+    li, si = np.nonzero(long_.numpy())[0], np.nonzero(short.numpy())[0]
+    idx = np.unique(np.r_[li[:5], si[:5], si[-3:], 9])
+    kc, vc, small_tab = _pages_to_host(wl, wl.tables[0], idx, cfg)
+    qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
+    ref = oracle.paged_attention_v1(qn, kc, vc, cfg.num_heads, wl.scale, small_tab, lens.numpy()[idx], cfg.block_size, threads=8)
+    assert_close(got.cpu().numpy()[idx], ref, f"{kind}: default entry, sampled vs model")
 
 
 def test_head_128_default_entry_is_a_gated_double_launch():

@@ -57,12 +57,14 @@ constexpr int QLATE_MAX = 512;   // ... ranked by ONE retired wave beside the wo
 // q_flags (PAParams): experiment / test knobs; 0 = automatic
 //   bits 0-1  mode      0 auto, 1 force S (when every item has a wave), 2 force Q
 //   bits 2-4  WQ        workers per workgroup in mode Q (0 -> 2)
+//   bit  10   teams only: no solo quads for the short items of a heavy-tailed batch
 //   bit  11   no ranking (index order)
 //   bits 12-13 team     0 auto, 1 force solo workers, 2 force teams (mode Q only)
 //   bit  14   no statistics (with a forced mode)      bit 15   rank everything up front (solo workers too)
 constexpr int QF_MODE(int f) { return f & 3; }
 constexpr int QF_TEAM(int f) { return (f >> 12) & 3; }
 constexpr int QF_WQ(int f) { return (f >> 2) & 7; }
+constexpr int QF_NOHYBRID = 1 << 10;  // teams take EVERY item (round 2's team mode), short ones included
 constexpr int QF_NOSORT = 1 << 11;
 constexpr int QF_EARLYSORT = 1 << 15;  // rank every sequence before the first item (no first round in index order)
 constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at all (with a forced mode)
@@ -79,7 +81,7 @@ constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at a
 //     summation order (dtype_float16.cuh:292-298); the V pass keeps its fp16 rounding points on the VALU.  Built for the
 //     fp8 kernels, whose K pass is VALU-pressed (16 decodes + 8 packed FMAs + the butterfly per 16 dims): the decode to
 //     half pairs feeds the MFMA directly.  M = 1 of 16 rows is useful work — the matrix pipe is idle otherwise.
-template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false>
+template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1>
 // (second launch bound = minimum waves per SIMD: 3 workgroups of 4 waves per CU must all be resident in mode S, i.e.
 //  <= 168 VGPRs; head size 128 — twice the registers per block — runs 2 workgroups per CU, 256 VGPRs)
 __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ? 2 : 3) pa_q_kernel(const PAParams p) {
@@ -157,6 +159,8 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   int maxL = 0;
   float sumL = 0.f;
   bool have_sum = false;
+  bool ragged = false;
+  int nlong_est = 0;
   // Statistics: every wave reads ALL the lengths once (8 loads in flight per trip of the loop) and leaves them, clamped,
   // in LDS for the counting sort below — the passes of the sort must not go back to memory (three dependent round
   // trips in front of the first page).
@@ -169,9 +173,13 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     });
     sumL = sum;
     have_sum = true;
-    const bool ragged = batch_is_ragged(maxL, sum, B);
+    ragged = batch_is_ragged(maxL, sum, B);
     if ((flags & QF_GATE_RAGGED) && !ragged) return;  // gated double launch: the kernel in front of me did this batch
     queue = queue || ragged;
+    if (rankable && ragged) {  // how many sequences are LONG (more than a quarter of the longest)?  From my own LDS copy
+      for (int c = 0; c < B; c += 64)  // of the lengths: a wave reads what it wrote itself, no barrier
+        nlong_est += (int)__popcll(__ballot(c + lane < B && 4 * (int)len16[c + lane] > maxL));
+    }
   }
   if (QF_MODE(flags) == 1 && N <= nwaves) queue = false;
   if (QF_MODE(flags) == 2) queue = true;
@@ -180,11 +188,16 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   // batch) to finish with the others; when a few sequences are much longer than the rest — the usual shape of a
   // serving batch — the four waves of a workgroup work on ONE item together instead (blocks dealt round-robin, three
   // LDS barriers per item), which makes the longest item four times shorter.
+  // Round 3: the same when the batch is BIMODAL — at most 70 % of the sequences are long (more than a quarter of the
+  // longest).  Solo workers then hold a few long items each, and a worker that happens to get one more than its
+  // neighbours finishes that much later (half the sequences full, half 1/16: 94 us with solo workers against 81 us;
+  // cfg4 413 against 383), whatever the ratio to its share says.  Continuous spreads (U{1..L}: 75 % long) stay with solo
+  // workers, whose snake pairs a long item with a short one (67 us against 74).  profiles/r03c_heavy_tailed_batches.md
   bool team = false;
   if (queue && have_sum) {
     const int wq0 = QF_WQ(flags) ? QF_WQ(flags) : 2;
     const float share = sumL * (float)H / (float)(gridDim.x * wq0);  // tokens per solo worker
-    team = (float)maxL > 1.15f * share;
+    team = (float)maxL > 1.15f * share || (ragged && rankable && nlong_est * 10 <= 7 * B);
   }
   if (QF_TEAM(flags) == 1) team = false;
   if (QF_TEAM(flags) == 2) team = queue;
@@ -198,7 +211,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   //      k), index order inside a bucket — deterministic, so every workgroup computes the same table for itself.
   //      `nsw` waves share the 64-sequence chunks (this one is number `me` of them): all four with a workgroup barrier
   //      between the passes, or ONE wave on its own, without any barrier.  B <= QSORT_MAX. ----
-  auto rank_sequences = [&](int lo, int me, int nsw) {
+  //      Returns how many of the ranked sequences are LONG — longer than a quarter of the longest (buckets 0..47) — i.e.
+  //      the rank at which the short ones start (wave-uniform, the same in every wave that calls this).
+  auto rank_sequences = [&](int lo, int me, int nsw) -> int {
     uint16_t* cnt = order + QSORT_MAX;  // [chunk][bucket]: sequences of the chunk in the bucket
     const int nch = (B + 63) >> 6;
     const float bscale = 64.f / (float)(maxL + 1);
@@ -242,6 +257,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       }
       run += cnt[c * 64 + lane];
     }
+    return __builtin_amdgcn_readlane(incl, 47);
   };
 
   // ---- solo workers, FIRST ROUND IN INDEX ORDER ("late" ranking).  Ranking everything first puts the sort and one more
@@ -280,7 +296,8 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   float* osm = red + 8;                                                                                  // [4][D]
 
   // QMODE = false is mode S: one item, nothing to hand out or to prefetch — compiled without any of that.
-  auto run = [&](auto utag, auto teamtag, auto qtag, const Meta& first) {
+  // `handout(k, seq, head)` names this worker's k-th item (k = 1, 2, ... after `first`) or returns false (wave-uniform).
+  auto run = [&](auto utag, auto teamtag, auto qtag, const Meta& first, auto&& handout) {
     constexpr int UU = decltype(utag)::value;
     constexpr bool TEAM = decltype(teamtag)::value;
     constexpr bool QMODE = decltype(qtag)::value;
@@ -458,21 +475,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       auto fetch_next = [&]() {  // wave-uniform decision + the requests for the next item's metadata
         if constexpr (QMODE) {
           int s, h;
-          if (!TEAM && late) {  // the snake over the ranks of the sequences behind the first round, by my place v in it
-            const int64_t t64 = (int64_t)round * nworkers + ((round & 1) ? vrank : nworkers - 1 - vrank);
-            has_next = t64 < N - nworkers;
-            if (has_next && round == 0)  // the retired wave's ranking must be complete before its first use
-              while (*sorted != 1) __builtin_amdgcn_s_sleep(1);
-            const int t = has_next ? (int)t64 : 0;
-            const int r = t / H;
-            h = t - r * H;
-            s = has_next ? (int)__builtin_amdgcn_readfirstlane((int)order[r]) : 0;
-          } else {
-            const int k = round + 1;  // the snake over the ranks
-            const int64_t t64 = (int64_t)k * nworkers + ((k & 1) ? (nworkers - 1 - wq) : wq);
-            has_next = t64 < N;
-            ids_of(has_next ? (int)t64 : 0, s, h);
-          }
+          has_next = handout(round + 1, s, h);
           meta_issue(nxt, s, h, T, sub);  // requested unconditionally (item 0 when there is no next one): no phi
         }
       };
@@ -645,18 +648,85 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   // identical hot loops and identical rocprofv3 kernel time: profiles/r02m_late_ranking.md).
   if (!queue) {
     if (wq >= N) return;
-    run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{}, cur);
+    run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{}, cur, [](int, int&, int&) { return false; });
     return;
   }
 
-  if (queue) {
-    if (!late) {
-      if (ranked) rank_sequences(0, wave, 4);
-      __syncthreads();
-    } else if (more) {
-      if (tid == 0) *sorted = 0;
-      lds_barrier();
+  int nlong = B;  // teams: ranks [0, nlong) are the long sequences (everything when the batch is not ranked)
+  if (!late) {
+    if (ranked) nlong = rank_sequences(0, wave, 4);
+    __syncthreads();
+  } else if (more) {
+    if (tid == 0) *sorted = 0;
+    lds_barrier();
+  }
+
+  // ---- hand-out of a solo worker's items after its first one; ONE functor for the three schedules (so that `run` is
+  //      instantiated once for solo workers), the schedule is wave-uniform ----
+  int hmode = 1;           // 0: late-ranked snake by vrank, 1: snake over the ranks by wq, 2: quads behind the long items
+  int64_t NL_items = N;    // hmode 2: long items come first in rank order ...
+  int64_t nunits = N;      // ... then the quads: units in all
+  int k1 = 0;              // hmode 2: this workgroup's first unit behind the long items
+  const int G = gridDim.x, g = blockIdx.x;
+  auto unit = [&](int k) -> int64_t { return (int64_t)k * G + ((k & 1) ? (G - 1 - g) : g); };  // the snake over workgroups
+  auto quad_item = [&](int k) -> int64_t {  // my wave's item of this workgroup's (k1 + k)-th unit, N if there is none
+    const int64_t u = unit(k1 + k);
+    const int64_t t = NL_items + 4 * (u - NL_items) + wave;
+    return u < nunits && t < N ? t : (int64_t)N;
+  };
+  auto solo_handout = [&](int k, int& s, int& h) -> bool {
+    if (hmode == 0) {  // the snake over the ranks of the sequences behind the first round, by my place v in it
+      const int rd = k - 1;
+      const int64_t t64 = (int64_t)rd * nworkers + ((rd & 1) ? vrank : nworkers - 1 - vrank);
+      const bool has = t64 < N - nworkers;
+      if (has && rd == 0)  // the retired wave's ranking must be complete before its first use
+        while (*sorted != 1) __builtin_amdgcn_s_sleep(1);
+      const int t = has ? (int)t64 : 0;
+      const int r = t / H;
+      h = t - r * H;
+      s = has ? (int)__builtin_amdgcn_readfirstlane((int)order[r]) : 0;
+      return has;
     }
+    const int64_t t64 = hmode == 1 ? (int64_t)k * nworkers + ((k & 1) ? (nworkers - 1 - wq) : wq) : quad_item(k);
+    const bool has = t64 < N;
+    ids_of(has ? (int)t64 : 0, s, h);
+    return has;
+  };
+
+  Meta first;  // (a variable of its own: sharing `cur` with mode S made the two paths' values one register, spilled)
+  if (team) {
+    // ---- TEAMS FOR THE LONG ITEMS, SOLO QUADS FOR THE SHORT ONES (round 3).  A heavy-tailed batch (a few long sequences
+    //      among many short ones) made every item a team item in round 2: the long ones became four times shorter, but
+    //      each short one still paid a team's fixed cost (three barriers, a softmax and an output exchange for a handful
+    //      of blocks) — 2.3-3.7 us per item, seven items in a row on the workgroups without a long one.  Now the unit
+    //      handed to a workgroup is either ONE long item (length > maxL/4: ranks [0, nlong), done by the four waves
+    //      together) or a QUAD of four short items of consecutive rank (one per wave, each wave on its own: no barrier,
+    //      four items' fixed costs side by side).  A short item run by one wave is no longer than the longest item run
+    //      by four, so units are comparable and the same snake over the ranked units balances them.  The units of a
+    //      workgroup come in rank order: first its long items (phase 1), then its quads (phase 2). ----
+    const bool hybrid = ranked && !(flags & QF_NOHYBRID);
+    NL_items = hybrid ? (int64_t)nlong * H : (int64_t)N;
+    nunits = NL_items + ((int64_t)N - NL_items + 3) / 4;
+    if (g < NL_items) {
+      Meta tfirst;
+      int s0, h0;
+      ids_of(g, s0, h0);
+      meta_issue(tfirst, s0, h0, 4, wave);
+      run(std::integral_constant<int, UT>{}, std::true_type{}, std::true_type{}, tfirst, [&](int k, int& s, int& h) {
+        const int64_t u = unit(k);
+        const bool has = u < NL_items;
+        ids_of(has ? (int)u : 0, s, h);
+        return has;
+      });
+    }
+    if (NL_items >= N) return;
+    while (unit(k1) < NL_items) ++k1;
+    if (quad_item(0) >= N) return;
+    hmode = 2;
+    int s0, h0;
+    ids_of((int)quad_item(0), s0, h0);
+    meta_issue(first, s0, h0, 1, 0);
+  } else {
     if (wave >= WQ) {  // not a worker in this mode
       if (late && more && wave == WQ) {
         rank_sequences(R0, 0, 1);
@@ -665,29 +735,25 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       }
       return;
     }
-  }
-  if (wq >= N) return;  // more workers than items (forced modes only)
-  Meta first;  // (a variable of its own: sharing `cur` with mode S made the two paths' values one register, spilled)
-  if (late) {
-    first = firstq;  // first item = item wq in index order: asked for at the top of the kernel
-    const int myL = (int)len16[sq0];  // (every wave staged all the lengths itself: no barrier needed)
-    int a = 0;
-    for (int j0 = 0; j0 < R0; j0 += 64) {
-      const int j = j0 + lane;
-      const int lj = j < R0 ? (int)len16[j] : -1;
-      a += (int)__popcll(__ballot(lj > myL || (lj == myL && j < sq0)));
+    if (wq >= N) return;  // more workers than items (forced modes only)
+    if (late) {
+      hmode = 0;
+      first = firstq;  // first item = item wq in index order: asked for at the top of the kernel
+      const int myL = (int)len16[sq0];  // (every wave staged all the lengths itself: no barrier needed)
+      int a = 0;
+      for (int j0 = 0; j0 < R0; j0 += 64) {
+        const int j = j0 + lane;
+        const int lj = j < R0 ? (int)len16[j] : -1;
+        a += (int)__popcll(__ballot(lj > myL || (lj == myL && j < sq0)));
+      }
+      vrank = a * H + hq0;
+    } else {  // first item of worker wq = rank order position wq
+      int s0, h0;
+      ids_of(wq, s0, h0);
+      meta_issue(first, s0, h0, 1, 0);
     }
-    vrank = a * H + hq0;
-  } else if (queue) {  // first item of worker wq = rank order position wq
-    int s, h;
-    ids_of(wq, s, h);
-    meta_issue(first, s, h, team ? 4 : 1, team ? wave : 0);
   }
-
-
-  if (team) run(std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{}, first);
-  else run(std::integral_constant<int, UQ>{}, std::false_type{}, std::true_type{}, first);
-
+  run(std::integral_constant<int, UQ>{}, std::false_type{}, std::true_type{}, first, solo_handout);
 }
 
 }  // namespace vmi
