@@ -728,7 +728,13 @@ def main(argv=None):
     ms_per_step = elapsed / args.steps * 1e3
     # ---- the attention kernel's duration: its own pass ------------------------------------------------------------------
     ks = kernel_stats(kernel_pass(wl, out, args.kernel_samples, args.variant, dev, op=args.op), dist, dev)
-    achieved = alg_bytes(cfg) / (ks["median"] * 1e-6) / 1e9
+    line_bytes = alg_bytes(cfg)
+    if args.ragged or args.ragged_sorted:      # the bytes that exist in THIS batch (lengths differ), not the config's
+        tok = int(wl.seq_lens.sum().item())
+        line_bytes = 2 * tok * cfg.kv_heads * cfg.head_size * (1 if args.kv.startswith("fp8") else 2) + \
+            2 * cfg.batch * cfg.num_heads * cfg.head_size * 2 + \
+            int(((wl.seq_lens + cfg.block_size - 1) // cfg.block_size).sum().item()) * 4 + cfg.batch * 4
+    achieved = line_bytes / (ks["median"] * 1e-6) / 1e9
     # the variant the library actually launched (it knows the launch's kv_scale, the pick queries do not)
     vid = args.variant or (ops.last_variant() if args.op in ("v1", "fused") else 0)
     vname = ops.variant_names()[vid - 1] if vid else f"paged_attention_v2 variant {args.variant or 'auto'}"
@@ -781,9 +787,12 @@ def main(argv=None):
             "traffic": traffic,
             "traffic_source": traffic_src,
             "kernel": "pa_q_kernel" if vname.startswith(("q_d", "bf16_q_d", "fp8_q_d")) else "pa_v1_kernel",
-            "algorithmic_bytes_per_launch": alg_bytes(cfg),
-            "mfma": 0, "mfma_note": "multi-head decode is M = 1 per KV head: both contractions are GEMVs, the kernel "
-                                    "issues no MFMA (SQ_INSTS_MFMA = 0, profiles/pmc_cfg3_latest.json)",
+            "algorithmic_bytes_per_launch": line_bytes,
+            **({"mfma": "q.K^T of the K pass", "mfma_note": "fp8 pages: the decoded K tile is the B operand of v_mfma_f32_16x16x32_f16, q "
+                "the A operand with 16 equal rows — 1 of 16 result rows is useful work, the matrix pipe is otherwise idle; "
+                "p.V stays on the VALU (profiles/r03b_k_pass_on_mfma.md)"} if vname.endswith("m") and "_q_d" in vname else
+               {"mfma": 0, "mfma_note": "multi-head decode is M = 1 per KV head: both contractions are GEMVs, the kernel "
+                                        "issues no MFMA (SQ_INSTS_MFMA = 0, profiles/pmc_cfg3_latest.json)"}),
         },
     }
     if dist is not None:
@@ -849,6 +858,7 @@ def main(argv=None):
         out4 = torch.empty((c4.batch, c4.num_heads, c4.head_size), dtype=torch.float16, device=dev)
         rec, _ = pair_record(wl4, out4, args, 0, dist, dev, c4.batch * world * args.steps, alg_bytes(c4, "auto"))
         v4 = ops.variant_names()[ops.last_variant() - 1]
+        rec["launch"] = ops.last_launch_label()
         t4, t4src = pmc_traffic("cfg4", v4)
         line["cfg4_step"] = {"op": "reshape_and_cache + paged_attention_v1, BASELINE configs[3]: batch 128/GPU, seq_len 2048, "
                                    "32 heads x 128, block_size 16, num_blocks 32768, fp16", **rec,

@@ -357,6 +357,13 @@ int vmi_set_pv_mfma(int32_t on);
  * measurement with the kernel that produced it; the pick functions above answer without the launch's kv_scale.
  */
 int vmi_paged_attention_v1_last_variant(void);
+/*
+ * Head size 128 on a full chip goes out as a GATED DOUBLE LAUNCH: the kernel vmi_paged_attention_v1_last_variant names
+ * (built for equal lengths) and, behind it, a balanced kernel; each reads seq_lens on the device and leaves at once
+ * unless the batch is its kind, so the host cannot know which of the two did the work.  This returns the id of that
+ * second kernel for the calling thread's last launch, 0 when the launch was a single kernel.
+ */
+int vmi_paged_attention_v1_last_partner(void);
 
 /*
  * 1 when `variant` can serve a launch with this max_seq_len (its logits rows fit the 160 KiB of LDS) and, with

@@ -382,6 +382,8 @@ def test_head_128_default_entry_is_a_gated_double_launch():
         assert torch.equal(got.view(torch.int16), alone.view(torch.int16)), what
     lens = torch.randint(1, cfg.seq_len + 1, (cfg.batch,), generator=g).to(torch.int32)
     got = attend(lens.to(dev))
+    label = ops.last_launch_label()        # both kernels of the double launch are named, whichever did the work
+    assert label.startswith("d128_mh4_h4_u1_nt1_lock | q_d128_s1q1") and "gated" in label, label
     order = np.argsort(-lens.numpy(), kind="stable")
     idx = np.unique(np.r_[order[:3], order[-3:], 0, cfg.batch - 1])
     kc, vc, small_tab = _pages_to_host(wl, wl.tables[0], idx, cfg)

@@ -55,6 +55,22 @@ def _worker(rank, world, port, tmpdir):
         want = torch.tensor([i * 10 + shard.owner_of(i, B, world) for i in range(B)], dtype=torch.int64)
         assert torch.equal(allids, want)
 
+        # ... and the even-batch fast path (ONE all_gather_into_tensor into a preallocated buffer: what bench.py and the
+        # scheduler run under RCCL), with and without `out`, from a non-contiguous source, and its argument checks
+        B8 = 8
+        lo8, hi8 = shard.shard_range(B8, rank, world)
+        ids8 = torch.arange(lo8, hi8, dtype=torch.int64) * 7 + 1
+        want8 = torch.arange(B8, dtype=torch.int64) * 7 + 1
+        assert torch.equal(shard.gather_token_ids(ids8, B8, dist), want8)
+        buf = torch.full((B8,), -1, dtype=torch.int64)
+        got8 = shard.gather_token_ids(ids8, B8, dist, out=buf)
+        assert got8 is buf and torch.equal(buf, want8)
+        strided = torch.stack([ids8, ids8 + 100], dim=1)[:, 0]          # a view with stride 2
+        assert not strided.is_contiguous() and torch.equal(shard.gather_token_ids(strided, B8, dist), want8)
+        for bad in (torch.empty(B8 + 1, dtype=torch.int64), torch.empty(B8, dtype=torch.int32)):
+            with pytest.raises(ValueError):
+                shard.gather_token_ids(ids8, B8, dist, out=bad)
+
         # private pools: the same seq ids on different ranks never collide (independent free lists)
         pool = PagedKVPool(64, H, D, 16, 4, 2, device="cpu", allocate_tensors=False)
         for sid in range(lo, hi):

@@ -65,6 +65,7 @@ SIGNATURES = {
     "vmi_paged_attention_v1_pick_variant_gqa": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "vmi_set_pv_mfma": (ctypes.c_int, [_i32]),
     "vmi_paged_attention_v1_last_variant": (ctypes.c_int, []),
+    "vmi_paged_attention_v1_last_partner": (ctypes.c_int, []),
     "vmi_paged_attention_v1_variant_fits": (ctypes.c_int, [_i32, _i32, _i32]),
     "vmi_paged_attention_v1_pick_variant_hint": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v2_f16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32]),

@@ -754,6 +754,7 @@ static thread_local int g_queue_flags = clamp_queue_flags(env_int("VMI_QUEUE_FLA
 static constexpr int g_queue_flags = 0;
 #endif
 static thread_local int g_last_variant = 0;  // what this thread's last paged_attention_v1 launch ran (0: none yet / block-sparse)
+static thread_local int g_last_partner = 0;  // ... and the balanced kernel launched behind it in a gated double launch (0: none)
 
 static int device_cus(int device) {  // caller holds the device current
   if (device < 0 || device >= MAX_DEVICES) return 256;
@@ -964,6 +965,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   p.num_seqs = num_seqs;
   p.q_flags = 0;
   g_last_variant = sparse_v ? 0 : variant;
+  g_last_partner = 0;
 
   // the balanced kernel's launch: persistent geometry — as many 4-wave workgroups as stay resident (3 per CU while their
   // LDS fits, 2 for head size 128), never more than one wave per item; the kernel picks its mode from seq_lens
@@ -996,14 +998,19 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   // that leaves costs a launch boundary, about 2 us of a 300-600 us call.
   Variant* partner = nullptr;
   if (gate_ok && v.D == 128 && v.BS == 16 && v.WPH == 1 && !v.GQS && !v.F8 && !v.SPARSE &&
-      num_seqs <= 65535 && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
+      // (every wave of BOTH kernels reads all the lengths for the verdict — 4*B bytes per wave out of L2: bounded by 2048, the
+      //  size the balanced kernel ranks in LDS; a larger batch runs the lockstep kernel alone, as a one-kernel launch)
+      num_seqs <= 2048 && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
     for (int i = 0; i < g_queue_nvariants; ++i)
       if (g_queue_variants[i].D == v.D && g_queue_variants[i].BF == v.BF && g_queue_variants[i].BS == v.BS &&
           g_queue_variants[i].F8 == v.F8 && !g_queue_variants[i].KM &&
           2 * variant_lds_bytes(g_queue_variants[i], lpad) <= (size_t)160 * 1024)
         partner = &g_queue_variants[i];
   }
-  if (partner) p.q_flags |= QF_GATE_UNIFORM;
+  if (partner) {
+    p.q_flags |= QF_GATE_UNIFORM;
+    g_last_partner = nvariants_v1() - g_stage_nvariants - g_queue_nvariants + (int)(partner - g_queue_variants) + 1;
+  }
 
   dim3 block(v.HPW * v.WPH * 64);
   // gridDim.y is limited to 65535: longer batches go out as consecutive launches over slices
@@ -1502,6 +1509,7 @@ int vmi_set_pv_mfma(int on) {
 }
 
 int vmi_paged_attention_v1_last_variant(void) { return vmi::g_last_variant; }
+int vmi_paged_attention_v1_last_partner(void) { return vmi::g_last_partner; }
 
 #ifdef VMI_DIAG
 int vmi_debug_set_queue_flags(int flags) {

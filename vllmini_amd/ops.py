@@ -479,7 +479,9 @@ def variant_names_v2() -> list[str]:
 
 
 def set_pv_mfma(on: bool) -> bool:
-    """Opt-in (process-wide, default off; returns the previous setting): with grouped-query attention let the
+    """Opt-in (PER HOST THREAD since C-ABI 17 — thread-local in the library: set it on the thread that issues the
+    launches; a setting made on the main thread does not reach a worker thread — default off; returns the calling
+    thread's previous setting): with grouped-query attention let the
     operators pick the "_pvm" kernels, which also run probabilities x V on the matrix cores.  Results then match
     the reference kernel to the north-star 1e-3 instead of 1-2 fp16 ulp (include/vmi_paged_attention.h,
     vmi_set_pv_mfma); 1.2x faster with 8 query heads per KV head."""
@@ -495,6 +497,17 @@ def variant_fits(variant: int, max_seq_len: int, for_append: bool = False) -> bo
 def last_variant() -> int:
     """Id of the variant the calling thread's last paged_attention_v1 launch ran (0: none yet / block-sparse)."""
     return int(_lib.load().vmi_paged_attention_v1_last_variant())
+
+
+def last_launch_label() -> str:
+    """Name(s) of what the calling thread's last paged_attention_v1 launch ran: "a", or "a | b (gated double launch: one
+    of the two, chosen on the device from seq_lens)" — for labelling measurements."""
+    lib = _lib.load()
+    a, b = int(lib.vmi_paged_attention_v1_last_variant()), int(lib.vmi_paged_attention_v1_last_partner())
+    if not a:
+        return ""
+    names = variant_names()
+    return names[a - 1] if not b else f"{names[a - 1]} | {names[b - 1]} (gated double launch: the device picks one from seq_lens)"
 
 
 def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16,

@@ -85,7 +85,10 @@ def gather_token_ids(local_ids: torch.Tensor, global_batch: int, dist=None,
     if global_batch % world == 0:
         if out is None:
             out = torch.empty(global_batch, dtype=torch.int64, device=local_ids.device)
-        dist.all_gather_into_tensor(out, local_ids)
+        elif out.shape != (global_batch,) or out.dtype != torch.int64 or out.device != local_ids.device or \
+                not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous int64 [{global_batch}] tensor on {local_ids.device}")
+        dist.all_gather_into_tensor(out, local_ids.contiguous())
         return out
     width = -(-global_batch // world)
     padded = torch.zeros(width, dtype=torch.int64, device=local_ids.device)
