@@ -9,9 +9,9 @@ and only as the checker.  vllmini_amd/ (the product) never does.
                  against and uses where it has no kernel (vllmini/model/gpt2.py:71-78,
                  vllmini/tests/kernels/paged_attention.py:102-110)
 
-Pin status: see pa_kernel_model.c header and DESIGN.md — "parity unpinned" against the CUDA
-kernel's own outputs (cannot be produced here), pinned against the reference's Python eager
-path via tests/golden/.
+Pin status (pa_kernel_model.c header): PINNED by fixtures generated from the imported reference Python
+(tests/golden/: its eager attention, its own unittest run against this model, its scheduler's op-call trace).  The CUDA
+kernel's own outputs cannot be produced in this pipeline; fidelity to its rounding points rests on the restatement.
 """
 from .kernel_model import (  # noqa: F401
     bf16_bits_to_f32,

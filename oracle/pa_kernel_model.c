@@ -23,14 +23,16 @@
  * for bit is the GPU's approximate transcendental hardware: __expf (:335, ex2.approx) and
  * __fdividef (:342, rcp.approx) are replaced by libm expf and an IEEE divide (<= 2 ulp fp32).
  *
- * PARITY PIN STATUS: the reference CUDA kernel cannot be built or run in this pipeline (no
- * nvcc, no NVIDIA GPU; its USE_ROCM branch includes files that do not exist in the tree,
- * quantization/fp8/amd/quant_utils.cuh:8-10), and the reference ships no golden vectors for
- * it.  So this model is "parity unpinned" against the CUDA kernel's own outputs.  It IS pinned
- * against everything the reference can produce here: the eager attention the reference's test
- * compares its kernel with (vllmini/tests/kernels/paged_attention.py:102-138, atol 1e-2; same
- * expression as vllmini/model/gpt2.py:71-78) — golden vectors generated by importing that
- * Python (tests/golden/gen_golden.py) — and the layout round trip that test asserts (:63-82).
+ * PARITY PIN STATUS: PINNED by fixtures generated here from the IMPORTED reference Python (tests/golden/gen_golden.py,
+ * committed with its outputs): ref_eager.npz — the eager attention the reference's own test compares its kernel with
+ * (vllmini/tests/kernels/paged_attention.py:102-138, atol 1e-2; same expression as vllmini/model/gpt2.py:71-78) —,
+ * ref_selftest.json — that unittest executed against this model through a stub paged_attention_cuda —, seam_trace.npz —
+ * every op call of the reference scheduler stack for config 1 — and the layout round trip that test asserts (:63-82);
+ * tests/test_oracle.py checks all of them.  What no vector in this pipeline can pin is the CUDA kernel's OWN output: it
+ * cannot be built or run here (no nvcc, no NVIDIA GPU; its USE_ROCM branch includes files missing from the tree,
+ * quantization/fp8/amd/quant_utils.cuh:8-10) and the reference ships no golden vectors for it.  Fidelity to the kernel's
+ * rounding points therefore rests on this line-by-line restatement (every cited line can be read against the source),
+ * inside the bound the reference's own test sets between its kernel and its eager path.
  *
  * Generic over head_size (multiple of 8*THREAD_GROUP_SIZE... the reference set 64..256) and
  * block_size in {8, 16, 32} by following the reference's constexpr formulas (:138-168, :360-369).
