@@ -81,7 +81,8 @@ dists = {
     "one full, rest 1/16": torch.where(torch.arange(B) < 1, Lm, Lm // 16),
     "4 full, rest 1/32": torch.where(torch.arange(B) < 4, Lm, Lm // 32),
 }
-MODES = [("auto", flags()), ("teams only (r02)", flags(2, 0, 0, 2, 1)), ("hybrid forced", flags(2, 0, 0, 2)), ("solo forced", flags(2, 2, 0, 1))]
+MODES = [("auto", flags()), ("teams only (r02)", flags(2, 0, 0, 2, 1)), ("hybrid forced", flags(2, 0, 0, 2)), ("solo forced", flags(2, 2, 0, 1)),
+         ("solo 4 workers", flags(2, 4, 0, 1))]
 res = {}
 print(f"{cfg.name} {args.kv} {qn}: median kernel us by HIP events ({args.iters} launches)")
 for dname, lens in dists.items():

@@ -193,6 +193,46 @@ def test_pa_v1_seq_len_zero_gives_zero_rows():
     assert_close(got, ref, "L=0 rows")
 
 
+def test_empty_batch_is_a_no_op_for_every_operator():
+    """num_seqs == 0 / num_tokens == 0: a scheduler between requests hands in empty tensors (torch gives them null data
+    pointers).  Every operator returns without touching the caches — v1, v2, the fused append, reshape_and_cache, over
+    fp16 and fp8 pages.  (The reference would launch a zero-sized grid: a CUDA launch error.)"""
+    ext = _ext()
+    from vllmini_amd import ops
+
+    dev = _dev()
+    H, D, NB = 12, 64, 8
+    g = torch.Generator(device=dev).manual_seed(1)
+    kc = torch.rand((NB, H, D // 8, BS, 8), device=dev, generator=g).to(torch.float16)
+    vc = torch.rand((NB, H, D, BS), device=dev, generator=g).to(torch.float16)
+    k8 = torch.randint(0, 64, (NB, H, D // 16, BS, 16), dtype=torch.uint8, device=dev, generator=g)
+    v8 = torch.randint(0, 64, (NB, H, D, BS), dtype=torch.uint8, device=dev, generator=g)
+    before = [t.clone() for t in (kc, vc, k8, v8)]
+    q = torch.zeros((0, H, D), dtype=torch.float16, device=dev)
+    out = torch.empty_like(q)
+    tab = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    lens = torch.zeros((0,), dtype=torch.int32, device=dev)
+    slots = torch.zeros((0,), dtype=torch.int64, device=dev)
+    tail = (H, 0.125, tab, lens, BS, 64, None)
+    assert q.data_ptr() == 0                                        # what the C-ABI sees for an empty tensor
+    ext.paged_attention_v1(out, q, kc, vc, *tail, "auto", 1.0, 0, 0, 1, 1, 0)
+    ext.paged_attention_v1(out, q, k8, v8, *tail, "fp8", 1.0, 0, 0, 1, 1, 0)
+    es = torch.empty((0, H, 1), dtype=torch.float32, device=dev)
+    ext.paged_attention_v2(out, es, es.clone(), torch.empty((0, H, 1, D), dtype=torch.float16, device=dev), q, kc, vc, *tail,
+                           "auto", 1.0, 0, 0, 1, 1, 0)
+    ext.cache_ops.reshape_and_cache(q, q, kc, vc, slots, "auto", 1.0)
+    ext.cache_ops.reshape_and_cache(q, q, k8, v8, slots, "fp8", 1.0)
+    ops.paged_attention_v1_append(out, q, q, q, kc, vc, H, 0.125, tab, lens, BS, 64)
+    torch.cuda.synchronize()
+    for t, b in zip((kc, vc, k8, v8), before):
+        assert torch.equal(t, b)
+    with pytest.raises(RuntimeError, match="Unsupported head size"):    # validation still runs on an empty batch
+        ext.paged_attention_v1(torch.empty((0, H, 72), dtype=torch.float16, device=dev),
+                               torch.empty((0, H, 72), dtype=torch.float16, device=dev),
+                               torch.zeros((NB, H, 9, BS, 8), dtype=torch.float16, device=dev),
+                               torch.zeros((NB, H, 72, BS), dtype=torch.float16, device=dev), *tail, "auto", 1.0, 0, 0, 1, 1, 0)
+
+
 def test_pa_v1_out_with_extra_unit_dim_like_reference_test():
     # reference test passes out as [S, H, 1, D] (tests/kernels/paged_attention.py:114)
     rng = np.random.default_rng(7)

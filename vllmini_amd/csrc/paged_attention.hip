@@ -826,14 +826,16 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         bool bf = false, bool append = false, const void* key = nullptr,
                         const void* value = nullptr, int64_t key_stride = 0, int64_t value_stride = 0,
                         int f8 = false, float kv_scale = 1.0f, const int32_t* bsp = nullptr) {
-  if (!out || !query || !key_cache || !value_cache || !block_tables || !seq_lens)
+  // (an EMPTY batch — num_seqs == 0: the per-sequence tensors have no storage, torch hands out null data pointers — is
+  //  a no-op below, not an error; the caches must exist either way)
+  if (!key_cache || !value_cache || (num_seqs != 0 && (!out || !query || !block_tables || !seq_lens)))
     return fail(VMI_E_NULL_POINTER, "paged_attention_v1: NULL tensor pointer");
   if (bsp) {
     if (int rc = check_sparse("paged_attention_v1", bsp)) return rc;
     if (append || f8) return fail(VMI_E_VARIANT, "paged_attention_v1: block-sparse attention is built for fp16 / bf16 caches, without the fused append");
   }
   if (append) {
-    if (!key || !value) return fail(VMI_E_NULL_POINTER, "paged_attention_v1_append: NULL key/value pointer");
+    if (num_seqs != 0 && (!key || !value)) return fail(VMI_E_NULL_POINTER, "paged_attention_v1_append: NULL key/value pointer");
     // the fused kernel moves a key row as 16-B chunks (the stand-alone reshape_and_cache has a scalar path)
     if (!aligned16(key) || (key_stride & 7))
       return fail(VMI_E_ALIGNMENT, "paged_attention_v1_append: key rows must be 16-byte aligned "
@@ -1139,8 +1141,8 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
     if (int rc = check_sparse("paged_attention_v2", bsp)) return rc;
     if (f8) return fail(VMI_E_VARIANT, "paged_attention_v2: block-sparse attention is built for fp16 / bf16 caches");
   }
-  if (!out || !exp_sums || !max_logits || !tmp_out || !query || !key_cache || !value_cache ||
-      !block_tables || !seq_lens)
+  if (!key_cache || !value_cache ||
+      (num_seqs != 0 && (!out || !exp_sums || !max_logits || !tmp_out || !query || !block_tables || !seq_lens)))
     return fail(VMI_E_NULL_POINTER, "paged_attention_v2: NULL tensor pointer");
   if (!head_size_supported(head_size))
     return fail(VMI_E_HEAD_SIZE, "Unsupported head size: %d", head_size);
@@ -1562,7 +1564,7 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
                               int64_t key_stride, int64_t value_stride, int32_t device,
                               void* stream) {
   using namespace vmi;
-  if (!key || !value || !key_cache || !value_cache || !slot_mapping)
+  if (!key_cache || !value_cache || (num_tokens != 0 && (!key || !value || !slot_mapping)))  // no tokens: a no-op below
     return fail(VMI_E_NULL_POINTER, "reshape_and_cache: NULL tensor pointer");
   if (x != 8) return fail(VMI_E_X, "reshape_and_cache: key_cache.size(4) must be 8, got %d", x);
   if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || (head_size & 7))
@@ -1632,7 +1634,7 @@ static int reshape_and_cache_fp8_impl(const void* key, const void* value, void* 
                                       int64_t value_stride, float kv_scale, int32_t device, void* stream, bool bf,
                                       bool e5 = false) {
   using namespace vmi;
-  if (!key || !value || !key_cache || !value_cache || !slot_mapping)
+  if (!key_cache || !value_cache || (num_tokens != 0 && (!key || !value || !slot_mapping)))
     return fail(VMI_E_NULL_POINTER, "reshape_and_cache (fp8): NULL tensor pointer");
   if (x != 16) return fail(VMI_E_X, "reshape_and_cache (fp8): key_cache.size(4) must be 16, got %d", x);
   if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || (head_size & 15))
