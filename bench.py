@@ -362,6 +362,17 @@ def kernel_pass(wl, out, n, variant, dev, op="v1", warm=5):
     return [a.elapsed_time(b) for a, b in ev]
 
 
+def empty_event_pair_us(dev, n=40):
+    """What an event pair reads with NOTHING between its two records (median, us): the part of every kernel_pass sample
+    that is instrumentation, not kernel — for reconciling the event figures with rocprofv3's kernel durations."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        b.record()
+    torch.cuda.synchronize(dev)
+    return statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
+
+
 def exchange_pass(n, dist, dev):
     """Median duration of the token all_gather alone (event pair around each of n exchanges), us."""
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -776,6 +787,7 @@ def main(argv=None):
         "paged_attention_v1_us_mean": ks["mean"],
         "paged_attention_v1_us_min": ks["min"],
         "kernel_event_samples": args.kernel_samples,
+        "empty_event_pair_us": empty_event_pair_us(dev),
         "kernel_event_pass": "separate from the timed region: one HIP event pair around every attention launch of "
                              f"{args.kernel_samples} call pairs; roofline.achieved uses the median",
         "roofline": {

@@ -48,7 +48,7 @@ def run(out, t):
 
 
 def timeit(out):
-    for i in range(5):
+    for i in range(25):      # (the first launches after a pause run on a lower clock: 5 warm-ups read 3 us high)
         run(out, i % len(wl.tables))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
     torch.cuda.synchronize()
