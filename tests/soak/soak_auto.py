@@ -1,0 +1,135 @@
+"""Soak run of the DEFAULT entry on the PRODUCT library (no knob, no variant): whatever the library picks for a shape —
+several waves per head, the balanced kernel in any of its modes (one item per wave, ranked solo workers, teams for the long
+items + solo quads for the short ones), the gated double launch at head size 128, the fp8 kernels — over shapes wider
+than the unit tests': 1 .. 2500 sequences, 1 .. 32 heads (grouped KV heads sometimes), head size 64 / 128, contexts up
+to 4096, fp16 and fp8 pages, ALiBi sometimes, length distributions from equal to "one long among hundreds of one-token
+sequences", empty sequences, max_seq_len above the longest length.  Each case: every row finite, deterministic, within
+the tolerance of the plain one-wave-per-head kernel (which the sampled CPU kernel model pins), and a sample of sequences
+against the model itself (checker only).
+`PYTHONPATH=.:tests python tests/soak/soak_auto.py [n_cases] [first_seed]`; exit code 1 if anything failed."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "tests")
+import oracle  # noqa: E402  (checker)
+from vllmini_amd import _lib, ops  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+dev = torch.device("cuda:0")
+assert _lib.load().vmi_is_diag_build() == 0
+names = {n: i + 1 for i, n in enumerate(ops.variant_names())}
+BS = 16
+fails, t0, picked = 0, time.time(), {}
+for seed in range(first, first + n_cases):
+    rng = np.random.default_rng(seed)
+    f8 = seed % 3 == 0
+    D = int(rng.choice([64, 64, 128]))
+    qpk = int(rng.choice([1, 1, 1, 2, 4]))
+    hkv = int(rng.choice([1, 2, 3, 4, 8, 12] if D == 64 else [1, 2, 4, 8]))
+    H = hkv * qpk
+    B = int(rng.choice([1, 3, 17, 64, 128, 256, 300, 512, 700, 1500, 2500], p=[.05, .05, .1, .1, .1, .2, .1, .1, .1, .05, .05]))
+    top = int(rng.choice([16, 100, 520, 1024, 2048, 4096], p=[.1, .2, .25, .25, .1, .1]))
+    if seed % 5 < 3 and B * H < 3100:             # three cases in five fill the chip: the balanced kernels' territory
+        B = -(-int(rng.integers(3100, 5000)) // H)
+        top = max(top, 300)
+    if B * H * top > 6e6:                         # keep a case's pool below ~3 GB
+        top = max(16, int(6e6 / (B * H)) // 16 * 16)
+    kind = int(rng.integers(0, 7))
+    if kind == 0:
+        lens = np.full(B, top)
+    elif kind == 1:
+        lens = rng.integers(0, top + 1, B)
+    elif kind == 2:
+        lens = np.minimum((rng.exponential(1.0, B) * top / 6).astype(np.int64) + 1, top)
+    elif kind == 3:
+        lens = np.where(rng.random(B) < 0.08, top, max(top // 16, 1))
+    elif kind == 4:
+        lens = np.where(rng.random(B) < 0.5, top, max(top // 16, 1))
+    elif kind == 5:
+        lens = np.ones(B, dtype=np.int64)
+    else:
+        lens = np.where(rng.random(B) < 0.3, rng.integers(top // 2, top + 1, B), rng.integers(0, max(top // 20, 1) + 1, B))
+    lens = lens.astype(np.int32)
+    lens[int(rng.integers(0, B))] = top
+    if B > 4:
+        lens[int(rng.integers(0, B))] = 0
+    msl = top + int(rng.choice([0, 0, 16, 333]))   # capacity above the longest length (scheduler.py:97)
+    nblk = (lens + BS - 1) // BS
+    need = int(nblk.sum())
+    MB = max(int(nblk.max()), 1) + int(rng.integers(0, 3))
+    NB = need + 5
+    g = torch.Generator(device=dev).manual_seed(seed)
+    if f8:
+        kc = (torch.randint(0, 64, (NB, hkv, D // 16, BS, 16), dtype=torch.uint8, device=dev, generator=g)
+              | (torch.randint(0, 2, (NB, hkv, D // 16, BS, 16), dtype=torch.uint8, device=dev, generator=g) << 7))
+        vc = (torch.randint(0, 64, (NB, hkv, D, BS), dtype=torch.uint8, device=dev, generator=g)
+              | (torch.randint(0, 2, (NB, hkv, D, BS), dtype=torch.uint8, device=dev, generator=g) << 7))
+    else:
+        kc = (torch.rand((NB, hkv, D // 8, BS, 8), device=dev, generator=g) * 2 - 1).to(torch.float16)
+        vc = (torch.rand((NB, hkv, D, BS), device=dev, generator=g) * 2 - 1).to(torch.float16)
+    qbuf = torch.randn((B, 3 * H * D), device=dev, generator=g).to(torch.float16)
+    q = qbuf[:, : H * D].view(B, H, D)                       # strided like the fused-qkv view
+    perm = rng.permutation(NB)[:need].astype(np.int32)
+    tables = np.full((B, MB), -1, dtype=np.int32)
+    pos = 0
+    for s in range(B):
+        n = int(nblk[s])
+        tables[s, :n] = perm[pos:pos + n]
+        pos += n
+    tab, lens_d = torch.from_numpy(tables).to(dev), torch.from_numpy(lens).to(dev)
+    alibi = (2.0 ** -(1 + np.arange(H) % 8)).astype(np.float32) if seed % 5 == 0 else None
+    al = None if alibi is None else torch.from_numpy(alibi).to(dev)
+    scale = float(D) ** -0.5
+    kvd = "fp8" if f8 else "auto"
+
+    def attend(variant):
+        out = torch.full((B, H, D), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v1(out, q, kc, vc, hkv, scale, tab, lens_d, BS, msl, al, kvd, 1.0, 0, 0, 1, 1, 0, _variant=variant)
+        torch.cuda.synchronize()
+        return out
+
+    what = f"seed {seed}: B{B} H{H}/{hkv} D{D} top {top} msl {msl} kind {kind}{' fp8' if f8 else ''}{' alibi' if al is not None else ''}"
+    ok = True
+    try:
+        got = attend(0)
+        label = ops.last_launch_label()
+        picked[label.split(" ")[0]] = picked.get(label.split(" ")[0], 0) + 1
+        again = attend(0)
+        plain = attend(names[("fp8_d%d_bs16_h1_w1_u1_nt1" % D) if f8 else f"d{D}_h1_w1_u1_nt1"])
+    except RuntimeError as e:
+        print(f"FAIL {what}: {e}")
+        fails += 1
+        continue
+    if not bool(torch.isfinite(got).all()):
+        print(f"FAIL {what} [{label}]: non-finite rows")
+        ok = False
+    if not torch.equal(got.view(torch.int16), again.view(torch.int16)):
+        print(f"FAIL {what} [{label}]: not deterministic")
+        ok = False
+    d = (got.float() - plain.float()).abs().max().item()
+    if not d <= 1e-3 * (2.0 if f8 else 1.0):      # north-star bound x max|v| (fp8 codes here reach 1.875), as in the tests
+        print(f"FAIL {what} [{label}]: max|d| vs the plain kernel {d:.3e}")
+        ok = False
+    idx = np.unique(np.r_[np.argsort(-lens, kind="stable")[:3], rng.integers(0, B, 4), 0, B - 1])
+    blocks = np.unique(np.concatenate([tables[i, : nblk[i]] for i in idx])) if need else np.zeros(1, dtype=np.int32)
+    remap = {int(b): j for j, b in enumerate(blocks)}
+    small = np.full((len(idx), MB), -1, dtype=np.int32)
+    for r, i in enumerate(idx):
+        small[r, : nblk[i]] = [remap[int(b)] for b in tables[i, : nblk[i]]]
+    bsel = torch.from_numpy(blocks.astype(np.int64)).to(dev)
+    qs = np.ascontiguousarray(q[torch.from_numpy(idx).to(dev)].cpu().numpy())
+    ks, vs = kc[bsel].cpu().numpy(), vc[bsel].cpu().numpy()
+    ref = (oracle.paged_attention_v1_fp8(qs, ks, vs, hkv, scale, small, lens[idx], BS, kv_scale=1.0, alibi_slopes=alibi) if f8 else
+           oracle.paged_attention_v1(qs, ks, vs, hkv, scale, small, lens[idx], BS, alibi_slopes=alibi, threads=8))
+    d = np.abs(got.cpu().numpy()[idx].astype(np.float64) - ref.astype(np.float64)).max()
+    if not d <= 1e-3 * (2.0 if f8 else 1.0):
+        print(f"FAIL {what} [{label}]: default entry vs model {d:.3e}")
+        ok = False
+    fails += 0 if ok else 1
+print(f"soak_auto: {n_cases} cases from seed {first}, {fails} failed, {time.time() - t0:.0f} s; kernels picked: "
+      + ", ".join(f"{k} x{v}" for k, v in sorted(picked.items(), key=lambda kv: -kv[1])))
+sys.exit(1 if fails else 0)
