@@ -25,7 +25,9 @@
 //                                           at an item boundary.
 //                                           Solo workers take their FIRST item in index order (requested at the top of
 //                                           the kernel) while a retired wave ranks the rest; 4-wave TEAMS (heavy-tailed
-//                                           batches) rank everything up front.  Both are described where they are coded.
+//                                           and bimodal batches) rank everything up front, run the LONG items (more than
+//                                           a quarter of the longest) four waves to an item and hand the SHORT ones out
+//                                           in quads, one per wave (round 3).  All of it is described where it is coded.
 //
 // Mode S is entered before any of mode Q's preparation code (see the end of the kernel): what lies between the top of
 // the kernel and a mode's first page request is paid by every launch (profiles/r02m_late_ranking.md).
