@@ -6,7 +6,7 @@ OUT=gpurun_out/batch_latency; mkdir -p $OUT
 echo "batch,seq_len,kernel,avg_us,min_us,GB_per_s" > $OUT/summary.csv
 for B in ${BATCHES:-1 2 4 8 16 32 64 128 256}; do
   D=$OUT/b$B
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o t -- python bench.py --batch $B ${SEQLEN:+--seq-len $SEQLEN} --steps 40 --warmup 5 --no-cpu-baseline --no-fused --no-fp8 --no-ragged --no-graph > $D.json 2>/dev/null
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o t -- python bench.py --batch $B ${SEQLEN:+--seq-len $SEQLEN} --steps 40 --warmup 5 --headline-only > $D.json 2>/dev/null
   python - "$D" "$B" "${SEQLEN:-1024}" >> $OUT/summary.csv <<'PY'
 import csv, json, sys
 d, b, L = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

@@ -9,7 +9,7 @@ for B in ${BATCHES:-32 64 128 192}; do
     if [ "$NAME" = auto ]; then V=0; else V=$(python -c "
 from vllmini_amd import ops; print(ops.variant_names().index('$NAME')+1)"); fi
     D=$OUT/b${B}_${NAME}
-    rocprofv3 --kernel-trace --stats --output-format csv -d $D -o t -- python bench.py --batch $B ${SEQLEN:+--seq-len $SEQLEN} --variant $V --steps 40 --warmup 5 --no-cpu-baseline --no-fused --no-fp8 > /dev/null 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $D -o t -- python bench.py --batch $B ${SEQLEN:+--seq-len $SEQLEN} --variant $V --steps 40 --warmup 5 --headline-only > /dev/null 2>&1
     python - "$D" "$B" "$NAME" >> $OUT/summary.csv <<'PY'
 import csv,sys
 d,b,v=sys.argv[1:4]

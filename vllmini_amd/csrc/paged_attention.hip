@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256)
 #ifdef VMI_DIAG   // the diagnostic library only (build.py --diag): not in the product .so
 // ----------------------------------------------------------------------------------------
 // diagnostics (not part of the reference surface): what read bandwidth does this box give a
-// plain coalesced 16-B/lane stream?  Used by bench.py --diag to state the achievable ceiling
+// plain coalesced 16-B/lane stream?  Used by scripts/bench_diag.py --diag to state the achievable ceiling
 // next to the attention kernel's number.
 // ----------------------------------------------------------------------------------------
 template <bool NT>
