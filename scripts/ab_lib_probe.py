@@ -45,14 +45,14 @@ for tag, ragged, lens in cases:
         wl.seq_lens = lens.to(torch.int32).to(dev)
     out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
-    for i in range(args.iters + 10):
-        if i >= 10:
-            ev[i - 10][0].record()
+    for i in range(args.iters + 30):
+        if i >= 30:
+            ev[i - 30][0].record()
         ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, cfg.kv_heads, wl.scale,
                                wl.tables[i % len(wl.tables)], wl.seq_lens, cfg.block_size, cfg.seq_len, None, "auto", 1.0,
                                0, 0, 1, 1, 0)
-        if i >= 10:
-            ev[i - 10][1].record()
+        if i >= 30:
+            ev[i - 30][1].record()
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
     print(f"{os.path.basename(args.lib):32s} flags {args.flags:#x} {tag:22s} mean {sum(ts) / len(ts):7.1f} us  "

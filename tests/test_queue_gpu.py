@@ -348,6 +348,69 @@ def test_default_entry_on_heavy_tailed_batches_product_library(kind):
     assert_close(got.cpu().numpy()[idx], ref, f"{kind}: default entry, sampled vs model")
 
 
+@pytest.mark.parametrize("kvd", ["auto", "fp8"])
+@pytest.mark.parametrize("B,spread", [(257, 0.0), (288, 0.15), (320, 0.0)])
+def test_default_entry_a_little_more_items_than_waves_runs_the_overflow_twin(B, spread, kvd):
+    """PRODUCT library, no knob: 12 heads x (257 .. 320) sequences of (nearly) equal length are a little more items than
+    the balanced kernel's grid has waves (3072 on 256 CUs).  The launcher picks the OVF twin: every wave takes one item as
+    in mode S — those rows are bit-identical to the one-wave-per-head kernel — and the remainder, the LAST rows, is run by
+    4-wave teams (other fp32 summation order: within the team tolerance).  Every row written, deterministic, a sample of
+    first, middle and remainder sequences against the CPU kernel model."""
+    import dataclasses
+
+    from vllmini_amd import _lib, ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    assert _lib.load().vmi_is_diag_build() == 0
+    dev = _dev()
+    if torch.cuda.get_device_properties(dev).multi_processor_count != 256:
+        pytest.skip("sized for the 256 CUs of an MI355X")
+    names = _names()
+    cfg = dataclasses.replace(CONFIGS["cfg3"], name=f"b{B}", batch=B, num_blocks=B * 64 + 8)
+    wl = make_workload(cfg, dev, seed=70 + B, table_sets=1)
+    g = torch.Generator().manual_seed(B)
+    lens = (cfg.seq_len - (torch.rand(B, generator=g) * spread * cfg.seq_len).long()).to(torch.int32)
+    lens[0] = cfg.seq_len
+    t_len = lens.to(dev)
+    f8 = kvd == "fp8"
+    if f8:
+        g8 = torch.Generator(device=dev).manual_seed(9)
+        D = cfg.head_size
+        kc = torch.randint(0, 64, (cfg.num_blocks, cfg.kv_heads, D // 16, 16, 16), dtype=torch.uint8, device=dev, generator=g8)
+        vc = torch.randint(0, 64, (cfg.num_blocks, cfg.kv_heads, D, 16), dtype=torch.uint8, device=dev, generator=g8)
+    else:
+        kc, vc = wl.key_cache, wl.value_cache
+
+    def attend(variant=0):
+        out = torch.full((B, cfg.num_heads, cfg.head_size), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v1(out, wl.query, kc, vc, cfg.num_heads, wl.scale, wl.tables[0], t_len, cfg.block_size, cfg.seq_len,
+                               None, kvd, 1.0, 0, 0, 1, 1, 0, _variant=variant)
+        torch.cuda.synchronize()
+        return out
+
+    got = attend()
+    twin = "fp8_q_d64_s2q4mo" if f8 else "q_d64_s1q2o"
+    assert ops.last_launch_label() == twin
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, attend())
+    plain = attend(names["fp8_q_d64_s2q4m" if f8 else "d64_h4_w1_u1_nt1"])    # (fp8: the same kernel's solo rounds)
+    nw = 3072 // cfg.num_heads                     # sequences wholly inside the one-item-per-wave part
+    assert torch.equal(got[:nw].view(torch.int16), plain[:nw].view(torch.int16)), "a mode-S row differs"
+    assert float((got[nw:].float() - plain[nw:].float()).abs().max()) <= 1e-3 * (2.0 if f8 else 1.0)
+    idx = np.unique(np.r_[0, 1, nw - 1, nw, B - 2, B - 1, B // 2])
+    tab_dev = wl.tables[0][torch.from_numpy(idx).to(dev)][:, : cfg.blocks_per_seq].clamp(min=0)
+    flat = tab_dev.reshape(-1).to(torch.int64)
+    small_tab = np.arange(flat.numel(), dtype=np.int32).reshape(len(idx), cfg.blocks_per_seq)
+    qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
+    if f8:
+        ref = oracle.paged_attention_v1_fp8(qn, kc[flat].cpu().numpy(), vc[flat].cpu().numpy(), cfg.num_heads, wl.scale,
+                                            small_tab, lens.numpy()[idx], cfg.block_size, kv_scale=1.0, threads=8)
+    else:
+        ref = oracle.paged_attention_v1(qn, kc[flat].cpu().numpy(), vc[flat].cpu().numpy(), cfg.num_heads, wl.scale, small_tab,
+                                        lens.numpy()[idx], cfg.block_size, threads=8)
+    assert_close(got.cpu().numpy()[idx], ref, f"B{B} {kvd}: overflow twin, sampled vs model", vmax=2.0 if f8 else 1.0)
+
+
 def test_head_128_default_entry_is_a_gated_double_launch():
     """BASELINE cfg4 (B128 H32 D128 L2048): the default entry launches the lockstep multi-head kernel AND the balanced
     kernel; each decides on the device, from the same statistics, whether the batch is its kind.  Equal lengths: rows

@@ -648,11 +648,11 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
     // full chip, head size 64: the balanced kernel over fp8 pages (pa_queue.hpp) — ragged batches without a hint
     for (int id = 1; id <= nvariants_v1(); ++id) {
       const Variant& c = variant_v1(id);
-      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == 2 && c.KM) return id;  // K pass on MFMA
+      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == 2 && c.KM && !c.OVF) return id;  // K pass on MFMA
     }
     for (int id = 1; id <= nvariants_v1(); ++id) {  // (formats without an "m" kernel: E5M2)
       const Variant& c = variant_v1(id);
-      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == 2) return id;
+      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == 2 && !c.OVF) return id;
     }
   }
   if (mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3)
@@ -696,7 +696,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
       // (sequence, head) on equal lengths, ranked work lists on ragged ones; needs 3 workgroups' LDS per CU
       for (int id = 1; id <= nvariants_v1(); ++id) {
         const Variant& c = variant_v1(id);
-        if (c.QUEUE && c.BF == bf && c.D == head_size && c.BS == 16 && !c.F8 && !c.KM) return id;
+        if (c.QUEUE && c.BF == bf && c.D == head_size && c.BS == 16 && !c.F8 && !c.KM && !c.OVF) return id;
       }
     }
     if (wph == 1 && u == 1 && nt) {  // full chip, one wave per head: the adaptive-depth form where one is built
@@ -867,6 +867,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
   auto lds_of = [&](const Variant& c) { return variant_lds_bytes(c, lpad); };
   const bool gate_ok = variant == 0 && !append && !bsp && !f8;  // an explicit variant is run as asked
+  const bool auto_variant = variant == 0;                       // (... and so is a balanced kernel's OVF twin: chosen only here)
   g_cus = device_cus(device);  // the heuristics size the launch for THIS device
   Variant* sparse_v = nullptr;
   if (bsp) {  // one or four waves per head, by how many (seq, head) units there are to fill the chip with
@@ -983,9 +984,25 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     const int64_t items = (int64_t)num_seqs * num_heads;
     int64_t g = (int64_t)cus * per_cu;
     if (g * 4 > items) g = (items + 3) / 4;
+    pa_kernel_t fn = q.fn;
+    if (auto_variant && !gate && !q.OVF && items > g * 4 && items - g * 4 <= g) {
+      // a little more items than the grid has waves: the twin that knows the overflow schedule (same geometry and LDS)
+      for (int i = 0; i < g_queue_nvariants; ++i) {
+        const Variant& o = g_queue_variants[i];
+        if (o.OVF && o.D == q.D && o.BF == q.BF && o.F8 == q.F8 && o.KM == q.KM && o.U == q.U) {
+          if (qlds > 48 * 1024) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(o.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
+            if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+          }
+          fn = o.fn;
+          g_last_variant = nvariants_v1() - g_stage_nvariants - g_queue_nvariants + i + 1;
+          break;
+        }
+      }
+    }
     PAParams pq = p;
     pq.q_flags = g_queue_flags | gate;
-    hipLaunchKernelGGL(q.fn, dim3((unsigned)g), dim3(256), qlds, static_cast<hipStream_t>(stream), pq);
+    hipLaunchKernelGGL(fn, dim3((unsigned)g), dim3(256), qlds, static_cast<hipStream_t>(stream), pq);
     hipError_t el = hipGetLastError();
     if (el != hipSuccess) return hip_fail(el, "paged_attention_v1 launch");
     return VMI_OK;
@@ -1005,7 +1022,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
       num_seqs <= 2048 && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
     for (int i = 0; i < g_queue_nvariants; ++i)
       if (g_queue_variants[i].D == v.D && g_queue_variants[i].BF == v.BF && g_queue_variants[i].BS == v.BS &&
-          g_queue_variants[i].F8 == v.F8 && !g_queue_variants[i].KM &&
+          g_queue_variants[i].F8 == v.F8 && !g_queue_variants[i].KM && !g_queue_variants[i].OVF &&
           2 * variant_lds_bytes(g_queue_variants[i], lpad) <= (size_t)160 * 1024)
         partner = &g_queue_variants[i];
   }
