@@ -642,6 +642,8 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
   while (wph < 16 && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  // (a nearly full chip stays with two waves per head here: over fp8 pages the balanced kernel ties it on equal lengths
+  //  — 57.1 / 59.1 / 63.4 against 56.1 / 60.0 / 63.6 us at batch 208 / 224 / 240 — and loses 7 % on ragged ones)
   if (unit_scale && wph == 1 && !bf && block_size == 16 && head_size == 64 &&
       4.0 * (double)units * max_seq_len * head_size > 256e6 &&  // (2 bytes per token and dim: past the Infinity Cache)
       3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024) {
@@ -681,7 +683,12 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   const int nt = kv_bytes > 128e6 ? 1 : 0;
   // (a batch the caller knows to be ragged: many waves per head, so that the hardware dispatcher balances the chip —
   //  except where the balanced kernel below does that itself, from the lengths it reads on the device)
-  const bool balanced = allow_balanced && wph == 1 && nt && block_size == 16 && head_size == 64 &&
+  // The balanced kernel also serves a chip that is only NEARLY full (from 80 % of the resident waves on: 208 sequences x
+  // 12 heads): its one-item-per-wave mode then beats two waves per head on equal lengths (batch 224: 114.6 -> 109.5 us,
+  // 240: 122.4 -> 115.9; 192: 95.6 against 100.9, so not below 80 %) and its ranked modes beat it on ragged ones (224:
+  // 69.0 -> 64.4 us).  Round 3, profiles/r03l_nearly_full_chip.md.
+  const bool near_full = wph == 2 && units * 5 >= full_chip_waves() * 4;
+  const bool balanced = allow_balanced && (wph == 1 || near_full) && nt && block_size == 16 && head_size == 64 &&
                         3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
   const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
   if (ragged)
@@ -691,7 +698,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
     const double tile_kib = head_size * 16 * 2 / 1024.0;
     int u = 1;
     while (u < 4 && waves_per_cu * u * tile_kib < 24.0) u *= 2;
-    if (balanced && u == 1) {
+    if (balanced && (u == 1 || near_full)) {
       // full chip: the balanced kernel (pa_queue.hpp) — it reads seq_lens on the device and runs one wave per
       // (sequence, head) on equal lengths, ranked work lists on ragged ones; needs 3 workgroups' LDS per CU
       for (int id = 1; id <= nvariants_v1(); ++id) {
