@@ -256,7 +256,14 @@ def test_heuristic_picks_follow_the_host_hint():
     assert pick(256, 12, 64, 1024, mean_seq_len=1024) == "q_d64_s1q2"
     assert pick(256, 12, 64, 1024, mean_seq_len=512) == "q_d64_s1q2"
     assert pick(2048, 12, 64, 1024) == "q_d64_s1q2"
-    assert pick(256, 12, 64, 8192) == "d64_h4_w1_u1a4_nt1"            # 3 x 16 x 8192 B of logits do not fit a CU
+    # the balanced kernel's LDS (4 waves' logits + the ranking, three workgroups per CU) ends at ~2400 tokens; past it the
+    # choice is by how well the launch's workgroups fill the resident slots: 4-head workgroups of one-wave heads ...
+    assert pick(256, 12, 64, 3000) == "d64_h4_w1_u1a4_nt1"            # 768 workgroups on 768 slots
+    assert pick(320, 12, 64, 3000) == "d64_h1_w2_u1_nt1"              # 960 on 768 would idle 37 % of the second round
+    assert pick(256, 12, 64, 4096) == "d64_h1_w2_u1_nt1"              # two 64-KiB workgroups per CU: 768 on 512 slots
+    assert pick(320, 12, 64, 4096) == "d64_h4_w1_u1a4_nt1"            # 960 on 512: 94 % busy, finer forms do not beat it
+    assert pick(256, 12, 64, 8192) == "d64_h1_w4_u1_nt1"              # one 4-wave workgroup per CU is too few waves
+    assert pick(256, 12, 64, 16384) == "d64_h1_w8_u1_nt1"
     assert pick(256, 12, 64, 8192, mean_seq_len=2000) == "d64_h1_w8_u1_nt1"
     lib = ops._lib.load()
     q = names.index("q_d64_s1q2") + 1
@@ -269,7 +276,7 @@ def test_heuristic_picks_follow_the_host_hint():
     assert pick(128, 32, 128, 2048, mean_seq_len=1000) == "d128_h1_w8_u1_nt1"
     assert "_w16_" in pick(1, 12, 64, 1024)
     assert pick(256, 12, 64, 1024, bf16=True) == "bf16_q_d64_s1q2"
-    assert pick(256, 12, 64, 8192, bf16=True).startswith("bf16_d64_bs16_h4_w1")
+    assert pick(256, 12, 64, 8192, bf16=True) == "bf16_d64_bs16_h1_w4_u1_nt1"   # (the same rule for bfloat16)
     assert pick(256, 12, 64, 8192, mean_seq_len=300, bf16=True) == "bf16_d64_bs16_h1_w8_u1_nt1"
     assert pick(256, 5, 80, 1024, 32) == "d80_bs32_h1_w4_u1_nt1"       # 1280 (seq, head) units do not fill 256 CUs
     assert pick(1024, 5, 80, 1024, 32) == "d80_bs32_h1_w1_u1_nt1"

@@ -693,6 +693,41 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
   if (ragged)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  // A FULL CHIP WITHOUT THE BALANCED KERNEL (its LDS does not fit: contexts past ~2400 tokens) — round 3,
+  // profiles/r03m_long_context_full_chip.md.  The one-wave-per-head kernels come as 4-head workgroups whose logits
+  // (4 bytes per token and head) decide how many fit a CU — three at 3000 tokens, two at 4096, one at 8192 — and a batch
+  // that is not a multiple of those slots runs a nearly empty last round: 256 x 12 heads at 4096 tokens 548 us (0.74 of
+  // the roofline), 352: 816 us (0.68); at 8192 tokens one 4-wave workgroup per CU is also too few waves: 1379 us (0.58).
+  // Workgroups of ONE head cut into 2 / 4 / 8 waves share a logits row (6 bytes per token and head), fit several times
+  // per CU and quantise finer: 477 us (0.84) / 664 us (0.83) / 947 us (0.85).  Chosen by the fraction of the resident
+  // slots the launch's rounds keep busy (what equal lengths would see), times a penalty for fewer than 8 waves per CU.
+  if (wph == 1 && !balanced && nt && head_size == 64 && block_size == 16) {
+    const size_t lp = (size_t)((max_seq_len + 31) / 32) * 32;
+    auto score = [&](int hpw, int w) -> double {
+      const size_t lds = (size_t)hpw * (lp * 4 + 2 * w * 4 + (size_t)w * head_size * 4 + (w > 1 ? lp * 2 : 0));
+      long per_cu = (long)((size_t)160 * 1024 / lds);
+      if (per_cu * hpw * w > 32) per_cu = 32 / (hpw * w);  // 32 waves per CU
+      if (per_cu > 16) per_cu = 16;
+      if (per_cu < 1) return 0.0;
+      const double slots = (double)g_cus * per_cu;
+      const double wgs = (double)num_seqs * ((num_heads + hpw - 1) / hpw);
+      const double rounds = (double)(long)((wgs + slots - 1) / slots);
+      const double waves = (double)per_cu * hpw * w;
+      const double fill = wgs > slots ? wgs / slots : 1.0;  // (a launch that fits one round has no tail)
+      return fill / rounds * (waves >= 8 ? 1.0 : 0.4 + 0.075 * waves);
+    };
+    double best = score(num_heads % 4 == 0 ? 4 : 1, 1);
+    for (int w = 2; w <= 16 && w <= (nblk > 0 ? nblk : 1); w *= 2) {
+      // a finer form must be 5 % ahead of what is chosen so far; eight and sixteen waves per head only where a one-head
+      // workgroup fits a CU just once (contexts past ~13 600 tokens)
+      if (w >= 8 && lp * 6 * 2 <= (size_t)160 * 1024) break;  // (a one-head workgroup still fits twice per CU)
+      const double sc = score(1, w);
+      if (sc > best * 1.05) {  // (the 4-head workgroups stay unless something is clearly ahead: they are the tuned form)
+        best = sc;
+        wph = w;
+      }
+    }
+  }
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {  // core table: full menu
     const double waves_per_cu = (double)units * wph / (double)g_cus;
     const double tile_kib = head_size * 16 * 2 / 1024.0;
