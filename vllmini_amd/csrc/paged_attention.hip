@@ -633,6 +633,48 @@ static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_si
   return 0;
 }
 
+// A FULL CHIP WITHOUT THE BALANCED KERNEL (its LDS does not fit: contexts past ~2400 tokens) — round 3,
+// profiles/r03m_long_context_full_chip.md.  The one-wave-per-head kernels come as 4-head workgroups whose logits
+// (4 bytes per token and head) decide how many fit a CU — three at 3000 tokens, two at 4096, one at 8192 — and a batch
+// that is not a multiple of those slots runs a nearly empty last round: 256 x 12 heads at 4096 tokens 548 us (0.74 of
+// the roofline), 352: 816 us (0.68); at 8192 tokens one 4-wave workgroup per CU is also too few waves: 1379 us (0.58).
+// Workgroups of ONE head cut into 2 / 4 / 8 waves share a logits row (6 bytes per token and head), fit several times
+// per CU and quantise finer: 477 us (0.84) / 664 us (0.83) / 947 us (0.85).  Chosen by the fraction of the resident
+// slots the launch's rounds keep busy (what equal lengths would see), times a penalty for fewer than 8 waves per CU.
+// `wph` = what the launch would use otherwise (1 on a full chip; 2, 4, ... when (sequence, head) units alone do not fill
+// it): only that form and finer ones are considered — a chip that is not full and contexts past ~4000 tokens meet the
+// same LDS limit (two waves per head: 6 bytes per token, three such workgroups per CU at 8192 tokens = 6 waves; fp8 pages,
+// 128 sequences x 12 heads: 380 us = 4.2 TB/s).
+static int waves_per_head_without_balancing(int num_seqs, int num_heads, int head_size, int max_seq_len, int nblk,
+                                            int wph = 1) {
+  const size_t lp = (size_t)((max_seq_len + 31) / 32) * 32;
+  auto score = [&](int hpw, int w) -> double {
+    const size_t lds = (size_t)hpw * (lp * 4 + 2 * w * 4 + (size_t)w * head_size * 4 + (w > 1 ? lp * 2 : 0));
+    long per_cu = (long)((size_t)160 * 1024 / lds);
+    if (per_cu * hpw * w > 32) per_cu = 32 / (hpw * w);  // 32 waves per CU
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu < 1) return 0.0;
+    const double slots = (double)g_cus * per_cu;
+    const double wgs = (double)num_seqs * ((num_heads + hpw - 1) / hpw);
+    const double rounds = (double)(long)((wgs + slots - 1) / slots);
+    const double waves = (double)per_cu * hpw * w;
+    const double fill = wgs > slots ? wgs / slots : 1.0;  // (a launch that fits one round has no tail)
+    return fill / rounds * (waves >= 8 ? 1.0 : 0.4 + 0.075 * waves);
+  };
+  double best = wph == 1 ? score(num_heads % 4 == 0 ? 4 : 1, 1) : score(1, wph);
+  for (int w = wph * 2; w <= 16 && w <= (nblk > 0 ? nblk : 1); w *= 2) {
+    // a finer form must be 5 % ahead of what is chosen so far; eight and sixteen waves per head only where nothing smaller
+    // keeps three quarters of the chip busy (a one-head workgroup that fits a CU just once: contexts past ~13 600 tokens)
+    if (w >= 8 && best >= 0.75) break;  // (... or nothing smaller keeps three quarters of the chip busy)
+    const double sc = score(1, w);
+    if (sc > best * 1.05) {  // (the 4-head workgroups stay unless something is clearly ahead: they are the tuned form)
+      best = sc;
+      wph = w;
+    }
+  }
+  return wph;
+}
+
 // fp8 cache: a (block, head) tile is half the bytes; measured picks in profiles/r01h_fp8_kv.md
 // unit_scale: the caller's kv_scale is 1 (the balanced fp8 kernels are built for that case only; the pick queries of
 // the C-ABI, which carry no scale, describe the general case)
@@ -659,6 +701,11 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   }
   if (mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  // (a full chip past the balanced kernel's LDS: the same choice by round efficiency as over fp16 pages — the logits are
+  //  fp32 either way; fp8 pages at 8192 tokens ran 906 us = 3.6 TB/s with one 4-head workgroup per CU)
+  if (head_size == 64 && block_size == 16 && 2.0 * (double)units * max_seq_len * head_size > 128e6 &&
+      (wph == 1 || max_seq_len > 3400))
+    wph = waves_per_head_without_balancing(num_seqs, num_heads, head_size, max_seq_len, nblk, wph);
   int v = 0;
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {
     if (wph == 1) {
@@ -693,41 +740,8 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
   if (ragged)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
-  // A FULL CHIP WITHOUT THE BALANCED KERNEL (its LDS does not fit: contexts past ~2400 tokens) — round 3,
-  // profiles/r03m_long_context_full_chip.md.  The one-wave-per-head kernels come as 4-head workgroups whose logits
-  // (4 bytes per token and head) decide how many fit a CU — three at 3000 tokens, two at 4096, one at 8192 — and a batch
-  // that is not a multiple of those slots runs a nearly empty last round: 256 x 12 heads at 4096 tokens 548 us (0.74 of
-  // the roofline), 352: 816 us (0.68); at 8192 tokens one 4-wave workgroup per CU is also too few waves: 1379 us (0.58).
-  // Workgroups of ONE head cut into 2 / 4 / 8 waves share a logits row (6 bytes per token and head), fit several times
-  // per CU and quantise finer: 477 us (0.84) / 664 us (0.83) / 947 us (0.85).  Chosen by the fraction of the resident
-  // slots the launch's rounds keep busy (what equal lengths would see), times a penalty for fewer than 8 waves per CU.
-  if (wph == 1 && !balanced && nt && head_size == 64 && block_size == 16) {
-    const size_t lp = (size_t)((max_seq_len + 31) / 32) * 32;
-    auto score = [&](int hpw, int w) -> double {
-      const size_t lds = (size_t)hpw * (lp * 4 + 2 * w * 4 + (size_t)w * head_size * 4 + (w > 1 ? lp * 2 : 0));
-      long per_cu = (long)((size_t)160 * 1024 / lds);
-      if (per_cu * hpw * w > 32) per_cu = 32 / (hpw * w);  // 32 waves per CU
-      if (per_cu > 16) per_cu = 16;
-      if (per_cu < 1) return 0.0;
-      const double slots = (double)g_cus * per_cu;
-      const double wgs = (double)num_seqs * ((num_heads + hpw - 1) / hpw);
-      const double rounds = (double)(long)((wgs + slots - 1) / slots);
-      const double waves = (double)per_cu * hpw * w;
-      const double fill = wgs > slots ? wgs / slots : 1.0;  // (a launch that fits one round has no tail)
-      return fill / rounds * (waves >= 8 ? 1.0 : 0.4 + 0.075 * waves);
-    };
-    double best = score(num_heads % 4 == 0 ? 4 : 1, 1);
-    for (int w = 2; w <= 16 && w <= (nblk > 0 ? nblk : 1); w *= 2) {
-      // a finer form must be 5 % ahead of what is chosen so far; eight and sixteen waves per head only where a one-head
-      // workgroup fits a CU just once (contexts past ~13 600 tokens)
-      if (w >= 8 && lp * 6 * 2 <= (size_t)160 * 1024) break;  // (a one-head workgroup still fits twice per CU)
-      const double sc = score(1, w);
-      if (sc > best * 1.05) {  // (the 4-head workgroups stay unless something is clearly ahead: they are the tuned form)
-        best = sc;
-        wph = w;
-      }
-    }
-  }
+  if (!balanced && nt && head_size == 64 && block_size == 16 && (wph == 1 || max_seq_len > 3400))
+    wph = waves_per_head_without_balancing(num_seqs, num_heads, head_size, max_seq_len, nblk, wph);
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {  // core table: full menu
     const double waves_per_cu = (double)units * wph / (double)g_cus;
     const double tile_kib = head_size * 16 * 2 / 1024.0;
@@ -749,7 +763,13 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
           return id;
       }
     }
-    if (wph == 1 && head_size == 128 && nt && num_heads % 16 == 0 && waves_per_cu >= 12.0) {
+    // (the lockstep 4-heads-per-wave kernel needs the whole register file: ONE 16-head workgroup per CU, so it pays only
+    //  where the launch's workgroups fill whole rounds of those slots — 128 x 32 heads: 630 us against 641 for the
+    //  4-head workgroups; 129 sequences: 1120 against 701, 160: 1142 against 797, 96: 571 against 483.  Round 3,
+    //  profiles/r03n_head_128_round_fit.md)
+    const double lock_fill = (double)num_seqs * (num_heads / 16) / (double)g_cus;
+    const double lock_eff = lock_fill / (double)(long)(lock_fill + 0.999999);
+    if (wph == 1 && head_size == 128 && nt && num_heads % 16 == 0 && waves_per_cu >= 12.0 && lock_eff >= 0.97) {
       for (int id = 1; id <= nvariants_v1(); ++id) {  // d128_mh4_h4_u1_nt1_lock
         const Variant& c = variant_v1(id);
         if (c.BF == bf && c.D == 128 && c.HPT == 4 && c.HPW == 4 && c.U == 1 && !c.QUEUE) return id;
