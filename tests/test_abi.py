@@ -261,7 +261,8 @@ def test_heuristic_picks_follow_the_host_hint():
     assert pick(256, 12, 64, 3000) == "d64_h4_w1_u1a4_nt1"            # 768 workgroups on 768 slots
     assert pick(320, 12, 64, 3000) == "d64_h1_w2_u1_nt1"              # 960 on 768 would idle 37 % of the second round
     assert pick(256, 12, 64, 4096) == "d64_h1_w2_u1_nt1"              # two 64-KiB workgroups per CU: 768 on 512 slots
-    assert pick(320, 12, 64, 4096) == "d64_h4_w1_u1a4_nt1"            # 960 on 512: 94 % busy, finer forms do not beat it
+    assert pick(320, 12, 64, 4096) == "d64_h1_w2_u1_nt1"              # (within 15 % on paper: the finer form, for ragged batches)
+    assert pick(256, 12, 64, 2500) == "d64_h4_w1_u1a4_nt1"            # 768 on 768 slots against 3072 on 2304: stays
     assert pick(256, 12, 64, 8192) == "d64_h1_w4_u1_nt1"              # one 4-wave workgroup per CU is too few waves
     assert pick(256, 12, 64, 16384) == "d64_h1_w8_u1_nt1"
     assert pick(256, 12, 64, 8192, mean_seq_len=2000) == "d64_h1_w8_u1_nt1"

@@ -667,7 +667,11 @@ static int waves_per_head_without_balancing(int num_seqs, int num_heads, int hea
     // keeps three quarters of the chip busy (a one-head workgroup that fits a CU just once: contexts past ~13 600 tokens)
     if (w >= 8 && best >= 0.75) break;  // (... or nothing smaller keeps three quarters of the chip busy)
     const double sc = score(1, w);
-    if (sc > best * 1.05) {  // (the 4-head workgroups stay unless something is clearly ahead: they are the tuned form)
+    // The score is what EQUAL lengths would see; the lengths are a device tensor and at these contexts batches are
+    // usually ragged, where one-head workgroups were ahead in every cell measured (4096 tokens, 320 sequences: 363 against
+    // 391 us on U{1..L}, 618 against 599 on equal lengths).  So two waves per head need not win on paper: within 15 % of
+    // the 4-head form is enough; beyond two, a form must be 5 % ahead of what is chosen so far.
+    if (w == 2 && wph == 1 ? sc * 1.15 > best : sc > best * 1.05) {
       best = sc;
       wph = w;
     }
@@ -704,7 +708,7 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   // (a full chip past the balanced kernel's LDS: the same choice by round efficiency as over fp16 pages — the logits are
   //  fp32 either way; fp8 pages at 8192 tokens ran 906 us = 3.6 TB/s with one 4-head workgroup per CU)
   if (head_size == 64 && block_size == 16 && 2.0 * (double)units * max_seq_len * head_size > 128e6 &&
-      (wph == 1 || max_seq_len > 3400))
+      3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) > (size_t)160 * 1024 && (wph == 1 || max_seq_len > 3400))
     wph = waves_per_head_without_balancing(num_seqs, num_heads, head_size, max_seq_len, nblk, wph);
   int v = 0;
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {
@@ -740,7 +744,10 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
   if (ragged)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
-  if (!balanced && nt && head_size == 64 && block_size == 16 && (wph == 1 || max_seq_len > 3400))
+  // (only where the balanced kernel's LDS does not fit: shorter contexts keep the tuned picks — the fused append, which
+  //  has no balanced twin, stays bit-identical to the call pair there)
+  const bool balanced_lds_fits = 3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
+  if (!balanced && !balanced_lds_fits && nt && head_size == 64 && block_size == 16 && (wph == 1 || max_seq_len > 3400))
     wph = waves_per_head_without_balancing(num_seqs, num_heads, head_size, max_seq_len, nblk, wph);
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {  // core table: full menu
     const double waves_per_cu = (double)units * wph / (double)g_cus;
