@@ -2,7 +2,7 @@
 several waves per head, the balanced kernel in any of its modes (one item per wave, ranked solo workers, teams for the long
 items + solo quads for the short ones), the gated double launch at head size 128, the fp8 kernels — over shapes wider
 than the unit tests': 1 .. 2500 sequences, 1 .. 32 heads (grouped KV heads sometimes), head size 64 / 128, contexts up
-to 4096, fp16 and fp8 pages, ALiBi sometimes, length distributions from equal to "one long among hundreds of one-token
+to 8192 (every 7th case fills the chip at 2 500 .. 8 192 tokens), fp16 and fp8 pages, ALiBi sometimes, length distributions from equal to "one long among hundreds of one-token
 sequences", empty sequences, max_seq_len above the longest length.  Each case: every row finite, deterministic, within
 the tolerance of the plain one-wave-per-head kernel (which the sampled CPU kernel model pins), and a sample of sequences
 against the model itself (checker only).
@@ -36,8 +36,14 @@ for seed in range(first, first + n_cases):
     if seed % 5 < 3 and B * H < 3100:             # three cases in five fill the chip: the balanced kernels' territory
         B = -(-int(rng.integers(3100, 5000)) // H)
         top = max(top, 300)
-    if B * H * top > 6e6:                         # keep a case's pool below ~3 GB
-        top = max(16, int(6e6 / (B * H)) // 16 * 16)
+    longctx = seed % 7 == 0                       # every 7th case: a full chip at a LONG context (2 400 .. 8 192 tokens: past
+    if longctx:                                   # the balanced kernel's LDS, the round-efficiency picks of pick_variant)
+        D = 64 if seed % 14 == 0 else D
+        top = int(rng.choice([2500, 3000, 4096, 6144, 8192]))
+        B = -(-int(rng.integers(2600, 4600)) // H)
+    cap = 4e7 if longctx else 6e6                 # keep a case's pool below ~3 GB (long-context cases: ~20 GB)
+    if B * H * top > cap:
+        top = max(16, int(cap / (B * H)) // 16 * 16)
     kind = int(rng.integers(0, 7))
     if kind == 0:
         lens = np.full(B, top)
