@@ -658,6 +658,9 @@ def main(argv=None):
     args = parse_args(argv)
     if needs_self_launch(args):
         sys.exit(self_launch(args, argv))
+    if args.kv == "fp8_e5m2":           # E5M2 pages are outside the hot path: libvmi_paged_attention_extras.so (a probe option)
+        from vllmini_amd import _lib
+        _lib.use_extras().__enter__()
     RESHAPE_OTHER = args.reshape_other_set
     if not args.standin_cpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists for the product kernels)")

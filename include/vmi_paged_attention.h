@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 18
+#define VMI_ABI_VERSION 19
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -54,7 +54,8 @@ enum {
   VMI_E_SHAPE = 6,               /* negative or inconsistent size                                     */
   VMI_E_MAX_SEQ_LEN = 7,         /* logits for max_seq_len do not fit in the 160 KiB LDS of one CU    */
   VMI_E_VARIANT = 8,             /* unknown tuning variant id                                         */
-  VMI_E_X = 9                    /* key_cache innermost dimension is not 8 halves                     */
+  VMI_E_X = 9,                   /* key_cache innermost dimension is not 8 halves                     */
+  VMI_E_NOT_BUILT = 10           /* an out-of-scope operator asked of the product library (see vmi_has_extras) */
 };
 
 /* Library identity / diagnostics. */
@@ -496,6 +497,16 @@ int vmi_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_hos
  * "loads only" and LDS-staging experiment kernels; same sources otherwise).
  */
 int vmi_is_diag_build(void);
+
+/*
+ * 0 for the product library (libvmi_paged_attention.so): the hot path of SURVEY.md §8 — float16 tensors over float16 or
+ * fp8-E4M3 pages, every head / block size of the reference's dispatch, grouped-query heads, ALiBi, paged_attention_v2, the
+ * fused append, copy/swap_blocks.  1 for libvmi_paged_attention_extras.so (`build.py --extras`), which adds the rest of the
+ * reference's dispatch surface — bfloat16 and float32 tensors, fp8-E5M2 pages, block-sparse attention,
+ * reshape_and_cache_flash, convert_fp8 (out of the path's scope).  Every entry of this header
+ * exists in both; in the product library the out-of-scope ones return VMI_E_NOT_BUILT and their kernel menus are empty.
+ */
+int vmi_has_extras(void);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,8 @@
 dense operator and the fraction of cache blocks the pattern attends.  PYTHONPATH=. python scripts/blocksparse_probe.py"""
 import torch
 from vllmini_amd import ops
+from vllmini_amd import _lib
+_lib.use_extras().__enter__()   # bfloat16 / float32 / E5M2 / block-sparse live in libvmi_paged_attention_extras.so (build.py --extras)
 from vllmini_amd.workload import CONFIGS, make_workload
 
 dev = torch.device("cuda:0")

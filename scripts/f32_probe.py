@@ -2,6 +2,8 @@
 PYTHONPATH=. python scripts/f32_probe.py"""
 import torch
 from vllmini_amd import ops
+from vllmini_amd import _lib
+_lib.use_extras().__enter__()   # bfloat16 / float32 / E5M2 / block-sparse live in libvmi_paged_attention_extras.so (build.py --extras)
 
 dev = torch.device("cuda:0")
 for name, B, H, D, L in (("cfg3", 256, 12, 64, 1024), ("cfg4", 128, 32, 128, 2048)):

@@ -13,6 +13,8 @@ import oracle  # noqa: E402  (checker)
 import test_parity_gpu as T  # noqa: E402
 from helpers import make_case  # noqa: E402
 from vllmini_amd import ops  # noqa: E402
+from vllmini_amd import _lib  # noqa: E402
+_lib.use_extras().__enter__()   # bfloat16 / float32 / E5M2 / block-sparse live in libvmi_paged_attention_extras.so (build.py --extras)
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 9000

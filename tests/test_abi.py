@@ -45,9 +45,67 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 18
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 19
     assert typed.vmi_target_arch() == b"gfx950"
-    assert typed.vmi_is_diag_build() == 0
+    assert typed.vmi_is_diag_build() == 0 and typed.vmi_has_extras() == 0
+
+
+OUT_OF_SCOPE = re.compile(r"bf16|e5m2|_sp_|sparse|f32_kernel|convert_fp8_kernel|flash_kernel", re.I)
+
+
+def test_product_library_holds_the_hot_path_and_nothing_else():
+    """libvmi_paged_attention.so = SURVEY.md §8: float16 tensors over float16 / fp8-E4M3 pages.  The out-of-scope corners of
+    the reference's dispatch (bfloat16 / float32 tensors, E5M2 pages, block-sparse attention, reshape_and_cache_flash,
+    convert_fp8: SURVEY.md §2 rows 8-10) are NOT in it — no kernel in its symbol table, no row in its menus, and their
+    C-ABI entries (which exist in every build, so one header serves both) return VMI_E_NOT_BUILT with a message that says
+    where they live.  libvmi_paged_attention_extras.so holds the same objects plus those."""
+    from vllmini_amd import _lib, build, ops
+
+    path = build.build()
+    syms = _exported(path)
+    assert not [s for s in syms if re.search(r"f32_kernel|convert_fp8_kernel|flash_kernel", s)]
+    targs = lambda sym: [int(a[2:-1]) for a in re.findall(r"L[ib]\d+E", sym.split("_kernelI", 1)[1])]      # noqa: E731
+    v1 = [targs(s) for s in syms if "12pa_v1_kernelI" in s]          # <D,HPW,WPH,U,NT,LO,PART,BS,LOCK,BF,HPT,APP,UMAX,F8,GQS,FPV,SPARSE>
+    q = [targs(s) for s in syms if "11pa_q_kernelI" in s]            # <D,BF,NT,US,UQ,F8,KM,UT,OVF>
+    sc = [targs(s) for s in syms if "reshape_and_cache_fp8_kernelI" in s]   # <VEC,BF,E5>
+    assert len(v1) > 200 and len(q) >= 8 and len(sc) >= 2      # (kernel + its host stub: two symbols each)
+    assert all(a[9] == 0 and a[13] in (0, 1) and a[16] == 0 for a in v1)     # float16 query, fp16 / E4M3 pages, not block-sparse
+    assert all(a[1] == 0 and a[5] in (0, 1) for a in q)
+    assert all(a[1] == 0 and a[2] == 0 for a in sc)
+    names = ops.variant_names() + ops.variant_names_v2()
+    assert names and not [n for n in names if OUT_OF_SCOPE.search(n) or n.startswith("bf16_")]
+    assert any(n.startswith("q_d64") for n in names) and any(n.startswith("fp8_q_d64") for n in names)
+    lib = _lib.load()
+    assert lib.vmi_has_extras() == 0
+    rc = lib.vmi_convert_fp8(None, None, 16, 1.0, 0, 0, 0, None)
+    assert rc == 10 and "not in this build" in _lib.last_error() and "extras" in _lib.last_error()
+    for entry, extra in (("vmi_paged_attention_v1_bf16", [0]), ("vmi_paged_attention_v1_fp8_e5m2", [1.0, 0, 0])):
+        one = ctypes.c_void_p(16)         # any non-NULL pointers: the gate is in front of every use of them
+        rc = getattr(lib, entry)(one, one, one, one, 1, 4, 64, 4, 1.0, one, one, 16, 16, 1, None, 256, 4096, 1024, 0, None, *extra)
+        assert rc == 10 and "not in this build" in _lib.last_error(), (entry, rc, _lib.last_error())
+    # every bfloat16 / E5M2 pick says "no kernel"
+    assert lib.vmi_paged_attention_v1_pick_variant_gqa(256, 12, 12, 64, 16, 1024, 1, 0) == 0
+    assert lib.vmi_paged_attention_v1_pick_variant_fp8_e5m2(256, 12, 64, 16, 1024, 0, 0) == 0
+    assert lib.vmi_paged_attention_v1_pick_variant_gqa(256, 12, 12, 64, 16, 1024, 0, 0) > 0
+
+
+def test_extras_library_is_the_product_plus_the_out_of_scope_operators():
+    from vllmini_amd import _lib, build, ops
+
+    path = build.build(extras=True)
+    assert path.endswith("libvmi_paged_attention_extras.so") and os.path.exists(build.LIB_PATH)
+    syms = _exported(path)
+    assert {s for s in syms if s.startswith("vmi_")} == set(_declared_symbols())
+    product_names, product_v2 = ops.variant_names(), ops.variant_names_v2()
+    with _lib.use_extras() as lib:
+        assert lib.vmi_has_extras() == 1 and lib.vmi_is_diag_build() == 0 and _lib.load() is lib
+        names, names_v2 = ops.variant_names(), ops.variant_names_v2()
+        assert lib.vmi_paged_attention_v1_pick_variant_gqa(256, 12, 12, 64, 16, 1024, 1, 0) > 0
+    assert _lib.load().vmi_has_extras() == 0               # the switch ends with the context
+    extra = [n for n in names + names_v2 if n not in product_names + product_v2]
+    assert extra and all(OUT_OF_SCOPE.search(n) or n.startswith("bf16_") for n in extra), [n for n in extra if not OUT_OF_SCOPE.search(n)][:5]
+    assert [n for n in names if n in product_names] == product_names          # same kernels, same order
+    assert [n for n in names_v2 if n in product_v2] == product_v2
 
 
 def test_product_library_exports_no_diagnostic_symbol_and_no_diagnostic_kernel():
@@ -69,7 +127,7 @@ def test_product_library_exports_no_diagnostic_symbol_and_no_diagnostic_kernel()
     assert not [n for n in names if "LOADSONLY" in n or n.startswith("stage_")]
 
 
-def test_diagnostic_library_is_the_product_plus_the_diagnostics():
+def test_diagnostic_library_is_the_extras_library_plus_the_diagnostics():
     from vllmini_amd import _lib, build, ops
 
     path = build.build(diag=True)
@@ -77,14 +135,15 @@ def test_diagnostic_library_is_the_product_plus_the_diagnostics():
     syms = _exported(path)
     for name in [*_declared_symbols(), *_declared_symbols("vmi_paged_attention_diag.h")]:
         assert name in syms, name
-    product_names = ops.variant_names()
+    with _lib.use_extras():
+        full_names = ops.variant_names()                   # (the diagnostic build is the EXTRAS library under -DVMI_DIAG)
     with _lib.use_diag() as lib:
-        assert lib.vmi_is_diag_build() == 1 and _lib.load() is lib
+        assert lib.vmi_is_diag_build() == 1 and lib.vmi_has_extras() == 1 and _lib.load() is lib
         diag_names = ops.variant_names()
     assert _lib.load().vmi_is_diag_build() == 0            # the switch ends with the context
-    extra = [n for n in diag_names if n not in product_names]
+    extra = [n for n in diag_names if n not in full_names]
     assert extra and all("LOADSONLY" in n or n.startswith("stage_") for n in extra), extra
-    assert [n for n in diag_names if n in product_names] == product_names     # same kernels, same order
+    assert [n for n in diag_names if n in full_names] == full_names           # same kernels, same order
 
 
 def test_library_is_gfx950_only_and_has_no_torch_dependency(tmp_path):
@@ -276,11 +335,15 @@ def test_heuristic_picks_follow_the_host_hint():
     assert pick(128, 32, 128, 2048) == "d128_mh4_h4_u1_nt1_lock"
     assert pick(128, 32, 128, 2048, mean_seq_len=1000) == "d128_h1_w8_u1_nt1"
     assert "_w16_" in pick(1, 12, 64, 1024)
-    assert pick(256, 12, 64, 1024, bf16=True) == "bf16_q_d64_s1q2"
-    assert pick(256, 12, 64, 8192, bf16=True) == "bf16_d64_bs16_h1_w4_u1_nt1"   # (the same rule for bfloat16)
-    assert pick(256, 12, 64, 8192, mean_seq_len=300, bf16=True) == "bf16_d64_bs16_h1_w8_u1_nt1"
+    assert ops.pick_variant(256, 12, 64, 1024, bf16=True) == 0         # bfloat16 kernels are not in the product library
     assert pick(256, 5, 80, 1024, 32) == "d80_bs32_h1_w4_u1_nt1"       # 1280 (seq, head) units do not fill 256 CUs
     assert pick(1024, 5, 80, 1024, 32) == "d80_bs32_h1_w1_u1_nt1"
+    with ops._lib.use_extras():                                        # (the same rules for bfloat16, in the extras library)
+        names = ops.variant_names()
+        assert pick(256, 12, 64, 1024) == "q_d64_s1q2"
+        assert pick(256, 12, 64, 1024, bf16=True) == "bf16_q_d64_s1q2"
+        assert pick(256, 12, 64, 8192, bf16=True) == "bf16_d64_bs16_h1_w4_u1_nt1"
+        assert pick(256, 12, 64, 8192, mean_seq_len=300, bf16=True) == "bf16_d64_bs16_h1_w8_u1_nt1"
 
 
 def test_driver_entry_points_compile_and_parse_arguments():
@@ -298,19 +361,25 @@ def test_driver_entry_points_compile_and_parse_arguments():
 
 
 def test_makefile_lists_the_same_translation_units_as_build_py():
-    """`make` and `python -m vllmini_amd.build` must produce the same library."""
+    """`make` and `python -m vllmini_amd.build` must produce the same libraries."""
     import re
 
     from vllmini_amd import build as b
 
     mk = open(os.path.join(REPO, "Makefile")).read()
-    units = re.search(r"UNITS\s*:=\s*((?:.*\\\n)*.*)\n", mk).group(1).replace("\\\n", " ").split()
-    assert sorted(units) == sorted(os.path.basename(s)[: -len(".hip")] for s in b.SOURCES)
-    diag_units = re.search(r"DIAG_UNITS\s*:=\s*(.*)\n", mk).group(1).split()
-    assert sorted(diag_units) == sorted(os.path.basename(s)[: -len(".hip")] for s in [*b.DIAG_UNITS, *b.DIAG_ONLY])
-    for flag in ("-O3", "-std=c++17", "-ffp-contract=off", "-fno-gpu-rdc"):
-        assert flag in mk and flag in b.HIPCC_FLAGS
 
+    def units(var):
+        return re.search(var + r"\s*:=\s*((?:.*\\\n)*.*)\n", mk).group(1).replace("\\\n", " ").split()
+
+    base = lambda srcs: sorted(os.path.basename(s)[: -len(".hip")] for s in srcs)      # noqa: E731
+    assert sorted(units("CORE_UNITS")) == base(b.CORE)
+    assert sorted(units("ABSENT_UNITS")) == base([b.SRC_ABSENT])
+    assert sorted(units("EXTRAS_UNITS")) == base(b.EXTRAS)
+    assert sorted(units("DIAG_UNITS")) == base([*b.DIAG_UNITS, *b.DIAG_ONLY])
+    # the product library: the core units + the stub that stands in for the out-of-scope ones — and none of those
+    assert [s for s, _ in b.PRODUCT_UNITS] == [*b.CORE, b.SRC_ABSENT]
+    assert not set(b.EXTRAS) & {s for s, _ in b.PRODUCT_UNITS}
+    assert b.SRC_ABSENT not in [s for s, _ in b.EXTRAS_UNITS]
 
 def test_c_abi_is_callable_from_several_host_threads():
     """Error strings and the opt-in switches are per thread: two threads that fail differently each read their own

@@ -23,6 +23,10 @@ from helpers import BS, make_case, ulp16
 
 pytestmark = pytest.mark.gpu
 
+# A test that covers a hot-path case AND its bfloat16 / block-sparse counterpart runs twice: on the product library (the
+# hot-path half) and, marked `extras` (tests/conftest.py switches the library), on libvmi_paged_attention_extras.so.
+BOTH_LIBRARIES = pytest.mark.parametrize("extras", [False, pytest.param(True, marks=pytest.mark.extras)], ids=["product", "extras"])
+
 ATOL = 1e-3          # north_star bound vs the reference kernel (model)
 
 
@@ -522,7 +526,8 @@ def test_full_size_cfg5_per_gpu_workload_properties():
 # ------------------------------------------------------------------------------------------------
 # error behaviour at the seam (reference: TORCH_CHECK -> RuntimeError)
 # ------------------------------------------------------------------------------------------------
-def test_errors_raise_runtimeerror():
+@BOTH_LIBRARIES
+def test_errors_raise_runtimeerror(extras):
     ext = _ext()
     dev = _dev()
     rng = np.random.default_rng(0)
@@ -547,7 +552,15 @@ def test_errors_raise_runtimeerror():
         call(good, kvd="fp8")                                        # fp8 needs byte caches
     with pytest.raises(RuntimeError, match="kv cache"):
         call(good, kvd="int4")                                       # quant_utils.cuh:564
-    call(good, vert=2)                                               # block-sparse attention is built (test_blocksparse_*)
+    if extras:
+        call(good, vert=2)                                           # block-sparse attention is built (test_blocksparse_*) ...
+    else:                                                            # ... outside the product library, which says so
+        with pytest.raises(RuntimeError, match="block-sparse attention: not in this build"):
+            call(good, vert=2)
+        with pytest.raises(RuntimeError, match="bfloat16 tensors: not in this build"):
+            call(good, out=torch.empty(good["q"].shape, dtype=torch.bfloat16, device=dev),
+                 q=torch.from_numpy(good["q"].copy()).to(dev).to(torch.bfloat16),
+                 kc=torch.from_numpy(good["kc"]).to(dev).to(torch.bfloat16), vc=torch.from_numpy(good["vc"]).to(dev).to(torch.bfloat16))
     with pytest.raises(RuntimeError, match="int32"):
         call(good, lens=torch.from_numpy(good["lens"].astype(np.int64)).to(dev))
     with pytest.raises(RuntimeError, match="Unsupported input type"):
@@ -882,6 +895,7 @@ def test_reshape_and_cache_then_attend_other_layouts(D, bs):
     assert np.abs(out.cpu().numpy()[0].astype(np.float64) - exact).max() <= 3e-3
 
 
+@pytest.mark.extras
 def test_reshape_and_cache_flash_bit_exact():
     ext = _ext()
     dev = _dev()
@@ -966,6 +980,7 @@ def assert_close_bf16(got_bits, ref_bits, what="", vmax=None):
     assert not bad.any(), f"{what}: {bad.sum()} outputs off by more than 2 bf16 ulp (max {d.max():.3e})"
 
 
+@pytest.mark.extras
 @pytest.mark.parametrize("bs", ALL_BLOCKS)
 @pytest.mark.parametrize("D", ALL_HEADS)
 def test_bf16_every_head_and_block_size_v1_and_v2(D, bs):
@@ -989,6 +1004,7 @@ def test_bf16_every_head_and_block_size_v1_and_v2(D, bs):
             assert_close_bf16(run_hip_bf16(case, variant=vid, max_seq_len=1024, v2=True), ref2, name)
 
 
+@pytest.mark.extras
 def test_bf16_vs_exact_and_mixed_dtype_errors():
     rng = np.random.default_rng(51)
     lens = [3, 64, 1000]
@@ -1109,22 +1125,30 @@ def test_append_every_variant_bit_identical_to_two_ops(D):
 
 @pytest.mark.parametrize("D", [64, 80, 96, 112, 128, 192, 256])
 @pytest.mark.parametrize("bs", [8, 16, 32])
-def test_append_every_head_and_block_size_gqa_fp16_bf16(D, bs):
+@BOTH_LIBRARIES
+def test_append_every_head_and_block_size_gqa_fp16_bf16(D, bs, extras):
     from vllmini_amd import ops
 
     rng = np.random.default_rng(400 + D + bs)
     lens = [1, bs, bs + 1, 5 * bs - 1, 300, 2]
     case = make_case(rng, len(lens), 4, D, lens, q_row_pad=1, block_size=bs, num_kv_heads=2)
-    _append_vs_two_ops(case, 0, what=f"fp16 D{D} bs{bs}")
-    _append_vs_two_ops(case, 0, dtype=torch.bfloat16, what=f"bf16 D{D} bs{bs}")
+    if extras:
+        _append_vs_two_ops(case, 0, dtype=torch.bfloat16, what=f"bf16 D{D} bs{bs}")
+    else:
+        _append_vs_two_ops(case, 0, what=f"fp16 D{D} bs{bs}")
     tag16, tagbf = (f"d{D}_" if bs == 16 else f"d{D}_bs{bs}_"), f"bf16_d{D}_bs{bs}_"
+    ran = 0
     for vid, name in enumerate(ops.variant_names(), start=1):
         if "LOADSONLY" in name:
             continue
-        if name.startswith(tag16) and (bs != 16 or "_bs" not in name) and _gq_ok(name, 2):
+        if not extras and (name.startswith(tag16) and (bs != 16 or "_bs" not in name) or name.startswith(f"d{D}_bs{bs}_")) \
+                and _gq_ok(name, 2):
             _append_vs_two_ops(case, vid, what=name)
-        elif name.startswith(tagbf):
+            ran += 1
+        elif extras and name.startswith(tagbf):
             _append_vs_two_ops(case, vid, dtype=torch.bfloat16, what=name)
+            ran += 1
+    assert ran >= 2
 
 
 def test_append_full_size_cfg3_step_equals_two_ops():
@@ -1153,8 +1177,9 @@ def test_append_full_size_cfg3_step_equals_two_ops():
 # randomized sweep: shapes, strides, GQA, ALiBi, ragged lengths, table padding, forced decompositions —
 # 60 seeded cases, every one checked against the kernel model (v1, v2) and the call pair (append)
 # ------------------------------------------------------------------------------------------------
+@BOTH_LIBRARIES
 @pytest.mark.parametrize("chunk", range(6))
-def test_randomized_parity_sweep(chunk):
+def test_randomized_parity_sweep(chunk, extras):
     from vllmini_amd import ops
 
     names = ops.variant_names()
@@ -1196,7 +1221,8 @@ def test_randomized_parity_sweep(chunk):
         if alibi is None and not case["kc"].dtype == np.float32:
             clean = dict(case)
             _append_vs_two_ops(clean, 0, seed=seed, what=what + " append")
-            _append_vs_two_ops(clean, 0, dtype=torch.bfloat16, seed=seed, what=what + " append bf16")
+            if extras:
+                _append_vs_two_ops(clean, 0, dtype=torch.bfloat16, seed=seed, what=what + " append bf16")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1467,6 +1493,7 @@ def test_pa_v1_long_max_seq_len_falls_back_to_one_head_per_workgroup():
 # ------------------------------------------------------------------------------------------------
 # bfloat16 query / rows over the fp8 E4M3 cache (the reference dispatches bf16 x uint8 too)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.extras
 @pytest.mark.parametrize("kv_scale", [1.0, 2.5])
 def test_reshape_and_cache_fp8_every_bf16_value_bit_exact(kv_scale):
     ext = _ext()
@@ -1488,6 +1515,7 @@ def test_reshape_and_cache_fp8_every_bf16_value_bit_exact(kv_scale):
     assert np.array_equal(t_vc.cpu().numpy(), vc)
 
 
+@pytest.mark.extras
 @pytest.mark.parametrize("D,bs", [(64, 16), (128, 16), (80, 16), (112, 32), (192, 32), (256, 16), (96, 32)])
 def test_pa_v1_bf16_query_over_fp8_cache_matches_kernel_model(D, bs):
     from vllmini_amd import ops
@@ -1557,6 +1585,7 @@ def test_gqa_shared_tile_kernels_match_kernel_model(D):
 # ------------------------------------------------------------------------------------------------
 # float32 tensors: the (float, float) dispatch branch (x = 4)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.extras
 @pytest.mark.parametrize("bs", ALL_BLOCKS)
 @pytest.mark.parametrize("D", ALL_HEADS)
 def test_f32_every_head_and_block_size(D, bs):
@@ -1605,6 +1634,7 @@ def test_f32_every_head_and_block_size(D, bs):
     assert np.array_equal(kc2.cpu().numpy(), rk) and np.array_equal(vc2.cpu().numpy(), rv)
 
 
+@pytest.mark.extras
 def test_f32_limits_are_runtime_errors():
     from test_oracle import f32_case
 
@@ -1623,6 +1653,7 @@ def test_f32_limits_are_runtime_errors():
                                0, 0, 1, 1, 0)
 
 
+@pytest.mark.extras
 def test_convert_fp8_every_value_both_directions():
     """cache_ops.convert_fp8 (cache_kernels.cu:320-392): half / bfloat16 / float -> fp8 E4M3 and back, every 16-bit
     pattern and every fp8 code, against the oracle's converters."""
@@ -1705,6 +1736,7 @@ def _run_e5m2(case, kv_scale, variant=0, alibi=None, bf16=False, v2_msl=0):
     return out.view(torch.int16).cpu().numpy().view(np.uint16) if bf16 else out.cpu().numpy()
 
 
+@pytest.mark.extras
 def test_fp8_e5m2_hardware_decode_for_every_code():
     """One token per sequence => out[d] = half(1.0 * v[d]): all 250 non-NaN E5M2 codes (infinities included)
     decode to the upper-byte-of-a-half value, at kv_scale 1 (byte shuffle path) and at other scales."""
@@ -1733,6 +1765,7 @@ def test_fp8_e5m2_hardware_decode_for_every_code():
         assert (got[~nz] == 0).all()
 
 
+@pytest.mark.extras
 @pytest.mark.parametrize("kv_scale", [1.0, 0.5, 3.7])
 def test_reshape_and_cache_fp8_e5m2_every_half_and_bf16_value_bit_exact(kv_scale):
     ext = _ext()
@@ -1758,6 +1791,7 @@ def test_reshape_and_cache_fp8_e5m2_every_half_and_bf16_value_bit_exact(kv_scale
         assert np.array_equal(t_vc.cpu().numpy(), vc), bf16
 
 
+@pytest.mark.extras
 @pytest.mark.parametrize("D", [64, 80, 96, 112, 128, 192, 256])
 @pytest.mark.parametrize("bs", [16, 32])
 def test_pa_fp8_e5m2_matches_kernel_model(D, bs):
@@ -1794,6 +1828,7 @@ def test_pa_fp8_e5m2_matches_kernel_model(D, bs):
             assert_close(_run_e5m2(case, 0.8, variant=vid, v2_msl=1024), r2, name, vmax=1.6)
 
 
+@pytest.mark.extras
 @pytest.mark.parametrize("D,bs", [(64, 16), (128, 16), (80, 32), (256, 16), (112, 16), (192, 32), (96, 32)])
 def test_pa_v2_bf16_query_over_fp8_pages(D, bs):
     """Split-KV with a bfloat16 query over E4M3 and E5M2 pages: merged output against the kernel model, auto pick
@@ -1825,6 +1860,7 @@ def test_pa_v2_bf16_query_over_fp8_pages(D, bs):
             assert_close_bf16(out.view(torch.int16).cpu().numpy().view(np.uint16), ref, f"bf16 x {kvd} v2 D{D} bs{bs} variant {vid}", vmax=1.6)
 
 
+@pytest.mark.extras
 def test_fp8_e5m2_grouped_query_kernels_and_opt_in():
     from vllmini_amd import ops
 
@@ -1883,6 +1919,7 @@ def _run_sparse(case, sparse, tp_rank=0, alibi=None, bf16=False, v2_msl=0):
 SPARSE_PATTERNS = [((2, 4, 64, 1), 0), ((1, 3, 32, -1), 1), ((0, 2, 16, 2), 0), ((4, 8, 64, 0), 3), ((1, 2, 128, 1), 0)]
 
 
+@pytest.mark.extras
 @pytest.mark.parametrize("bs", ALL_BLOCKS)
 @pytest.mark.parametrize("D", ALL_HEADS)
 def test_blocksparse_every_head_and_block_size(D, bs):
@@ -1906,6 +1943,7 @@ def test_blocksparse_every_head_and_block_size(D, bs):
     assert_close_bf16(_run_sparse(cb, sparse, tp, bf16=True, v2_msl=1024), refb2, f"sparse bf16 v2 D{D} bs{bs}")
 
 
+@pytest.mark.extras
 def test_blocksparse_patterns_alibi_small_and_large_batches():
     """Every pattern incl. all-blocks-skipped heads (local_blocks = 0), ALiBi, a batch large enough for the
     one-wave-per-head kernels and one small enough for four waves per head."""
@@ -1922,6 +1960,7 @@ def test_blocksparse_patterns_alibi_small_and_large_batches():
                 assert_close(_run_sparse(case, sparse, tp, alibi=al), ref, f"sparse S{S} {sparse} alibi={al is not None}")
 
 
+@pytest.mark.extras
 def test_blocksparse_argument_errors():
     rng = np.random.default_rng(5)
     case = make_case(rng, 2, 4, 64, [40, 70])
@@ -1937,7 +1976,8 @@ def test_blocksparse_argument_errors():
                                16, 70, None, "fp8", 1.0, 0, 1, 2, 16, 1)
 
 
-def test_gqa_pv_on_matrix_cores_is_opt_in():
+@BOTH_LIBRARIES
+def test_gqa_pv_on_matrix_cores_is_opt_in(extras):
     """vmi_set_pv_mfma: off by default (picks never name a _pvm kernel); on, grouped-query launches use them and stay
     inside the north-star bound, for fp16 and bf16; multi-head attention and fp8 picks are unaffected."""
     from vllmini_amd import ops
@@ -1961,7 +2001,7 @@ def test_gqa_pv_on_matrix_cores_is_opt_in():
             fast = run_hip(case)
             assert_close(fast, ref, f"pvm auto H{H}/{hkv} D{D} ({picked})", tight=False)
             assert np.abs(fast.astype(np.float64) - exact.astype(np.float64)).max() <= 1e-3
-            if D == 128:
+            if D == 128 and extras:
                 cb = _to_bf16_case(case)
                 refb = oracle.paged_attention_v1(cb["q"], cb["kc"], cb["vc"], hkv, cb["scale"], cb["tables"], cb["lens"],
                                                  16, threads=8, bf16=True)
@@ -1969,6 +2009,7 @@ def test_gqa_pv_on_matrix_cores_is_opt_in():
                 assert "_pvm" in pb and pb.startswith("bf16_"), pb
                 got = oracle.bf16_bits_to_f32(run_hip_bf16(case=cb, max_seq_len=1024)).astype(np.float64)
                 assert np.abs(got - oracle.bf16_bits_to_f32(refb)).max() <= 2.0 ** -7            # 2 bf16 ulp at 1.0
+            if D == 128:
                 c8 = _fp8_case(rng, len(lens), H, D, lens, 16, num_kv_heads=hkv)                 # fp8 pages
                 for kv_scale in (1.0, 0.8):
                     r8 = oracle.paged_attention_v1_fp8(c8["q"], c8["kq"], c8["vq"], hkv, c8["scale"], c8["tables"],
@@ -1979,7 +2020,8 @@ def test_gqa_pv_on_matrix_cores_is_opt_in():
         ops.set_pv_mfma(False)
 
 
-def test_gqa_shared_tile_kernels_bf16_and_fp8():
+@BOTH_LIBRARIES
+def test_gqa_shared_tile_kernels_bf16_and_fp8(extras):
     from vllmini_amd import ops
 
     dev = _dev()
@@ -1992,11 +2034,12 @@ def test_gqa_shared_tile_kernels_bf16_and_fp8():
         # bf16
         case = _to_bf16_case(make_case(rng, len(lens), H, D, lens, num_kv_heads=hkv, q_row_pad=1))
         ref = oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], hkv, case["scale"], case["tables"], case["lens"],
-                                        bs, threads=8, bf16=True)
-        assert "_gq" in names[ops.pick_variant(len(lens), H, D, 600, 16, bf16=True, num_kv_heads=hkv) - 1]
-        assert_close_bf16(run_hip_bf16(case), ref, f"bf16 gqa auto D{D}")
+                                        bs, threads=8, bf16=True) if extras else None
+        if extras:
+            assert "_gq" in names[ops.pick_variant(len(lens), H, D, 600, 16, bf16=True, num_kv_heads=hkv) - 1]
+            assert_close_bf16(run_hip_bf16(case), ref, f"bf16 gqa auto D{D}")
         for vid, name in enumerate(names, start=1):
-            if name.startswith(f"bf16_d{D}_gq") and _gq_ok(name, qpk):
+            if extras and name.startswith(f"bf16_d{D}_gq") and _gq_ok(name, qpk):
                 if "_pvm" in name:        # opt-in kernels: north-star bound (here: 2 bf16 ulp at 1.0)
                     got = oracle.bf16_bits_to_f32(run_hip_bf16(case, variant=vid)).astype(np.float64)
                     assert np.abs(got - oracle.bf16_bits_to_f32(ref)).max() <= 2.0 ** -7, name

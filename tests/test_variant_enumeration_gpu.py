@@ -150,24 +150,33 @@ def _walk(names, v2, cases):
     return checked, refused_everywhere, unparsed
 
 
-def test_every_v1_variant_of_the_product_library_is_oracle_checked():
+# (the second run of each walk, marked `extras`, is over libvmi_paged_attention_extras.so — the product's kernels again plus
+#  the bfloat16 / E5M2 / block-sparse menus; tests/conftest.py switches the library for the marker)
+BOTH_LIBRARIES = pytest.mark.parametrize("extras", [False, pytest.param(True, marks=pytest.mark.extras)], ids=["product", "extras"])
+
+
+@BOTH_LIBRARIES
+def test_every_v1_variant_of_the_product_library_is_oracle_checked(extras):
     from vllmini_amd import _lib, ops
 
-    assert _lib.load().vmi_is_diag_build() == 0
+    assert _lib.load().vmi_is_diag_build() == 0 and _lib.load().vmi_has_extras() == int(extras)
     names = ops.variant_names()
-    assert len(names) == _lib.load().vmi_paged_attention_v1_variant_count() >= 300
+    assert len(names) == _lib.load().vmi_paged_attention_v1_variant_count() >= (390 if extras else 195)
     assert not [n for n in names if "LOADSONLY" in n or n.startswith("stage_")]
+    assert bool([n for n in names if n.startswith("bf16_") or "e5m2" in n]) == extras
     checked, refused, unparsed = _walk(names, False, Cases())
     assert not unparsed, unparsed[:5]
     assert not refused, refused[:5]
     assert checked == len(names)
 
 
-def test_every_v2_variant_of_the_product_library_is_oracle_checked():
+@BOTH_LIBRARIES
+def test_every_v2_variant_of_the_product_library_is_oracle_checked(extras):
     from vllmini_amd import _lib, ops
 
     names = ops.variant_names_v2()
-    assert len(names) == _lib.load().vmi_paged_attention_v2_variant_count() >= 100
+    assert len(names) == _lib.load().vmi_paged_attention_v2_variant_count() >= (210 if extras else 88)
+    assert bool([n for n in names if n.startswith("bf16_") or "e5m2" in n]) == extras
     checked, refused, unparsed = _walk(names, True, Cases())
     assert not unparsed, unparsed[:5]
     assert not refused, refused[:5]
@@ -184,7 +193,8 @@ def test_unknown_variant_ids_are_rejected():
             _launch(case, vid, False, "auto", 1.0, None)
 
 
-def test_name_pattern_covers_every_name_without_a_gpu_assumption():
+@BOTH_LIBRARIES
+def test_name_pattern_covers_every_name_without_a_gpu_assumption(extras):
     """(runs on the GPU box with the others; the pattern itself needs no device)"""
     from vllmini_amd import ops
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "vmi_copy_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _i32, _c_void_p, _i32, _i64, _i32, _c_void_p]),
     "vmi_swap_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i32, _i64, _i32, _i32, _c_void_p]),
     "vmi_is_diag_build": (ctypes.c_int, []),
+    "vmi_has_extras": (ctypes.c_int, []),
     "vmi_reshape_and_cache_f16": (ctypes.c_int, [
         _c_void_p, _c_void_p, _c_void_p, _c_void_p,  # key, value, key_cache, value_cache
         _c_void_p,                                   # slot_mapping
@@ -92,12 +93,13 @@ DIAG_SIGNATURES = {
     "vmi_diag_stream_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _c_void_p]),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lock = threading.Lock()
 _product = None      # libvmi_paged_attention.so
+_extras = None       # libvmi_paged_attention_extras.so (opt-in: the reference's out-of-scope dispatch corners)
 _diag = None         # libvmi_paged_attention_diag.so (tests / probes only)
-_active = None       # what load() hands to the operators: the product library unless a test switched (use_diag)
+_active = None       # what load() hands to the operators: the product library unless the process switched (use_extras / use_diag)
 
 
 class NativeLibraryError(RuntimeError):
@@ -108,10 +110,11 @@ def lib_path() -> str:
     return _build.LIB_PATH
 
 
-def _open(path: str, signatures: dict, want_diag: int) -> ctypes.CDLL:
+def _open(path: str, signatures: dict, want_diag: int, want_extras: int = 0) -> ctypes.CDLL:
     if not os.path.exists(path):
+        flag = " --diag" if want_diag else " --extras" if want_extras else ""
         raise NativeLibraryError(
-            f"{path} not found: build it with `python -m vllmini_amd.build{' --diag' if want_diag else ''}` "
+            f"{path} not found: build it with `python -m vllmini_amd.build{flag}` "
             "(or __graft_entry__.build()). There is no CPU/torch fallback for these ops.")
     try:
         lib = ctypes.CDLL(path)
@@ -129,6 +132,8 @@ def _open(path: str, signatures: dict, want_diag: int) -> ctypes.CDLL:
         raise NativeLibraryError(f"{path}: ABI version {got}, Python side expects {ABI_VERSION}")
     if lib.vmi_is_diag_build() != want_diag:
         raise NativeLibraryError(f"{path}: vmi_is_diag_build() = {lib.vmi_is_diag_build()}, expected {want_diag}")
+    if lib.vmi_has_extras() != want_extras:
+        raise NativeLibraryError(f"{path}: vmi_has_extras() = {lib.vmi_has_extras()}, expected {want_extras}")
     return lib
 
 
@@ -153,13 +158,44 @@ def load_diag() -> ctypes.CDLL:
     global _diag
     with _lock:
         if _diag is None:
-            _diag = _open(_build.DIAG_LIB_PATH, {**SIGNATURES, **DIAG_SIGNATURES}, 1)
+            _diag = _open(_build.DIAG_LIB_PATH, {**SIGNATURES, **DIAG_SIGNATURES}, 1, 1)
         return _diag
+
+
+def load_extras() -> ctypes.CDLL:
+    """libvmi_paged_attention_extras.so: the product's objects plus the corners of the reference's dispatch that lie
+    outside the hot path (bfloat16 / float32 tensors, fp8-E5M2 pages, block-sparse attention, reshape_and_cache_flash,
+    convert_fp8 — SURVEY.md §2 rows 8-10).  Loading it does not change what the operators call; use_extras() does."""
+    global _extras
+    with _lock:
+        if _extras is None:
+            _extras = _open(_build.EXTRAS_LIB_PATH, SIGNATURES, 0, 1)
+        return _extras
+
+
+class use_extras:
+    """Opt in to the out-of-scope operators: inside this context (or after `use_extras().__enter__()` for a whole process)
+    the operators run on libvmi_paged_attention_extras.so.  The product library answers those calls with
+    RuntimeError("... not in this build of the library ...").  Variant ids differ between the libraries (the extras one has
+    more rows): resolve names inside."""
+
+    def __enter__(self):
+        global _active
+        load()
+        self._prev = _active
+        lib = load_extras()
+        _active = lib
+        return lib
+
+    def __exit__(self, *exc):
+        global _active
+        _active = self._prev
+        return False
 
 
 class use_diag:
     """Context manager for tests and probes: inside it the operators of this process run on the diagnostic library
-    (same sources, -DVMI_DIAG), so that kernel modes can be forced and the experiment kernels selected by variant id.
+    (the extras library's sources under -DVMI_DIAG), so that kernel modes can be forced and the experiment kernels selected by variant id.
     Variant ids differ between the two libraries (the diagnostic one has more rows): resolve names inside."""
 
     def __enter__(self):

@@ -4,18 +4,29 @@ The reference builds its kernels as a torch CUDAExtension for sm_70..sm_89
 (paged_attention_ext/setup.py:21-46, build.sh:3-5).  Here there is no torch/pybind in the
 native code at all: hipcc translation units compiled concurrently and linked into
 
-  vllmini_amd/_C/libvmi_paged_attention.so        the PRODUCT library — what ops.py / cache_ops.py load (ctypes,
-                                                  vllmini_amd/_lib.py).  No diagnostic entry, no kernel that is wrong
-                                                  by design, no experiment kernel.
-  vllmini_amd/_C/libvmi_paged_attention_diag.so   the DIAGNOSTIC library (`--diag`): the same sources with -DVMI_DIAG —
-                                                  adds include/vmi_paged_attention_diag.h's entries (read-bandwidth
-                                                  probes, the balanced kernels' mode knob), the "loads only" variants
-                                                  and the LDS-staging experiment (pa_stage.hip).  Only the three units
-                                                  -DVMI_DIAG changes are compiled a second time; every other object
-                                                  is shared with the product library.  Used by tests that force kernel
-                                                  modes, scripts/ and scripts/bench_diag.py — never by the operators.
+  vllmini_amd/_C/libvmi_paged_attention.so          the PRODUCT library — what ops.py / cache_ops.py load (ctypes,
+                                                    vllmini_amd/_lib.py): the hot path of SURVEY.md §8 and nothing else —
+                                                    float16 tensors over float16 or fp8-E4M3 pages (every head / block
+                                                    size of the reference's dispatch, grouped-query heads, ALiBi,
+                                                    paged_attention_v2, the fused append, copy/swap_blocks).  Seven units.
+                                                    No diagnostic entry, no kernel that is wrong by design, no experiment
+                                                    kernel, and none of the out-of-scope element types and operators: their
+                                                    kernel menus are EMPTY here and their C-ABI entries return
+                                                    VMI_E_NOT_BUILT (pa_extras_absent.hip, chosen at link time).
+  vllmini_amd/_C/libvmi_paged_attention_extras.so   (`--extras`) the product's objects plus the rest of the reference's
+                                                    dispatch surface (out of the path's scope):
+                                                    bfloat16 and float32 tensors, fp8-E5M2 pages, block-sparse attention,
+                                                    reshape_and_cache_flash, convert_fp8.  Opt-in: `_lib.use_extras()`;
+                                                    the operators raise RuntimeError("... not in this build ...") without it.
+  vllmini_amd/_C/libvmi_paged_attention_diag.so     (`--diag`) the extras library with -DVMI_DIAG — adds
+                                                    include/vmi_paged_attention_diag.h's entries (read-bandwidth probes, the
+                                                    balanced kernels' mode knob), the "loads only" variants and the
+                                                    LDS-staging experiment (pa_stage.hip).  Only the units -DVMI_DIAG changes
+                                                    are compiled a second time.  Used by tests that force kernel modes,
+                                                    scripts/ and scripts/bench_diag.py — never by the operators.
 
-hipcc cross-compiles without a GPU, so this runs in the build container; the .so files are
+Every object is compiled once and shared by the libraries that hold it (pa_queue.hip twice: its bfloat16 / E5M2 rows are
+behind -DVMI_EXTRAS).  hipcc cross-compiles without a GPU, so this runs in the build container; the .so files are
 git-ignored but travel to the GPU box with the repo snapshot (the objects do not: .gpurunignore).
 """
 from __future__ import annotations
@@ -41,18 +52,28 @@ SRC_FP8_E5M2 = [os.path.join(CSRC, f"pa_variants_fp8_e5m2{t}.hip") for t in ("",
 SRC_F32 = os.path.join(CSRC, "pa_f32.hip")                    # float32 tensors (x = 4)
 SRC_QUEUE = os.path.join(CSRC, "pa_queue.hip")                # balanced (work-queue) kernels for ragged batches
 SRC_STAGE = os.path.join(CSRC, "pa_stage.hip")                # experiment: pages staged through LDS (diagnostic library only)
-SOURCES = [SRC, SRC_EXTRA, SRC_BF16, *SRC_APPEND, SRC_FP8, SRC_FP8_BF16, *SRC_FP8_E5M2, *SRC_SPARSE, SRC_F32, SRC_QUEUE]
+SRC_ABSENT = os.path.join(CSRC, "pa_extras_absent.hip")      # product library: empty out-of-scope menus, VMI_E_NOT_BUILT entries
+SRC_EXTRAS_CACHE = os.path.join(CSRC, "pa_extras_cache.hip")  # extras: convert_fp8, reshape_and_cache_flash, bf16 / E5M2 fp8 scatter
+# (source, flavor): flavor "" = plain, "extras" = -DVMI_EXTRAS, "diag" = -DVMI_DIAG (+ -DVMI_EXTRAS)
+CORE = [SRC, SRC_EXTRA, SRC_APPEND[0], SRC_APPEND[1], SRC_FP8, SRC_QUEUE]          # the hot path
+EXTRAS = [SRC_BF16, SRC_APPEND[2], SRC_FP8_BF16, *SRC_FP8_E5M2, *SRC_SPARSE, SRC_F32, SRC_EXTRAS_CACHE]
+PRODUCT_UNITS = [(s, "") for s in CORE] + [(SRC_ABSENT, "")]
+EXTRAS_UNITS = [(s, "extras" if s == SRC_QUEUE else "") for s in CORE] + [(s, "") for s in EXTRAS]
 # the diagnostic library: these units are compiled again with -DVMI_DIAG (it changes their variant tables / entries),
-# pa_stage.hip exists only there, every other unit's object is the product's
+# pa_stage.hip exists only there, every other object is the extras library's
 DIAG_UNITS = [SRC, SRC_APPEND[0]]
 DIAG_ONLY = [SRC_STAGE]
+DIAG_LIB_UNITS = [(s, "diag") if s in DIAG_UNITS else (s, f) for s, f in EXTRAS_UNITS] + [(s, "diag") for s in DIAG_ONLY]
+SOURCES = [*CORE, SRC_ABSENT, *EXTRAS]                        # every unit of the product and extras libraries
 HDR = os.path.join(CSRC, "pa_kernel.hpp")
 HDR_QUEUE = os.path.join(CSRC, "pa_queue.hpp")
+HDRS_HOST = [os.path.join(CSRC, "pa_host.hpp"), os.path.join(CSRC, "pa_cache_fp8.hpp")]
 INCLUDE = os.path.join(REPO_ROOT, "include")
 OUT_DIR = os.path.join(PKG_DIR, "_C")
 LIB_NAME = "libvmi_paged_attention.so"
 LIB_PATH = os.path.join(OUT_DIR, LIB_NAME)
 DIAG_LIB_PATH = os.path.join(OUT_DIR, "libvmi_paged_attention_diag.so")
+EXTRAS_LIB_PATH = os.path.join(OUT_DIR, "libvmi_paged_attention_extras.so")
 
 ARCH = "gfx950"
 # -ffp-contract=off: the fp16 p*v products must be rounded before the fp16 adds (reference
@@ -75,36 +96,48 @@ def _hipcc() -> str:
     return exe
 
 
-def _deps(diag: bool = False) -> list[str]:
-    return [*SOURCES, *(DIAG_ONLY if diag else []), *TABLES, HDR, HDR_QUEUE,
+def _lib_of(kind: str) -> str:
+    return {"product": LIB_PATH, "extras": EXTRAS_LIB_PATH, "diag": DIAG_LIB_PATH}[kind]
+
+
+def _units_of(kind: str):
+    return {"product": PRODUCT_UNITS, "extras": EXTRAS_UNITS, "diag": DIAG_LIB_UNITS}[kind]
+
+
+def _deps(kind: str = "product") -> list[str]:
+    return [*(s for s, _ in _units_of(kind)), *TABLES, HDR, HDR_QUEUE, *HDRS_HOST,
             os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.join(INCLUDE, "vmi_paged_attention_diag.h"),
             os.path.abspath(__file__)]
 
 
-def is_stale(diag: bool = False) -> bool:
-    lib = DIAG_LIB_PATH if diag else LIB_PATH
+def is_stale(kind="product") -> bool:
+    kind = {False: "product", True: "diag"}.get(kind, kind)      # (older callers pass diag: bool)
+    lib = _lib_of(kind)
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    return any(os.path.getmtime(d) > t for d in _deps(diag))
+    return any(os.path.getmtime(d) > t for d in _deps(kind))
 
 
-def _obj_of(src: str, diag: bool = False) -> str:
-    return os.path.join(OUT_DIR, os.path.basename(src) + (".diag.o" if diag else ".o"))
+def _obj_of(src: str, flavor="") -> str:
+    flavor = {False: "", True: "diag"}.get(flavor, flavor)
+    return os.path.join(OUT_DIR, os.path.basename(src) + (f".{flavor}.o" if flavor else ".o"))
 
 
-def _flags(diag: bool) -> list[str]:
-    return [*HIPCC_FLAGS, *(["-DVMI_DIAG"] if diag else [])]
+def _flags(flavor="") -> list[str]:
+    flavor = {False: "", True: "diag"}.get(flavor, flavor)
+    extra = {"": [], "extras": ["-DVMI_EXTRAS"], "diag": ["-DVMI_DIAG", "-DVMI_EXTRAS"]}[flavor]
+    return [*HIPCC_FLAGS, *extra]
 
 
-def _obj_stale(src: str, diag: bool = False) -> bool:
+def _obj_stale(src: str, flavor="") -> bool:
     """An object is rebuilt when it is missing, older than anything its depfile (hipcc -MD) lists, or was
     compiled with other flags."""
-    obj = _obj_of(src, diag)
+    obj = _obj_of(src, flavor)
     dep, stamp = obj + ".d", obj + ".flags"
     if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(stamp)):
         return True
-    if open(stamp).read() != " ".join(_flags(diag)):
+    if open(stamp).read() != " ".join(_flags(flavor)):
         return True
     t = os.path.getmtime(obj)
     text = open(dep).read().replace("\\\n", " ")
@@ -116,22 +149,22 @@ def _obj_stale(src: str, diag: bool = False) -> bool:
 
 
 def _compile(units, verbose: bool) -> None:
-    """units: [(src, diag)] — compiled concurrently."""
+    """units: [(src, flavor)] — compiled concurrently."""
     procs = []
-    for src, diag in units:
-        obj = _obj_of(src, diag)
-        cmd = [_hipcc(), *_flags(diag), "-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
+    for src, flavor in units:
+        obj = _obj_of(src, flavor)
+        cmd = [_hipcc(), *_flags(flavor), "-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, diag, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        procs.append((src, flavor, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     failed = None
-    for src, diag, cmd, proc in procs:
+    for src, flavor, cmd, proc in procs:
         out, err = proc.communicate()
         if proc.returncode != 0:
             failed = failed or RuntimeError(f"hipcc failed ({proc.returncode}): {' '.join(cmd)}\n{out}\n{err}")
             continue                                   # (let the other units finish: their objects stay valid)
-        with open(_obj_of(src, diag) + ".flags", "w") as f:
-            f.write(" ".join(_flags(diag)))
+        with open(_obj_of(src, flavor) + ".flags", "w") as f:
+            f.write(" ".join(_flags(flavor)))
     if failed:
         raise failed
 
@@ -152,30 +185,29 @@ def _have_objects() -> bool:
     return os.path.isdir(OUT_DIR) and any(f.endswith(".o") for f in os.listdir(OUT_DIR))
 
 
-def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
-    """Compile the translation units that are missing or stale (all of them with force=True), link; return the
-    library's path.  diag=True builds BOTH libraries (the diagnostic one shares the product's objects) and returns
-    the diagnostic library's path.
+def build(force: bool = False, verbose: bool = False, diag: bool = False, extras: bool = False) -> str:
+    """Compile the translation units that are missing or stale (all of them with force=True), link; return the path of
+    the last library asked for: the product library, then (extras=True) libvmi_paged_attention_extras.so, then (diag=True)
+    the diagnostic library — which is the extras library under -DVMI_DIAG, so diag=True builds all three.
 
     A tree that holds current libraries but NO objects — the GPU box: objects do not travel (.gpurunignore) — is
     complete as it is: nothing is recompiled there."""
     os.makedirs(OUT_DIR, exist_ok=True)
-    want = [LIB_PATH] + ([DIAG_LIB_PATH] if diag else [])
-    if not force and not _have_objects() and not is_stale(False) and (not diag or not is_stale(True)):
-        return want[-1]
-    units = [(s, False) for s in SOURCES if force or _obj_stale(s)]
-    if diag:
-        units += [(s, True) for s in [*DIAG_UNITS, *DIAG_ONLY] if force or _obj_stale(s, True)]
-    if not units and all(os.path.exists(w) for w in want) and not is_stale(False) and (not diag or not is_stale(True)):
-        return want[-1]
+    kinds = ["product"] + (["extras"] if (extras or diag) else []) + (["diag"] if diag else [])
+    if not force and not _have_objects() and not any(is_stale(k) for k in kinds):
+        return _lib_of(kinds[-1])
+    wanted = []
+    for k in kinds:
+        for u in _units_of(k):
+            if u not in wanted:
+                wanted.append(u)
+    units = [u for u in wanted if force or _obj_stale(*u)]
     _compile(units, verbose)
-    if any(not d for _, d in units) or not os.path.exists(LIB_PATH) or is_stale(False):
-        _link([_obj_of(s) for s in SOURCES], LIB_PATH, verbose)
-    if diag:
-        objs = [_obj_of(s, s in DIAG_UNITS) for s in SOURCES] + [_obj_of(s, True) for s in DIAG_ONLY]
-        _link(objs, DIAG_LIB_PATH, verbose)
-    return want[-1]
+    for k in kinds:
+        if force or is_stale(k) or any(u in units for u in _units_of(k)):
+            _link([_obj_of(*u) for u in _units_of(k)], _lib_of(k), verbose)
+    return _lib_of(kinds[-1])
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv, extras="--extras" in sys.argv))

@@ -4,7 +4,11 @@
 // Nobody serves from an fp32 KV cache — the reference's callers use half (scheduler.py:13) — so this is one
 // straightforward kernel per (head size, block size), not a tuned menu: one workgroup of four waves per (sequence, head),
 // the blocks dealt round-robin to the waves, a (block, head) tile fetched as 1-KiB wave loads in the layout's own order.
+// Out of the hot-path scope: linked into libvmi_paged_attention_extras.so only (kernels AND their two C-ABI entries; the
+// product library's entries of the same names, pa_extras_absent.hip, return VMI_E_NOT_BUILT).
+#include "vmi_paged_attention.h"
 #include "pa_kernel.hpp"
+#include "pa_host.hpp"
 
 namespace vmi {
 
@@ -182,3 +186,89 @@ void reshape_and_cache_f32_launch(const float* key, const float* value, float* k
 }
 
 }  // namespace vmi
+
+extern "C" {
+
+// ---- float32 tensors: the (float, float) branch of the dispatch (pa_f32.hip) ----
+int vmi_paged_attention_v1_f32(void* out, const void* query, const void* key_cache, const void* value_cache,
+                               int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+                               float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                               int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+                               const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                               int64_t kv_head_stride, int32_t device, void* stream) {
+  using namespace vmi;
+  if (!out || !query || !key_cache || !value_cache || !block_tables || !seq_lens)
+    return fail(VMI_E_NULL_POINTER, "paged_attention_v1 (float32): NULL tensor pointer");
+  if (!head_size_supported(head_size)) return fail(VMI_E_HEAD_SIZE, "Unsupported head size: %d", head_size);
+  if (!block_size_supported(block_size)) return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: %d", block_size);
+  if (num_seqs < 0 || num_heads <= 0 || max_seq_len < 0 || max_num_blocks_per_seq < 0)
+    return fail(VMI_E_SHAPE, "paged_attention_v1 (float32): negative size");
+  if (num_heads > 65535) return fail(VMI_E_SHAPE, "paged_attention_v1 (float32): num_heads above the 65535 grid limit");
+  if (num_kv_heads <= 0 || num_heads % num_kv_heads != 0)
+    return fail(VMI_E_KV_HEADS, "paged_attention_v1: num_heads=%d not divisible by num_kv_heads=%d", num_heads, num_kv_heads);
+  if (!aligned16(query) || !aligned16(key_cache) || !aligned16(value_cache) || (q_stride & 3) || (kv_block_stride & 3) ||
+      (kv_head_stride & 3))
+    return fail(VMI_E_ALIGNMENT, "paged_attention_v1 (float32): pointers and strides must be 16-byte aligned");
+  if (num_seqs == 0) return VMI_OK;
+  const int lpad = ((max_seq_len + 31) / 32) * 32;
+  const size_t lds = ((size_t)lpad + 8 + 4 * (size_t)head_size) * sizeof(float);
+  if (lds > 160 * 1024)
+    return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v1 (float32): max_seq_len=%d needs %zu B of LDS, limit 163840", max_seq_len, lds);
+  pa_f32_kernel_t fn = pa_v1_f32_kernel_for(head_size, block_size);
+  if (!fn) return fail(VMI_E_HEAD_SIZE, "Unsupported head size: %d", head_size);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  if (lds > 48 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  }
+  PAF32Params p;
+  p.alibi = alibi_slopes;
+  p.num_heads = num_heads;
+  p.num_kv_heads = num_kv_heads;
+  p.scale = scale;
+  p.max_blocks_per_seq = max_num_blocks_per_seq;
+  p.q_stride = q_stride;
+  p.kv_block_stride = kv_block_stride;
+  p.kv_head_stride = kv_head_stride;
+  p.lpad = lpad;
+  p.kc = static_cast<const float*>(key_cache);
+  p.vc = static_cast<const float*>(value_cache);
+  for (int32_t s0 = 0; s0 < num_seqs; s0 += 65535) {
+    const int32_t ns = (num_seqs - s0) < 65535 ? (num_seqs - s0) : 65535;
+    p.out = static_cast<float*>(out) + (int64_t)s0 * num_heads * head_size;
+    p.q = static_cast<const float*>(query) + (int64_t)s0 * q_stride;
+    p.block_tables = block_tables + (int64_t)s0 * max_num_blocks_per_seq;
+    p.seq_lens = seq_lens + s0;
+    hipLaunchKernelGGL(fn, dim3(num_heads, ns), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 (float32) launch");
+  }
+  return VMI_OK;
+}
+
+int vmi_reshape_and_cache_f32(const void* key, const void* value, void* key_cache, void* value_cache,
+                              const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
+                              int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
+                              int64_t value_stride, int32_t device, void* stream) {
+  using namespace vmi;
+  if (!key || !value || !key_cache || !value_cache || !slot_mapping)
+    return fail(VMI_E_NULL_POINTER, "reshape_and_cache (float32): NULL tensor pointer");
+  if (x != 4) return fail(VMI_E_X, "reshape_and_cache (float32): key_cache.size(4) must be 4, got %d", x);
+  if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || (head_size & 3))
+    return fail(VMI_E_SHAPE, "reshape_and_cache (float32): bad sizes");
+  if (block_size <= 0) return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: %d", block_size);
+  if (num_tokens == 0) return VMI_OK;
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  reshape_and_cache_f32_launch(static_cast<const float*>(key), static_cast<const float*>(value),
+                               static_cast<float*>(key_cache), static_cast<float*>(value_cache), slot_mapping, key_stride,
+                               value_stride, num_tokens, num_heads, head_size, block_size, static_cast<hipStream_t>(stream));
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "reshape_and_cache (float32) launch");
+  return VMI_OK;
+}
+
+}  // extern "C"

@@ -1411,6 +1411,9 @@ typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const 
   {NAME, D, BS, 1, WPH, U, true, 1, BF,                                                                            \
    (pa_kernel_t)pa_v1_kernel<D, 1, WPH, U, true, false, PART, BS, false, BF, 1, false, 0, false, false, false, true>, \
    0, 0, 0, false, false, false, true},
+// false in the product library (pa_extras_absent.hip: the out-of-scope menus below are EMPTY there), true in
+// libvmi_paged_attention_extras.so (pa_extras_cache.hip)
+extern const bool g_has_extras;
 extern Variant g_sparse_variants[];
 extern const int g_sparse_nvariants;
 extern Variant g_sparse_bf16_variants[];

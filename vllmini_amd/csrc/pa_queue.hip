@@ -24,15 +24,21 @@ namespace vmi {
 Variant g_queue_variants[] = {
     // head size 64: one block per group when every item has its own wave, two when workers run items in turn
     VMI_ROW_Q("q_d64_s1q2", 64, false, 1, 2, 2)
+#ifdef VMI_EXTRAS   // (bfloat16 / E5M2 rows: libvmi_paged_attention_extras.so only — this unit is compiled once for each library)
     VMI_ROW_Q("bf16_q_d64_s1q2", 64, true, 1, 2, 2)
+#endif
     // head size 128: twice the registers per block -> one block per group in both modes, 2 workgroups per CU
     VMI_ROW_Q("q_d128_s1q1", 128, false, 1, 1, 1)
+#ifdef VMI_EXTRAS
     VMI_ROW_Q("bf16_q_d128_s1q1", 128, true, 1, 1, 1)
+#endif
     // fp8 pages, kv_scale == 1 (any other scale stays with pa_v1_kernel): a tile is half the bytes, so twice the blocks
     // per register group keep the bytes in flight where the 16-bit kernels have them
     VMI_ROW_Q8("fp8_q_d64_s2q4", 64, 2, 4, 1, 4)
     VMI_ROW_Q8("fp8_q_d64_s1q2", 64, 1, 2, 1, 2)
+#ifdef VMI_EXTRAS
     VMI_ROW_Q8("fp8e5m2_q_d64_s2q4", 64, 2, 4, 2, 4)
+#endif
     VMI_ROW_Q8("fp8_q_d128_s1q2", 128, 1, 2, 1, 1)
     // the same with q.K^T of the K pass on the matrix cores ("m", pa_queue.hpp KM): the default over fp8 pages — equal
     // lengths unchanged (the 1-KiB tile request pattern is the bound there), ragged batches 47.8 -> 45.1 us on cfg3

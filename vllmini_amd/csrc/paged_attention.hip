@@ -47,12 +47,14 @@
 #include "vmi_paged_attention_diag.h"
 #endif
 #include "pa_kernel.hpp"
+#include "pa_host.hpp"
+#include "pa_cache_fp8.hpp"
 
 namespace vmi {
 
-static thread_local char g_err[512] = "";
+thread_local char g_err[512] = "";
 
-static int fail(int code, const char* fmt, ...) {
+int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -60,27 +62,14 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-// Make `device` current for the duration of a call and restore the caller's device afterwards
-// (the reference wraps its launches in at::cuda::OptionalCUDAGuard, attention_kernels.cu:736).
-struct DeviceGuard {
-  int prev = -1;
-  bool changed = false;
-  hipError_t err;
-  explicit DeviceGuard(int device) {
-    err = hipGetDevice(&prev);
-    if (err == hipSuccess && prev != device) {
-      err = hipSetDevice(device);
-      changed = (err == hipSuccess);
-    }
-  }
-  ~DeviceGuard() {
-    if (changed) (void)hipSetDevice(prev);
-  }
-};
-
-static int hip_fail(hipError_t e, const char* what) {
+int hip_fail(hipError_t e, const char* what) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
   return -(int)e;
+}
+
+int not_built(const char* what) {
+  return fail(VMI_E_NOT_BUILT, "%s: not in this build of the library (the product library holds the float16 / fp8-E4M3 "
+              "path; `python -m vllmini_amd.build --extras` builds libvmi_paged_attention_extras.so)", what);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -146,128 +135,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-
-// ----------------------------------------------------------------------------------------
-// reshape_and_cache with kv_cache_dtype "fp8": cache element = fp8_e4m3(float(x) / kv_scale), round to nearest
-// even, saturating at +-448, NaN kept (reference cache_kernels.cu:200-205 -> quant_utils.cuh:458-464,
-// __nv_cvt_float_to_fp8(..., __NV_SATFINITE, __NV_E4M3)).  Layout x = 16: K[blk, h, d/16, off, d%16], V[blk, h, d, off].
-// The conversion is integer arithmetic on the fp32 bit pattern (no dependence on a hardware rounding mode).
-// ----------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t f32_to_fp8e4m3_satfinite(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  const uint32_t sign = (u >> 24) & 0x80u;
-  u &= 0x7fffffffu;
-  if (u > 0x7f800000u) return sign | 0x7fu;   // NaN
-  if (u >= 0x43e80000u) return sign | 0x7eu;  // |x| >= 464 (the midpoint past 448) and infinity: saturate
-  if (u < 0x3c800000u) {                      // |x| < 2^-6: subnormal range, step 2^-9; 8 * 2^-9 encodes as the smallest normal
-    return sign | (uint32_t)__builtin_rintf(__builtin_bit_cast(float, u) * 512.f);
-  }
-  u += 0x7ffffu + ((u >> 20) & 1u);           // RNE to 3 mantissa bits; a carry moves into the exponent
-  return sign | ((u >> 20) - ((127u - 7u) << 3));
-}
-
-// fp8 E5M2 (kv_cache_dtype "fp8_e5m2"): the upper byte of an IEEE half.  RNE on 2 mantissa bits, saturating at +-57344
-// (__NV_SATFINITE: infinities saturate too), NaN kept as a NaN code.  Integer arithmetic on the fp32 bit pattern.
-__device__ __forceinline__ uint32_t f32_to_fp8e5m2_satfinite(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  const uint32_t sign = (u >> 24) & 0x80u;
-  u &= 0x7fffffffu;
-  if (u > 0x7f800000u) return sign | 0x7fu;   // NaN
-  if (u >= 0x47700000u) return sign | 0x7bu;  // |x| >= 61440 (the midpoint past 57344) and infinity: saturate
-  if (u < 0x38800000u) {                      // |x| < 2^-14: subnormal range, step 2^-16; 4 * 2^-16 encodes as the smallest normal
-    return sign | (uint32_t)__builtin_rintf(__builtin_bit_cast(float, u) * 65536.f);
-  }
-  u += 0xfffffu + ((u >> 21) & 1u);           // RNE to 2 mantissa bits; a carry moves into the exponent
-  return sign | ((u >> 21) - ((127u - 15u) << 2));
-}
-
-template <bool VEC, bool BF = false, bool E5 = false>
-__global__ void __launch_bounds__(256)
-    reshape_and_cache_fp8_kernel(const h16* __restrict__ key, const h16* __restrict__ value,
-                                 uint8_t* __restrict__ kc, uint8_t* __restrict__ vc,
-                                 const int64_t* __restrict__ slot_mapping, int64_t key_stride,
-                                 int64_t value_stride, int H, int D, int BS, float kv_scale) {
-  const int64_t token = blockIdx.x;
-  const int64_t slot = slot_mapping[token];
-  if (slot < 0) return;  // padding token (ref cache_kernels.cu:165-169)
-  const int64_t blk = slot / BS, off = slot % BS;
-  const h16* ksrc = key + token * key_stride;
-  const h16* vsrc = value + token * value_stride;
-  const int n16 = (H * D) >> 4;
-  const int cph = D >> 4;  // 16-dim chunks (lanes) per head
-  for (int c = threadIdx.x; c < n16; c += blockDim.x) {
-    const int i = c << 4, h = i / D, d = i - h * D;
-    const int cc = d >> 4;  // this lane's chunk within its head
-    // K: the lane's 16 consecutive dims are one 16-byte unit of the tile.
-    // V: the lanes of a head take the rows e*cph + cc (not 16*cc + e), so that store instruction e writes cph CONSECUTIVE
-    // rows of the tile — one 64- or 128-byte piece of a line per token instead of cph pieces of cph lines; and both are
-    // stored NON-TEMPORALLY: dirty partial lines left in L2 are paid for by the attention launch behind this one
-    // (profiles/r02b_call_pair_aftermath.md).
-    h16 kv[16], vv[16];
-    if constexpr (VEC) {
-#pragma unroll
-      for (int w = 0; w < 2; ++w) {
-        const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(ksrc + i + 8 * w));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) kv[8 * w + e] = a[e];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) kv[e] = ksrc[i + e];
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) vv[e] = vsrc[h * D + e * cph + cc];
-    u32x4 kq = {0u, 0u, 0u, 0u};
-    uint8_t* vdst = vc + ((blk * H + h) * (int64_t)D + cc) * BS + off;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      // bfloat16 rows (quant_utils.cuh:468-478) widen by a 16-bit shift; float16 rows by v_cvt_f32_f16
-      const float kf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, kv[e]) << 16) : (float)kv[e];
-      const float vf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, vv[e]) << 16) : (float)vv[e];
-      kq[e >> 2] |= (E5 ? f32_to_fp8e5m2_satfinite(kf / kv_scale) : f32_to_fp8e4m3_satfinite(kf / kv_scale)) << (8 * (e & 3));
-      __builtin_nontemporal_store((uint8_t)(E5 ? f32_to_fp8e5m2_satfinite(vf / kv_scale) : f32_to_fp8e4m3_satfinite(vf / kv_scale)),
-                                  vdst + (int64_t)(e * cph) * BS);
-    }
-    __builtin_nontemporal_store(kq, reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (D >> 4) + (d >> 4)) * BS + off) * 16));
-  }
-}
-
-// ----------------------------------------------------------------------------------------
-// convert_fp8 (cache_kernels.cu:320-392, "only for testing" there): elementwise conversion of a whole cache between
-// fp8 E4M3 bytes and float / half / bfloat16 — dst = scaled_convert(src, kv_scale) (quant_utils.cuh):
-//   to fp8:   fp8(float(x) / kv_scale), RNE, saturating      from fp8:  half(float(fp8) * kv_scale), bf16(...), float(...)
-// KIND: 0 half, 1 bfloat16, 2 float.  Pure streaming: 16 elements per thread.
-// ----------------------------------------------------------------------------------------
-template <int KIND, bool TO_FP8>
-__global__ void __launch_bounds__(256)
-    convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, int64_t n, float kv_scale) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 16;
-  for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i0 < n; i0 += stride) {
-    const int cnt = (n - i0) < 16 ? (int)(n - i0) : 16;
-    for (int e = 0; e < cnt; ++e) {
-      const int64_t i = i0 + e;
-      if constexpr (TO_FP8) {
-        float x;
-        if constexpr (KIND == 0) x = (float)static_cast<const h16*>(src)[i];
-        else if constexpr (KIND == 1) x = __builtin_bit_cast(float, (uint32_t)static_cast<const uint16_t*>(src)[i] << 16);
-        else x = static_cast<const float*>(src)[i];
-        static_cast<uint8_t*>(dst)[i] = (uint8_t)f32_to_fp8e4m3_satfinite(x / kv_scale);
-      } else {
-        const uint32_t b = static_cast<const uint8_t*>(src)[i];
-        const float f = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false)[0];  // exact
-        // the two zero codes are written as signed zeros directly: hipcc fuses half(f * s) into v_fma_mixlo_f16(s, f, +0),
-        // and (-0 * s) + (+0) is +0 — invisible inside the attention sums, visible in a bit-exact conversion
-        const bool zero = (b & 0x7fu) == 0;
-        if constexpr (KIND == 0)
-          static_cast<uint16_t*>(dst)[i] = zero ? (uint16_t)(b << 8) : __builtin_bit_cast(uint16_t, (h16)(f * kv_scale));
-        else if constexpr (KIND == 1)
-          static_cast<uint16_t*>(dst)[i] = zero ? (uint16_t)(b << 8) : to_elem<true>(f * kv_scale);
-        else
-          static_cast<float*>(dst)[i] = zero ? __builtin_bit_cast(float, b << 24) : f * kv_scale;
-      }
-    }
-  }
-}
 
 // ----------------------------------------------------------------------------------------
 // reshape_and_cache, run form (calls of >= 2*block_size tokens).  A prompt's tokens arrive with consecutive slots, so
@@ -371,37 +238,6 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int e = 0; e < 8; ++e) __builtin_nontemporal_store(vv[e], vdst + (int64_t)e * BS);
       }
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------------------
-// reshape_and_cache_flash: scatter new-token rows into the flash layout
-// [num_blocks, block_size, num_heads, head_size] — reference cache_kernels.cu:209-240 (kernel),
-// :283-317 (host).  A token's H*D row stays contiguous, so this is one 16-B copy per lane per chunk.
-// Works for any 2-byte element type (pure copy).
-// ----------------------------------------------------------------------------------------
-template <bool VEC>
-__global__ void __launch_bounds__(256)
-    reshape_and_cache_flash_kernel(const h16* __restrict__ key, const h16* __restrict__ value,
-                                   h16* __restrict__ kc, h16* __restrict__ vc,
-                                   const int64_t* __restrict__ slot_mapping, int64_t block_stride,
-                                   int64_t key_stride, int64_t value_stride, int n, int BS) {
-  const int64_t token = blockIdx.x;
-  const int64_t slot = slot_mapping[token];
-  if (slot < 0) return;  // :218-221
-  const int64_t dst = (slot / BS) * block_stride + (slot % BS) * (int64_t)n;  // :226-228
-  const h16* ks = key + token * key_stride;
-  const h16* vs = value + token * value_stride;
-  if constexpr (VEC) {
-    for (int c = threadIdx.x; c < (n >> 3); c += blockDim.x) {
-      *reinterpret_cast<u32x4*>(kc + dst + (c << 3)) = *reinterpret_cast<const u32x4*>(ks + (c << 3));
-      *reinterpret_cast<u32x4*>(vc + dst + (c << 3)) = *reinterpret_cast<const u32x4*>(vs + (c << 3));
-    }
-  } else {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      kc[dst + i] = ks[i];
-      vc[dst + i] = vs[i];
     }
   }
 }
@@ -550,10 +386,10 @@ static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = a
   return 0;
 }
 
-static bool head_size_supported(int d) {  // the reference's switch, attention_kernels.cu:738-766
+bool head_size_supported(int d) {  // the reference's switch, attention_kernels.cu:738-766
   return d == 64 || d == 80 || d == 96 || d == 112 || d == 128 || d == 192 || d == 256;
 }
-static bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }  // :789-803
+bool block_size_supported(int b) { return b == 8 || b == 16 || b == 32; }  // :789-803
 
 // Heuristic (measured on MI355X, profiles/r01c_*):
 //  * waves: one wave per (seq, head) once that gives >= 3072 waves (12 per CU); otherwise deal each
@@ -847,8 +683,6 @@ static size_t variant_lds_bytes(const Variant& c, int lpad) {
           (c.SPARSE ? (size_t)lpad / 2 : 0));  // SPARSE: the list of attended blocks, one int per block (BS >= 8)
 }
 
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
 // fused-append twin of a v1 variant id (same row of the same menu, pa_append_*.hip)
 static Variant* app_variant_v1(int id) {
   if (g_app_core_nvariants != g_ncore || g_app_extra_nvariants != g_extra_nvariants_v1 ||
@@ -885,6 +719,16 @@ static void fill_sparse(PAParams& p, const int32_t* bsp) {
   p.bs_head_sliding_step = bsp ? bsp[4] : 0;
 }
 
+// The out-of-scope corners of the reference's dispatch live in libvmi_paged_attention_extras.so;
+// in the product library their kernel menus are empty (pa_extras_absent.hip) and the launchers say so by name.
+static int extras_gate(const char* op, bool bf, int f8, const int32_t* bsp) {
+  if (g_has_extras) return VMI_OK;
+  char what[96];
+  snprintf(what, sizeof(what), "%s %s", op,
+           bsp ? "with block-sparse attention" : bf ? "over bfloat16 tensors" : "over fp8-E5M2 pages");
+  return (bsp || bf || f8 == 2) ? not_built(what) : VMI_OK;
+}
+
 static int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         const void* value_cache, int32_t num_seqs, int32_t num_heads,
                         int32_t head_size, int32_t num_kv_heads, float scale,
@@ -899,6 +743,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   //  a no-op below, not an error; the caches must exist either way)
   if (!key_cache || !value_cache || (num_seqs != 0 && (!out || !query || !block_tables || !seq_lens)))
     return fail(VMI_E_NULL_POINTER, "paged_attention_v1: NULL tensor pointer");
+  if (int rc = extras_gate(append ? "paged_attention_v1_append" : "paged_attention_v1", bf, f8, bsp)) return rc;
   if (bsp) {
     if (int rc = check_sparse("paged_attention_v1", bsp)) return rc;
     if (append || f8) return fail(VMI_E_VARIANT, "paged_attention_v1: block-sparse attention is built for fp16 / bf16 caches, without the fused append");
@@ -1223,6 +1068,7 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
                         int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
                         int32_t device, void* stream, int32_t variant, bool bf = false, int f8 = false,
                         float kv_scale = 1.0f, const int32_t* bsp = nullptr) {
+  if (int rc = extras_gate("paged_attention_v2", bf, f8, bsp)) return rc;
   if (bsp) {
     if (int rc = check_sparse("paged_attention_v2", bsp)) return rc;
     if (f8) return fail(VMI_E_VARIANT, "paged_attention_v2: block-sparse attention is built for fp16 / bf16 caches");
@@ -1607,6 +1453,8 @@ int vmi_debug_set_queue_flags(int flags) {
 }
 #endif
 
+int vmi_has_extras(void) { return vmi::g_has_extras ? 1 : 0; }
+
 int vmi_is_diag_build(void) {
 #ifdef VMI_DIAG
   return 1;
@@ -1738,12 +1586,10 @@ static int reshape_and_cache_fp8_impl(const void* key, const void* value, void* 
   int threads = ((n16 + 63) / 64) * 64;
   if (threads > 256) threads = 256;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  typedef void (*fp8_fn)(const h16*, const h16*, uint8_t*, uint8_t*, const int64_t*, int64_t, int64_t, int, int, int, float);
-  const fp8_fn fns[8] = {(fp8_fn)reshape_and_cache_fp8_kernel<false, false, false>, (fp8_fn)reshape_and_cache_fp8_kernel<true, false, false>,
-                         (fp8_fn)reshape_and_cache_fp8_kernel<false, true, false>,  (fp8_fn)reshape_and_cache_fp8_kernel<true, true, false>,
-                         (fp8_fn)reshape_and_cache_fp8_kernel<false, false, true>,  (fp8_fn)reshape_and_cache_fp8_kernel<true, false, true>,
-                         (fp8_fn)reshape_and_cache_fp8_kernel<false, true, true>,   (fp8_fn)reshape_and_cache_fp8_kernel<true, true, true>};
-  const fp8_fn fn = fns[(e5 ? 4 : 0) + (bf ? 2 : 0) + (vec ? 1 : 0)];
+  const fp8_scatter_fn fn = (bf || e5) ? fp8_scatter_extra_kernel(vec, bf, e5)   // out-of-scope instantiations
+                            : vec      ? (fp8_scatter_fn)reshape_and_cache_fp8_kernel<true, false, false>
+                                       : (fp8_scatter_fn)reshape_and_cache_fp8_kernel<false, false, false>;
+  if (!fn) return not_built(e5 ? "reshape_and_cache over fp8-E5M2 pages" : "reshape_and_cache (fp8) over bfloat16 rows");
   hipLaunchKernelGGL(fn, dim3(num_tokens), dim3(threads), 0, st, static_cast<const h16*>(key),
                      static_cast<const h16*>(value), static_cast<uint8_t*>(key_cache),
                      static_cast<uint8_t*>(value_cache), slot_mapping, key_stride, value_stride, num_heads, head_size,
@@ -1775,145 +1621,6 @@ int vmi_reshape_and_cache_fp8_e5m2(const void* key, const void* value, void* key
                                    int64_t value_stride, float kv_scale, int32_t device, void* stream, int32_t is_bf16) {
   return reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
                                     block_size, x, key_stride, value_stride, kv_scale, device, stream, is_bf16 != 0, true);
-}
-
-// ---- float32 tensors: the (float, float) branch of the dispatch (pa_f32.hip) ----
-int vmi_paged_attention_v1_f32(void* out, const void* query, const void* key_cache, const void* value_cache,
-                               int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-                               float scale, const int32_t* block_tables, const int32_t* seq_lens,
-                               int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-                               const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
-                               int64_t kv_head_stride, int32_t device, void* stream) {
-  using namespace vmi;
-  if (!out || !query || !key_cache || !value_cache || !block_tables || !seq_lens)
-    return fail(VMI_E_NULL_POINTER, "paged_attention_v1 (float32): NULL tensor pointer");
-  if (!head_size_supported(head_size)) return fail(VMI_E_HEAD_SIZE, "Unsupported head size: %d", head_size);
-  if (!block_size_supported(block_size)) return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: %d", block_size);
-  if (num_seqs < 0 || num_heads <= 0 || max_seq_len < 0 || max_num_blocks_per_seq < 0)
-    return fail(VMI_E_SHAPE, "paged_attention_v1 (float32): negative size");
-  if (num_heads > 65535) return fail(VMI_E_SHAPE, "paged_attention_v1 (float32): num_heads above the 65535 grid limit");
-  if (num_kv_heads <= 0 || num_heads % num_kv_heads != 0)
-    return fail(VMI_E_KV_HEADS, "paged_attention_v1: num_heads=%d not divisible by num_kv_heads=%d", num_heads, num_kv_heads);
-  if (!aligned16(query) || !aligned16(key_cache) || !aligned16(value_cache) || (q_stride & 3) || (kv_block_stride & 3) ||
-      (kv_head_stride & 3))
-    return fail(VMI_E_ALIGNMENT, "paged_attention_v1 (float32): pointers and strides must be 16-byte aligned");
-  if (num_seqs == 0) return VMI_OK;
-  const int lpad = ((max_seq_len + 31) / 32) * 32;
-  const size_t lds = ((size_t)lpad + 8 + 4 * (size_t)head_size) * sizeof(float);
-  if (lds > 160 * 1024)
-    return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v1 (float32): max_seq_len=%d needs %zu B of LDS, limit 163840", max_seq_len, lds);
-  pa_f32_kernel_t fn = pa_v1_f32_kernel_for(head_size, block_size);
-  if (!fn) return fail(VMI_E_HEAD_SIZE, "Unsupported head size: %d", head_size);
-  DeviceGuard guard(device);
-  hipError_t e = guard.err;
-  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  if (lds > 48 * 1024) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-  }
-  PAF32Params p;
-  p.alibi = alibi_slopes;
-  p.num_heads = num_heads;
-  p.num_kv_heads = num_kv_heads;
-  p.scale = scale;
-  p.max_blocks_per_seq = max_num_blocks_per_seq;
-  p.q_stride = q_stride;
-  p.kv_block_stride = kv_block_stride;
-  p.kv_head_stride = kv_head_stride;
-  p.lpad = lpad;
-  p.kc = static_cast<const float*>(key_cache);
-  p.vc = static_cast<const float*>(value_cache);
-  for (int32_t s0 = 0; s0 < num_seqs; s0 += 65535) {
-    const int32_t ns = (num_seqs - s0) < 65535 ? (num_seqs - s0) : 65535;
-    p.out = static_cast<float*>(out) + (int64_t)s0 * num_heads * head_size;
-    p.q = static_cast<const float*>(query) + (int64_t)s0 * q_stride;
-    p.block_tables = block_tables + (int64_t)s0 * max_num_blocks_per_seq;
-    p.seq_lens = seq_lens + s0;
-    hipLaunchKernelGGL(fn, dim3(num_heads, ns), dim3(256), lds, static_cast<hipStream_t>(stream), p);
-    e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 (float32) launch");
-  }
-  return VMI_OK;
-}
-
-int vmi_reshape_and_cache_f32(const void* key, const void* value, void* key_cache, void* value_cache,
-                              const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
-                              int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
-                              int64_t value_stride, int32_t device, void* stream) {
-  using namespace vmi;
-  if (!key || !value || !key_cache || !value_cache || !slot_mapping)
-    return fail(VMI_E_NULL_POINTER, "reshape_and_cache (float32): NULL tensor pointer");
-  if (x != 4) return fail(VMI_E_X, "reshape_and_cache (float32): key_cache.size(4) must be 4, got %d", x);
-  if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || (head_size & 3))
-    return fail(VMI_E_SHAPE, "reshape_and_cache (float32): bad sizes");
-  if (block_size <= 0) return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: %d", block_size);
-  if (num_tokens == 0) return VMI_OK;
-  DeviceGuard guard(device);
-  hipError_t e = guard.err;
-  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  reshape_and_cache_f32_launch(static_cast<const float*>(key), static_cast<const float*>(value),
-                               static_cast<float*>(key_cache), static_cast<float*>(value_cache), slot_mapping, key_stride,
-                               value_stride, num_tokens, num_heads, head_size, block_size, static_cast<hipStream_t>(stream));
-  e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "reshape_and_cache (float32) launch");
-  return VMI_OK;
-}
-
-int vmi_convert_fp8(void* dst, const void* src, int64_t num_elements, float kv_scale, int32_t kind, int32_t to_fp8,
-                    int32_t device, void* stream) {
-  using namespace vmi;
-  if (num_elements < 0 || kind < 0 || kind > 2) return fail(VMI_E_SHAPE, "convert_fp8: bad arguments (n=%lld kind=%d)", (long long)num_elements, kind);
-  if (!(kv_scale > 0.f)) return fail(VMI_E_SHAPE, "convert_fp8: kv_scale must be positive, got %g", (double)kv_scale);
-  if (num_elements == 0) return VMI_OK;
-  if (!dst || !src) return fail(VMI_E_NULL_POINTER, "convert_fp8: NULL tensor pointer");
-  DeviceGuard guard(device);
-  hipError_t e = guard.err;
-  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  typedef void (*cv_fn)(void*, const void*, int64_t, float);
-  const cv_fn fns[6] = {(cv_fn)convert_fp8_kernel<0, false>, (cv_fn)convert_fp8_kernel<0, true>,
-                        (cv_fn)convert_fp8_kernel<1, false>, (cv_fn)convert_fp8_kernel<1, true>,
-                        (cv_fn)convert_fp8_kernel<2, false>, (cv_fn)convert_fp8_kernel<2, true>};
-  int64_t blocks = (num_elements + 256 * 16 - 1) / (256 * 16);
-  if (blocks > 256 * 64) blocks = 256 * 64;
-  hipLaunchKernelGGL(fns[2 * kind + (to_fp8 ? 1 : 0)], dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     dst, src, num_elements, kv_scale);
-  e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "convert_fp8 launch");
-  return VMI_OK;
-}
-
-int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_cache, void* v_cache,
-                                   const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
-                                   int32_t head_size, int32_t block_size, int64_t block_stride,
-                                   int64_t key_stride, int64_t value_stride, int32_t device, void* stream) {
-  using namespace vmi;
-  if (!key || !value || !k_cache || !v_cache || !slot_mapping)
-    return fail(VMI_E_NULL_POINTER, "reshape_and_cache_flash: NULL tensor pointer");
-  if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || block_size <= 0)
-    return fail(VMI_E_SHAPE, "reshape_and_cache_flash: bad sizes");
-  if (num_tokens == 0) return VMI_OK;
-  DeviceGuard guard(device);
-  hipError_t e = guard.err;
-  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  const int n = num_heads * head_size;
-  const bool vec = aligned16(key) && aligned16(value) && aligned16(k_cache) && aligned16(v_cache) &&
-                   !(key_stride & 7) && !(value_stride & 7) && !(block_stride & 7) && !(n & 7);
-  int threads = (((vec ? n >> 3 : n) + 63) / 64) * 64;
-  threads = threads > 256 ? 256 : threads;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (vec)
-    hipLaunchKernelGGL(reshape_and_cache_flash_kernel<true>, dim3(num_tokens), dim3(threads), 0, st,
-                       static_cast<const h16*>(key), static_cast<const h16*>(value), static_cast<h16*>(k_cache),
-                       static_cast<h16*>(v_cache), slot_mapping, block_stride, key_stride, value_stride, n,
-                       block_size);
-  else
-    hipLaunchKernelGGL(reshape_and_cache_flash_kernel<false>, dim3(num_tokens), dim3(threads), 0, st,
-                       static_cast<const h16*>(key), static_cast<const h16*>(value), static_cast<h16*>(k_cache),
-                       static_cast<h16*>(v_cache), slot_mapping, block_stride, key_stride, value_stride, n,
-                       block_size);
-  e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "reshape_and_cache_flash launch");
-  return VMI_OK;
 }
 
 int vmi_paged_attention_v2_f16(void* out, void* exp_sums, void* max_logits, void* tmp_out,
