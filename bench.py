@@ -312,8 +312,20 @@ def exchange_tokens(dist, i=None):
     on every EXCHANGE_EVERY-th step, starting with the first (i = None: unconditionally)."""
     if dist is None or (i is not None and i % EXCHANGE_EVERY):
         return
-    _EXCHANGE["gathered"] = shard.gather_token_ids(_EXCHANGE["ids"], _EXCHANGE["global_batch"], dist,
-                                                   out=_EXCHANGE["out"])
+    if i is None:      # measured alone (exchange_pass): the blocking form, the compute stream waits for the collective
+        _EXCHANGE["gathered"] = shard.gather_token_ids(_EXCHANGE["ids"], _EXCHANGE["global_batch"], dist,
+                                                       out=_EXCHANGE["out"][0])
+        return
+    # In the decode loop every rank samples its own sequences' ids, so the next token's layers do not depend on the
+    # gathered vector: the all_gather is issued asynchronously (the process group's stream, behind the kernels already
+    # enqueued) and runs BESIDE the next token's call pairs; the previous token's gather is waited for (stream-side) before
+    # its buffer's turn comes again — two buffers alternate.
+    k = (i // EXCHANGE_EVERY) & 1
+    prev = _EXCHANGE["work"][k]
+    if prev is not None:
+        prev.wait()
+    _EXCHANGE["gathered"], _EXCHANGE["work"][k] = shard.gather_token_ids_async(
+        _EXCHANGE["ids"], _EXCHANGE["global_batch"], dist, _EXCHANGE["out"][k])
 
 
 def setup_exchange(batch, dist, dev):
@@ -322,7 +334,8 @@ def setup_exchange(batch, dist, dev):
     world, rank = dist.get_world_size(), dist.get_rank()
     _EXCHANGE["global_batch"] = batch * world
     _EXCHANGE["ids"] = torch.arange(rank * batch, (rank + 1) * batch, dtype=torch.int64, device=dev)
-    _EXCHANGE["out"] = torch.empty(batch * world, dtype=torch.int64, device=dev)
+    _EXCHANGE["out"] = [torch.empty(batch * world, dtype=torch.int64, device=dev) for _ in range(2)]
+    _EXCHANGE["work"] = [None, None]
 
 
 def device_sync(dev):
@@ -339,8 +352,12 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
         one_step(wl, out, i, variant, op)
         exchange_tokens(dist, i)
 
-    elapsed = shard.timed_steps(step, steps, warmup, dist, sync=device_sync(dev))
-    if dist is not None:
+    elapsed = shard.timed_steps(step, steps, warmup, dist, sync=device_sync(dev))   # (its closing device synchronise
+    if dist is not None:                                                             #  covers the process group's stream)
+        for w in _EXCHANGE["work"]:
+            if w is not None:
+                w.wait()
+        _EXCHANGE["work"] = [None, None]
         g = _EXCHANGE["gathered"]
         assert g.numel() == _EXCHANGE["global_batch"] and int(g[0]) == 0 and int(g[-1]) == g.numel() - 1
     return elapsed
@@ -615,7 +632,12 @@ def standin_main(args, dist, rank, world, dev):
         x.mul_(1.0)
         exchange_tokens(dist, i)
 
-    elapsed = shard.max_over_ranks(shard.timed_steps(step, args.steps, args.warmup, dist), dist, dev)
+    elapsed = shard.timed_steps(step, args.steps, args.warmup, dist)
+    if dist is not None:
+        for w in _EXCHANGE["work"]:       # (on CPU there is no device synchronise: the asynchronous gathers end here)
+            if w is not None:
+                w.wait()
+    elapsed = shard.max_over_ranks(elapsed, dist, dev)
     if dist is not None:
         g = _EXCHANGE["gathered"]
         assert g.numel() == batch * world and int(g[-1]) == g.numel() - 1
@@ -814,8 +836,10 @@ def main(argv=None):
         line["token_exchange_us"] = shard.max_over_ranks(exchange_pass(args.kernel_samples, dist, dev), dist, dev)
         line["token_exchange"] = (f"all_gather of {cfg.batch} int64 ids per rank ({cfg.batch * world * 8} B in all), backend nccl "
                                   f"(RCCL); inside the timed region once per token = on every {EXCHANGE_EVERY}th layer step "
-                                  f"(steps 0, {EXCHANGE_EVERY}, ...); token_exchange_us = median of {args.kernel_samples} "
-                                  "exchanges alone, by HIP events")
+                                  f"(steps 0, {EXCHANGE_EVERY}, ...), issued ASYNCHRONOUSLY on the process group's stream — a rank "
+                                  "samples its own sequences' ids, the next token's layers do not wait for the gathered vector — "
+                                  "and waited for one token later and before the closing synchronise; token_exchange_us = median "
+                                  f"of {args.kernel_samples} BLOCKING exchanges alone, by HIP events")
         line["token_exchange_every_steps"] = EXCHANGE_EVERY
     if args.op == "v1" and not args.no_fused:
         # the same step as ONE launch (vmi_paged_attention_v1_append_f16: bit-identical caches and out,

@@ -71,6 +71,19 @@ def _worker(rank, world, port, tmpdir):
             with pytest.raises(ValueError):
                 shard.gather_token_ids(ids8, B8, dist, out=bad)
 
+        # the asynchronous form bench.py's timed region uses: issued, then waited for before `out` is read; two buffers
+        # in flight at once; argument checks
+        bufs = [torch.full((B8,), -1, dtype=torch.int64) for _ in range(2)]
+        o0, w0 = shard.gather_token_ids_async(ids8, B8, dist, bufs[0])
+        o1, w1 = shard.gather_token_ids_async(ids8 + 1000, B8, dist, bufs[1])
+        w0.wait()
+        w1.wait()
+        assert o0 is bufs[0] and torch.equal(bufs[0], want8) and torch.equal(bufs[1], want8 + 1000)
+        for bad_ids, bad_out in ((ids8, torch.empty(B8 + 1, dtype=torch.int64)), (ids8.to(torch.int32), bufs[0]),
+                                 (strided, bufs[0])):
+            with pytest.raises(ValueError):
+                shard.gather_token_ids_async(bad_ids, B8, dist, bad_out)
+
         # private pools: the same seq ids on different ranks never collide (independent free lists)
         pool = PagedKVPool(64, H, D, 16, 4, 2, device="cpu", allocate_tensors=False)
         for sid in range(lo, hi):

@@ -4,8 +4,9 @@ The path partitions into independent units: a sequence touches only its own KV p
 operator's grid is (heads, sequences) with no cross-sequence reduction (attention_kernels.cu:734).
 So: one process per GPU, every rank owns a PRIVATE KV pool, free list and block tables, and a
 contiguous slice of the global batch.  There is NO collective on the data path.  The only exchange a
-decode loop needs is the per-step hand-back of sampled token ids (8 bytes per sequence) — an
-all_gather over `torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in CPU tests).
+decode loop needs is the per-token hand-back of sampled token ids (8 bytes per sequence) — an
+all_gather over `torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in CPU tests), issued
+asynchronously on the process group's stream so that it runs beside the next token's layers (gather_token_ids_async).
 The reference has no distributed layer at all (last row).
 
 Timing helpers implement bench.py's contract: W untimed warm-up steps, then exactly K steps between
@@ -51,7 +52,13 @@ def timed_steps(step: Callable[[int], None], steps: int, warmup: int, dist=None,
                 timed_step: Optional[Callable[[int], None]] = None) -> float:
     """Run `warmup` untimed then exactly `steps` timed calls of step(i); returns local elapsed seconds.
     `sync` = device synchronise (torch.cuda.synchronize on GPU ranks, None on CPU).  `timed_step`, if
-    given, replaces `step` inside the timed region (same work plus per-launch event records)."""
+    given, replaces `step` inside the timed region (same work plus per-launch event records).
+
+    The K steps are bracketed by (synchronise, barrier, synchronise) on both sides.  The clock starts after the opening
+    bracket and stops when THIS rank's device has finished its K steps — after the closing bracket's first synchronise, in
+    front of its barrier: the barrier's own latency (an RCCL all-reduce plus a host wake-up, ~90 us: 3.5 % of twenty 130-us
+    steps) is not work of the path, and the caller takes the MAX over ranks, which is what a clock stopped behind the barrier
+    would read without it."""
     for i in range(warmup):
         step(i)
     barrier_sync(dist, sync)
@@ -59,8 +66,11 @@ def timed_steps(step: Callable[[int], None], steps: int, warmup: int, dist=None,
     body = timed_step or step
     for i in range(steps):
         body(i)
+    if sync is not None:
+        sync()
+    elapsed = time.perf_counter() - t0
     barrier_sync(dist, sync)
-    return time.perf_counter() - t0
+    return elapsed
 
 
 def max_over_ranks(value: float, dist=None, device: torch.device | str = "cpu") -> float:
@@ -100,6 +110,21 @@ def gather_token_ids(local_ids: torch.Tensor, global_batch: int, dist=None,
         a, b = shard_range(global_batch, r, world)
         parts.append(gathered[r][: b - a])
     return torch.cat(parts)
+
+
+def gather_token_ids_async(local_ids: torch.Tensor, global_batch: int, dist, out: torch.Tensor):
+    """The same all_gather issued WITHOUT making the compute stream wait for it: -> (out, work).  Every rank samples the
+    ids of its own sequences, so a rank's next decode step does not depend on the gathered vector (the
+    gather is the hand-back to the front end) — the collective runs on the process group's own stream, behind the kernels
+    already enqueued on the compute stream and BESIDE the next token's layers; `work.wait()` (a stream-side wait, no host
+    block on RCCL) belongs in front of whatever reads `out` or reuses it, at the latest one token later.  Even batches only
+    (global_batch % world == 0), `out` preallocated: nothing is allocated on the way."""
+    world = dist.get_world_size()
+    if global_batch % world or out.shape != (global_batch,) or out.dtype != torch.int64 or not out.is_contiguous() or \
+            local_ids.dtype != torch.int64 or local_ids.numel() != global_batch // world or not local_ids.is_contiguous():
+        raise ValueError(f"gather_token_ids_async: contiguous int64 [{global_batch // max(world, 1)}] ids of an even batch "
+                         f"into a contiguous int64 [{global_batch}] tensor")
+    return out, dist.all_gather_into_tensor(out, local_ids, async_op=True)
 
 
 def shard_rows(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
