@@ -559,12 +559,25 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
     ids = list(range(cfg.batch))
     tok = torch.randint(0, dims.vocab_size, (cfg.batch,), device=dev, generator=g)
 
+    # N > 1: the sampled ids go back to every rank once per token — asynchronously, beside the next token's layers
+    # (shard.gather_token_ids_async; a rank's next step needs only its own ids), two buffers alternating
+    gathered = [torch.empty(cfg.batch * world, dtype=torch.int64, device=dev) for _ in range(2)] if dist is not None else None
+    works = [None, None]
+
     def step(i):
         nonlocal tok
         logits = dec.decode(ids, tok, use_graph=not eager)
         tok = logits.argmax(-1)                       # greedy: stays on the device, no host sync
+        if dist is not None:
+            k = i & 1
+            if works[k] is not None:
+                works[k].wait()
+            _, works[k] = shard.gather_token_ids_async(tok, cfg.batch * world, dist, gathered[k])
 
     elapsed = shard.timed_steps(step, args.steps, args.warmup, dist, sync=device_sync(dev))
+    for w in works:
+        if w is not None:
+            w.wait()
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     note = ("12 x (c_attn, paged_attention_v1_append [fused], c_proj, MLP) + lm_head, hipGraph replay, greedy" if fused else
             "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy")
