@@ -78,8 +78,9 @@ def test_paged_attention_v1_meets_the_north_star_roofline_target(cfg_name):
 
 # Regression floors for the two BASELINE-shaped runs that sit furthest below the roofline (the driver line's `fp8_kv_step`
 # and `ragged_step`): measured 0.73-0.76 (fp8 pages: the 1-KiB gather line of the layout) and 0.73-0.75
-# (seq_lens ~ U{1..1024}: balanced kernel) by this event-pair measure; the floors sit 7 % below.
-@pytest.mark.parametrize("kv,ragged,floor", [("fp8", False, 0.68), ("auto", True, 0.68)])
+# (seq_lens ~ U{1..1024}: balanced kernel) by this event-pair measure on most boxes, 0.74 / 0.71 on the
+# slowest box seen (boxes differ by 2 - 4 %); the floors sit 10 % below the usual figures.
+@pytest.mark.parametrize("kv,ragged,floor", [("fp8", False, 0.66), ("auto", True, 0.64)])
 def test_fp8_pages_and_ragged_lengths_keep_their_measured_fraction(kv, ragged, floor):
     if torch.cuda.get_device_properties(0).multi_processor_count < 200:
         pytest.skip("the floors are stated for a whole MI355X (256 CUs)")
