@@ -19,7 +19,7 @@ _build.LIB_PATH = os.path.abspath(args.lib)
 from vllmini_amd import _lib, ops  # noqa: E402
 from vllmini_amd.workload import CONFIGS, make_workload  # noqa: E402
 
-if args.flags:        # the mode knob exists in a diagnostic build only: the path must name such a library
+if args.flags or "diag" in os.path.basename(args.lib):   # the mode knob exists in a diagnostic build only: the path must name such a library
     _build.DIAG_LIB_PATH = _build.LIB_PATH
     _build.LIB_PATH = os.path.join(_build.OUT_DIR, _build.LIB_NAME)
     lib = _lib.use_diag().__enter__()
