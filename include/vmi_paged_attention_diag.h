@@ -41,6 +41,14 @@ int vmi_diag_stream_read(const void* src, int64_t bytes, void* sink, int32_t blo
 int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chunk_kb, int32_t inflight_kb,
                          int32_t blocks, int32_t nt, int32_t device, void* stream);
 
+/*
+ * Diagnostic: a timeline of the balanced ("q_*") kernels' waves.  `records` is device memory for 4 x uint64 per wave of
+ * the launch (grid x 4 waves, in workgroup order: {start, end} in ticks of the constant 100 MHz clock (s_memrealtime),
+ * HW_REG_HW_ID, HW_REG_XCC_ID), written by every later launch of such a kernel on `device` until it is set to NULL again.
+ * scripts/wave_timeline_probe.py reads it: when the waves of a launch finish, per XCD and CU.  Synchronous.
+ */
+int vmi_diag_set_wave_timeline(void* records, int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,10 @@ MODES = {
     "Q team": (_flags(2, 0, 0, 2), False),         # long items by 4 waves (other fp32 summation order), short ones in solo quads
     "Q team only": (_flags(2, 0, 0, 2, 1), False),  # every item by 4 waves (what an unranked batch gets)
     "Q team unranked": (_flags(2, 0, 1, 2), False),
+    # page-queue depth experiments of mode S (diagnostic library only, profiles/r03w_wave_timeline.md): same arithmetic
+    "S, two blocks per group on the odd XCDs": (_flags(1) | (1 << 9), True),
+    "S, three groups in flight on the odd XCDs": (_flags(1) | (1 << 5), True),
+    "S, three groups in flight": (_flags(1) | (1 << 5) | (1 << 6), True),
 }
 
 
@@ -543,3 +547,43 @@ def test_queue_kernel_over_fp8_pages_every_mode(qname, kvd, queue_flags):
     with pytest.raises(RuntimeError, match="kv_scale 1"):
         attend(names[qname], kv_scale=0.5)
     assert_close(attend(0), ref, "default entry, kv_scale 1", vmax=2.0)
+
+
+def test_wave_timeline_of_the_diagnostic_library():
+    """vmi_diag_set_wave_timeline (include/vmi_paged_attention_diag.h): every wave of a balanced-kernel launch leaves its
+    start and end time, HW_ID and XCC_ID; switching it off stops the writes.  scripts/wave_timeline_probe.py is built on it."""
+    from vllmini_amd import _lib, ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    dev = torch.device("cuda:0")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    cfg = CONFIGS["cfg3"]
+    wl = make_workload(cfg, dev, seed=2, table_sets=1)
+    out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
+
+    def launch():
+        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, cfg.kv_heads, wl.scale, wl.tables[0], wl.seq_lens,
+                               cfg.block_size, cfg.seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0)
+
+    with _lib.use_diag() as lib:
+        launch()
+        if not ops.last_launch_label().startswith("q_d64"):
+            pytest.skip("the default entry did not pick the balanced kernel on this device")
+        waves = 3 * cus * 4
+        rec = torch.zeros((waves + 64, 4), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        assert lib.vmi_diag_set_wave_timeline(rec.data_ptr(), 0) == 0
+        launch()
+        torch.cuda.synchronize()
+        assert lib.vmi_diag_set_wave_timeline(None, 0) == 0
+        r = rec.cpu().numpy()
+        assert (r[waves:] == 0).all()                                  # nothing past the launch's waves
+        r = r[:waves]
+        assert (r[:, 0] > 0).all() and (r[:, 1] > r[:, 0]).all()
+        span_us = (r[:, 1].max() - r[:, 0].min()) * 0.01                # 100 MHz ticks
+        assert 20.0 < span_us < 1000.0, span_us
+        assert set(np.unique(r[:, 3] & 0xF).tolist()) <= set(range(8)) and len(np.unique(r[:, 3] & 0xF)) >= 2
+        rec.zero_()
+        launch()
+        torch.cuda.synchronize()
+        assert (rec == 0).all()                                        # switched off

@@ -91,6 +91,7 @@ DIAG_SIGNATURES = {
     "vmi_debug_set_queue_flags": (ctypes.c_int, [_i32]),
     "vmi_diag_gather_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _i32, _i32, _c_void_p]),
     "vmi_diag_stream_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _c_void_p]),
+    "vmi_diag_set_wave_timeline": (ctypes.c_int, [_c_void_p, _i32]),
 }
 
 ABI_VERSION = 19

@@ -22,7 +22,8 @@ native code at all: hipcc translation units compiled concurrently and linked int
                                                     include/vmi_paged_attention_diag.h's entries (read-bandwidth probes, the
                                                     balanced kernels' mode knob), the "loads only" variants and the
                                                     LDS-staging experiment (pa_stage.hip).  Only the units -DVMI_DIAG changes
-                                                    are compiled a second time.  Used by tests that force kernel modes,
+                                                    are compiled a second time (pa_queue.hip a third: its kernels record a
+                                                    per-wave timeline there).  Used by tests that force kernel modes,
                                                     scripts/ and scripts/bench_diag.py — never by the operators.
 
 Every object is compiled once and shared by the libraries that hold it (pa_queue.hip twice: its bfloat16 / E5M2 rows are
@@ -61,7 +62,7 @@ PRODUCT_UNITS = [(s, "") for s in CORE] + [(SRC_ABSENT, "")]
 EXTRAS_UNITS = [(s, "extras" if s == SRC_QUEUE else "") for s in CORE] + [(s, "") for s in EXTRAS]
 # the diagnostic library: these units are compiled again with -DVMI_DIAG (it changes their variant tables / entries),
 # pa_stage.hip exists only there, every other object is the extras library's
-DIAG_UNITS = [SRC, SRC_APPEND[0]]
+DIAG_UNITS = [SRC, SRC_APPEND[0], SRC_QUEUE]
 DIAG_ONLY = [SRC_STAGE]
 DIAG_LIB_UNITS = [(s, "diag") if s in DIAG_UNITS else (s, f) for s, f in EXTRAS_UNITS] + [(s, "diag") for s in DIAG_ONLY]
 SOURCES = [*CORE, SRC_ABSENT, *EXTRAS]                        # every unit of the product and extras libraries

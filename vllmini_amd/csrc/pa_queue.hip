@@ -53,4 +53,21 @@ Variant g_queue_variants[] = {
 };
 const int g_queue_nvariants = (int)(sizeof(g_queue_variants) / sizeof(g_queue_variants[0]));
 
+#ifdef VMI_DIAG
+__device__ uint64_t* g_wave_timeline = nullptr;
+#endif
+
 }  // namespace vmi
+
+#ifdef VMI_DIAG
+#include "vmi_paged_attention_diag.h"
+// include/vmi_paged_attention_diag.h: where the balanced kernels write one record per wave (nullptr: nowhere)
+extern "C" int vmi_diag_set_wave_timeline(void* records, int32_t device) {
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return -1;
+  uint64_t* ptr = static_cast<uint64_t*>(records);
+  const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(vmi::g_wave_timeline), &ptr, sizeof(ptr));   // (synchronous)
+  (void)hipSetDevice(prev);
+  return e == hipSuccess ? 0 : -(int)e;
+}
+#endif

@@ -63,6 +63,8 @@ constexpr int QLATE_MAX = 512;   // ... ranked by ONE retired wave beside the wo
 //   bit  11   no ranking (index order)
 //   bits 12-13 team     0 auto, 1 force solo workers, 2 force teams (mode Q only)
 //   bit  14   no statistics (with a forced mode)      bit 15   rank everything up front (solo workers too)
+//   bits 5, 6, 9   (diagnostic library only) mode S page-queue depth experiments: 9 = two blocks per group on the odd XCDs,
+//                  5 = three groups in flight on the odd XCDs, 5 + 6 = on every XCD
 constexpr int QF_MODE(int f) { return f & 3; }
 constexpr int QF_TEAM(int f) { return (f >> 12) & 3; }
 constexpr int QF_WQ(int f) { return (f >> 2) & 7; }
@@ -70,6 +72,13 @@ constexpr int QF_NOHYBRID = 1 << 10;  // teams take EVERY item (round 2's team m
 constexpr int QF_NOSORT = 1 << 11;
 constexpr int QF_EARLYSORT = 1 << 15;  // rank every sequence before the first item (no first round in index order)
 constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at all (with a forced mode)
+
+#ifdef VMI_DIAG
+// experiment (diagnostic library): mode S with THREE page groups in flight per wave instead of two — passed as `qtag`
+struct Deep3Tag { static constexpr bool value = false; };
+template <class T> constexpr bool deep3_of = false;
+template <> constexpr bool deep3_of<Deep3Tag> = true;
+#endif
 
 // grid = (G), block = 256.  LDS = 4*lpad*4 (logits / probabilities, one region per wave) + QSORT_MAX*2 (ranking)
 //                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + QSORT_MAX*2 (the
@@ -88,10 +97,20 @@ constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at a
 //      below).  A twin, not a branch of the default instantiation: that one sits exactly at its register budget, and
 //      even the twenty-odd lines of the overflow schedule — with unchanged spill counts — cost it 1.3 % on equal lengths
 //      (120.6 -> 122.1 us, same-box alternation) and 2 % on ragged ones.  With OVF = false every line of it folds away.
+// (diagnostic library only — this header is compiled once more with -DVMI_DIAG for it: the kernel's body becomes a function
+//  and the kernel a wrapper that writes each wave's start and end time to g_wave_timeline, see the end of this file; with
+//  VMI_DIAG undefined the text of the kernel is exactly what it was)
+#ifdef VMI_DIAG
+extern __device__ uint64_t* g_wave_timeline;  // [gridDim.x * 4][4]: start, end (100 MHz ticks), HW_ID, XCC_ID; nullptr = off
+#endif
 template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1, bool OVF = false>
 // (second launch bound = minimum waves per SIMD: 3 workgroups of 4 waves per CU must all be resident in mode S, i.e.
 //  <= 168 VGPRs; head size 128 — twice the registers per block — runs 2 workgroups per CU, 256 VGPRs)
+#ifdef VMI_DIAG
+__device__ __forceinline__ void pa_q_body(const PAParams& p) {
+#else
 __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ? 2 : 3) pa_q_kernel(const PAParams p) {
+#endif
   constexpr int BS = 16;
   // F8: the pages hold fp8 bytes (1 = E4M3, 2 = E5M2; kv_scale == 1 only — the launcher sends any other scale to
   // pa_v1_kernel): a 16-byte unit carries 16 elements, a (block, head) tile is D*16 BYTES; every element becomes
@@ -486,6 +505,81 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     if (nmy > 0) load_group(rn, p.kc, 0);
     int round = 0;  // items this worker has finished
 
+#ifdef VMI_DIAG
+    // Experiment: ONE item with three page groups in flight.  The K groups 0 .. n-1 and the V groups n-1 .. 0 form one
+    // stream of 2n "virtual groups" that rotates through rn, ra, rb; the softmax runs when the stream reaches its first V
+    // group (two more V groups are in flight across it).  Same per-block arithmetic, same block order: bit-identical.
+    if constexpr (deep3_of<std::decay_t<decltype(qtag)>>) {
+      static_assert(!TEAM, "one wave per item");
+      if (L <= 0) {
+        for (int d = lane; d < D; d += 64) outp[d] = 0;
+        return;
+      }
+      const int n = (nmy + UU - 1) / UU;
+      if (n >= 4) {   // (shorter items: the two-deep loop below)
+      qk_max = -FLT_MAX;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) acc[i] = 0.f;
+      // virtual group vg: K group vg (vg < n), then V group 2n-1-vg.  The request is UNCONDITIONAL (pointer and index are
+      // selected, not branched on): the compiler can then count the loads in flight instead of draining them at a join.
+      auto issue = [&](u32x4(&r)[UU][NL], int vg) {
+        const bool isk = vg < n;
+        load_group(r, isk ? p.kc : p.vc, isk ? vg : 2 * n - 1 - vg);
+      };
+      auto softmax = [&]() {
+        const float m = wave_max(qk_max);
+        float e_sum = 0.f;
+        for (int i = lane; i < L; i += 64) {
+          const float e = __expf(lg[i] - m);
+          lg[i] = e;
+          e_sum += e;
+        }
+        const float inv_sum = __builtin_amdgcn_rcpf(wave_sum(e_sum) + 1e-6f);
+        for (int t = lane; t < nblk * BS; t += 64) {
+          const float e = lg[t];
+          pr[t] = t < L ? to_elem<BF>(e * inv_sum) : (uint16_t)0;
+        }
+      };
+      auto consume = [&](u32x4(&r)[UU][NL], int vg) {
+        if (vg < n) {
+          compute_k(r, vg);
+        } else {
+          if (vg == n) softmax();
+          compute_v(std::true_type{}, r, 2 * n - 1 - vg);
+        }
+      };
+      issue(ra, 1);
+      issue(rb, 2);
+      int vg = 0;
+      for (; vg + 5 < 2 * n; vg += 3) {   // three groups in flight throughout
+        consume(rn, vg);
+        issue(rn, vg + 3);
+        consume(ra, vg + 1);
+        issue(ra, vg + 4);
+        consume(rb, vg + 2);
+        issue(rb, vg + 5);
+      }
+      const int rest = 2 * n - vg;   // 3, 4 or 5 virtual groups left; rn, ra, rb hold vg, vg+1, vg+2
+      consume(rn, vg);
+      if (rest > 3) issue(rn, vg + 3);
+      consume(ra, vg + 1);
+      if (rest > 4) issue(ra, vg + 4);
+      consume(rb, vg + 2);
+      if (rest > 3) consume(rn, vg + 3);
+      if (rest > 4) consume(ra, vg + 4);
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int mm = 1; mm < UPR; mm <<= 1) acc[i] += __shfl_xor(acc[i], mm);
+      if (hf == 0) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) outp[RPL * i + rowl] = to_elem<BF>(acc[i]);
+      }
+      return;
+      }
+    }
+#endif
+
     for (;;) {
       Meta nxt;  // (deliberately uninitialised: a default value would become a phi, i.e. register copies that wait
                  //  for the loads the moment they are issued)
@@ -672,6 +766,19 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   } else {
     if (!queue) {
       if (wq >= N) return;
+#ifdef VMI_DIAG
+      // experiments (diagnostic library; profiles/r03w_wave_timeline.md): the waves of the ODD XCDs finish 5-6 % behind
+      // those of the even ones — flag bit 9: they keep twice the blocks in flight ...
+      if ((flags & (1 << 9)) && (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 1)) {
+        run(std::integral_constant<int, 2 * US>{}, std::false_type{}, std::false_type{}, cur, [](int, int&, int&) { return false; });
+        return;
+      }
+      // ... or three groups of US blocks (flag bit 5: on the odd XCDs; bits 5 and 6: on every XCD)
+      if ((flags & (1 << 5)) && ((flags & (1 << 6)) || (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 1))) {
+        run(std::integral_constant<int, US>{}, std::false_type{}, Deep3Tag{}, cur, [](int, int&, int&) { return false; });
+        return;
+      }
+#endif
       run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{}, cur, [](int, int&, int&) { return false; });
       return;
     }
@@ -787,5 +894,24 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   }
   run(std::integral_constant<int, UQ>{}, std::false_type{}, std::true_type{}, first, solo_handout);
 }
+
+#ifdef VMI_DIAG
+// The diagnostic flavour of the kernel: the same body, bracketed by two reads of the constant 100 MHz clock, one record per
+// wave (vmi_diag_set_wave_timeline).  A wave that retires early in mode Q records when it left.
+template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1, bool OVF = false>
+__global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ? 2 : 3) pa_q_kernel(const PAParams p) {
+  const uint64_t t0 = wall_clock64();
+  pa_q_body<D, BF, NT, US, UQ, F8, KM, UT, OVF>(p);
+  uint64_t* tl = g_wave_timeline;
+  if (tl && (threadIdx.x & 63) == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the wave's stores have left
+    uint64_t* rec = tl + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    rec[0] = t0;
+    rec[1] = wall_clock64();
+    rec[2] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: wave / SIMD / CU / SH / SE ids
+    rec[3] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+  }
+}
+#endif
 
 }  // namespace vmi
