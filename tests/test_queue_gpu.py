@@ -42,10 +42,6 @@ MODES = {
     "Q team": (_flags(2, 0, 0, 2), False),         # long items by 4 waves (other fp32 summation order), short ones in solo quads
     "Q team only": (_flags(2, 0, 0, 2, 1), False),  # every item by 4 waves (what an unranked batch gets)
     "Q team unranked": (_flags(2, 0, 1, 2), False),
-    # page-queue depth experiments of mode S (diagnostic library only, profiles/r03w_wave_timeline.md): same arithmetic
-    "S, two blocks per group on the odd XCDs": (_flags(1) | (1 << 9), True),
-    "S, three groups in flight on the odd XCDs": (_flags(1) | (1 << 5), True),
-    "S, three groups in flight": (_flags(1) | (1 << 5) | (1 << 6), True),
 }
 
 

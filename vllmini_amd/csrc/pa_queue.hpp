@@ -63,8 +63,6 @@ constexpr int QLATE_MAX = 512;   // ... ranked by ONE retired wave beside the wo
 //   bit  11   no ranking (index order)
 //   bits 12-13 team     0 auto, 1 force solo workers, 2 force teams (mode Q only)
 //   bit  14   no statistics (with a forced mode)      bit 15   rank everything up front (solo workers too)
-//   bits 5, 6, 9   (diagnostic library only) mode S page-queue depth experiments: 9 = two blocks per group on the odd XCDs,
-//                  5 = three groups in flight on the odd XCDs, 5 + 6 = on every XCD
 constexpr int QF_MODE(int f) { return f & 3; }
 constexpr int QF_TEAM(int f) { return (f >> 12) & 3; }
 constexpr int QF_WQ(int f) { return (f >> 2) & 7; }
@@ -72,13 +70,6 @@ constexpr int QF_NOHYBRID = 1 << 10;  // teams take EVERY item (round 2's team m
 constexpr int QF_NOSORT = 1 << 11;
 constexpr int QF_EARLYSORT = 1 << 15;  // rank every sequence before the first item (no first round in index order)
 constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at all (with a forced mode)
-
-#ifdef VMI_DIAG
-// experiment (diagnostic library): mode S with THREE page groups in flight per wave instead of two — passed as `qtag`
-struct Deep3Tag { static constexpr bool value = false; };
-template <class T> constexpr bool deep3_of = false;
-template <> constexpr bool deep3_of<Deep3Tag> = true;
-#endif
 
 // grid = (G), block = 256.  LDS = 4*lpad*4 (logits / probabilities, one region per wave) + QSORT_MAX*2 (ranking)
 //                                 + QSORT_MAX*2 (per-chunk bucket counts of the counting sort) + QSORT_MAX*2 (the
@@ -505,81 +496,6 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     if (nmy > 0) load_group(rn, p.kc, 0);
     int round = 0;  // items this worker has finished
 
-#ifdef VMI_DIAG
-    // Experiment: ONE item with three page groups in flight.  The K groups 0 .. n-1 and the V groups n-1 .. 0 form one
-    // stream of 2n "virtual groups" that rotates through rn, ra, rb; the softmax runs when the stream reaches its first V
-    // group (two more V groups are in flight across it).  Same per-block arithmetic, same block order: bit-identical.
-    if constexpr (deep3_of<std::decay_t<decltype(qtag)>>) {
-      static_assert(!TEAM, "one wave per item");
-      if (L <= 0) {
-        for (int d = lane; d < D; d += 64) outp[d] = 0;
-        return;
-      }
-      const int n = (nmy + UU - 1) / UU;
-      if (n >= 4) {   // (shorter items: the two-deep loop below)
-      qk_max = -FLT_MAX;
-#pragma unroll
-      for (int i = 0; i < NL; ++i) acc[i] = 0.f;
-      // virtual group vg: K group vg (vg < n), then V group 2n-1-vg.  The request is UNCONDITIONAL (pointer and index are
-      // selected, not branched on): the compiler can then count the loads in flight instead of draining them at a join.
-      auto issue = [&](u32x4(&r)[UU][NL], int vg) {
-        const bool isk = vg < n;
-        load_group(r, isk ? p.kc : p.vc, isk ? vg : 2 * n - 1 - vg);
-      };
-      auto softmax = [&]() {
-        const float m = wave_max(qk_max);
-        float e_sum = 0.f;
-        for (int i = lane; i < L; i += 64) {
-          const float e = __expf(lg[i] - m);
-          lg[i] = e;
-          e_sum += e;
-        }
-        const float inv_sum = __builtin_amdgcn_rcpf(wave_sum(e_sum) + 1e-6f);
-        for (int t = lane; t < nblk * BS; t += 64) {
-          const float e = lg[t];
-          pr[t] = t < L ? to_elem<BF>(e * inv_sum) : (uint16_t)0;
-        }
-      };
-      auto consume = [&](u32x4(&r)[UU][NL], int vg) {
-        if (vg < n) {
-          compute_k(r, vg);
-        } else {
-          if (vg == n) softmax();
-          compute_v(std::true_type{}, r, 2 * n - 1 - vg);
-        }
-      };
-      issue(ra, 1);
-      issue(rb, 2);
-      int vg = 0;
-      for (; vg + 5 < 2 * n; vg += 3) {   // three groups in flight throughout
-        consume(rn, vg);
-        issue(rn, vg + 3);
-        consume(ra, vg + 1);
-        issue(ra, vg + 4);
-        consume(rb, vg + 2);
-        issue(rb, vg + 5);
-      }
-      const int rest = 2 * n - vg;   // 3, 4 or 5 virtual groups left; rn, ra, rb hold vg, vg+1, vg+2
-      consume(rn, vg);
-      if (rest > 3) issue(rn, vg + 3);
-      consume(ra, vg + 1);
-      if (rest > 4) issue(ra, vg + 4);
-      consume(rb, vg + 2);
-      if (rest > 3) consume(rn, vg + 3);
-      if (rest > 4) consume(ra, vg + 4);
-#pragma unroll
-      for (int i = 0; i < NL; ++i)
-#pragma unroll
-        for (int mm = 1; mm < UPR; mm <<= 1) acc[i] += __shfl_xor(acc[i], mm);
-      if (hf == 0) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) outp[RPL * i + rowl] = to_elem<BF>(acc[i]);
-      }
-      return;
-      }
-    }
-#endif
-
     for (;;) {
       Meta nxt;  // (deliberately uninitialised: a default value would become a phi, i.e. register copies that wait
                  //  for the loads the moment they are issued)
@@ -766,19 +682,6 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   } else {
     if (!queue) {
       if (wq >= N) return;
-#ifdef VMI_DIAG
-      // experiments (diagnostic library; profiles/r03w_wave_timeline.md): the waves of the ODD XCDs finish 5-6 % behind
-      // those of the even ones — flag bit 9: they keep twice the blocks in flight ...
-      if ((flags & (1 << 9)) && (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 1)) {
-        run(std::integral_constant<int, 2 * US>{}, std::false_type{}, std::false_type{}, cur, [](int, int&, int&) { return false; });
-        return;
-      }
-      // ... or three groups of US blocks (flag bit 5: on the odd XCDs; bits 5 and 6: on every XCD)
-      if ((flags & (1 << 5)) && ((flags & (1 << 6)) || (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 1))) {
-        run(std::integral_constant<int, US>{}, std::false_type{}, Deep3Tag{}, cur, [](int, int&, int&) { return false; });
-        return;
-      }
-#endif
       run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{}, cur, [](int, int&, int&) { return false; });
       return;
     }
