@@ -166,12 +166,17 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   const int flags = p.q_flags;
   // ... and so is the item that would be this wave's FIRST as a solo worker of mode Q: item <worker index>, in INDEX order
   // (see "first round" below) — two waves per workgroup ask for a table slice and a q they may not need.
-  const int WQd = QF_WQ(flags) ? QF_WQ(flags) : 2;        // solo workers per workgroup
+  // Solo workers per workgroup: 2 over 16-bit pages (each with two blocks per register group: the bytes in flight of mode S
+  // with half the waves) — 4 over fp8 pages, whose half-size tiles want more requests in flight: wherever the kernel
+  // chooses solo workers, four of them are 4 - 13 % faster there (cfg3 fp8 U{1..L} 42.7 -> 40.2 us, batch 512 82.1 -> 72.0,
+  // cfg4 fp8 202 -> 180; over fp16 pages 67.0 -> 70.9: profiles/r03x_fp8_four_solo_workers.md).
+  constexpr int WQ_SOLO = F8 ? 4 : 2;
+  const int WQd = QF_WQ(flags) ? QF_WQ(flags) : WQ_SOLO;
   const int wq_solo = blockIdx.x * WQd + wave;
   const int sq0 = wq_solo < N ? wq_solo / H : 0;          // its sequence and head
   const int hq0 = wq_solo < N ? wq_solo - sq0 * H : 0;
   Meta firstq;
-  if (wave < WQd && !(flags & QF_EARLYSORT)) meta_issue(firstq, sq0, hq0, 1, 0);
+  if (wave < WQd && (F8 ? WQd < 4 : true) && !(flags & QF_EARLYSORT)) meta_issue(firstq, sq0, hq0, 1, 0);  // (4 workers: no late ranking)
   bool queue = N > nwaves;
   int maxL = 0;
   float sumL = 0.f;
@@ -212,7 +217,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   // workers, whose snake pairs a long item with a short one (67 us against 74).  profiles/r03c_heavy_tailed_batches.md
   bool team = false;
   if (queue && have_sum) {
-    const int wq0 = QF_WQ(flags) ? QF_WQ(flags) : 2;
+    const int wq0 = QF_WQ(flags) ? QF_WQ(flags) : 2;   // (the rule is calibrated on two workers, also where four run)
     const float share = sumL * (float)H / (float)(gridDim.x * wq0);  // tokens per solo worker
     team = (float)maxL > 1.15f * share || (ragged && rankable && nlong_est * 10 <= 7 * B);
   }
@@ -230,7 +235,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     team = team || ovf;
   }
   team = __builtin_amdgcn_readfirstlane(team);
-  const int WQ = team ? 4 : (QF_WQ(flags) ? QF_WQ(flags) : 2);
+  const int WQ = team ? 4 : (QF_WQ(flags) ? QF_WQ(flags) : WQ_SOLO);
   const bool ranked = queue && rankable && !ovf;
   const int nworkers = queue ? (team ? gridDim.x : gridDim.x * WQ) : nwaves;
   const int wq = queue ? (team ? blockIdx.x : blockIdx.x * WQ + wave) : w_nat;  // worker index
