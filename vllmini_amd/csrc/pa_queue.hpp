@@ -170,13 +170,15 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   // with half the waves) — 4 over fp8 pages, whose half-size tiles want more requests in flight: wherever the kernel
   // chooses solo workers, four of them are 4 - 13 % faster there (cfg3 fp8 U{1..L} 42.7 -> 40.2 us, batch 512 82.1 -> 72.0,
   // cfg4 fp8 202 -> 180; over fp16 pages 67.0 -> 70.9: profiles/r03x_fp8_four_solo_workers.md).
-  constexpr int WQ_SOLO = F8 ? 4 : 2;
+  // Head size 128 over 16-bit pages (two workgroups per CU: two workers each would be four waves per CU) likewise: cfg4
+  // U{1..L} 358.5 -> 351.9 us, batch 256 715 -> 677, U[1/8..1] 369 -> 353 / 742 -> 704.
+  constexpr int WQ_SOLO = (F8 || D > 64) ? 4 : 2;
   const int WQd = QF_WQ(flags) ? QF_WQ(flags) : WQ_SOLO;
   const int wq_solo = blockIdx.x * WQd + wave;
   const int sq0 = wq_solo < N ? wq_solo / H : 0;          // its sequence and head
   const int hq0 = wq_solo < N ? wq_solo - sq0 * H : 0;
   Meta firstq;
-  if (wave < WQd && (F8 ? WQd < 4 : true) && !(flags & QF_EARLYSORT)) meta_issue(firstq, sq0, hq0, 1, 0);  // (4 workers: no late ranking)
+  if (wave < WQd && ((F8 || D > 64) ? WQd < 4 : true) && !(flags & QF_EARLYSORT)) meta_issue(firstq, sq0, hq0, 1, 0);  // (4 workers: no late ranking)
   bool queue = N > nwaves;
   int maxL = 0;
   float sumL = 0.f;
