@@ -11,7 +11,8 @@
 //
 //   S  (equal lengths, one item per wave)   wave w owns item w, 1 block per register group: pa_v1_kernel's best form,
 //                                           same lane maps, same order of operations.
-//   Q  (ragged, or more items than waves)   2 waves per workgroup stay as WORKERS, the rest retire.  A worker runs
+//   Q  (ragged, or more items than waves)   2 waves per workgroup stay as WORKERS, the rest retire (fp8 pages and head
+//                                           size 128: all 4 stay, WQ_SOLO below).  A worker runs
 //                                           items one after the other, 2 blocks per register group, so the chip holds
 //                                           the same bytes in flight with half the waves.  Items are handed out
 //                                           longest first: the sequences are ranked by a deterministic 64-bucket
