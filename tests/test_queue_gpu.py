@@ -583,3 +583,48 @@ def test_wave_timeline_of_the_diagnostic_library():
         launch()
         torch.cuda.synchronize()
         assert (rec == 0).all()                                        # switched off
+
+
+@pytest.mark.parametrize("B,ragged", [(128, False), (128, True), (176, True)])
+def test_default_entry_over_fp8_pages_from_half_a_chip_on_is_the_balanced_kernel(B, ragged):
+    """PRODUCT library, no knob: over fp8 pages (kv_scale 1) the balanced kernel — four solo workers per workgroup there —
+    serves 12 heads x 128 .. 255 sequences too (half the resident waves or more; profiles/r03x_fp8_four_solo_workers.md).
+    Every row finite and deterministic, within the tolerance of the one-wave-per-head fp8 kernel; a sample of sequences
+    against the CPU kernel model."""
+    import dataclasses
+
+    from vllmini_amd import _lib, ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    assert _lib.load().vmi_is_diag_build() == 0
+    dev = _dev()
+    if torch.cuda.get_device_properties(dev).multi_processor_count != 256:
+        pytest.skip("sized for the 256 CUs of an MI355X")
+    names = _names()
+    cfg = dataclasses.replace(CONFIGS["cfg3"], name=f"b{B}", batch=B, num_blocks=B * 64 + 8)
+    wl = make_workload(cfg, dev, seed=90 + B, table_sets=1, ragged=ragged)
+    lens = wl.seq_lens.cpu().numpy()
+    D = cfg.head_size
+    g8 = torch.Generator(device=dev).manual_seed(11)
+    kc = torch.randint(0, 64, (cfg.num_blocks, cfg.kv_heads, D // 16, 16, 16), dtype=torch.uint8, device=dev, generator=g8)
+    vc = torch.randint(0, 64, (cfg.num_blocks, cfg.kv_heads, D, 16), dtype=torch.uint8, device=dev, generator=g8)
+
+    def attend(variant=0):
+        out = torch.full((B, cfg.num_heads, D), float("nan"), dtype=torch.float16, device=dev)
+        ops.paged_attention_v1(out, wl.query, kc, vc, cfg.num_heads, wl.scale, wl.tables[0], wl.seq_lens, cfg.block_size,
+                               cfg.seq_len, None, "fp8", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+        torch.cuda.synchronize()
+        return out
+
+    got = attend()
+    assert ops.last_launch_label() == "fp8_q_d64_s2q4m"
+    assert torch.isfinite(got).all() and torch.equal(got, attend())
+    plain = attend(names["fp8_d64_bs16_h1_w1_u1_nt1"])    # (the "m" kernel's q.K^T runs on the matrix cores: other fp32 summation
+    assert float((got.float() - plain.float()).abs().max()) <= 2e-3    #  order than the plain kernel's, same tolerance)
+    idx = np.unique(np.r_[0, 1, B // 2, B - 1, int(np.argmax(lens)), int(np.argmin(lens))])
+    tab_dev = wl.tables[0][torch.from_numpy(idx).to(dev)][:, : cfg.blocks_per_seq].clamp(min=0)
+    flat = tab_dev.reshape(-1).to(torch.int64)
+    small_tab = np.arange(flat.numel(), dtype=np.int32).reshape(len(idx), cfg.blocks_per_seq)
+    ref = oracle.paged_attention_v1_fp8(np.ascontiguousarray(wl.query.cpu().numpy()[idx]), kc[flat].cpu().numpy(), vc[flat].cpu().numpy(),
+                                        cfg.num_heads, wl.scale, small_tab, lens[idx], cfg.block_size, kv_scale=1.0, threads=8)
+    assert_close(got.cpu().numpy()[idx], ref, f"fp8 default entry, batch {B}", vmax=2.0)

@@ -524,9 +524,13 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
   while (wph < 16 && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
-  // (a nearly full chip stays with two waves per head here: over fp8 pages the balanced kernel ties it on equal lengths
-  //  — 57.1 / 59.1 / 63.4 against 56.1 / 60.0 / 63.6 us at batch 208 / 224 / 240 — and loses 7 % on ragged ones)
-  if (unit_scale && wph == 1 && !bf && block_size == 16 && head_size == 64 &&
+  // Over fp8 pages the balanced kernel serves the chip from HALF full on (two waves per head would be picked up to batch 255
+  // at 12 heads): since its solo workers are four per workgroup (pa_queue.hpp, WQ_SOLO) it ties two waves per head on equal
+  // lengths — batch 128 / 160 / 192 / 208 / 240 at 12 heads: 41.6 / 45.6 / 55.3 / 61.2 / 66.5 against 41.4 / 46.3 / 55.3 /
+  // 63.8 / 67.4 us — and is 3 - 8 % ahead on ragged ones (30.8 / 33.0 / 36.7 / 39.0 / 41.8 against 33.6 / 35.7 / 38.8 /
+  // 40.2 / 42.8); at batch 96 four waves per head are ahead (21.9 against 29.5).  profiles/r03x_fp8_four_solo_workers.md
+  const bool half_full = wph == 2 && units * 2 >= full_chip_waves();
+  if (unit_scale && (wph == 1 || half_full) && !bf && block_size == 16 && head_size == 64 &&
       4.0 * (double)units * max_seq_len * head_size > 256e6 &&  // (2 bytes per token and dim: past the Infinity Cache)
       3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024) {
     // full chip, head size 64: the balanced kernel over fp8 pages (pa_queue.hpp) — ragged batches without a hint
