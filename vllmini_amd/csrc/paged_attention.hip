@@ -530,17 +530,23 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   // 63.8 / 67.4 us — and is 3 - 8 % ahead on ragged ones (30.8 / 33.0 / 36.7 / 39.0 / 41.8 against 33.6 / 35.7 / 38.8 /
   // 40.2 / 42.8); at batch 96 four waves per head are ahead (21.9 against 29.5).  profiles/r03x_fp8_four_solo_workers.md
   const bool half_full = wph == 2 && units * 2 >= full_chip_waves();
-  if (unit_scale && (wph == 1 || half_full) && !bf && block_size == 16 && head_size == 64 &&
-      4.0 * (double)units * max_seq_len * head_size > 256e6 &&  // (2 bytes per token and dim: past the Infinity Cache)
-      3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024) {
-    // full chip, head size 64: the balanced kernel over fp8 pages (pa_queue.hpp) — ragged batches without a hint
+  // Head size 128 (two workgroups per CU): the balanced kernel on a full chip — the lockstep 4-head kernel it replaces is
+  // 0.8 % ahead on equal lengths (cfg4 fp8: 330.9 against 333.4 us) and 12 % behind on ragged ones (201.8 against 178.1);
+  // fp8 pages have no gated double launch (that pairs two fp16 kernels).
+  const size_t q_lds = 16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024;   // the balanced kernel's, per workgroup
+  const bool q64 = head_size == 64 && (wph == 1 || half_full) && 3 * q_lds <= (size_t)160 * 1024;
+  const bool q128 = head_size == 128 && wph == 1 && 2 * (q_lds + 4 * 1024) <= (size_t)160 * 1024;
+  if (unit_scale && (q64 || q128) && !bf && block_size == 16 &&
+      4.0 * (double)units * max_seq_len * head_size > 256e6) {  // (2 bytes per token and dim: past the Infinity Cache)
+    // the balanced kernel over fp8 pages (pa_queue.hpp) — ragged batches without a hint
+    const int us = head_size == 64 ? 2 : 1;   // (blocks per group of its mode S: the row's U)
     for (int id = 1; id <= nvariants_v1(); ++id) {
       const Variant& c = variant_v1(id);
-      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == 2 && c.KM && !c.OVF) return id;  // K pass on MFMA
+      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == us && c.KM && !c.OVF) return id;  // K pass on MFMA
     }
     for (int id = 1; id <= nvariants_v1(); ++id) {  // (formats without an "m" kernel: E5M2)
       const Variant& c = variant_v1(id);
-      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == 2 && !c.OVF) return id;
+      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == us && !c.OVF) return id;
     }
   }
   if (mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3)
