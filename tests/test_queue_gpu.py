@@ -585,12 +585,14 @@ def test_wave_timeline_of_the_diagnostic_library():
         assert (rec == 0).all()                                        # switched off
 
 
-@pytest.mark.parametrize("B,ragged", [(128, False), (128, True), (176, True)])
-def test_default_entry_over_fp8_pages_from_half_a_chip_on_is_the_balanced_kernel(B, ragged):
-    """PRODUCT library, no knob: over fp8 pages (kv_scale 1) the balanced kernel — four solo workers per workgroup there —
-    serves 12 heads x 128 .. 255 sequences too (half the resident waves or more; profiles/r03x_fp8_four_solo_workers.md).
-    Every row finite and deterministic, within the tolerance of the one-wave-per-head fp8 kernel; a sample of sequences
-    against the CPU kernel model."""
+@pytest.mark.parametrize("B,ragged,kernel", [(128, False, "fp8_d64_bs16_h1_w4_u2_nt1"), (176, True, "fp8_d64_bs16_h1_w4_u2_nt1"),
+                                             (224, True, "fp8_q_d64_s2q4m"), (224, False, "fp8_q_d64_s2q4m")])
+def test_default_entry_over_fp8_pages_between_half_a_chip_and_a_full_one(B, ragged, kernel):
+    """PRODUCT library, no knob, fp8 pages (kv_scale 1), 12 heads: from half the resident waves to 85 % of them (batch 128 ..
+    217) the default is FOUR waves per head (twice the resident waves: half-size tiles want the requests, and the dispatcher
+    balances ragged batches), from there on the balanced kernel (profiles/r03x_fp8_four_solo_workers.md).  Every row finite
+    and deterministic, within the tolerance of the one-wave-per-head fp8 kernel; a sample of sequences against the CPU
+    kernel model."""
     import dataclasses
 
     from vllmini_amd import _lib, ops
@@ -617,7 +619,7 @@ def test_default_entry_over_fp8_pages_from_half_a_chip_on_is_the_balanced_kernel
         return out
 
     got = attend()
-    assert ops.last_launch_label() == "fp8_q_d64_s2q4m"
+    assert ops.last_launch_label() == kernel
     assert torch.isfinite(got).all() and torch.equal(got, attend())
     plain = attend(names["fp8_d64_bs16_h1_w1_u1_nt1"])    # (the "m" kernel's q.K^T runs on the matrix cores: other fp32 summation
     assert float((got.float() - plain.float()).abs().max()) <= 2e-3    #  order than the plain kernel's, same tolerance)

@@ -524,17 +524,15 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
   while (wph < 16 && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
-  // Over fp8 pages the balanced kernel serves the chip from HALF full on (two waves per head would be picked up to batch 255
-  // at 12 heads): since its solo workers are four per workgroup (pa_queue.hpp, WQ_SOLO) it ties two waves per head on equal
-  // lengths — batch 128 / 160 / 192 / 208 / 240 at 12 heads: 41.6 / 45.6 / 55.3 / 61.2 / 66.5 against 41.4 / 46.3 / 55.3 /
-  // 63.8 / 67.4 us — and is 3 - 8 % ahead on ragged ones (30.8 / 33.0 / 36.7 / 39.0 / 41.8 against 33.6 / 35.7 / 38.8 /
-  // 40.2 / 42.8); at batch 96 four waves per head are ahead (21.9 against 29.5).  profiles/r03x_fp8_four_solo_workers.md
-  const bool half_full = wph == 2 && units * 2 >= full_chip_waves();
+  // A nearly full chip (85 % of the resident waves and more: batch 218 at 12 heads) goes to the balanced kernel: since its solo
+  // workers are four per workgroup over fp8 pages (pa_queue.hpp, WQ_SOLO) it is ahead of several waves per head there on equal
+  // lengths (batch 224: 61.4 against 64.4 - 66.7 us) and level on ragged ones (39.7 / 39.9).  profiles/r03x_fp8_four_solo_workers.md
+  const bool near_full = wph == 2 && units * 20 >= full_chip_waves() * 17;
   // Head size 128 (two workgroups per CU): the balanced kernel on a full chip — the lockstep 4-head kernel it replaces is
   // 0.8 % ahead on equal lengths (cfg4 fp8: 330.9 against 333.4 us) and 12 % behind on ragged ones (201.8 against 178.1);
   // fp8 pages have no gated double launch (that pairs two fp16 kernels).
   const size_t q_lds = 16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024;   // the balanced kernel's, per workgroup
-  const bool q64 = head_size == 64 && (wph == 1 || half_full) && 3 * q_lds <= (size_t)160 * 1024;
+  const bool q64 = head_size == 64 && (wph == 1 || near_full) && 3 * q_lds <= (size_t)160 * 1024;
   const bool q128 = head_size == 128 && wph == 1 && 2 * (q_lds + 4 * 1024) <= (size_t)160 * 1024;
   if (unit_scale && (q64 || q128) && !bf && block_size == 16 &&
       4.0 * (double)units * max_seq_len * head_size > 256e6) {  // (2 bytes per token and dim: past the Infinity Cache)
@@ -549,6 +547,12 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
       if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == us && !c.OVF) return id;
     }
   }
+  // Half a chip to 85 % of one (batch 128 .. 217 at 12 heads): FOUR waves per head, not the two that would just fill the
+  // resident waves — an fp8 tile is half the bytes, two waves per head leave the memory system short of requests, and twice
+  // the resident waves let the dispatcher balance a ragged batch: batch 128 / 144 / 176 / 208, equal lengths 42.2 / 42.6 /
+  // 50.5 / 61.6 -> 36.9 / 41.3 / 51.5 / 59.5 us, U{1..L} 34.2 / 34.1 / 36.9 / 40.7 -> 26.5 / 27.8 / 32.5 / 37.8 (the balanced
+  // kernel there: 42.6 / 43.5 / 52.6 / 61.2 and 31.2 / 32.2 / 34.4 / 39.5).  Below batch 128 the rule above already gives four.
+  if (head_size == 64 && block_size == 16 && wph == 2 && nblk >= 8) wph = 4;
   if (mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   // (a full chip past the balanced kernel's LDS: the same choice by round efficiency as over fp16 pages — the logits are
