@@ -588,12 +588,22 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   // 12 heads): its one-item-per-wave mode then beats two waves per head on equal lengths (batch 224: 114.6 -> 109.5 us,
   // 240: 122.4 -> 115.9; 192: 95.6 against 100.9, so not below 80 %) and its ranked modes beat it on ragged ones (224:
   // 69.0 -> 64.4 us).  Round 3, profiles/r03l_nearly_full_chip.md.
-  const bool near_full = wph == 2 && units * 5 >= full_chip_waves() * 4;
+  // (end of round 3: the alternative below the threshold is now EIGHT waves per head, see below, which moves the crossover from
+  //  80 % to 7/8 of the resident waves: batch 208: 103.3 / 58.7 us against the balanced kernel's 104.6 / 61.9 on equal / ragged
+  //  lengths, 224: 110.5 / 64.7 against 109.8 / 67.1, 240: 121.0 / 69.7 against 116.3 / 71.2)
+  const bool near_full = wph == 2 && units * 8 >= full_chip_waves() * 7;
   const bool balanced = allow_balanced && (wph == 1 || near_full) && nt && block_size == 16 && head_size == 64 &&
                         3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
   const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
   if (ragged)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  // A chip that two or four waves per head would just fill (batch 64 .. 223 at 12 heads) gets EIGHT, hint or no hint: several
+  // times the resident waves cost equal lengths nothing (batch 128 / 160 / 192, 1024 tokens: 65.0 / 80.0 / 94.6 -> 63.8 / 79.5 /
+  // 95.0 us) and let the hardware dispatcher balance a ragged batch (44.4 / 51.8 / 59.3 -> 38.4 / 49.0 / 55.5; 2048 tokens,
+  // batch 192: 111.4 -> 104.1; 4096: 251 -> 219).  From 512 tokens on (shorter contexts are launch-bound either way) and where
+  // the long-context scoring below does not apply.  profiles/r03z_eight_waves_per_head.md
+  const bool lds_fits_q = 3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
+  if (!balanced && lds_fits_q && head_size == 64 && block_size == 16 && (wph == 2 || wph == 4) && nblk >= 32) wph = 8;
   // (only where the balanced kernel's LDS does not fit: shorter contexts keep the tuned picks — the fused append, which
   //  has no balanced twin, stays bit-identical to the call pair there)
   const bool balanced_lds_fits = 3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
