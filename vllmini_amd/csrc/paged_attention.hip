@@ -603,7 +603,9 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   // batch 192: 111.4 -> 104.1; 4096: 251 -> 219).  From 512 tokens on (shorter contexts are launch-bound either way) and where
   // the long-context scoring below does not apply.  profiles/r03z_eight_waves_per_head.md
   const bool lds_fits_q = 3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
-  if (!balanced && lds_fits_q && head_size == 64 && block_size == 16 && (wph == 2 || wph == 4) && nblk >= 32) wph = 8;
+  // (head size 128 likewise, by a smaller margin: 32 heads x 48 sequences of 2048 tokens 253 -> 244 us equal, 155 -> 148 ragged)
+  if (!balanced && lds_fits_q && (head_size == 64 || head_size == 128) && block_size == 16 && (wph == 2 || wph == 4) && nblk >= 32)
+    wph = 8;
   // (only where the balanced kernel's LDS does not fit: shorter contexts keep the tuned picks — the fused append, which
   //  has no balanced twin, stays bit-identical to the call pair there)
   const bool balanced_lds_fits = 3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
