@@ -349,13 +349,13 @@ def test_default_entry_on_heavy_tailed_batches_product_library(kind):
 
 
 @pytest.mark.parametrize("kvd", ["auto", "fp8"])
-@pytest.mark.parametrize("B,spread", [(257, 0.0), (288, 0.15), (320, 0.0)])
-def test_default_entry_a_little_more_items_than_waves_runs_the_overflow_twin(B, spread, kvd):
-    """PRODUCT library, no knob: 12 heads x (257 .. 320) sequences of (nearly) equal length are a little more items than
-    the balanced kernel's grid has waves (3072 on 256 CUs).  The launcher picks the OVF twin: every wave takes one item as
-    in mode S — those rows are bit-identical to the one-wave-per-head kernel — and the remainder, the LAST rows, is run by
-    4-wave teams (other fp32 summation order: within the team tolerance).  Every row written, deterministic, a sample of
-    first, middle and remainder sequences against the CPU kernel model."""
+@pytest.mark.parametrize("B,spread", [(257, 0.0), (288, 0.15), (320, 0.0), (512, 0.5)])
+def test_default_entry_more_items_than_resident_waves_is_several_waves_per_head(B, spread, kvd):
+    """PRODUCT library, no knob: 12 heads x (257 ...) sequences are more items than the chip holds waves (3072 on 256 CUs).
+    Since the end of round 3 the default there is a plain several-waves-per-head kernel — eight over fp16 pages, four over
+    fp8 pages: many times the resident waves, balanced by the hardware dispatcher — not the balanced kernel (whose overflow
+    twin it replaced: level on equal lengths, ahead on ragged ones; profiles/r03z_eight_waves_per_head.md).  Every row
+    written, deterministic, within the tolerance of the one-wave-per-head kernel, a sample against the CPU kernel model."""
     import dataclasses
 
     from vllmini_amd import _lib, ops
@@ -389,26 +389,23 @@ def test_default_entry_a_little_more_items_than_waves_runs_the_overflow_twin(B, 
         return out
 
     got = attend()
-    twin = "fp8_q_d64_s2q4mo" if f8 else "q_d64_s1q2o"
-    assert ops.last_launch_label() == twin
+    assert ops.last_launch_label() == ("fp8_d64_bs16_h1_w4_u2_nt1" if f8 else "d64_h1_w8_u1_nt1")
     assert torch.isfinite(got).all()
     assert torch.equal(got, attend())
-    plain = attend(names["fp8_q_d64_s2q4m" if f8 else "d64_h4_w1_u1_nt1"])    # (fp8: the same kernel's solo rounds)
-    nw = 3072 // cfg.num_heads                     # sequences wholly inside the one-item-per-wave part
-    assert torch.equal(got[:nw].view(torch.int16), plain[:nw].view(torch.int16)), "a mode-S row differs"
-    assert float((got[nw:].float() - plain[nw:].float()).abs().max()) <= 1e-3 * (2.0 if f8 else 1.0)
-    idx = np.unique(np.r_[0, 1, nw - 1, nw, B - 2, B - 1, B // 2])
+    plain = attend(names["fp8_d64_bs16_h1_w1_u1_nt1" if f8 else "d64_h4_w1_u1_nt1"])
+    assert float((got.float() - plain.float()).abs().max()) <= 1e-3 * (2.0 if f8 else 1.0)
+    idx = np.unique(np.r_[0, 1, B // 2, B - 2, B - 1])
     tab_dev = wl.tables[0][torch.from_numpy(idx).to(dev)][:, : cfg.blocks_per_seq].clamp(min=0)
     flat = tab_dev.reshape(-1).to(torch.int64)
     small_tab = np.arange(flat.numel(), dtype=np.int32).reshape(len(idx), cfg.blocks_per_seq)
     qn = np.ascontiguousarray(wl.query.cpu().numpy()[idx])
     if f8:
-        ref = oracle.paged_attention_v1_fp8(qn, kc[flat].cpu().numpy(), vc[flat].cpu().numpy(), cfg.num_heads, wl.scale,
-                                            small_tab, lens.numpy()[idx], cfg.block_size, kv_scale=1.0, threads=8)
+        ref = oracle.paged_attention_v1_fp8(qn, kc[flat].cpu().numpy(), vc[flat].cpu().numpy(), cfg.num_heads, wl.scale, small_tab,
+                                            lens.numpy()[idx], cfg.block_size, kv_scale=1.0, threads=8)
     else:
         ref = oracle.paged_attention_v1(qn, kc[flat].cpu().numpy(), vc[flat].cpu().numpy(), cfg.num_heads, wl.scale, small_tab,
                                         lens.numpy()[idx], cfg.block_size, threads=8)
-    assert_close(got.cpu().numpy()[idx], ref, f"B{B} {kvd}: overflow twin, sampled vs model", vmax=2.0 if f8 else 1.0)
+    assert_close(got.cpu().numpy()[idx], ref, f"batch {B} {kvd}: default entry, sampled vs model", vmax=2.0 if f8 else 1.0)
 
 
 def test_head_128_default_entry_is_a_gated_double_launch():

@@ -1362,7 +1362,6 @@ struct Variant {
   bool QUEUE;        // balanced kernel (pa_queue.hpp): persistent grid of 3 workgroups per CU, mode chosen on the device
   bool STAGE;        // experiment (pa_stage.hip): pages staged through an LDS ring of U slots by global_load_lds
   bool KM;           // balanced kernels: q.K^T of the K pass on the matrix cores (pa_queue.hpp); "m" names
-  bool OVF;          // balanced kernels: the twin for a little more items than resident waves (pa_queue.hpp OVF); "o" names
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);

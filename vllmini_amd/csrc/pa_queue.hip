@@ -11,12 +11,6 @@ namespace vmi {
 #define VMI_ROW_Q8M(NAME, D, US, UQ, F8, UT) /* ... with q.K^T of the K pass on the matrix cores (pa_queue.hpp, KM) */ \
   {NAME, D, 16, 4, 1, US, true, 1, false, (pa_kernel_t)pa_q_kernel<D, false, true, US, UQ, F8, true, UT>, 0, 0, 0, F8, false, false, false, true, false, true},
 
-// OVF twins ("o" names): what launch_pa_v1 sends a batch with a little more items than the grid has waves to
-#define VMI_ROW_QO(NAME, D, US, UQ, UT)                                                                            \
-  {NAME, D, 16, 4, 1, US, true, 1, false, (pa_kernel_t)pa_q_kernel<D, false, true, US, UQ, 0, false, UT, true>, 0, 0, 0, 0, false, false, false, true, false, false, true},
-#define VMI_ROW_Q8MO(NAME, D, US, UQ, F8, UT)                                                                      \
-  {NAME, D, 16, 4, 1, US, true, 1, false, (pa_kernel_t)pa_q_kernel<D, false, true, US, UQ, F8, true, UT, true>, 0, 0, 0, F8, false, false, false, true, false, true, true},
-
 // (last argument: UT, blocks per register group of a 4-wave team — a long item's waves on a chip that is mostly idle
 //  are bound by their own bytes in flight: "4 full, rest 1/32" 22.5 -> 19.4 us with 2 instead of 1 at head size 64;
 //  fp8 pages 20.6 -> 17.5 -> 16.2 us with 1 / 2 / 4; head size 128 has no registers for 2 (spills: 58.7 -> 66.3 us);
@@ -46,10 +40,6 @@ Variant g_queue_variants[] = {
     // over fp16 pages the same change is neutral and is not built (profiles/r03b_k_pass_on_mfma.md)
     VMI_ROW_Q8M("fp8_q_d64_s2q4m", 64, 2, 4, 1, 4)
     VMI_ROW_Q8M("fp8_q_d128_s1q2m", 128, 1, 2, 1, 1)
-    // a little more items than resident waves (batch 257 .. 320 at 12 heads): one item per wave as in mode S, then the
-    // remainder by teams (pa_queue.hpp, `ovf`): 257 sequences 148 -> 128 us, 288: 152 -> 141, 320: 162 -> 156
-    VMI_ROW_QO("q_d64_s1q2o", 64, 1, 2, 2)
-    VMI_ROW_Q8MO("fp8_q_d64_s2q4mo", 64, 2, 4, 1, 4)
 };
 const int g_queue_nvariants = (int)(sizeof(g_queue_variants) / sizeof(g_queue_variants[0]));
 

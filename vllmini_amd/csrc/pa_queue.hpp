@@ -84,18 +84,13 @@ constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at a
 //     summation order (dtype_float16.cuh:292-298); the V pass keeps its fp16 rounding points on the VALU.  Built for the
 //     fp8 kernels, whose K pass is VALU-pressed (16 decodes + 8 packed FMAs + the butterfly per 16 dims): the decode to
 //     half pairs feeds the MFMA directly.  M = 1 of 16 rows is useful work — the matrix pipe is idle otherwise.
-// OVF: the twin the launcher picks for a batch with A LITTLE MORE ITEMS THAN THE GRID HAS WAVES (known on the host:
-//      nwaves < num_seqs * num_heads <= nwaves + workgroups).  It is this kernel plus the OVERFLOW schedule (see `ovf`
-//      below).  A twin, not a branch of the default instantiation: that one sits exactly at its register budget, and
-//      even the twenty-odd lines of the overflow schedule — with unchanged spill counts — cost it 1.3 % on equal lengths
-//      (120.6 -> 122.1 us, same-box alternation) and 2 % on ragged ones.  With OVF = false every line of it folds away.
 // (diagnostic library only — this header is compiled once more with -DVMI_DIAG for it: the kernel's body becomes a function
 //  and the kernel a wrapper that writes each wave's start and end time to g_wave_timeline, see the end of this file; with
 //  VMI_DIAG undefined the text of the kernel is exactly what it was)
 #ifdef VMI_DIAG
 extern __device__ uint64_t* g_wave_timeline;  // [gridDim.x * 4][4]: start, end (100 MHz ticks), HW_ID, XCC_ID; nullptr = off
 #endif
-template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1, bool OVF = false>
+template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1>
 // (second launch bound = minimum waves per SIMD: 3 workgroups of 4 waves per CU must all be resident in mode S, i.e.
 //  <= 168 VGPRs; head size 128 — twice the registers per block — runs 2 workgroups per CU, 256 VGPRs)
 #ifdef VMI_DIAG
@@ -226,20 +221,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   }
   if (QF_TEAM(flags) == 1) team = false;
   if (QF_TEAM(flags) == 2) team = queue;
-  // OVERFLOW (round 3, the OVF twin): (nearly) equal lengths and a little more items than waves — a batch slightly larger
-  // than the chip holds.  Solo workers run ceil(N / workers) rounds and the last one may hold a handful of items: 257
-  // sequences x 12 heads took 146.7 us against 119.1 for 256 (the 12 extra items ran a whole extra round).  Instead every
-  // wave takes ONE item exactly as in mode S, and the remainder (at most one item per workgroup: beyond that three rounds
-  // of solo workers are no slower) is then run by the teams below — an item four times shorter, at the end.
-  bool ovf = false;
-  if constexpr (OVF) {
-    ovf = __builtin_amdgcn_readfirstlane(have_sum && !ragged && N > nwaves && N - nwaves <= (int)gridDim.x &&
-                                         (flags & 0xffff) == 0);
-    team = team || ovf;
-  }
   team = __builtin_amdgcn_readfirstlane(team);
   const int WQ = team ? 4 : (QF_WQ(flags) ? QF_WQ(flags) : WQ_SOLO);
-  const bool ranked = queue && rankable && !ovf;
+  const bool ranked = queue && rankable;
   const int nworkers = queue ? (team ? gridDim.x : gridDim.x * WQ) : nwaves;
   const int wq = queue ? (team ? blockIdx.x : blockIdx.x * WQ + wave) : w_nat;  // worker index
 
@@ -682,17 +666,10 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   // lives only as far as here.  Kept across the ranking code below it was spilled and reloaded on the way into the
   // item, and equal lengths ran 2.7 us slower than in pa_v1_kernel (124.5 -> 121.8 us by HIP events, same box, with
   // identical hot loops and identical rocprofv3 kernel time: profiles/r02m_late_ranking.md).
-  if constexpr (OVF) {
-    if (!queue || ovf) {  // overflow: one item per wave first (every wave has one), then on to the teams
-      if (w_nat < N) run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{}, cur, [](int, int&, int&) { return false; });
-      if (!ovf) return;
-    }
-  } else {
-    if (!queue) {
-      if (wq >= N) return;
-      run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{}, cur, [](int, int&, int&) { return false; });
-      return;
-    }
+  if (!queue) {
+    if (wq >= N) return;
+    run(std::integral_constant<int, US>{}, std::false_type{}, std::false_type{}, cur, [](int, int&, int&) { return false; });
+    return;
   }
 
   int nlong = B;  // teams: ranks [0, nlong) are the long sequences (everything when the batch is not ranked)
@@ -749,27 +726,20 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     //      workgroup come in rank order: first its long items (phase 1), then its quads (phase 2). ----
     const bool hybrid = ranked && !(flags & QF_NOHYBRID);
     NL_items = hybrid ? (int64_t)nlong * H : (int64_t)N;
-    int toff = 0;  // first team item (overflow: the teams' items are the remainder [nwaves, N), in index order)
-    if constexpr (OVF) {
-      if (ovf) {
-        NL_items = N - nwaves;
-        toff = nwaves;
-      }
-    }
     nunits = NL_items + ((int64_t)N - NL_items + 3) / 4;
     if (g < NL_items) {
       Meta tfirst;
       int s0, h0;
-      ids_of(toff + g, s0, h0);
+      ids_of(g, s0, h0);
       meta_issue(tfirst, s0, h0, 4, wave);
       run(std::integral_constant<int, UT>{}, std::true_type{}, std::true_type{}, tfirst, [&](int k, int& s, int& h) {
         const int64_t u = unit(k);
         const bool has = u < NL_items;
-        ids_of(has ? toff + (int)u : 0, s, h);
+        ids_of(has ? (int)u : 0, s, h);
         return has;
       });
     }
-    if (NL_items >= N || ovf) return;
+    if (NL_items >= N) return;
     while (unit(k1) < NL_items) ++k1;
     if (quad_item(0) >= N) return;
     hmode = 2;
@@ -809,10 +779,10 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
 #ifdef VMI_DIAG
 // The diagnostic flavour of the kernel: the same body, bracketed by two reads of the constant 100 MHz clock, one record per
 // wave (vmi_diag_set_wave_timeline).  A wave that retires early in mode Q records when it left.
-template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1, bool OVF = false>
+template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1>
 __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ? 2 : 3) pa_q_kernel(const PAParams p) {
   const uint64_t t0 = wall_clock64();
-  pa_q_body<D, BF, NT, US, UQ, F8, KM, UT, OVF>(p);
+  pa_q_body<D, BF, NT, US, UQ, F8, KM, UT>(p);
   uint64_t* tl = g_wave_timeline;
   if (tl && (threadIdx.x & 63) == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the wave's stores have left

@@ -532,7 +532,12 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   // 0.8 % ahead on equal lengths (cfg4 fp8: 330.9 against 333.4 us) and 12 % behind on ragged ones (201.8 against 178.1);
   // fp8 pages have no gated double launch (that pairs two fp16 kernels).
   const size_t q_lds = 16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024;   // the balanced kernel's, per workgroup
-  const bool q64 = head_size == 64 && (wph == 1 || near_full) && 3 * q_lds <= (size_t)160 * 1024;
+  // (more items than resident waves: FOUR waves per head instead — batch 288 / 384 / 768 at 12 heads, equal lengths 78.4 /
+  //  98.6 / 187.3 against the balanced kernel's 77.1 / 105.4 / 195.0 us, U{1..L} 46.3 / 56.7 / 103.2 against 45.4 / 59.3 / 107.7,
+  //  "3/4 full" 61.9 / 77.3 / 145.3 against 65.8 / 92.2 / 152.0, exponential 25.5 / 35.2 / 57.3 against 30.5 / 37.6 / 62.8;
+  //  behind only on "1/16 full, rest 1/16": 23.3 / 27.0 against 19.7 / 24.7)
+  const bool over_full = units > full_chip_waves() && head_size == 64 && block_size == 16 && nblk >= 32 && 3 * q_lds <= (size_t)160 * 1024;
+  const bool q64 = head_size == 64 && !over_full && (wph == 1 || near_full) && 3 * q_lds <= (size_t)160 * 1024;
   const bool q128 = head_size == 128 && wph == 1 && 2 * (q_lds + 4 * 1024) <= (size_t)160 * 1024;
   if (unit_scale && (q64 || q128) && !bf && block_size == 16 &&
       4.0 * (double)units * max_seq_len * head_size > 256e6) {  // (2 bytes per token and dim: past the Infinity Cache)
@@ -540,11 +545,11 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
     const int us = head_size == 64 ? 2 : 1;   // (blocks per group of its mode S: the row's U)
     for (int id = 1; id <= nvariants_v1(); ++id) {
       const Variant& c = variant_v1(id);
-      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == us && c.KM && !c.OVF) return id;  // K pass on MFMA
+      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == us && c.KM) return id;  // K pass on MFMA
     }
     for (int id = 1; id <= nvariants_v1(); ++id) {  // (formats without an "m" kernel: E5M2)
       const Variant& c = variant_v1(id);
-      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == us && !c.OVF) return id;
+      if (c.QUEUE && c.F8 == fmt && c.D == head_size && c.BS == 16 && c.U == us) return id;
     }
   }
   // Half a chip to 85 % of one (batch 128 .. 217 at 12 heads): FOUR waves per head, not the two that would just fill the
@@ -553,6 +558,7 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   // 50.5 / 61.6 -> 36.9 / 41.3 / 51.5 / 59.5 us, U{1..L} 34.2 / 34.1 / 36.9 / 40.7 -> 26.5 / 27.8 / 32.5 / 37.8 (the balanced
   // kernel there: 42.6 / 43.5 / 52.6 / 61.2 and 31.2 / 32.2 / 34.4 / 39.5).  Below batch 128 the rule above already gives four.
   if (head_size == 64 && block_size == 16 && wph == 2 && nblk >= 8) wph = 4;
+  if (over_full && wph == 1) wph = 4;
   if (mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   // (a full chip past the balanced kernel's LDS: the same choice by round efficiency as over fp16 pages — the logits are
@@ -592,8 +598,17 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   //  80 % to 7/8 of the resident waves: batch 208: 103.3 / 58.7 us against the balanced kernel's 104.6 / 61.9 on equal / ragged
   //  lengths, 224: 110.5 / 64.7 against 109.8 / 67.1, 240: 121.0 / 69.7 against 116.3 / 71.2)
   const bool near_full = wph == 2 && units * 8 >= full_chip_waves() * 7;
-  const bool balanced = allow_balanced && (wph == 1 || near_full) && nt && block_size == 16 && head_size == 64 &&
-                        3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
+  const bool lds_fits_q = 3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
+  // MORE items than resident waves (batch 257 and up at 12 heads): several waves per head again — eight from 1024 tokens on,
+  // four from 512 — i.e. many times the resident waves, handed out by the hardware dispatcher as workgroups finish.  Measured
+  // against the balanced kernel's ranked hand-out over 12 length distributions (scripts/default_vs_waves_probe.py,
+  // profiles/r03z_eight_waves_per_head.md): equal lengths level (batch 288 / 384 / 512 / 768: 144.1 / 182.7 / 240.0 / 355.3
+  // against 144.2 / 185.4 / 244.0 / 365.2 us), continuous spreads 3 - 13 % faster (U{1..L} 78.8 / 100.5 / 124.6 / 186.1 against
+  // 83.7 / 108.6 / 133.4 / 195.2), bimodal ones 3 - 9 %; behind only where nearly every sequence is very short (1/16 of them
+  // full, the rest 64 tokens: + 4 ... + 18 %).  The balanced kernel keeps the chip it was built for: 7/8 ... 1 x the resident waves.
+  const bool over_full = units > full_chip_waves() && head_size == 64 && block_size == 16 && nblk >= 32 && lds_fits_q;
+  const bool balanced = allow_balanced && !over_full && (wph == 1 || near_full) && nt && block_size == 16 && head_size == 64 &&
+                        lds_fits_q;
   const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
   if (ragged)
     while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
@@ -602,9 +617,10 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   // 95.0 us) and let the hardware dispatcher balance a ragged batch (44.4 / 51.8 / 59.3 -> 38.4 / 49.0 / 55.5; 2048 tokens,
   // batch 192: 111.4 -> 104.1; 4096: 251 -> 219).  From 512 tokens on (shorter contexts are launch-bound either way) and where
   // the long-context scoring below does not apply.  profiles/r03z_eight_waves_per_head.md
-  const bool lds_fits_q = 3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
+  if (over_full && wph == 1) wph = nblk >= 64 ? 8 : 4;
   // (head size 128 likewise, by a smaller margin: 32 heads x 48 sequences of 2048 tokens 253 -> 244 us equal, 155 -> 148 ragged)
-  if (!balanced && lds_fits_q && (head_size == 64 || head_size == 128) && block_size == 16 && (wph == 2 || wph == 4) && nblk >= 32)
+  if (!balanced && !over_full && lds_fits_q && (head_size == 64 || head_size == 128) && block_size == 16 && (wph == 2 || wph == 4) &&
+      nblk >= 32)
     wph = 8;
   // (only where the balanced kernel's LDS does not fit: shorter contexts keep the tuned picks — the fused append, which
   //  has no balanced twin, stays bit-identical to the call pair there)
@@ -621,7 +637,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
       // (sequence, head) on equal lengths, ranked work lists on ragged ones; needs 3 workgroups' LDS per CU
       for (int id = 1; id <= nvariants_v1(); ++id) {
         const Variant& c = variant_v1(id);
-        if (c.QUEUE && c.BF == bf && c.D == head_size && c.BS == 16 && !c.F8 && !c.KM && !c.OVF) return id;
+        if (c.QUEUE && c.BF == bf && c.D == head_size && c.BS == 16 && !c.F8 && !c.KM) return id;
       }
     }
     if (wph == 1 && u == 1 && nt) {  // full chip, one wave per head: the adaptive-depth form where one is built
@@ -807,7 +823,6 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
   const int lpad = ((max_seq_len + 31) / 32) * 32;  // whole blocks for every block size, 16-B aligned rows
   auto lds_of = [&](const Variant& c) { return variant_lds_bytes(c, lpad); };
   const bool gate_ok = variant == 0 && !append && !bsp && !f8;  // an explicit variant is run as asked
-  const bool auto_variant = variant == 0;                       // (... and so is a balanced kernel's OVF twin: chosen only here)
   g_cus = device_cus(device);  // the heuristics size the launch for THIS device
   Variant* sparse_v = nullptr;
   if (bsp) {  // one or four waves per head, by how many (seq, head) units there are to fill the chip with
@@ -925,21 +940,6 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
     int64_t g = (int64_t)cus * per_cu;
     if (g * 4 > items) g = (items + 3) / 4;
     pa_kernel_t fn = q.fn;
-    if (auto_variant && !gate && !q.OVF && items > g * 4 && items - g * 4 <= g) {
-      // a little more items than the grid has waves: the twin that knows the overflow schedule (same geometry and LDS)
-      for (int i = 0; i < g_queue_nvariants; ++i) {
-        const Variant& o = g_queue_variants[i];
-        if (o.OVF && o.D == q.D && o.BF == q.BF && o.F8 == q.F8 && o.KM == q.KM && o.U == q.U) {
-          if (qlds > 48 * 1024) {
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(o.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
-            if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-          }
-          fn = o.fn;
-          g_last_variant = nvariants_v1() - g_stage_nvariants - g_queue_nvariants + i + 1;
-          break;
-        }
-      }
-    }
     PAParams pq = p;
     pq.q_flags = g_queue_flags | gate;
     hipLaunchKernelGGL(fn, dim3((unsigned)g), dim3(256), qlds, static_cast<hipStream_t>(stream), pq);
@@ -962,7 +962,7 @@ static int launch_pa_v1(void* out, const void* query, const void* key_cache,
       num_seqs <= 2048 && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
     for (int i = 0; i < g_queue_nvariants; ++i)
       if (g_queue_variants[i].D == v.D && g_queue_variants[i].BF == v.BF && g_queue_variants[i].BS == v.BS &&
-          g_queue_variants[i].F8 == v.F8 && !g_queue_variants[i].KM && !g_queue_variants[i].OVF &&
+          g_queue_variants[i].F8 == v.F8 && !g_queue_variants[i].KM &&
           2 * variant_lds_bytes(g_queue_variants[i], lpad) <= (size_t)160 * 1024)
         partner = &g_queue_variants[i];
   }
