@@ -25,7 +25,7 @@ from test_parity_gpu import _bf16_tensor, _dev, _e5m2_case, _fp8_case, assert_cl
 pytestmark = pytest.mark.gpu
 
 NAME = re.compile(r"^(?P<bf>bf16_)?(?P<kv>fp8e5m2_|fp8_)?(?P<v2>v2_)?(?P<q>q_)?d(?P<D>\d+)(?:_bs(?P<bs>\d+))?"
-                  r"(?:_mh(?P<mh>\d+))?(?:_gq(?P<gq>\d+))?(?:_h(?P<h>\d+))?(?:_w(?P<w>\d+))?(?:_s(?P<s>\d+)q(?P<uq>\d+)(?P<km>m)?(?P<ovf>o)?)?"
+                  r"(?:_mh(?P<mh>\d+))?(?:_gq(?P<gq>\d+))?(?:_h(?P<h>\d+))?(?:_w(?P<w>\d+))?(?:_s(?P<s>\d+)q(?P<uq>\d+)(?P<km>m)?)?"
                   r"(?:_u(?P<u>\d+)(?:a(?P<a>\d+))?)?(?:_nt(?P<nt>\d))?(?P<pvm>_pvm)?(?P<lock>_lock)?$")
 
 
