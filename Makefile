@@ -1,4 +1,4 @@
-# Builds the C-ABI libraries (include/vmi_paged_attention.h) without Python: `make -j` — the same commands as
+# Builds the C-ABI libraries (include/vmi_paged_attention.h; the extras library also include/vmi_paged_attention_extras.h) without Python: `make -j` — the same commands as
 # `python -m vllmini_amd.build [--extras] [--diag]` (vllmini_amd/build.py), one object per translation unit.  gfx950 only.
 #   make            the PRODUCT library (what the operators load: the hot path of SURVEY.md §8 — float16 tensors over
 #                   float16 / fp8-E4M3 pages; the out-of-scope kernel menus are empty, pa_extras_absent.hip) + the CPU oracle
@@ -16,7 +16,7 @@ OUTDIR := vllmini_amd/_C
 CORE_UNITS := paged_attention pa_variants_extra pa_append_core pa_append_extra pa_variants_fp8 pa_queue
 ABSENT_UNITS := pa_extras_absent
 EXTRAS_UNITS := pa_variants_bf16 pa_append_bf16 pa_variants_fp8_bf16 pa_variants_fp8_e5m2 pa_variants_fp8_e5m2_bf16 \
-          pa_variants_sparse pa_variants_sparse_bf16 pa_f32 pa_extras_cache
+          pa_variants_sparse pa_variants_sparse_bf16 pa_f32 pa_extras_cache pa_extras_abi
 DIAG_UNITS := paged_attention pa_append_core pa_queue pa_stage
 # pa_queue.hip holds its bfloat16 / E5M2 rows behind -DVMI_EXTRAS: one object for the product, one for the other two
 OBJS   := $(CORE_UNITS:%=$(OUTDIR)/%.hip.o) $(ABSENT_UNITS:%=$(OUTDIR)/%.hip.o)
@@ -26,7 +26,7 @@ DIAG_OBJS := $(DIAG_UNITS:%=$(OUTDIR)/%.hip.diag.o) $(filter-out $(DIAG_UNITS:%=
 LIB    := $(OUTDIR)/libvmi_paged_attention.so
 EXTRAS_LIB := $(OUTDIR)/libvmi_paged_attention_extras.so
 DIAG_LIB := $(OUTDIR)/libvmi_paged_attention_diag.so
-DEPS   := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/vmi_paged_attention.h
+DEPS   := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/vmi_paged_attention.h include/vmi_paged_attention_extras.h
 
 all: $(LIB) oracle
 

@@ -101,6 +101,8 @@ def build_parser():
     ap.add_argument("--no-ragged", action="store_true", help="skip the extra ragged-batch measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the extra BASELINE configs[3] measurement")
+    ap.add_argument("--no-cfg2", action="store_true", help="skip the extra BASELINE configs[1] measurement")
+    ap.add_argument("--no-strong", action="store_true", help="skip the N = 1 anchor of the strong-scaling curve (batch 2048 on one GPU)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the extra end-to-end GPT-2 measurement")
     ap.add_argument("--noop-instead-of-reshape", action="store_true",
                     help="diagnostic: a 4-byte fill kernel takes reshape_and_cache's place in the step")
@@ -133,7 +135,7 @@ def parse_args(argv=None):
     args = build_parser().parse_args(argv)
     if args.headline_only:
         args.no_cpu_baseline = args.no_fused = args.no_fp8 = args.no_ragged = args.no_graph = True
-        args.no_cfg4 = args.no_e2e = True
+        args.no_cfg4 = args.no_e2e = args.no_cfg2 = args.no_strong = True
     args.kernel_samples = max(50, args.kernel_samples)
     return args
 
@@ -342,7 +344,7 @@ def device_sync(dev):
     return (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else None
 
 
-def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
+def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1", legacy=False):
     """W untimed steps, then EXACTLY K timed steps between barrier+synchronize pairs
     (vllmini_amd/shard.py:timed_steps — the same code the 2-rank gloo test exercises).  The timed region holds the
     steps and, for N > 1, the per-step token exchange: no event records, no host reads."""
@@ -350,9 +352,12 @@ def time_steps(wl, out, steps, warmup, variant, dist, dev, op="v1"):
 
     def step(i):
         one_step(wl, out, i, variant, op)
-        exchange_tokens(dist, i)
+        if legacy:      # rounds 1-2: a BLOCKING exchange on every step (the compute stream waits for the collective)
+            exchange_tokens(dist, None)
+        else:
+            exchange_tokens(dist, i)
 
-    elapsed = shard.timed_steps(step, steps, warmup, dist, sync=device_sync(dev))   # (its closing device synchronise
+    elapsed = shard.timed_steps(step, steps, warmup, dist, sync=device_sync(dev), clock_behind_barrier=legacy)   # (its closing device synchronise
     if dist is not None:                                                             #  covers the process group's stream)
         for w in _EXCHANGE["work"]:
             if w is not None:
@@ -402,9 +407,11 @@ def exchange_pass(n, dist, dev):
 
 
 def kernel_stats(kern_ms, dist, dev):
-    """mean / median / min of one rank's samples; for N > 1 the slowest rank's figure of each."""
-    return {k: shard.max_over_ranks(f(kern_ms), dist, dev) * 1e3
-            for k, f in (("mean", statistics.mean), ("median", statistics.median), ("min", min))}
+    """mean / median / min of one rank's samples; for N > 1 the slowest rank's figure of each, and every rank's median."""
+    ks = {k: shard.max_over_ranks(f(kern_ms), dist, dev) * 1e3
+          for k, f in (("mean", statistics.mean), ("median", statistics.median), ("min", min))}
+    ks["median_per_rank"] = [m * 1e3 for m in shard.all_ranks(statistics.median(kern_ms), dist, dev)]
+    return ks
 
 
 def graph_steps(wl, out, steps, variant, dev, per_graph=1):
@@ -650,7 +657,19 @@ def standin_main(args, dist, rank, world, dev):
         for w in _EXCHANGE["work"]:       # (on CPU there is no device synchronise: the asynchronous gathers end here)
             if w is not None:
                 w.wait()
+        _EXCHANGE["work"] = [None, None]
+    per_rank = shard.all_ranks(elapsed / args.steps * 1e3, dist, dev)     # the N > 1 line's per-rank figures, same code path
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    legacy = None
+    if dist is not None:     # the rounds-1-2 method beside it: blocking exchange on every step, clock behind the barrier
+
+        def legacy_step(i):
+            x.mul_(1.0)
+            exchange_tokens(dist, None)
+
+        l_el = shard.max_over_ranks(shard.timed_steps(legacy_step, args.steps, args.warmup, dist, clock_behind_barrier=True), dist, dev)
+        legacy = {"method_version": 2, "ms_per_step": l_el / args.steps * 1e3, "value": batch * world * args.steps / l_el,
+                  "unit": "tokens/s", "timing_bracket": shard.TIMING_BRACKET_LEGACY, "token_exchange": "blocking all_gather on every step"}
     if dist is not None:
         g = _EXCHANGE["gathered"]
         assert g.numel() == batch * world and int(g[-1]) == g.numel() - 1
@@ -663,6 +682,8 @@ def standin_main(args, dist, rank, world, dev):
                    "vs_baseline": None, "dtype": "f32", "data": "stand-in",
                    "config": {"workload": "stand-in step on CPU over gloo", "global_batch": batch * world},
                    "roofline": None, "cpu_baseline": None,
+                   "method_version": 3, "timing_bracket": shard.TIMING_BRACKET, "ms_per_step_per_rank": per_rank,
+                   "legacy_method_step": legacy,
                    "self_launched": os.environ.get("VMI_BENCH_SELF_LAUNCHED") == "1"})
 
 
@@ -679,6 +700,69 @@ def pair_record(wl, out, args, variant, dist, dev, tokens, nbytes, op="v1"):
         gbps = nbytes / (ks["median"] * 1e-6) / 1e9
         rec.update({"algorithmic_bytes_per_launch": nbytes, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS})
     return rec, ks
+
+
+def rocprof_kernel_us(cfg_name: str, kernel_variant: str):
+    """The attention kernel's average duration in the latest committed rocprofv3 --kernel-trace --stats pass for this workload
+    and kernel (profiles/pmc_<cfg>_latest.json), or None — bench.py cannot run a profiler around itself."""
+    path = os.path.join(REPO, "profiles", f"pmc_{cfg_name}_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("kernel_variant") and d["kernel_variant"] != kernel_variant:
+            return None, None
+        return d["rocprofv3_kernel_us"]["mean"], os.path.relpath(path, REPO)
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
+
+
+def cfg2_record(args, dist, rank, world, dev):
+    """BASELINE configs[1]: batch 32, seq_len 512, 12 heads x 64, num_blocks 4096 — 50 MB per launch, resident in the 256 MiB
+    Infinity Cache, 384 (sequence, head) units on 256 CUs: a LATENCY chain, not a stream, so no fraction of the HBM peak is
+    quoted.  The launch is shorter than the host's work per call, so three figures: the plain call pair (host-bound), the
+    attention kernel between HIP events (reads empty_event_pair_us high), and the pair replayed from a hipGraph of 48 pairs
+    (the device's own time per pair)."""
+    from vllmini_amd import ops
+    c2 = CONFIGS["cfg2"]
+    wl2 = make_workload(c2, dev, seed=55 + rank, table_sets=2)
+    out2 = torch.empty((c2.batch, c2.num_heads, c2.head_size), dtype=torch.float16, device=dev)
+    rec, _ = pair_record(wl2, out2, args, 0, dist, dev, c2.batch * world * args.steps, 0)
+    v2 = ops.variant_names()[ops.last_variant() - 1]
+    n_g = 96
+    g = graph_steps(wl2, out2, n_g, 0, dev, per_graph=48)
+    us, src = rocprof_kernel_us("cfg2", v2)
+    return {"op": "reshape_and_cache + paged_attention_v1, BASELINE configs[1]: batch 32/GPU, seq_len 512, 12 heads x 64, "
+                  "block_size 16, num_blocks 4096, fp16", **rec, "kernel_variant": v2,
+            "algorithmic_bytes_per_launch": alg_bytes(c2, "auto"),
+            "graph_us_per_pair": g / n_g * 1e6,
+            "rocprofv3_kernel_us": us, "rocprofv3_source": src,
+            "regime": "Infinity-Cache-resident (50 MB per launch, two table sets = 100 MB of a 201 MB pool) and under-filled (384 "
+                      "units on 256 CUs): a latency chain — launch, table + q, K pages, barrier, softmax, V pages, barrier, store "
+                      "(profiles/r04_underfilled_chip.md) — not an HBM stream: no frac quoted",
+            "note": "ms_per_step is host-bound (the call pair's Python + launch work exceeds its 17 us of kernels); "
+                    "kernel_us_* include the event pair's own empty_event_pair_us; graph_us_per_pair = reshape_and_cache + "
+                    "paged_attention_v1 + gaps on the device, 48 pairs per graph"}
+
+
+def strong_n1_record(args, dev):
+    """The N = 1 anchor of the STRONG-scaling curve (BASELINE.md §2 last row): all 2048 sequences of BASELINE
+    configs[4] on one GPU, pool = max(65536, what two disjoint table sets need) blocks.  2048 = QSORT_MAX, the most sequences
+    the balanced kernel ranks (pa_queue.hpp); the default entry's pick is reported."""
+    import dataclasses
+    from vllmini_amd import ops
+    c5 = CONFIGS["cfg5"]
+    b_ = 2048
+    c5 = dataclasses.replace(c5, name="cfg5_strong_n1", batch=b_, num_blocks=max(c5.num_blocks, 2 * b_ * c5.blocks_per_seq))
+    wl5 = make_workload(c5, dev, seed=91, table_sets=2)
+    out5 = torch.empty((b_, c5.num_heads, c5.head_size), dtype=torch.float16, device=dev)
+    rec, _ = pair_record(wl5, out5, args, 0, None, dev, b_ * args.steps, alg_bytes(c5, "auto"))
+    v5 = ops.variant_names()[ops.last_variant() - 1]
+    del wl5, out5
+    torch.cuda.empty_cache()
+    return {"op": "reshape_and_cache + paged_attention_v1, BASELINE configs[4] on ONE GPU: batch 2048, seq_len 1024, 12 heads x 64, "
+                  f"block_size 16, num_blocks {c5.num_blocks}, fp16", **rec, "kernel_variant": v5,
+            "note": "N = 1 point of `--scaling strong` (2048 sequences in all, 2048/N per GPU); batch 2048 = QSORT_MAX; "
+                    "the weak-scaling N = 1 point is the headline itself (256 sequences per GPU)"}
 
 
 def random_fp8_codes(shape, dev, gen):
@@ -755,7 +839,7 @@ def main(argv=None):
         KV_DTYPE = args.kv
         if args.op != "v1":
             raise SystemExit("--kv fp8 is built for --op v1")
-        args.no_fused = args.no_cpu_baseline = args.no_cfg4 = args.no_e2e = True
+        args.no_fused = args.no_cpu_baseline = args.no_cfg4 = args.no_e2e = args.no_cfg2 = args.no_strong = True
         gk = torch.Generator(device=dev).manual_seed(99 + rank)
         kshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size // 16, cfg.block_size, 16)
         vshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size, cfg.block_size)
@@ -824,8 +908,15 @@ def main(argv=None):
         "paged_attention_v1_us_median": ks["median"],
         "paged_attention_v1_us_mean": ks["mean"],
         "paged_attention_v1_us_min": ks["min"],
+        "paged_attention_v1_us_median_per_rank": ks["median_per_rank"],
         "kernel_event_samples": args.kernel_samples,
         "empty_event_pair_us": empty_event_pair_us(dev),
+        "method_version": 3,
+        "method": "v3 (round 3 on): event-free timed region; " + shard.TIMING_BRACKET + "; for N > 1 the token all_gather runs "
+                  f"once per token (every {EXCHANGE_EVERY}th layer step), asynchronously on the process group's stream.  v2 (rounds "
+                  "1-2): a blocking all_gather on EVERY step, clock stopped behind the closing barrier — for N > 1 the line carries "
+                  "that figure too (`legacy_method_step`), so round-over-round comparisons need not mix method and kernel changes",
+        "timing_bracket": shard.TIMING_BRACKET,
         "kernel_event_pass": "separate from the timed region: one HIP event pair around every attention launch of "
                              f"{args.kernel_samples} call pairs; roofline.achieved uses the median",
         "roofline": {
@@ -854,6 +945,12 @@ def main(argv=None):
                                   "and waited for one token later and before the closing synchronise; token_exchange_us = median "
                                   f"of {args.kernel_samples} BLOCKING exchanges alone, by HIP events")
         line["token_exchange_every_steps"] = EXCHANGE_EVERY
+        # the SAME K steps the way rounds 1-2 measured them: blocking exchange on every step, clock behind the barrier
+        l_elapsed = shard.max_over_ranks(time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op, legacy=True),
+                                         dist, dev)
+        line["legacy_method_step"] = {"method_version": 2, "ms_per_step": l_elapsed / args.steps * 1e3, "value": tokens / l_elapsed,
+                                      "unit": "tokens/s", "timing_bracket": shard.TIMING_BRACKET_LEGACY,
+                                      "token_exchange": "blocking all_gather on every step"}
     if args.op == "v1" and not args.no_fused:
         # the same step as ONE launch (vmi_paged_attention_v1_append_f16: bit-identical caches and out,
         # tests/test_parity_gpu.py); reported beside `value`, which stays the reference's two-op call pair
@@ -876,14 +973,19 @@ def main(argv=None):
             wl.key_cache, wl.value_cache = k16, v16
         line["fp8_kv_step"] = {"op": "reshape_and_cache + paged_attention_v1, kv_cache_dtype='fp8' (E4M3), kv_scale 1.0", **rec}
     if plain and not args.no_graph and dist is None and not args.skip_reshape:
-        g_elapsed = graph_steps(wl, out, args.steps, args.variant, dev)
-        line["graph_step"] = {"op": "reshape_and_cache + paged_attention_v1 replayed from one hipGraph per table set",
-                              "value": cfg.batch * args.steps / g_elapsed, "unit": "tokens/s",
-                              "ms_per_step": g_elapsed / args.steps * 1e3}
-        # ... and the way a decode loop would use it: the 12 layers' call pairs of one token in ONE graph
-        g_elapsed = graph_steps(wl, out, max(args.steps, 24), args.variant, dev, per_graph=12)
-        line["graph_step"]["steps_per_graph"] = {"steps": 12, "ms_per_step": g_elapsed / max(args.steps, 24) * 1e3,
-                                                 "value": cfg.batch * max(args.steps, 24) / g_elapsed}
+        # what a decode loop captures: the 12 layers' call pairs of one token in ONE hipGraph (gpt2_decode.py replays the whole
+        # step that way).  The record is THAT form; one pair per graph is kept only as the measured cost of a graph launch.
+        n_g = max(args.steps, 24)
+        g12 = graph_steps(wl, out, n_g, args.variant, dev, per_graph=12)
+        g1 = graph_steps(wl, out, args.steps, args.variant, dev)
+        line["graph_step"] = {"op": "reshape_and_cache + paged_attention_v1, a token's 12 layer call pairs replayed from ONE hipGraph",
+                              "value": cfg.batch * n_g / g12, "unit": "tokens/s", "ms_per_step": g12 / n_g * 1e3,
+                              "pairs_per_graph": 12,
+                              "one_pair_per_graph_ms_per_step": g1 / args.steps * 1e3,
+                              "note": "level with plain launches (the call pair is not launch-bound: ms_per_step above); with ONE "
+                                      "pair per graph a step costs one_pair_per_graph_ms_per_step — a hipGraphLaunch costs "
+                                      f"{(g1 / args.steps - g12 / n_g) * 1e6:.1f} us more than the two kernel launches it replaces on this "
+                                      "ROCm, amortised over the 12 pairs here"}
     if plain and not args.no_ragged and not args.variant and not args.sequential_tables:
         # the same call pair, same default entry (no hint, no variant), on a RAGGED batch: seq_lens ~ U{1..seq_len}
         pools = (wl.key_cache, wl.value_cache)
@@ -921,6 +1023,10 @@ def main(argv=None):
                                      "kernel issues NO MFMA; the matrix cores are used by the grouped-query kernels only"}
         del wl4, out4
         torch.cuda.empty_cache()
+    if plain and not args.no_cfg2 and args.config == "cfg3" and not args.variant:
+        line["cfg2_step"] = cfg2_record(args, dist, rank, world, dev)
+    if plain and not args.no_strong and args.config == "cfg3" and not args.variant and dist is None:
+        line["cfg5_strong_n1"] = strong_n1_record(args, dev)
     if plain and not args.no_e2e and args.config == "cfg3" and not args.variant:
         res = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context)
         line["e2e_step"] = {k: res[k] for k in ("metric", "value", "unit", "ms_per_step", "context", "batch_per_gpu", "note",

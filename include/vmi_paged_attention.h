@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 19
+#define VMI_ABI_VERSION 20
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -55,7 +55,9 @@ enum {
   VMI_E_MAX_SEQ_LEN = 7,         /* logits for max_seq_len do not fit in the 160 KiB LDS of one CU    */
   VMI_E_VARIANT = 8,             /* unknown tuning variant id                                         */
   VMI_E_X = 9,                   /* key_cache innermost dimension is not 8 halves                     */
-  VMI_E_NOT_BUILT = 10           /* an out-of-scope operator asked of the product library (see vmi_has_extras) */
+  VMI_E_NOT_BUILT = 10           /* internal guard: a kernel menu of this library is empty for the case asked; no entry of
+                                    THIS header can return it (ABI 20: the out-of-scope entries left for
+                                    vmi_paged_attention_extras.h and are not exported by the product library) */
 };
 
 /* Library identity / diagnostics. */
@@ -71,8 +73,8 @@ const char* vmi_target_arch(void);
  *           block_tables, seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
  *           kv_scale, tp_rank, blocksparse_*)          — attention_kernels.cu:805-826.
  * kv_cache_dtype / kv_scale select the _fp8 entries below; tp_rank and the blocksparse arguments only matter with
- * blocksparse_vert_stride > 1, which is vmi_paged_attention_v1_blocksparse (the reference callers pass "auto" and
- * block-sparse disabled; vllmini/model/gpt2.py:94-113).
+ * blocksparse_vert_stride > 1, which is out of this path's scope (vmi_paged_attention_extras.h; the reference callers pass
+ * "auto" and block-sparse disabled; vllmini/model/gpt2.py:94-113).
  *
  *   out            [num_seqs, num_heads, head_size] fp16, contiguous          (written)
  *   query          [num_seqs, num_heads, head_size] fp16, row stride q_stride (may be 3*hidden)
@@ -97,44 +99,6 @@ int vmi_paged_attention_v1_f16(
     int32_t device, void* stream);
 
 /*
- * Block-sparse attention: paged_attention_v1 / paged_attention_v2 called with blocksparse_vert_stride > 1
- * (is_block_sparse, attention_kernels.cu:822 / :987; kernel :209-254, :385-393).  fp16 or bf16 tensors
- * (is_bf16), "auto" cache.  A cache block is read when the sparse block (blocksparse_block_size tokens) holding its
- * first token is
- *   "remote": (sparse_block + offset) % blocksparse_vert_stride == 0, with
- *             offset = (tp_rank * num_heads + head) * head_sliding_step + 1             (head_sliding_step >= 0)
- *                    = (tp_rank * num_kv_heads + kv_head) * (-head_sliding_step) + 1    (head_sliding_step <  0), or
- *   "local":  sparse_block > (seq_len - 1) / blocksparse_block_size - blocksparse_local_blocks;
- * every other block is skipped: not loaded, logits -FLT_MAX, no P.V contribution.  Same results as the dense
- * operator's arithmetic restricted to the attended blocks (oracle/pa_kernel_model.c, checked against a masked fp64
- * attention).  blocksparse_vert_stride <= 1 is an error here (call the dense entry).  No tuning variants.
- * The reference's own callers never enable this (gpt2.py:109-112 passes 0, 1, 1, 0).
- */
-int vmi_paged_attention_v1_blocksparse(
-    void* out, const void* query, const void* key_cache, const void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream, int32_t is_bf16, int32_t tp_rank,
-    int32_t blocksparse_local_blocks, int32_t blocksparse_vert_stride,
-    int32_t blocksparse_block_size, int32_t blocksparse_head_sliding_step);
-int vmi_paged_attention_v2_blocksparse(
-    void* out, float* exp_sums, float* max_logits, void* tmp_out,
-    const void* query, const void* key_cache, const void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream, int32_t is_bf16, int32_t tp_rank,
-    int32_t blocksparse_local_blocks, int32_t blocksparse_vert_stride,
-    int32_t blocksparse_block_size, int32_t blocksparse_head_sliding_step);
-
-/*
  * Same operator with an explicit tuning variant (work decomposition only — results are
  * identical across variants up to fp32 summation order).  variant = 0 selects the
  * built-in heuristic, i.e. exactly what vmi_paged_attention_v1_f16 runs.
@@ -142,32 +106,6 @@ int vmi_paged_attention_v2_blocksparse(
  */
 int vmi_paged_attention_v1_f16_variant(
     void* out, const void* query, const void* key_cache, const void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream, int32_t variant);
-
-/*
- * bfloat16 forms of the two attention operators (the reference dispatches on the element type,
- * quant_utils.cuh:529-566; arithmetic dtype_bfloat16.cuh).  Same arguments as the _f16 entries plus an
- * explicit variant (0 = heuristic; bf16 variant names start with "bf16_").  query/out/caches hold bfloat16.
- * reshape_and_cache / reshape_and_cache_flash / copy_blocks / swap_blocks are byte copies and serve both types.
- */
-int vmi_paged_attention_v1_bf16(
-    void* out, const void* query, const void* key_cache, const void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream, int32_t variant);
-int vmi_paged_attention_v2_bf16(
-    void* out, void* exp_sums, void* max_logits, void* tmp_out,
-    const void* query, const void* key_cache, const void* value_cache,
     int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
     float scale,
     const int32_t* block_tables, const int32_t* seq_lens,
@@ -192,17 +130,6 @@ int vmi_paged_attention_v2_bf16(
  * The first 20 arguments are those of vmi_paged_attention_v1_f16 (caches mutable here).
  */
 int vmi_paged_attention_v1_append_f16(
-    void* out, const void* query, void* key_cache, void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream,
-    const void* key, const void* value, int64_t key_stride, int64_t value_stride,
-    int32_t variant);
-int vmi_paged_attention_v1_append_bf16(
     void* out, const void* query, void* key_cache, void* value_cache,
     int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
     float scale,
@@ -253,77 +180,6 @@ int vmi_reshape_and_cache_fp8(
     int32_t device, void* stream);
 int vmi_paged_attention_v1_pick_variant_fp8(int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                             int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len);
-/* bfloat16 query / key / value over the same fp8 caches (the reference dispatches bf16 x uint8 as well):
- * load __float2bfloat16(float(fp8) * kv_scale) (quant_utils.cuh:350-359), store fp8(float(bf16) / kv_scale) (:468-478). */
-int vmi_paged_attention_v1_fp8_bf16(
-    void* out, const void* query, const void* key_cache, const void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream,
-    float kv_scale, int32_t variant);
-int vmi_reshape_and_cache_fp8_bf16(
-    const void* key, const void* value, void* key_cache, void* value_cache,
-    const int64_t* slot_mapping,
-    int32_t num_tokens, int32_t num_heads, int32_t head_size, int32_t block_size, int32_t x,
-    int64_t key_stride, int64_t value_stride, float kv_scale,
-    int32_t device, void* stream);
-int vmi_paged_attention_v1_pick_variant_fp8_bf16(int32_t num_seqs, int32_t num_heads, int32_t head_size,
-                                                 int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len);
-
-/*
- * kv_cache_dtype "fp8_e5m2" (Fp8KVCacheDataType::kFp8E5M2, __NV_E5M2: quant_utils.cuh:552-558): the same operators
- * over fp8 E5M2 bytes — an E5M2 byte is the upper byte of an IEEE half, infinities and NaNs included.  Element seen
- * by the attention arithmetic = half(float(fp8) * kv_scale) (bfloat16 query: bf16(float(fp8) * kv_scale)), cache
- * byte written by reshape_and_cache = fp8(float(x) / kv_scale), round to nearest even, saturating at +-57344
- * (__NV_SATFINITE).  Same layouts and limits as the E4M3 entries above (x = 16; block sizes 16 and 32);
- * is_bf16 selects bfloat16 query / rows.  Variant ids: the "fp8e5m2_" / "bf16_fp8e5m2_" names.
- */
-int vmi_paged_attention_v1_fp8_e5m2(
-    void* out, const void* query, const void* key_cache, const void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream,
-    float kv_scale, int32_t variant, int32_t is_bf16);
-int vmi_paged_attention_v2_fp8_e5m2(   /* float16 query */
-    void* out, void* exp_sums, void* max_logits, void* tmp_out,
-    const void* query, const void* key_cache, const void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream,
-    float kv_scale, int32_t variant);
-/* paged_attention_v2, bfloat16 query / out / tmp_out over fp8 pages of either format (is_e5m2) */
-int vmi_paged_attention_v2_fp8_bf16(
-    void* out, void* exp_sums, void* max_logits, void* tmp_out,
-    const void* query, const void* key_cache, const void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream,
-    float kv_scale, int32_t variant, int32_t is_e5m2);
-int vmi_reshape_and_cache_fp8_e5m2(
-    const void* key, const void* value, void* key_cache, void* value_cache,
-    const int64_t* slot_mapping,
-    int32_t num_tokens, int32_t num_heads, int32_t head_size, int32_t block_size, int32_t x,
-    int64_t key_stride, int64_t value_stride, float kv_scale,
-    int32_t device, void* stream, int32_t is_bf16);
-int vmi_paged_attention_v1_pick_variant_fp8_e5m2(int32_t num_seqs, int32_t num_heads, int32_t head_size,
-                                                 int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len,
-                                                 int32_t is_bf16);
 
 /* Number of tuning variants (valid ids are 1..count) and a short name for each. */
 int vmi_paged_attention_v1_variant_count(void);
@@ -338,7 +194,8 @@ int vmi_paged_attention_v1_pick_variant(int32_t num_seqs, int32_t num_heads, int
  */
 int vmi_paged_attention_v1_pick_variant_gqa(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads,
                                             int32_t head_size, int32_t block_size, int32_t max_seq_len,
-                                            int32_t is_bf16, int32_t is_fp8 /* 0, 1 = E4M3, 2 = E5M2 */);
+                                            int32_t is_bf16 /* extras library only; the product answers 0 */,
+                                            int32_t is_fp8 /* 0, 1 = E4M3; 2 = E5M2: extras library only */);
 
 /*
  * Opt-in accuracy/speed switch for grouped-query attention (process-wide, default 0; returns the previous value).
@@ -431,48 +288,6 @@ int vmi_reshape_and_cache_f16(
     int32_t device, void* stream);
 
 /*
- * cache_ops.reshape_and_cache_flash — cache_kernels.cu:283-317 (kernel :209-240): scatter rows into the
- * flash layout k_cache / v_cache [num_blocks, block_size, num_heads, head_size]; any 2-byte element type.
- * block_stride = k_cache.stride(0) (must equal v_cache.stride(0), :302).
- */
-int vmi_reshape_and_cache_flash_16(const void* key, const void* value, void* k_cache, void* v_cache,
-                                   const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
-                                   int32_t head_size, int32_t block_size, int64_t block_stride,
-                                   int64_t key_stride, int64_t value_stride, int32_t device, void* stream);
-
-/*
- * float32 tensors — the (float, float) branch of the reference's dispatch (quant_utils.cuh:529-535): query / out /
- * caches float32, x = 16 / sizeof(float) = 4: key_cache [NB, H, D/4, BS, 4], value_cache [NB, H, D, BS]; strides in
- * elements; every operation in fp32 (dtype_float32.cuh).  The reference's callers never use it (scheduler.py:13 runs the
- * model in half): one plain kernel per (head size, block size), no tuning variants, paged_attention_v1 and
- * reshape_and_cache only.
- */
-int vmi_paged_attention_v1_f32(
-    void* out, const void* query, const void* key_cache, const void* value_cache,
-    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-    float scale,
-    const int32_t* block_tables, const int32_t* seq_lens,
-    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-    const float* alibi_slopes,
-    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    int32_t device, void* stream);
-int vmi_reshape_and_cache_f32(
-    const void* key, const void* value, void* key_cache, void* value_cache,
-    const int64_t* slot_mapping,
-    int32_t num_tokens, int32_t num_heads, int32_t head_size, int32_t block_size, int32_t x,
-    int64_t key_stride, int64_t value_stride,
-    int32_t device, void* stream);
-
-/*
- * cache_ops.convert_fp8(dst_cache, src_cache, kv_scale, kv_cache_dtype) — cache_kernels.cu:320-392 ("only for
- * testing" in the reference; compiled to assert(false) in its shipped build).  Elementwise over num_elements contiguous
- * elements: to_fp8 != 0: dst (uint8 E4M3) = fp8(float(src) / kv_scale), RNE, saturating; to_fp8 == 0: dst =
- * half / bfloat16 / float of (float(fp8) * kv_scale).  kind: 0 = half, 1 = bfloat16, 2 = float (the non-fp8 side).
- */
-int vmi_convert_fp8(void* dst, const void* src, int64_t num_elements, float kv_scale, int32_t kind, int32_t to_fp8,
-                    int32_t device, void* stream);
-
-/*
  * cache_ops.copy_blocks — cache_kernels.cu:96-148 (kernel :68-94).  For every layer l and pair p:
  * K_l[dst_p] = K_l[src_p], V_l[dst_p] = V_l[src_p].
  *   key_cache_ptrs / value_cache_ptrs   HOST arrays of num_layers DEVICE pointers (one cache per layer)
@@ -501,10 +316,10 @@ int vmi_is_diag_build(void);
 /*
  * 0 for the product library (libvmi_paged_attention.so): the hot path of SURVEY.md §8 — float16 tensors over float16 or
  * fp8-E4M3 pages, every head / block size of the reference's dispatch, grouped-query heads, ALiBi, paged_attention_v2, the
- * fused append, copy/swap_blocks.  1 for libvmi_paged_attention_extras.so (`build.py --extras`), which adds the rest of the
+ * fused append, copy/swap_blocks — i.e. exactly the entries of THIS header.  1 for libvmi_paged_attention_extras.so
+ * (`build.py --extras`), which exports, in addition, the entries of vmi_paged_attention_extras.h: the rest of the
  * reference's dispatch surface — bfloat16 and float32 tensors, fp8-E5M2 pages, block-sparse attention,
- * reshape_and_cache_flash, convert_fp8 (out of the path's scope).  Every entry of this header
- * exists in both; in the product library the out-of-scope ones return VMI_E_NOT_BUILT and their kernel menus are empty.
+ * reshape_and_cache_flash, convert_fp8 (out of the path's scope).
  */
 int vmi_has_extras(void);
 

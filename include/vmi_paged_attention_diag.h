@@ -49,6 +49,16 @@ int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chu
  */
 int vmi_diag_set_wave_timeline(void* records, int32_t device);
 
+/*
+ * Diagnostic: stage stamps of pa_v1_kernel (the kernels of the block-16 x head-64/128 menu, pa_table_core.inc).
+ * `records` is device memory for 12 x uint64 per wave of the launch, in (z, y, x) workgroup order x wave: ten stamps in ticks
+ * of the constant 100 MHz clock — entry, seq_len known, first pages requested, first K group consumed, K pass done, maxima
+ * exchanged, probabilities written, V pass done, partial outputs exchanged, out stored — then HW_REG_HW_ID and
+ * HW_REG_XCC_ID | (blocks of this wave << 8).  Written by every later launch on `device` until set to NULL again.
+ * scripts/stage_timeline_probe.py reads it: the latency chain of an under-filled chip, term by term.  Synchronous.
+ */
+int vmi_diag_set_stage_stamps(void* records, int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,10 @@ Fixtures written:
                     32 tokens, block 16, max_blocks_per_seq 4), with strides, plus the allocator state
                     (free list, block tables) after every decode step -> pins the host-side
                     mirror and replays reference-produced inputs through the HIP kernels.
+  capacity_trace.npz  the same stack (tiny random-weight config) with max_length ABOVE the capacity of a sequence's block
+                    table (max_blocks_per_seq * block_size = the max_seq_len of scheduler.py:97): every seam call and
+                    allocator state up to the step where the reference itself fails (block_manager.py:36-39 finds no -1 in
+                    a full row) -> pins what the reference's callers can and cannot hand to the kernel at capacity.
   gpt2_tiny_decode.npz  the reference's GPT2LMHeadModel + BlockManager (tiny random-weight config, fp16,
                     prompt of 6 tokens then 30 forced decode tokens crossing two block boundaries): weights,
                     tokens and the logits of every step -> pins the batched decode harness
@@ -259,6 +263,74 @@ def gen_seam_trace(out_path: str, rec: SeamRecorder):
 
 
 # ------------------------------------------------------------------------------------------------
+# fixture 2b: a sequence that reaches the CAPACITY of its block table (round 4)
+# ------------------------------------------------------------------------------------------------
+def gen_capacity_trace(out_path: str, rec: SeamRecorder):
+    """The reference's Scheduler passes max_seq_len = max_blocks_per_seq * block_size — the capacity of a sequence's block
+    table — to every paged_attention_v1 call (scheduler.py:97) and lets a sequence grow until max_length.  With max_length
+    ABOVE that capacity the reference never gets as far as seq_len > max_seq_len: BlockManager.decode_step looks for the
+    first -1 of the table row to find the last block (block_manager.py:36-39), and once the row is full there is none — the
+    step after the last block was appended dies in Python.  This fixture records that run to its end: every seam call, the
+    allocator after every completed decode step, the largest seq_len the kernel ever saw against max_seq_len, and how the
+    reference failed.  The drop-in's own behaviour past that point (seq_len > max_seq_len: truncated; the reference kernel
+    would overflow its logits buffer) is therefore OUTSIDE what the reference's callers can produce; tests/ pin both facts."""
+    from transformers import GPT2Config
+    from vllmini.block_manager import BlockManager
+    from vllmini.model.gpt2 import GPT2LMHeadModel
+    from vllmini.scheduler import Scheduler
+
+    torch.manual_seed(3)
+    cfg = GPT2Config(vocab_size=512, n_positions=128, n_embd=256, n_layer=2, n_head=4, eos_token_id=511)
+    model = GPT2LMHeadModel(cfg).eval()
+    num_blocks, block_size, max_blocks_per_seq, max_length = 64, 16, 4, 80      # capacity 64 tokens < max_length
+    H, D = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    bm = BlockManager(num_blocks, block_size, H, D, max_blocks_per_seq)
+    sched = Scheduler(model, bm, max_length=max_length)
+    alloc_trace = []
+    orig_decode_step = bm.decode_step
+
+    def traced_decode_step(seq_id, input_len):
+        tables, slots = orig_decode_step(seq_id, input_len)
+        alloc_trace.append({"free_blocks": list(bm.kv_cache.free_blocks),
+                            "block_tables": np.stack([t.numpy().copy() for t in tables]),
+                            "slots": np.array([int(s_.item()) for s_ in slots], dtype=np.int64)})
+        return tables, slots
+
+    bm.decode_step = traced_decode_step
+    rec.calls.clear()
+    prompt = torch.tensor([[17, 301, 45, 7, 222]], dtype=torch.long)
+    failure = None
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        seq_id = sched.add_sequence(prompt)
+        try:
+            sched.run()
+        except Exception as e:  # noqa: BLE001 — whatever the reference does at capacity IS the datum
+            failure = {"type": type(e).__name__, "message": str(e)}
+    assert failure is not None, "the reference was expected to fail once the table row is full"
+    pa = [c for c in rec.calls if c["op"] == "paged_attention_v1"]
+    arrays = {"meta": np.array(json.dumps({
+        "num_blocks": num_blocks, "block_size": block_size, "max_blocks_per_seq": max_blocks_per_seq, "max_length": max_length,
+        "num_layers": cfg.num_hidden_layers, "num_heads": H, "head_size": D, "prompt_len": int(prompt.shape[1]),
+        "num_calls": len(rec.calls), "num_decode_steps": len(alloc_trace), "failure": failure,
+        "sequence_length_at_failure": int(sched.sequence_lengths[seq_id]),
+        "max_seq_len_passed": int(pa[-1]["max_seq_len"]), "largest_seq_len_passed": int(max(int(c["seq_lens"][0]) for c in pa)),
+        "free_blocks_at_failure": list(bm.kv_cache.free_blocks)})),
+        "final_key_cache": bm.kv_cache.key_cache.numpy(), "final_value_cache": bm.kv_cache.value_cache.numpy(),
+        "final_table": np.stack([t.numpy().copy() for t in bm.kv_cache.paged_attention_block_tables[seq_id]])}
+    for i, c in enumerate(rec.calls):
+        for k, v in c.items():
+            if k in ("key_strides", "value_strides", "query_strides", "out_shape"):
+                v = np.array(v, dtype=np.int64)
+            arrays[f"call{i:04d}/{k}"] = np.array(v)
+    for i, a_ in enumerate(alloc_trace):
+        for k, v in a_.items():
+            arrays[f"alloc{i:03d}/{k}"] = np.array(v, dtype=np.int64) if k != "block_tables" else v
+    np.savez_compressed(out_path, **arrays)
+    print(f"wrote {out_path}: {len(rec.calls)} seam calls, {len(alloc_trace)} decode steps, failure={failure}, "
+          f"largest seq_len {arrays['meta']}")
+
+
+# ------------------------------------------------------------------------------------------------
 # fixture 3: the reference model as the caller (tiny GPT-2, forced tokens)
 # ------------------------------------------------------------------------------------------------
 def gen_gpt2_tiny(out_path: str):
@@ -343,11 +415,18 @@ def main():
     oracle.build()
     rec = SeamRecorder()
     install_stub(rec)
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""     # e.g. `--only capacity`: leave the others as committed
     with CudaToCpu():
-        gen_ref_eager(os.path.join(HERE, "ref_eager.npz"))
-        gen_seam_trace(os.path.join(HERE, "seam_trace.npz"), rec)
-        gen_gpt2_tiny(os.path.join(HERE, "gpt2_tiny_decode.npz"))
-        run_reference_selftest(os.path.join(HERE, "ref_selftest.json"))
+        if only in ("", "eager"):
+            gen_ref_eager(os.path.join(HERE, "ref_eager.npz"))
+        if only in ("", "seam"):
+            gen_seam_trace(os.path.join(HERE, "seam_trace.npz"), rec)
+        if only in ("", "capacity"):
+            gen_capacity_trace(os.path.join(HERE, "capacity_trace.npz"), rec)
+        if only in ("", "gpt2"):
+            gen_gpt2_tiny(os.path.join(HERE, "gpt2_tiny_decode.npz"))
+        if only in ("", "selftest"):
+            run_reference_selftest(os.path.join(HERE, "ref_selftest.json"))
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert os.path.exists(path)
     lib = ctypes.CDLL(path)
     assert sorted(os.path.basename(h) for h in glob.glob(os.path.join(REPO, "include", "*.h"))) == \
-        ["vmi_paged_attention.h", "vmi_paged_attention_diag.h"]
+        ["vmi_paged_attention.h", "vmi_paged_attention_diag.h", "vmi_paged_attention_extras.h"]
     declared = _declared_symbols()
     assert {"vmi_paged_attention_v1_f16", "vmi_reshape_and_cache_f16", "vmi_last_error_string",
             "vmi_abi_version"} <= set(declared)
@@ -45,7 +45,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 19
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 20
     assert typed.vmi_target_arch() == b"gfx950"
     assert typed.vmi_is_diag_build() == 0 and typed.vmi_has_extras() == 0
 
@@ -57,8 +57,8 @@ def test_product_library_holds_the_hot_path_and_nothing_else():
     """libvmi_paged_attention.so = SURVEY.md §8: float16 tensors over float16 / fp8-E4M3 pages.  The out-of-scope corners of
     the reference's dispatch (bfloat16 / float32 tensors, E5M2 pages, block-sparse attention, reshape_and_cache_flash,
     convert_fp8: SURVEY.md §2 rows 8-10) are NOT in it — no kernel in its symbol table, no row in its menus, and their
-    C-ABI entries (which exist in every build, so one header serves both) return VMI_E_NOT_BUILT with a message that says
-    where they live.  libvmi_paged_attention_extras.so holds the same objects plus those."""
+    C-ABI entries (include/vmi_paged_attention_extras.h) are not exported by it; the Python operators raise RuntimeError with a
+    message that says where they live.  libvmi_paged_attention_extras.so holds the same objects plus those."""
     from vllmini_amd import _lib, build, ops
 
     path = build.build()
@@ -77,15 +77,18 @@ def test_product_library_holds_the_hot_path_and_nothing_else():
     assert any(n.startswith("q_d64") for n in names) and any(n.startswith("fp8_q_d64") for n in names)
     lib = _lib.load()
     assert lib.vmi_has_extras() == 0
-    rc = lib.vmi_convert_fp8(None, None, 16, 1.0, 0, 0, 0, None)
-    assert rc == 10 and "not in this build" in _lib.last_error() and "extras" in _lib.last_error()
-    for entry, extra in (("vmi_paged_attention_v1_bf16", [0]), ("vmi_paged_attention_v1_fp8_e5m2", [1.0, 0, 0])):
-        one = ctypes.c_void_p(16)         # any non-NULL pointers: the gate is in front of every use of them
-        rc = getattr(lib, entry)(one, one, one, one, 1, 4, 64, 4, 1.0, one, one, 16, 16, 1, None, 256, 4096, 1024, 0, None, *extra)
-        assert rc == 10 and "not in this build" in _lib.last_error(), (entry, rc, _lib.last_error())
+    # ABI 20: the out-of-scope entries are declared in vmi_paged_attention_extras.h and are NOT exported by the product library
+    # (no entry that could only answer VMI_E_NOT_BUILT); the Python operators raise in front of them
+    extras_only = set(_declared_symbols("vmi_paged_attention_extras.h")) - set(_declared_symbols())
+    assert extras_only == set(_lib.EXTRAS_SIGNATURES) and len(extras_only) == 17
+    assert not (extras_only & syms), extras_only & syms
+    assert {s_ for s_ in syms if s_.startswith("vmi_")} == set(_declared_symbols())
+    with pytest.raises(RuntimeError, match="convert_fp8: not in this build.*extras"):
+        _lib.require_extras("convert_fp8")
     # every bfloat16 / E5M2 pick says "no kernel"
     assert lib.vmi_paged_attention_v1_pick_variant_gqa(256, 12, 12, 64, 16, 1024, 1, 0) == 0
-    assert lib.vmi_paged_attention_v1_pick_variant_fp8_e5m2(256, 12, 64, 16, 1024, 0, 0) == 0
+    assert ops.pick_variant(256, 12, 64, 1024, fp8="e5m2") == 0 and ops.pick_variant(256, 12, 64, 1024, fp8=True, bf16=True) == 0
+    assert ops.pick_variant(256, 12, 64, 1024, fp8=True) > 0
     assert lib.vmi_paged_attention_v1_pick_variant_gqa(256, 12, 12, 64, 16, 1024, 0, 0) > 0
 
 
@@ -95,7 +98,7 @@ def test_extras_library_is_the_product_plus_the_out_of_scope_operators():
     path = build.build(extras=True)
     assert path.endswith("libvmi_paged_attention_extras.so") and os.path.exists(build.LIB_PATH)
     syms = _exported(path)
-    assert {s for s in syms if s.startswith("vmi_")} == set(_declared_symbols())
+    assert {s for s in syms if s.startswith("vmi_")} == set(_declared_symbols()) | set(_declared_symbols("vmi_paged_attention_extras.h"))
     product_names, product_v2 = ops.variant_names(), ops.variant_names_v2()
     with _lib.use_extras() as lib:
         assert lib.vmi_has_extras() == 1 and lib.vmi_is_diag_build() == 0 and _lib.load() is lib
@@ -133,7 +136,7 @@ def test_diagnostic_library_is_the_extras_library_plus_the_diagnostics():
     path = build.build(diag=True)
     assert path.endswith("libvmi_paged_attention_diag.so") and os.path.exists(build.LIB_PATH)
     syms = _exported(path)
-    for name in [*_declared_symbols(), *_declared_symbols("vmi_paged_attention_diag.h")]:
+    for name in [*_declared_symbols(), *_declared_symbols("vmi_paged_attention_extras.h"), *_declared_symbols("vmi_paged_attention_diag.h")]:
         assert name in syms, name
     with _lib.use_extras():
         full_names = ops.variant_names()                   # (the diagnostic build is the EXTRAS library under -DVMI_DIAG)
@@ -236,7 +239,6 @@ def test_native_library_missing_is_a_loud_error(tmp_path, monkeypatch):
     from vllmini_amd import _lib, build
 
     monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "nope.so"))
-    monkeypatch.setattr(_lib, "_active", None)
     monkeypatch.setattr(_lib, "_product", None)
     with pytest.raises(_lib.NativeLibraryError, match="no CPU/torch fallback"):
         _lib.load()
@@ -245,6 +247,36 @@ def test_native_library_missing_is_a_loud_error(tmp_path, monkeypatch):
     x = torch.zeros(1)
     with pytest.raises(RuntimeError):
         ext.paged_attention_v1(x, x, x, x, 1, 1.0, x, x, 16, 16, None, "auto", 1.0, 0, 0, 1, 1, 0)
+
+
+def test_build_returns_at_once_on_a_tree_with_current_libraries_and_no_objects(tmp_path, monkeypatch):
+    """The GPU box: the .so files travel with the snapshot, the objects do not (.gpurunignore).  build() — what
+    __graft_entry__.build() and _lib.load(build_if_missing=True) call — must then return the library WITHOUT invoking
+    hipcc (round 3's ADVICE: the per-object staleness test would have recompiled everything there); with a stale library
+    and no objects it must compile."""
+    import shutil
+
+    from vllmini_amd import build
+
+    out = tmp_path / "_C"
+    out.mkdir()
+    for kind in ("LIB_PATH", "EXTRAS_LIB_PATH", "DIAG_LIB_PATH"):
+        dst = out / os.path.basename(getattr(build, kind))
+        shutil.copy(getattr(build, kind), dst)
+        os.utime(dst, None)                                  # newer than every source
+        monkeypatch.setattr(build, kind, str(dst))
+    monkeypatch.setattr(build, "OUT_DIR", str(out))
+    calls = []
+    monkeypatch.setattr(build, "_compile", lambda units, verbose: calls.append(("compile", len(units))))
+    monkeypatch.setattr(build, "_link", lambda objs, lib, verbose: calls.append(("link", lib)))
+    monkeypatch.setattr(build, "_hipcc", lambda: (_ for _ in ()).throw(AssertionError("hipcc asked for")))
+    assert not build._have_objects()
+    assert build.build() == str(out / "libvmi_paged_attention.so") and not calls
+    assert build.build(extras=True).endswith("libvmi_paged_attention_extras.so") and not calls
+    assert build.build(diag=True).endswith("libvmi_paged_attention_diag.so") and not calls
+    os.utime(out / "libvmi_paged_attention.so", (1, 1))      # a library older than its sources IS rebuilt, objects or not
+    build.build()
+    assert calls and calls[0][0] == "compile" and calls[0][1] == len(build.PRODUCT_UNITS) and calls[-1][0] == "link"
 
 
 def test_c_abi_validation_codes_without_gpu():

@@ -40,6 +40,12 @@ def test_plain_python_bench_gpus_n_launches_its_own_ranks(n):
     assert line["config"]["global_batch"] == 8 * n
     assert line["value"] > 0 and line["ms_per_step"] > 0
     assert "STAND-IN" in line["metric"]          # can never be mistaken for a measurement
+    # the N > 1 line says how it was timed and carries every rank's figure, not only the max; and the same K steps the
+    # way rounds 1-2 measured them (blocking exchange on every step, clock behind the closing barrier)
+    assert line["method_version"] == 3 and "in front of the closing barrier" in line["timing_bracket"]
+    assert len(line["ms_per_step_per_rank"]) == n and max(line["ms_per_step_per_rank"]) == pytest.approx(line["ms_per_step"])
+    leg = line["legacy_method_step"]
+    assert leg["method_version"] == 2 and leg["ms_per_step"] > 0 and "BEHIND" in leg["timing_bracket"]
 
 
 def test_bench_under_an_external_launcher_does_not_relaunch():
@@ -91,6 +97,7 @@ def test_launch_decision_and_cpu_thread_candidates():
     assert bench.parse_args(["--kernel-samples", "10"]).kernel_samples == 50      # never fewer than 50 probed launches
     h = bench.parse_args(["--headline-only"])
     assert h.no_cpu_baseline and h.no_fused and h.no_fp8 and h.no_ragged and h.no_graph and h.no_cfg4 and h.no_e2e
+    assert h.no_cfg2 and h.no_strong
     assert bench.cpu_thread_candidates(256, 128) == [8, 16, 32, 64, 128, 256]
     assert bench.cpu_thread_candidates(8, 4) == [1, 2, 4, 8]
     assert bench.cpu_thread_candidates(2, 1) == [1, 2]

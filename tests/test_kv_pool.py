@@ -44,6 +44,31 @@ def test_replays_reference_allocator_trace(golden_dir):
     assert pool.free_blocks == meta["final_free_blocks"]
 
 
+def test_capacity_trace_the_mirror_stops_where_the_reference_stops(golden_dir):
+    """capacity_trace.npz: the reference's Scheduler with max_length above the capacity of a block-table row.  The reference
+    completes 44 decode steps — the 44th appends the row's last block — and dies in the 45th (block_manager.py:36-39 finds no
+    -1 in a full row: UnboundLocalError); the mirror hands out the same tables, slots and free lists step by step and refuses
+    the same step with a RuntimeError that says why.  What the kernel saw on the way: seq_len <= 48 under max_seq_len = 64
+    (scheduler.py:96-97), i.e. the reference's own callers never reach seq_len > max_seq_len."""
+    z = np.load(os.path.join(golden_dir, "capacity_trace.npz"))
+    meta = json.loads(str(z["meta"]))
+    assert meta["failure"] == {"type": "UnboundLocalError", "message": "local variable 'last_block_info' referenced before assignment"}
+    cap = meta["max_blocks_per_seq"] * meta["block_size"]
+    assert meta["max_seq_len_passed"] == cap == 64 and meta["largest_seq_len_passed"] == 48 and meta["sequence_length_at_failure"] == 49
+    pool = _pool(meta)
+    pool.allocate_for_prefill(3, meta["prompt_len"])
+    for step in range(meta["num_decode_steps"]):
+        tab, slot = pool.decode_step(3, 1)
+        assert np.array_equal(tab, z[f"alloc{step:03d}/block_tables"][:, 0, :]), step
+        assert np.array_equal(slot, z[f"alloc{step:03d}/slots"]), step
+        assert np.array_equal(np.array(pool.free_blocks), z[f"alloc{step:03d}/free_blocks"]), step
+    assert pool.seq_len(3) == meta["sequence_length_at_failure"] and (pool.table(3) >= 0).all()      # every row full
+    assert np.array_equal(pool.table(3), z["final_table"][:, 0, :])
+    with pytest.raises(RuntimeError, match="table of 4 entries is full"):
+        pool.decode_step(3, 1)
+    assert pool.free_blocks == meta["free_blocks_at_failure"]           # the refused step handed nothing out
+
+
 def test_batched_decode_equals_per_sequence_reference_order():
     """decode_step_batch == calling the reference-compatible per-sequence step in order; tables are
     [layers, B, MB] int32, slots [layers, B] int64."""

@@ -433,6 +433,66 @@ def test_golden_seam_trace_replay(golden_dir):
     assert np.array_equal(t_vc.cpu().numpy().view(np.uint16), z["final_value_cache"].view(np.uint16))
 
 
+def test_capacity_trace_replay_and_what_lies_beyond_it(golden_dir):
+    """tests/golden/capacity_trace.npz: the reference's Scheduler run with max_length ABOVE the capacity of a block-table row
+    (max_seq_len = max_blocks_per_seq * block_size, scheduler.py:97).  (1) Every seam call the reference made before it failed —
+    the last ones over a FULL table row, no -1 padding left — replays through the drop-in: caches bit-identical, attention
+    within tolerance of the model.  (2) The reference never handed the kernel seq_len > max_seq_len (largest 48 of 64: its own
+    block manager dies first, block_manager.py:36-39), so the drop-in's behaviour there is not a deviation any caller of the
+    reference can observe; it is pinned here all the same: seq_len > max_seq_len attends to the first max_seq_len tokens
+    (the reference kernel would overrun its logits buffer), bit-identical to seq_len = max_seq_len."""
+    ext = _ext()
+    dev = _dev()
+    z = np.load(os.path.join(golden_dir, "capacity_trace.npz"))
+    meta = json.loads(str(z["meta"]))
+    H, D, NB, MB = meta["num_heads"], meta["head_size"], meta["num_blocks"], meta["max_blocks_per_seq"]
+    assert meta["failure"]["type"] == "UnboundLocalError" and meta["largest_seq_len_passed"] <= meta["max_seq_len_passed"] == MB * BS
+    t_kc = torch.zeros((NB, H, D // 8, BS, 8), dtype=torch.float16, device=dev)
+    t_vc = torch.zeros((NB, H, D, BS), dtype=torch.float16, device=dev)
+    worst, n_pa, last = 0.0, 0, None
+    for i in range(meta["num_calls"]):
+        c = f"call{i:04d}/"
+        if str(z[c + "op"]) == "reshape_and_cache":
+            key, value = z[c + "key"], z[c + "value"]
+            T, row = key.shape[0], int(z[c + "key_strides"][0])
+            kbuf = torch.zeros((T, row), dtype=torch.float16, device=dev)
+            vbuf = torch.zeros((T, row), dtype=torch.float16, device=dev)
+            kview, vview = kbuf[:, : H * D].view(T, H, D), vbuf[:, : H * D].view(T, H, D)
+            kview.copy_(torch.from_numpy(key).to(dev))
+            vview.copy_(torch.from_numpy(value).to(dev))
+            ext.cache_ops.reshape_and_cache(kview, vview, t_kc, t_vc, torch.from_numpy(z[c + "slot_mapping"]).to(dev), "auto", 1.0)
+        else:
+            q, row = z[c + "query"], int(z[c + "query_strides"][0])
+            S = q.shape[0]
+            buf = torch.zeros((S, row), dtype=torch.float16, device=dev)
+            qview = buf[:, : H * D].view(S, H, D)
+            qview.copy_(torch.from_numpy(q).to(dev))
+            out = torch.empty((S, H, D), dtype=torch.float16, device=dev)
+            last = dict(q=qview, nkv=int(z[c + "num_kv_heads"]), scale=float(z[c + "scale"]),
+                        tab=torch.from_numpy(z[c + "block_tables"]).to(dev), bs=int(z[c + "block_size"]), msl=int(z[c + "max_seq_len"]))
+            ext.paged_attention_v1(out, qview, t_kc, t_vc, last["nkv"], last["scale"], last["tab"],
+                                   torch.from_numpy(z[c + "seq_lens"]).to(dev), last["bs"], last["msl"], None, "auto", 1.0, 0, 0, 1, 1, 0)
+            worst = max(worst, float(np.abs(out.cpu().numpy().astype(np.float64) - z[c + "oracle_out"].astype(np.float64)).max()))
+            n_pa += 1
+    torch.cuda.synchronize()
+    assert n_pa == meta["num_decode_steps"] * meta["num_layers"] and worst <= ATOL, worst
+    assert np.array_equal(t_kc.cpu().numpy().view(np.uint16), z["final_key_cache"].view(np.uint16))
+    assert np.array_equal(t_vc.cpu().numpy().view(np.uint16), z["final_value_cache"].view(np.uint16))
+    assert (last["tab"].cpu().numpy() >= 0).all() and last["tab"].shape[1] == MB         # the full row: no -1 left
+    # (2) beyond the reference's reach: lengths past max_seq_len are cut to it, whatever the tail of the last block holds
+
+    def attend(length):
+        o = torch.full((1, H, D), float("nan"), dtype=torch.float16, device=dev)
+        ext.paged_attention_v1(o, last["q"], t_kc, t_vc, last["nkv"], last["scale"], last["tab"],
+                               torch.tensor([length], dtype=torch.int32, device=dev), last["bs"], last["msl"], None, "auto", 1.0,
+                               0, 0, 1, 1, 0)
+        return o.cpu().numpy().view(np.uint16)
+
+    at_capacity = attend(MB * BS)
+    for beyond in (MB * BS + 1, meta["max_length"], 10 * MB * BS):
+        assert np.array_equal(attend(beyond), at_capacity), beyond
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties + a sampled oracle check
 # ------------------------------------------------------------------------------------------------

@@ -1,10 +1,12 @@
-"""ctypes binding of the C-ABI shared library (include/vmi_paged_attention.h).
+"""ctypes binding of the C-ABI shared libraries (include/vmi_paged_attention.h; the extras library also
+include/vmi_paged_attention_extras.h).
 
 There is NO fallback: if the HIP library is missing or does not export the declared
 symbols, loading raises.  The operators in ops.py never route around it.
 """
 from __future__ import annotations
 
+import contextvars
 import ctypes
 import os
 import threading
@@ -34,31 +36,12 @@ SIGNATURES = {
     "vmi_target_arch": (ctypes.c_char_p, []),
     "vmi_paged_attention_v1_f16": (ctypes.c_int, list(_PA_ARGS)),
     "vmi_paged_attention_v1_f16_variant": (ctypes.c_int, list(_PA_ARGS) + [_i32]),
-    "vmi_paged_attention_v1_bf16": (ctypes.c_int, list(_PA_ARGS) + [_i32]),
-    "vmi_paged_attention_v2_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32]),
-    "vmi_paged_attention_v1_blocksparse": (ctypes.c_int, list(_PA_ARGS) + [_i32] * 6),
-    "vmi_paged_attention_v2_blocksparse": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32] * 6),
     "vmi_paged_attention_v1_append_f16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
-    "vmi_paged_attention_v1_append_bf16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
     "vmi_paged_attention_v1_fp8": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32]),
-    "vmi_paged_attention_v1_fp8_bf16": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32]),
-    "vmi_reshape_and_cache_fp8_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                                                      _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _c_void_p]),
-    "vmi_paged_attention_v1_pick_variant_fp8_bf16": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v2_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32]),
     "vmi_reshape_and_cache_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                                  _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _c_void_p]),
     "vmi_paged_attention_v1_pick_variant_fp8": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
-    "vmi_paged_attention_v1_f32": (ctypes.c_int, list(_PA_ARGS)),
-    "vmi_reshape_and_cache_f32": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                                                 _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _c_void_p]),
-    "vmi_convert_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _f32, _i32, _i32, _i32, _c_void_p]),
-    "vmi_paged_attention_v1_fp8_e5m2": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32, _i32]),
-    "vmi_paged_attention_v2_fp8_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32, _i32]),
-    "vmi_paged_attention_v2_fp8_e5m2": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32]),
-    "vmi_reshape_and_cache_fp8_e5m2": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                                                      _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _c_void_p, _i32]),
-    "vmi_paged_attention_v1_pick_variant_fp8_e5m2": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v1_variant_count": (ctypes.c_int, []),
     "vmi_paged_attention_v1_variant_name": (ctypes.c_char_p, [_i32]),
     "vmi_paged_attention_v1_pick_variant": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
@@ -71,8 +54,6 @@ SIGNATURES = {
     "vmi_paged_attention_v2_f16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32]),
     "vmi_paged_attention_v2_variant_count": (ctypes.c_int, []),
     "vmi_paged_attention_v2_variant_name": (ctypes.c_char_p, [_i32]),
-    "vmi_reshape_and_cache_flash_16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                                                      _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _c_void_p]),
     "vmi_copy_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _i32, _c_void_p, _i32, _i64, _i32, _c_void_p]),
     "vmi_swap_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i32, _i64, _i32, _i32, _c_void_p]),
     "vmi_is_diag_build": (ctypes.c_int, []),
@@ -86,21 +67,53 @@ SIGNATURES = {
     ]),
 }
 
+# entries of include/vmi_paged_attention_extras.h: exported by libvmi_paged_attention_extras.so (and the diagnostic build) only —
+# the out-of-scope corners of the reference's dispatch
+EXTRAS_SIGNATURES = {
+    "vmi_paged_attention_v1_bf16": (ctypes.c_int, list(_PA_ARGS) + [_i32]),
+    "vmi_paged_attention_v2_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32]),
+    "vmi_paged_attention_v1_blocksparse": (ctypes.c_int, list(_PA_ARGS) + [_i32] * 6),
+    "vmi_paged_attention_v2_blocksparse": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_i32] * 6),
+    "vmi_paged_attention_v1_append_bf16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
+    "vmi_paged_attention_v1_fp8_bf16": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32]),
+    "vmi_reshape_and_cache_fp8_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                                      _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _c_void_p]),
+    "vmi_paged_attention_v1_pick_variant_fp8_bf16": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "vmi_paged_attention_v1_f32": (ctypes.c_int, list(_PA_ARGS)),
+    "vmi_reshape_and_cache_f32": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                                 _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i32, _c_void_p]),
+    "vmi_convert_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _f32, _i32, _i32, _i32, _c_void_p]),
+    "vmi_paged_attention_v1_fp8_e5m2": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32, _i32]),
+    "vmi_paged_attention_v2_fp8_bf16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32, _i32]),
+    "vmi_paged_attention_v2_fp8_e5m2": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32]),
+    "vmi_reshape_and_cache_fp8_e5m2": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                                      _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _c_void_p, _i32]),
+    "vmi_paged_attention_v1_pick_variant_fp8_e5m2": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "vmi_reshape_and_cache_flash_16": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                                      _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _c_void_p]),
+}
+
 # entries of include/vmi_paged_attention_diag.h: exported by the diagnostic build only
 DIAG_SIGNATURES = {
     "vmi_debug_set_queue_flags": (ctypes.c_int, [_i32]),
     "vmi_diag_gather_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _i32, _i32, _c_void_p]),
     "vmi_diag_stream_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "vmi_diag_set_wave_timeline": (ctypes.c_int, [_c_void_p, _i32]),
+    "vmi_diag_set_stage_stamps": (ctypes.c_int, [_c_void_p, _i32]),
 }
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lock = threading.Lock()
 _product = None      # libvmi_paged_attention.so
 _extras = None       # libvmi_paged_attention_extras.so (opt-in: the reference's out-of-scope dispatch corners)
 _diag = None         # libvmi_paged_attention_diag.so (tests / probes only)
-_active = None       # what load() hands to the operators: the product library unless the process switched (use_extras / use_diag)
+# What load() hands to the operators: the product library unless THIS CONTEXT switched (use_extras / use_diag).  A context
+# variable, not a process global: a `with use_extras():` on one thread does not move another thread's launches to the other
+# library (whose variant ids, thread-local last_variant and pv_mfma state are its own) — a new thread starts on the product
+# library and opts in for itself.  Variant ids, cached picks and hipGraphs captured under one library belong to it: resolve
+# names and replay graphs inside the same context.
+_active = contextvars.ContextVar("vmi_active_library", default=None)
 
 
 class NativeLibraryError(RuntimeError):
@@ -135,22 +148,39 @@ def _open(path: str, signatures: dict, want_diag: int, want_extras: int = 0) -> 
         raise NativeLibraryError(f"{path}: vmi_is_diag_build() = {lib.vmi_is_diag_build()}, expected {want_diag}")
     if lib.vmi_has_extras() != want_extras:
         raise NativeLibraryError(f"{path}: vmi_has_extras() = {lib.vmi_has_extras()}, expected {want_extras}")
+    lib._vmi_has_extras = bool(want_extras)
     return lib
 
 
+def _load_product(build_if_missing: bool = False) -> ctypes.CDLL:
+    global _product
+    if _product is None:
+        with _lock:
+            if _product is None:
+                if not os.path.exists(_build.LIB_PATH) and build_if_missing:
+                    _build.build()
+                _product = _open(_build.LIB_PATH, SIGNATURES, 0)
+    return _product
+
+
 def load(build_if_missing: bool = False) -> ctypes.CDLL:
-    """The library the operators call: the PRODUCT library (loaded and typed once), unless a test or probe switched
-    this process to the diagnostic build with use_diag().  Raises NativeLibraryError if unavailable."""
-    global _product, _active
-    if _active is not None:
-        return _active
-    with _lock:
-        if _active is None:
-            if not os.path.exists(_build.LIB_PATH) and build_if_missing:
-                _build.build()
-            _product = _open(_build.LIB_PATH, SIGNATURES, 0)
-            _active = _product
-        return _active
+    """The library the operators call: the PRODUCT library (loaded and typed once), unless the calling context switched
+    to the extras or the diagnostic build (use_extras / use_diag).  Raises NativeLibraryError if unavailable."""
+    lib = _active.get()
+    return lib if lib is not None else _load_product(build_if_missing)
+
+
+def require_extras(what: str) -> ctypes.CDLL:
+    """The active library if it holds the out-of-scope operators (include/vmi_paged_attention_extras.h), else the
+    RuntimeError every such call on the product library ends in — raised HERE, in front of any use of an entry the product
+    library does not export."""
+    lib = load()
+    if not getattr(lib, "_vmi_has_extras", False):
+        raise RuntimeError(
+            f"{what}: not in this build of the library (libvmi_paged_attention.so holds the float16 / fp8-E4M3 hot path; "
+            "`python -m vllmini_amd.build --extras` builds libvmi_paged_attention_extras.so, "
+            "`with vllmini_amd._lib.use_extras():` runs the operators on it)")
+    return lib
 
 
 def load_diag() -> ctypes.CDLL:
@@ -159,7 +189,7 @@ def load_diag() -> ctypes.CDLL:
     global _diag
     with _lock:
         if _diag is None:
-            _diag = _open(_build.DIAG_LIB_PATH, {**SIGNATURES, **DIAG_SIGNATURES}, 1, 1)
+            _diag = _open(_build.DIAG_LIB_PATH, {**SIGNATURES, **EXTRAS_SIGNATURES, **DIAG_SIGNATURES}, 1, 1)
         return _diag
 
 
@@ -170,7 +200,7 @@ def load_extras() -> ctypes.CDLL:
     global _extras
     with _lock:
         if _extras is None:
-            _extras = _open(_build.EXTRAS_LIB_PATH, SIGNATURES, 0, 1)
+            _extras = _open(_build.EXTRAS_LIB_PATH, {**SIGNATURES, **EXTRAS_SIGNATURES}, 0, 1)
         return _extras
 
 
@@ -181,16 +211,13 @@ class use_extras:
     more rows): resolve names inside."""
 
     def __enter__(self):
-        global _active
-        load()
-        self._prev = _active
+        _load_product()
         lib = load_extras()
-        _active = lib
+        self._token = _active.set(lib)
         return lib
 
     def __exit__(self, *exc):
-        global _active
-        _active = self._prev
+        _active.reset(self._token)
         return False
 
 
@@ -200,16 +227,13 @@ class use_diag:
     Variant ids differ between the two libraries (the diagnostic one has more rows): resolve names inside."""
 
     def __enter__(self):
-        global _active
-        load()
-        self._prev = _active
+        _load_product()
         lib = load_diag()
-        _active = lib
+        self._token = _active.set(lib)
         return lib
 
     def __exit__(self, *exc):
-        global _active
-        _active = self._prev
+        _active.reset(self._token)
         return False
 
 

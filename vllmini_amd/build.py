@@ -11,8 +11,9 @@ native code at all: hipcc translation units compiled concurrently and linked int
                                                     paged_attention_v2, the fused append, copy/swap_blocks).  Seven units.
                                                     No diagnostic entry, no kernel that is wrong by design, no experiment
                                                     kernel, and none of the out-of-scope element types and operators: their
-                                                    kernel menus are EMPTY here and their C-ABI entries return
-                                                    VMI_E_NOT_BUILT (pa_extras_absent.hip, chosen at link time).
+                                                    kernel menus are EMPTY here (pa_extras_absent.hip, chosen at link time)
+                                                    and their C-ABI entries (include/vmi_paged_attention_extras.h) do not
+                                                    exist in it.
   vllmini_amd/_C/libvmi_paged_attention_extras.so   (`--extras`) the product's objects plus the rest of the reference's
                                                     dispatch surface (out of the path's scope):
                                                     bfloat16 and float32 tensors, fp8-E5M2 pages, block-sparse attention,
@@ -55,9 +56,10 @@ SRC_QUEUE = os.path.join(CSRC, "pa_queue.hip")                # balanced (work-q
 SRC_STAGE = os.path.join(CSRC, "pa_stage.hip")                # experiment: pages staged through LDS (diagnostic library only)
 SRC_ABSENT = os.path.join(CSRC, "pa_extras_absent.hip")      # product library: empty out-of-scope menus, VMI_E_NOT_BUILT entries
 SRC_EXTRAS_CACHE = os.path.join(CSRC, "pa_extras_cache.hip")  # extras: convert_fp8, reshape_and_cache_flash, bf16 / E5M2 fp8 scatter
+SRC_EXTRAS_ABI = os.path.join(CSRC, "pa_extras_abi.hip")      # extras: the C-ABI entries of include/vmi_paged_attention_extras.h
 # (source, flavor): flavor "" = plain, "extras" = -DVMI_EXTRAS, "diag" = -DVMI_DIAG (+ -DVMI_EXTRAS)
 CORE = [SRC, SRC_EXTRA, SRC_APPEND[0], SRC_APPEND[1], SRC_FP8, SRC_QUEUE]          # the hot path
-EXTRAS = [SRC_BF16, SRC_APPEND[2], SRC_FP8_BF16, *SRC_FP8_E5M2, *SRC_SPARSE, SRC_F32, SRC_EXTRAS_CACHE]
+EXTRAS = [SRC_BF16, SRC_APPEND[2], SRC_FP8_BF16, *SRC_FP8_E5M2, *SRC_SPARSE, SRC_F32, SRC_EXTRAS_CACHE, SRC_EXTRAS_ABI]
 PRODUCT_UNITS = [(s, "") for s in CORE] + [(SRC_ABSENT, "")]
 EXTRAS_UNITS = [(s, "extras" if s == SRC_QUEUE else "") for s in CORE] + [(s, "") for s in EXTRAS]
 # the diagnostic library: these units are compiled again with -DVMI_DIAG (it changes their variant tables / entries),
@@ -107,7 +109,8 @@ def _units_of(kind: str):
 
 def _deps(kind: str = "product") -> list[str]:
     return [*(s for s, _ in _units_of(kind)), *TABLES, HDR, HDR_QUEUE, *HDRS_HOST,
-            os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.join(INCLUDE, "vmi_paged_attention_diag.h"),
+            os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.join(INCLUDE, "vmi_paged_attention_extras.h"),
+            os.path.join(INCLUDE, "vmi_paged_attention_diag.h"),
             os.path.abspath(__file__)]
 
 

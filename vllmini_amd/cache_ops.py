@@ -6,6 +6,8 @@
   reshape_and_cache_flash  cache_kernels.cu:283-317  scatter into the flash layout [NB, block_size, H, D]
   convert_fp8              cache_kernels.cu:320-392  whole-cache conversion fp8 E4M3 <-> float / half / bfloat16
                            ("only for testing" in the reference, compiled to assert(false) in its shipped build)
+                           (these two are outside the hot path: include/vmi_paged_attention_extras.h — they run inside
+                           `_lib.use_extras()` and raise RuntimeError("... not in this build ...") on the product library)
 """
 from __future__ import annotations
 
@@ -112,7 +114,7 @@ def reshape_and_cache_flash(key: torch.Tensor, value: torch.Tensor, k_cache: tor
         raise RuntimeError("key/value must be contiguous in their last two dimensions")
     if slot_mapping.dtype != torch.int64 or slot_mapping.numel() != num_tokens or not slot_mapping.is_contiguous():
         raise RuntimeError("slot_mapping must be a contiguous int64 [num_tokens] tensor")
-    rc = _lib.load().vmi_reshape_and_cache_flash_16(
+    rc = _lib.require_extras("reshape_and_cache_flash").vmi_reshape_and_cache_flash_16(
         key.data_ptr(), value.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr(),
         num_tokens, num_heads, head_size, int(k_cache.shape[1]), int(k_cache.stride(0)), int(key.stride(0)),
         int(value.stride(0)), dev.index if dev.index is not None else torch.cuda.current_device(),
@@ -147,9 +149,9 @@ def convert_fp8(dst_cache: torch.Tensor, src_cache: torch.Tensor, kv_scale: floa
     if src_cache.numel() != dst_cache.numel() or not src_cache.is_contiguous() or not dst_cache.is_contiguous():
         raise RuntimeError("convert_fp8: src and dst must be contiguous and hold the same number of elements")
     dev = src_cache.device
-    rc = _lib.load().vmi_convert_fp8(dst_cache.data_ptr(), src_cache.data_ptr(), int(src_cache.numel()), float(kv_scale),
-                                     kind, to_fp8, dev.index if dev.index is not None else torch.cuda.current_device(),
-                                     torch.cuda.current_stream(dev).cuda_stream)
+    rc = _lib.require_extras("convert_fp8").vmi_convert_fp8(
+        dst_cache.data_ptr(), src_cache.data_ptr(), int(src_cache.numel()), float(kv_scale), kind, to_fp8,
+        dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         _raise_native(rc)
     return None

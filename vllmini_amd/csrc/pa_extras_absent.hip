@@ -1,9 +1,9 @@
 // pa_extras_absent.hip — what the PRODUCT library (libvmi_paged_attention.so) links in place of the out-of-scope units
 // (bfloat16 / float32 tensors, E5M2 pages, block-sparse attention, reshape_and_cache_flash, convert_fp8: SURVEY.md §2 rows
 // 8-10; pa_variants_bf16 / _sparse* / _fp8_bf16 / _fp8_e5m2*, pa_append_bf16, pa_f32, pa_extras_cache): EMPTY kernel menus,
-// so no heuristic can pick and no variant id can name a kernel that is not there, and the C-ABI entries that live in those
-// units, returning VMI_E_NOT_BUILT.  The choice is made at LINK time — no #ifdef in the host code of the path.
-#include "vmi_paged_attention.h"
+// so no heuristic can pick and no variant id can name a kernel that is not there.  No C-ABI entry: the out-of-scope entries are
+// declared in include/vmi_paged_attention_extras.h and exist in the extras library only (pa_extras_abi.hip, pa_f32.hip,
+// pa_extras_cache.hip).  The choice is made at LINK time — no #ifdef in the host code of the path.
 #include "pa_kernel.hpp"
 #include "pa_host.hpp"
 #include "pa_cache_fp8.hpp"
@@ -31,24 +31,3 @@ pa_reduce_t bf16_reduce_kernel(int) { return nullptr; }
 fp8_scatter_fn fp8_scatter_extra_kernel(bool, bool, bool) { return nullptr; }
 
 }  // namespace vmi
-
-extern "C" {
-
-int vmi_paged_attention_v1_f32(void*, const void*, const void*, const void*, int32_t, int32_t, int32_t, int32_t, float,
-                               const int32_t*, const int32_t*, int32_t, int32_t, int32_t, const float*, int64_t, int64_t,
-                               int64_t, int32_t, void*) {
-  return vmi::not_built("paged_attention_v1 over float32 tensors");
-}
-int vmi_reshape_and_cache_f32(const void*, const void*, void*, void*, const int64_t*, int32_t, int32_t, int32_t, int32_t,
-                              int32_t, int64_t, int64_t, int32_t, void*) {
-  return vmi::not_built("reshape_and_cache over float32 tensors");
-}
-int vmi_convert_fp8(void*, const void*, int64_t, float, int32_t, int32_t, int32_t, void*) {
-  return vmi::not_built("convert_fp8");
-}
-int vmi_reshape_and_cache_flash_16(const void*, const void*, void*, void*, const int64_t*, int32_t, int32_t, int32_t,
-                                   int32_t, int64_t, int64_t, int64_t, int32_t, void*) {
-  return vmi::not_built("reshape_and_cache_flash");
-}
-
-}  // extern "C"

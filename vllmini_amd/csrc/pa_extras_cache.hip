@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "vmi_paged_attention.h"
+#include "vmi_paged_attention_extras.h"
 #include "pa_kernel.hpp"
 #include "pa_host.hpp"
 #include "pa_cache_fp8.hpp"

@@ -6,7 +6,7 @@
 // the blocks dealt round-robin to the waves, a (block, head) tile fetched as 1-KiB wave loads in the layout's own order.
 // Out of the hot-path scope: linked into libvmi_paged_attention_extras.so only (kernels AND their two C-ABI entries; the
 // product library's entries of the same names, pa_extras_absent.hip, return VMI_E_NOT_BUILT).
-#include "vmi_paged_attention.h"
+#include "vmi_paged_attention_extras.h"
 #include "pa_kernel.hpp"
 #include "pa_host.hpp"
 

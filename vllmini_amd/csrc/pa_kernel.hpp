@@ -301,6 +301,19 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Diagnostic library only (-DVMI_DIAG): pa_v1_kernel writes ten stage stamps per wave — ticks of the constant 100 MHz
+// clock at entry, lengths known, first pages requested, first K group consumed, K pass done, max exchanged, probabilities
+// written, V pass done, partial outputs exchanged, out stored — to g_stage_stamps (vmi_diag_set_stage_stamps;
+// scripts/stage_timeline_probe.py turns them into the account of a launch's latency chain).  One copy per translation
+// unit (no relocatable device code): the setter lives beside the core menu in paged_attention.hip and serves its kernels.
+// With VMI_DIAG undefined VMI_STAMP expands to nothing and the kernel text is what it was.
+#ifdef VMI_DIAG
+static __device__ uint64_t* g_stage_stamps = nullptr;  // [waves of the launch][12]: 10 stamps, HW_ID, XCC_ID | nmy << 8
+#define VMI_STAMP(k) do { if (tl_) ts_[k] = wall_clock64(); } while (0)
+#else
+#define VMI_STAMP(k) ((void)0)
+#endif
+
 struct PAParams {
   h16* out;
   const h16* q;
@@ -413,6 +426,11 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef VMI_DIAG
+  uint64_t* const tl_ = g_stage_stamps;
+  uint64_t ts_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  VMI_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -487,6 +505,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     }
     return;
   }
+  VMI_STAMP(1);
 
   // ---- per head: tile offset inside a block, ALiBi slope, this lane's q chunks (one per K load) ----
   const int c4 = lane / BS;  // chunk-within-load
@@ -852,13 +871,19 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     if (single) {
       load_group(ra, p.kc, 0);
       load_v(rb, 0);
+      VMI_STAMP(2);
       compute_k(std::integral_constant<bool, APP>{}, ra, 0);
+      VMI_STAMP(3);
     } else {
       if (ngroups > 0) load_group(ra, p.kc, 0);
+      VMI_STAMP(2);
       int g = 0;
       for (; g + 2 <= ngroups; g += 2) {
         load_group(rb, p.kc, g + 1);
         compute_k(std::false_type{}, ra, g);
+#ifdef VMI_DIAG
+        if (g == 0) VMI_STAMP(3);
+#endif
         if (g + 2 < ngroups) {
           load_group(ra, p.kc, g + 2);
           compute_k(std::false_type{}, rb, g + 1);
@@ -876,7 +901,18 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     // standing at the very end of the wave.  (Only the order of the fp32 accumulation over blocks changes; the fused
     // append walks the same order, so it stays bit-identical to the call pair.)
     constexpr bool VREV = true;
+    // VAHEAD (round 4, profiles/r04_underfilled_chip.md): the kernels with TEMPORAL page loads and several waves per head are
+    // the ones picked when the launch's working set fits the Infinity Cache and the chip is under-filled — there the launch is a
+    // chain, not a stream, and the 1.8 us between the end of a wave's K pass and the start of its V pass (barrier, softmax,
+    // barrier: every wave of the chip is in the same phase) left the memory system idle with ONE V group requested.  Both
+    // register buffers are free here, so these kernels request the first TWO V groups in front of the softmax.  The
+    // full-chip kernels (non-temporal loads, or one wave per head) keep one: there, fewer bytes in flight are faster.
+    constexpr bool VAHEAD = VREV && WPH > 1 && !NT;
+    VMI_STAMP(4);
     if (ngroups > 1) load_v(ra, VREV ? ngroups - 1 : 0);
+    if constexpr (VAHEAD) {
+      if (ngroups > 1) load_v(rb, ngroups - 2);
+    }
 
     if constexpr (QK_MFMA) {  // per-head maxima live in lanes (lane & 15) = head: fold the 4 row groups, then hand out
       qmaxB = fmaxf(qmaxB, __shfl_xor(qmaxB, 16));
@@ -897,6 +933,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       }
       if constexpr (WPH > 1) {
         lds_barrier();  // also: every wave's logits are in LDS
+        VMI_STAMP(5);
   #pragma unroll
         for (int hh = 0; hh < HPT; ++hh) {
           float mm = -FLT_MAX;
@@ -965,6 +1002,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       }
     }
 
+    VMI_STAMP(6);
     // =========================== V pass ====================================================
     // `masked` is a compile-time tag: only the LAST page group of a wave can contain the sequence's last
     // block, so only that call site compiles the tail masking in.
@@ -1117,7 +1155,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       // processing step s handles group ngroups-1-s; step 0 (the masked "final" group) is in ra, odd steps in rb
       const int last = ngroups - 1;
       if (ngroups > 1) {  // (a wave without blocks — more waves than blocks — has ngroups == 0; one group is `single`)
-        load_v(rb, last - 1);
+        if constexpr (!VAHEAD) load_v(rb, last - 1);
         compute_v(std::true_type{}, ra, last);
         int s = 1;
         for (; s + 1 < ngroups; s += 2) {
@@ -1142,7 +1180,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       }
       if (g < ngroups) compute_v(std::true_type{}, ra, g);  // final group of an odd count
     }
-
+    VMI_STAMP(7);
   };
 
   // Queue depth per wave.  On a full chip the shallowest queue is the fastest when every sequence has the same
@@ -1211,6 +1249,7 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
       }
     }
     lds_barrier();
+    VMI_STAMP(8);
     if (sub == 0) {
 #pragma unroll
       for (int hh = 0; hh < HPT; ++hh) {
@@ -1239,6 +1278,20 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
     }
   }
 
+#ifdef VMI_DIAG
+  if (tl_) {  // (the wave's stores have left: the last stamp is the end of its work)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ts_[9] = wall_clock64();
+    if (lane == 0) {
+      const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      uint64_t* rec = tl_ + (wg * (HPW * WPH) + wave) * 12;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) rec[k] = ts_[k];
+      rec[10] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);                               // HW_REG_HW_ID
+      rec[11] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((uint64_t)nmy << 8);       // HW_REG_XCC_ID
+    }
+  }
+#endif
   // APP: the cache write — what cache_ops.reshape_and_cache does for slot (table[lbA], offA),
   // cache_kernels.cu:219-260 — is the wave's LAST act.  Measured on the 124-us cfg3 launch
   // (profiles/r01f_fused_append_experiments.md): the same stores issued between the K and V passes +14 us (loads

@@ -135,7 +135,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-
 // ----------------------------------------------------------------------------------------
 // reshape_and_cache, run form (calls of >= 2*block_size tokens).  A prompt's tokens arrive with consecutive slots, so
 // BS consecutive tokens usually ARE one cache block.  The per-token kernel above then writes every 32-B V row in BS
@@ -415,7 +414,6 @@ static thread_local int g_pv_mfma = 0;
 // CU count the heuristics below size their launches for: the launch paths set it from hipDeviceProp (device_cus),
 // the pick queries of the C-ABI, which name no device, use the MI355X's 256
 static thread_local int g_cus = 256;
-static inline long full_chip_waves() { return 12L * g_cus; }  // 12 waves per CU: one (sequence, head) each
 
 static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_size, int block_size, int max_seq_len,
                                bool bf, int f8, bool fpv);
@@ -469,6 +467,94 @@ static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_si
   return 0;
 }
 
+// ----------------------------------------------------------------------------------------
+// THE MEASURED THRESHOLDS OF THE WORK-DECOMPOSITION HEURISTICS, IN ONE PLACE (round 4).
+//
+// pick_variant / pick_variant_fp8 / waves_per_head_without_balancing below are control flow over this table and nothing
+// else: no number in them that is not a field here.  Thresholds are expressed in RESIDENT WAVES, WORKGROUP SLOTS and
+// BYTES, not in batch sizes, so they carry over to other head counts: profiles/r04_pick_generalisation.md compares the
+// default pick with the best enumerated variant over H in {8, 16, 20, 25, 40} x D in {64, 128} at the regime edges.
+// Each field names the file under profiles/ that holds its measurement.
+// ----------------------------------------------------------------------------------------
+struct PickRules {
+  // ---- the chip ----
+  int waves_per_cu_full = 12;        // one wave per (sequence, head) fills the chip at 12 resident waves per CU (3 per SIMD at
+                                     //   <= 168 VGPRs): r01c_batch_sweep_auto.csv
+  int wave_slots_per_cu = 32;        // hardware wave slots per CU
+  size_t lds_per_cu = 160 * 1024;    // bytes
+  // ---- how many waves share one head (under-filled chip) ----
+  int max_waves_per_head = 16;
+  int min_blocks_per_wave = 2;       // a head is cut further only while every wave keeps >= 2 blocks: 256 tokens run 7 - 13 %
+                                     //   faster on 8 waves x 2 blocks than on 16 x 1 (r04_underfilled_sweep.md)
+  int waves16_max_units_per_cu = 1;  // 16 waves per head = a 1024-thread workgroup = a CU to itself: only while (sequence, head)
+                                     //   units <= CUs.  288 / 336 units (batch 24 / 28 at 12 heads) ran 1.33 - 1.59x slower on
+                                     //   16 waves per head than on 8 (r04_underfilled_sweep.md)
+  // ---- temporal or non-temporal page loads ----
+  double nt_kv_bytes = 128e6;        // non-temporal once the launch's K+V bytes pass half the 256 MiB Infinity Cache
+                                     //   (146 -> 133 us at cfg3; neutral inside it): r01_cfg3_sweep_cache_policy_bits.json
+  double nt_resident_factor = 1.25;  // ... or once the launch's waves exceed 1.25x the resident ones (a second round of
+                                     //   workgroups): the temporal kernels keep two V groups in flight across the softmax
+                                     //   (VAHEAD, pa_kernel.hpp), which pays only while every workgroup is resident — batch 48 /
+                                     //   56 at 12 heads: 5 - 15 % slower than the non-temporal form (r04_underfilled_sweep.md)
+  // ---- blocks per register group ----
+  double min_kib_in_flight_per_cu = 16.0;   // U = smallest of {1, 2, 4} with >= 16 KiB of register groups per CU.  On a full chip
+                                            //   (12 waves per CU) that is U = 1 — more congests: U=4 133, U=2 127, U=1 124 us,
+                                            //   r01c_cfg3_variant_sweep.json — and on the under-filled chip U = 2 pays only below
+                                            //   ~8 waves per CU (batch 8 x 12 heads on 16 waves each, 2048 tokens: 12.6 against
+                                            //   15.0 us) and costs 15 % from 9 waves per CU on (batch 24: 13.6 against 15.9):
+                                            //   r04_underfilled_sweep.md (round 1's 24 KiB came from kernels that, as found in
+                                            //   round 2, never had two groups in flight)
+  // ---- the balanced kernel (pa_queue.hpp): full chip, block 16, head 64 / 128 ----
+  size_t q_lds_per_token = 16;       // 4 waves' fp32 logits
+  size_t q_lds_fixed = 16 * 1024;    //   + ranking, masks, a team's exchange buffers
+  int q_wgs_per_cu_d64 = 3, q_wgs_per_cu_d128 = 2;        // must all be resident (mode S): bounds max_seq_len at ~2400 tokens
+  int near_full_num = 7, near_full_den = 8;               // fp16 pages: from 7/8 of the resident waves on (batch 224 at 12
+                                                          //   heads) it beats eight waves per head: r03l_nearly_full_chip.md,
+                                                          //   r03z_eight_waves_per_head.md
+  int near_full_fp8_num = 17, near_full_fp8_den = 20;     // fp8 pages: from 85 % on: r03x_fp8_four_solo_workers.md
+  double q_fp8_min_kv_bytes = 128e6;                      // fp8: only past the Infinity Cache (bytes of the fp8 pages)
+  // ---- more items than resident waves, or a chip that 2 / 4 waves per head would just fill: MANY waves per head, handed
+  //      out by the hardware dispatcher as workgroups finish (r03z_eight_waves_per_head.md) ----
+  int many_min_blocks = 32;          // from 512 tokens on (shorter contexts are launch-bound either way)
+  int many_waves_long = 8, many_waves_short = 4, many_long_blocks = 64;   // eight from 1024 tokens on, else four
+  int many_waves_fp8 = 4, many_fp8_min_blocks = 8;        // fp8 pages: half-size tiles want FOUR waves per head between half a
+                                                          //   chip and 85 % of one: r03x_fp8_four_solo_workers.md
+  int ragged_hint_num = 3, ragged_hint_den = 4;           // a caller's mean_seq_len below 3/4 of max_seq_len = ragged: up to
+  int ragged_hint_waves = 8;                              //   eight waves per head: r01g_ragged_batches.md
+  // ---- long contexts on a full chip, the balanced kernel's LDS does not fit (r03m_long_context_full_chip.md) ----
+  int long_ctx_tokens = 3400;        // an under-filled chip meets the same LDS limit from here on
+  int long_ctx_max_wgs_per_cu = 16;
+  double few_waves_base = 0.4, few_waves_slope = 0.075;   // score penalty below 8 resident waves per CU: 0.4 + 0.075 * waves
+  int enough_waves_per_cu = 8;
+  double two_waves_margin = 1.15;    // two waves per head need not win on paper (lengths are usually ragged there): within 15 %
+  double finer_margin = 1.05;        // beyond two, a finer form must be 5 % ahead
+  double fine_enough_fill = 0.75;    // eight / sixteen waves per head only where nothing smaller keeps 3/4 of the chip busy
+  // ---- head size 128: the lockstep 4-heads-per-wave kernel (one 16-head workgroup per CU: 365 VGPRs) ----
+  int lock_heads_per_wg = 16;
+  double lock_min_waves_per_cu = 12.0;
+  double lock_min_round_fill = 0.97; // only where the launch fills whole rounds of those slots: 129 x 32 heads ran 1120 us
+                                     //   against 701: r03n_head_128_round_fit.md
+};
+static constexpr PickRules R{};
+static inline long full_chip_waves() { return (long)R.waves_per_cu_full * g_cus; }  // one (sequence, head) per resident wave
+
+static inline size_t lpad32(int max_seq_len) { return (size_t)((max_seq_len + 31) / 32) * 32; }
+// LDS of one balanced-kernel workgroup, and whether the CU holds as many as mode S needs
+static inline size_t q_lds_bytes(int max_seq_len) { return R.q_lds_per_token * lpad32(max_seq_len) + R.q_lds_fixed; }
+static inline bool q_lds_fits(int max_seq_len, int head_size) {
+  return head_size == 128 ? R.q_wgs_per_cu_d128 * (q_lds_bytes(max_seq_len) + 4 * 1024) <= R.lds_per_cu
+                          : R.q_wgs_per_cu_d64 * q_lds_bytes(max_seq_len) <= R.lds_per_cu;
+}
+// waves per head that fill the resident waves from `units` (sequence, head) items, every wave keeping min_blocks_per_wave
+static int waves_to_fill_the_chip(long units, int nblk) {
+  const int nb = nblk > 0 ? nblk : 1;
+  int wph = 1;
+  while (wph < R.max_waves_per_head && units * wph < full_chip_waves() && wph * 2 * R.min_blocks_per_wave <= nb) wph *= 2;
+  if (wph == 1 && units * wph < full_chip_waves() && nb >= 2) wph = 2;   // (two or three blocks: two waves, one of them a block)
+  if (wph >= 16 && units > (long)R.waves16_max_units_per_cu * g_cus) wph = 8;
+  return wph;
+}
+
 // A FULL CHIP WITHOUT THE BALANCED KERNEL (its LDS does not fit: contexts past ~2400 tokens) — round 3,
 // profiles/r03m_long_context_full_chip.md.  The one-wave-per-head kernels come as 4-head workgroups whose logits
 // (4 bytes per token and head) decide how many fit a CU — three at 3000 tokens, two at 4096, one at 8192 — and a batch
@@ -483,31 +569,30 @@ static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_si
 // 128 sequences x 12 heads: 380 us = 4.2 TB/s).
 static int waves_per_head_without_balancing(int num_seqs, int num_heads, int head_size, int max_seq_len, int nblk,
                                             int wph = 1) {
-  const size_t lp = (size_t)((max_seq_len + 31) / 32) * 32;
+  const size_t lp = lpad32(max_seq_len);
   auto score = [&](int hpw, int w) -> double {
     const size_t lds = (size_t)hpw * (lp * 4 + 2 * w * 4 + (size_t)w * head_size * 4 + (w > 1 ? lp * 2 : 0));
-    long per_cu = (long)((size_t)160 * 1024 / lds);
-    if (per_cu * hpw * w > 32) per_cu = 32 / (hpw * w);  // 32 waves per CU
-    if (per_cu > 16) per_cu = 16;
+    long per_cu = (long)(R.lds_per_cu / lds);
+    if (per_cu * hpw * w > R.wave_slots_per_cu) per_cu = R.wave_slots_per_cu / (hpw * w);
+    if (per_cu > R.long_ctx_max_wgs_per_cu) per_cu = R.long_ctx_max_wgs_per_cu;
     if (per_cu < 1) return 0.0;
     const double slots = (double)g_cus * per_cu;
     const double wgs = (double)num_seqs * ((num_heads + hpw - 1) / hpw);
     const double rounds = (double)(long)((wgs + slots - 1) / slots);
     const double waves = (double)per_cu * hpw * w;
     const double fill = wgs > slots ? wgs / slots : 1.0;  // (a launch that fits one round has no tail)
-    return fill / rounds * (waves >= 8 ? 1.0 : 0.4 + 0.075 * waves);
+    return fill / rounds * (waves >= R.enough_waves_per_cu ? 1.0 : R.few_waves_base + R.few_waves_slope * waves);
   };
   double best = wph == 1 ? score(num_heads % 4 == 0 ? 4 : 1, 1) : score(1, wph);
-  for (int w = wph * 2; w <= 16 && w <= (nblk > 0 ? nblk : 1); w *= 2) {
-    // a finer form must be 5 % ahead of what is chosen so far; eight and sixteen waves per head only where nothing smaller
-    // keeps three quarters of the chip busy (a one-head workgroup that fits a CU just once: contexts past ~13 600 tokens)
-    if (w >= 8 && best >= 0.75) break;  // (... or nothing smaller keeps three quarters of the chip busy)
+  for (int w = wph * 2; w <= R.max_waves_per_head && w <= (nblk > 0 ? nblk : 1); w *= 2) {
+    // eight and sixteen waves per head only where nothing smaller keeps three quarters of the chip busy (a one-head
+    // workgroup that fits a CU just once: contexts past ~13 600 tokens)
+    if (w >= 8 && best >= R.fine_enough_fill) break;
     const double sc = score(1, w);
     // The score is what EQUAL lengths would see; the lengths are a device tensor and at these contexts batches are
     // usually ragged, where one-head workgroups were ahead in every cell measured (4096 tokens, 320 sequences: 363 against
-    // 391 us on U{1..L}, 618 against 599 on equal lengths).  So two waves per head need not win on paper: within 15 % of
-    // the 4-head form is enough; beyond two, a form must be 5 % ahead of what is chosen so far.
-    if (w == 2 && wph == 1 ? sc * 1.15 > best : sc > best * 1.05) {
+    // 391 us on U{1..L}, 618 against 599 on equal lengths).  So two waves per head need not win on paper.
+    if (w == 2 && wph == 1 ? sc * R.two_waves_margin > best : sc > best * R.finer_margin) {
       best = sc;
       wph = w;
     }
@@ -515,32 +600,32 @@ static int waves_per_head_without_balancing(int num_seqs, int num_heads, int hea
   return wph;
 }
 
-// fp8 cache: a (block, head) tile is half the bytes; measured picks in profiles/r01h_fp8_kv.md
+// fp8 cache: a (block, head) tile is half the bytes; measured picks in profiles/r01h_fp8_kv.md, r03x_fp8_four_solo_workers.md
 // unit_scale: the caller's kv_scale is 1 (the balanced fp8 kernels are built for that case only; the pick queries of
 // the C-ABI, which carry no scale, describe the general case)
-static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
-                            int mean_seq_len, bool bf = false, int fmt = 1, bool unit_scale = false) {
+int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len,
+                     int mean_seq_len, bool bf, int fmt, bool unit_scale) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
   int wph = 1;
-  while (wph < 16 && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
-  // A nearly full chip (85 % of the resident waves and more: batch 218 at 12 heads) goes to the balanced kernel: since its solo
-  // workers are four per workgroup over fp8 pages (pa_queue.hpp, WQ_SOLO) it is ahead of several waves per head there on equal
-  // lengths (batch 224: 61.4 against 64.4 - 66.7 us) and level on ragged ones (39.7 / 39.9).  profiles/r03x_fp8_four_solo_workers.md
-  const bool near_full = wph == 2 && units * 20 >= full_chip_waves() * 17;
+  while (wph < R.max_waves_per_head && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  // A nearly full chip goes to the balanced kernel: since its solo workers are four per workgroup over fp8 pages (pa_queue.hpp,
+  // WQ_SOLO) it is ahead of several waves per head there on equal lengths (batch 224: 61.4 against 64.4 - 66.7 us) and
+  // level on ragged ones (39.7 / 39.9).
+  const bool near_full = wph == 2 && units * R.near_full_fp8_den >= full_chip_waves() * R.near_full_fp8_num;
   // Head size 128 (two workgroups per CU): the balanced kernel on a full chip — the lockstep 4-head kernel it replaces is
   // 0.8 % ahead on equal lengths (cfg4 fp8: 330.9 against 333.4 us) and 12 % behind on ragged ones (201.8 against 178.1);
   // fp8 pages have no gated double launch (that pairs two fp16 kernels).
-  const size_t q_lds = 16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024;   // the balanced kernel's, per workgroup
   // (more items than resident waves: FOUR waves per head instead — batch 288 / 384 / 768 at 12 heads, equal lengths 78.4 /
   //  98.6 / 187.3 against the balanced kernel's 77.1 / 105.4 / 195.0 us, U{1..L} 46.3 / 56.7 / 103.2 against 45.4 / 59.3 / 107.7,
   //  "3/4 full" 61.9 / 77.3 / 145.3 against 65.8 / 92.2 / 152.0, exponential 25.5 / 35.2 / 57.3 against 30.5 / 37.6 / 62.8;
   //  behind only on "1/16 full, rest 1/16": 23.3 / 27.0 against 19.7 / 24.7)
-  const bool over_full = units > full_chip_waves() && head_size == 64 && block_size == 16 && nblk >= 32 && 3 * q_lds <= (size_t)160 * 1024;
-  const bool q64 = head_size == 64 && !over_full && (wph == 1 || near_full) && 3 * q_lds <= (size_t)160 * 1024;
-  const bool q128 = head_size == 128 && wph == 1 && 2 * (q_lds + 4 * 1024) <= (size_t)160 * 1024;
+  const bool over_full = units > full_chip_waves() && head_size == 64 && block_size == 16 && nblk >= R.many_min_blocks &&
+                         q_lds_fits(max_seq_len, 64);
+  const bool q64 = head_size == 64 && !over_full && (wph == 1 || near_full) && q_lds_fits(max_seq_len, 64);
+  const bool q128 = head_size == 128 && wph == 1 && q_lds_fits(max_seq_len, 128);
   if (unit_scale && (q64 || q128) && !bf && block_size == 16 &&
-      4.0 * (double)units * max_seq_len * head_size > 256e6) {  // (2 bytes per token and dim: past the Infinity Cache)
+      2.0 * (double)units * max_seq_len * head_size > R.q_fp8_min_kv_bytes) {  // (1 byte per token and dim, K and V)
     // the balanced kernel over fp8 pages (pa_queue.hpp) — ragged batches without a hint
     const int us = head_size == 64 ? 2 : 1;   // (blocks per group of its mode S: the row's U)
     for (int id = 1; id <= nvariants_v1(); ++id) {
@@ -557,14 +642,14 @@ static int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int bloc
   // the resident waves let the dispatcher balance a ragged batch: batch 128 / 144 / 176 / 208, equal lengths 42.2 / 42.6 /
   // 50.5 / 61.6 -> 36.9 / 41.3 / 51.5 / 59.5 us, U{1..L} 34.2 / 34.1 / 36.9 / 40.7 -> 26.5 / 27.8 / 32.5 / 37.8 (the balanced
   // kernel there: 42.6 / 43.5 / 52.6 / 61.2 and 31.2 / 32.2 / 34.4 / 39.5).  Below batch 128 the rule above already gives four.
-  if (head_size == 64 && block_size == 16 && wph == 2 && nblk >= 8) wph = 4;
-  if (over_full && wph == 1) wph = 4;
-  if (mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3)
-    while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  if (head_size == 64 && block_size == 16 && wph == 2 && nblk >= R.many_fp8_min_blocks) wph = R.many_waves_fp8;
+  if (over_full && wph == 1) wph = R.many_waves_fp8;
+  if (mean_seq_len > 0 && (long)mean_seq_len * R.ragged_hint_den < (long)max_seq_len * R.ragged_hint_num)
+    while (wph < R.ragged_hint_waves && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   // (a full chip past the balanced kernel's LDS: the same choice by round efficiency as over fp16 pages — the logits are
   //  fp32 either way; fp8 pages at 8192 tokens ran 906 us = 3.6 TB/s with one 4-head workgroup per CU)
-  if (head_size == 64 && block_size == 16 && 2.0 * (double)units * max_seq_len * head_size > 128e6 &&
-      3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) > (size_t)160 * 1024 && (wph == 1 || max_seq_len > 3400))
+  if (head_size == 64 && block_size == 16 && 2.0 * (double)units * max_seq_len * head_size > R.q_fp8_min_kv_bytes &&
+      !q_lds_fits(max_seq_len, 64) && (wph == 1 || max_seq_len > R.long_ctx_tokens))
     wph = waves_per_head_without_balancing(num_seqs, num_heads, head_size, max_seq_len, nblk, wph);
   int v = 0;
   if (block_size == 16 && (head_size == 64 || head_size == 128)) {
@@ -584,54 +669,49 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
                         bool bf = false, int mean_seq_len = 0, bool allow_balanced = true) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
+  const bool core = block_size == 16 && (head_size == 64 || head_size == 128);   // the tuned menu (pa_table_core.inc)
+  // (the other head / block sizes have one-wave and four-wave kernels only: the plain fill rule decides between them)
   int wph = 1;
-  while (wph < 16 && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  if (core) wph = waves_to_fill_the_chip(units, nblk);
+  else while (wph < R.max_waves_per_head && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   const double kv_bytes = 4.0 * (double)units * (double)max_seq_len * head_size;
-  const int nt = kv_bytes > 128e6 ? 1 : 0;
   // (a batch the caller knows to be ragged: many waves per head, so that the hardware dispatcher balances the chip —
   //  except where the balanced kernel below does that itself, from the lengths it reads on the device)
-  // The balanced kernel also serves a chip that is only NEARLY full (from 80 % of the resident waves on: 208 sequences x
-  // 12 heads): its one-item-per-wave mode then beats two waves per head on equal lengths (batch 224: 114.6 -> 109.5 us,
-  // 240: 122.4 -> 115.9; 192: 95.6 against 100.9, so not below 80 %) and its ranked modes beat it on ragged ones (224:
-  // 69.0 -> 64.4 us).  Round 3, profiles/r03l_nearly_full_chip.md.
-  // (end of round 3: the alternative below the threshold is now EIGHT waves per head, see below, which moves the crossover from
-  //  80 % to 7/8 of the resident waves: batch 208: 103.3 / 58.7 us against the balanced kernel's 104.6 / 61.9 on equal / ragged
-  //  lengths, 224: 110.5 / 64.7 against 109.8 / 67.1, 240: 121.0 / 69.7 against 116.3 / 71.2)
-  const bool near_full = wph == 2 && units * 8 >= full_chip_waves() * 7;
-  const bool lds_fits_q = 3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
-  // MORE items than resident waves (batch 257 and up at 12 heads): several waves per head again — eight from 1024 tokens on,
-  // four from 512 — i.e. many times the resident waves, handed out by the hardware dispatcher as workgroups finish.  Measured
-  // against the balanced kernel's ranked hand-out over 12 length distributions (scripts/default_vs_waves_probe.py,
-  // profiles/r03z_eight_waves_per_head.md): equal lengths level (batch 288 / 384 / 512 / 768: 144.1 / 182.7 / 240.0 / 355.3
-  // against 144.2 / 185.4 / 244.0 / 365.2 us), continuous spreads 3 - 13 % faster (U{1..L} 78.8 / 100.5 / 124.6 / 186.1 against
-  // 83.7 / 108.6 / 133.4 / 195.2), bimodal ones 3 - 9 %; behind only where nearly every sequence is very short (1/16 of them
-  // full, the rest 64 tokens: + 4 ... + 18 %).  The balanced kernel keeps the chip it was built for: 7/8 ... 1 x the resident waves.
-  const bool over_full = units > full_chip_waves() && head_size == 64 && block_size == 16 && nblk >= 32 && lds_fits_q;
-  const bool balanced = allow_balanced && !over_full && (wph == 1 || near_full) && nt && block_size == 16 && head_size == 64 &&
+  // The balanced kernel also serves a chip that is only NEARLY full: its one-item-per-wave mode then beats two waves per
+  // head on equal lengths and its ranked modes beat it on ragged ones (r03l_nearly_full_chip.md; since the alternative
+  // below the threshold is EIGHT waves per head the crossover sits at 7/8 of the resident waves: batch 208: 103.3 / 58.7 us
+  // against the balanced kernel's 104.6 / 61.9 on equal / ragged lengths, 224: 110.5 / 64.7 against 109.8 / 67.1).
+  const bool near_full = wph == 2 && units * R.near_full_den >= full_chip_waves() * R.near_full_num;
+  const bool lds_fits_q = q_lds_fits(max_seq_len, 64);
+  // MORE items than resident waves: several waves per head again, i.e. many times the resident waves, handed out by the
+  // hardware dispatcher as workgroups finish.  Measured against the balanced kernel's ranked hand-out over 12 length
+  // distributions (scripts/default_vs_waves_probe.py, r03z_eight_waves_per_head.md): equal lengths level, continuous
+  // spreads 3 - 13 % faster, bimodal ones 3 - 9 %; behind only where nearly every sequence is very short.  The balanced
+  // kernel keeps the chip it was built for: 7/8 ... 1 x the resident waves.
+  const bool over_full = units > full_chip_waves() && head_size == 64 && block_size == 16 && nblk >= R.many_min_blocks && lds_fits_q;
+  const bool nt_by_bytes = kv_bytes > R.nt_kv_bytes;
+  const bool balanced = allow_balanced && !over_full && (wph == 1 || near_full) && nt_by_bytes && block_size == 16 && head_size == 64 &&
                         lds_fits_q;
-  const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * 4 < (long)max_seq_len * 3;
+  const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * R.ragged_hint_den < (long)max_seq_len * R.ragged_hint_num;
   if (ragged)
-    while (wph < 8 && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+    while (wph < R.ragged_hint_waves && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  if (over_full && wph == 1) wph = nblk >= R.many_long_blocks ? R.many_waves_long : R.many_waves_short;
   // A chip that two or four waves per head would just fill (batch 64 .. 223 at 12 heads) gets EIGHT, hint or no hint: several
-  // times the resident waves cost equal lengths nothing (batch 128 / 160 / 192, 1024 tokens: 65.0 / 80.0 / 94.6 -> 63.8 / 79.5 /
-  // 95.0 us) and let the hardware dispatcher balance a ragged batch (44.4 / 51.8 / 59.3 -> 38.4 / 49.0 / 55.5; 2048 tokens,
-  // batch 192: 111.4 -> 104.1; 4096: 251 -> 219).  From 512 tokens on (shorter contexts are launch-bound either way) and where
-  // the long-context scoring below does not apply.  profiles/r03z_eight_waves_per_head.md
-  if (over_full && wph == 1) wph = nblk >= 64 ? 8 : 4;
-  // (head size 128 likewise, by a smaller margin: 32 heads x 48 sequences of 2048 tokens 253 -> 244 us equal, 155 -> 148 ragged)
-  if (!balanced && !over_full && lds_fits_q && (head_size == 64 || head_size == 128) && block_size == 16 && (wph == 2 || wph == 4) &&
-      nblk >= 32)
-    wph = 8;
+  // times the resident waves cost equal lengths nothing and let the hardware dispatcher balance a ragged batch (head size 128
+  // likewise, by a smaller margin).  Where the long-context scoring below does not apply.
+  if (!balanced && !over_full && lds_fits_q && core && (wph == 2 || wph == 4) && nblk >= R.many_min_blocks) wph = R.many_waves_long;
   // (only where the balanced kernel's LDS does not fit: shorter contexts keep the tuned picks — the fused append, which
   //  has no balanced twin, stays bit-identical to the call pair there)
-  const bool balanced_lds_fits = 3 * (16 * ((size_t)((max_seq_len + 31) / 32) * 32) + 16 * 1024) <= (size_t)160 * 1024;
-  if (!balanced && !balanced_lds_fits && nt && head_size == 64 && block_size == 16 && (wph == 1 || max_seq_len > 3400))
+  if (!balanced && !lds_fits_q && nt_by_bytes && head_size == 64 && block_size == 16 && (wph == 1 || max_seq_len > R.long_ctx_tokens))
     wph = waves_per_head_without_balancing(num_seqs, num_heads, head_size, max_seq_len, nblk, wph);
-  if (block_size == 16 && (head_size == 64 || head_size == 128)) {  // core table: full menu
+  // temporal loads (and two V groups across the softmax) only while the working set is cache-sized AND every workgroup is resident
+  const int nt = (nt_by_bytes || (wph > 1 && (double)units * wph > R.nt_resident_factor * (double)full_chip_waves())) ? 1 : 0;
+  if (core) {  // core table: full menu
     const double waves_per_cu = (double)units * wph / (double)g_cus;
     const double tile_kib = head_size * 16 * 2 / 1024.0;
     int u = 1;
-    while (u < 4 && waves_per_cu * u * tile_kib < 24.0) u *= 2;
+    while (u < 4 && waves_per_cu * u * tile_kib < R.min_kib_in_flight_per_cu) u *= 2;
+    while (u > 1 && wph > 1 && (long)u * wph > (nblk > 0 ? nblk : 1)) u /= 2;   // (never more register slots than a wave has blocks)
     if (balanced && (u == 1 || near_full)) {
       // full chip: the balanced kernel (pa_queue.hpp) — it reads seq_lens on the device and runs one wave per
       // (sequence, head) on equal lengths, ranked work lists on ragged ones; needs 3 workgroups' LDS per CU
@@ -650,11 +730,11 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
     }
     // (the lockstep 4-heads-per-wave kernel needs the whole register file: ONE 16-head workgroup per CU, so it pays only
     //  where the launch's workgroups fill whole rounds of those slots — 128 x 32 heads: 630 us against 641 for the
-    //  4-head workgroups; 129 sequences: 1120 against 701, 160: 1142 against 797, 96: 571 against 483.  Round 3,
-    //  profiles/r03n_head_128_round_fit.md)
-    const double lock_fill = (double)num_seqs * (num_heads / 16) / (double)g_cus;
+    //  4-head workgroups; 129 sequences: 1120 against 701, 160: 1142 against 797, 96: 571 against 483)
+    const double lock_fill = (double)num_seqs * (num_heads / R.lock_heads_per_wg) / (double)g_cus;
     const double lock_eff = lock_fill / (double)(long)(lock_fill + 0.999999);
-    if (wph == 1 && head_size == 128 && nt && num_heads % 16 == 0 && waves_per_cu >= 12.0 && lock_eff >= 0.97) {
+    if (wph == 1 && head_size == 128 && nt && num_heads % R.lock_heads_per_wg == 0 && waves_per_cu >= R.lock_min_waves_per_cu &&
+        lock_eff >= R.lock_min_round_fill) {
       for (int id = 1; id <= nvariants_v1(); ++id) {  // d128_mh4_h4_u1_nt1_lock
         const Variant& c = variant_v1(id);
         if (c.BF == bf && c.D == 128 && c.HPT == 4 && c.HPW == 4 && c.U == 1 && !c.QUEUE) return id;
@@ -771,16 +851,15 @@ static int extras_gate(const char* op, bool bf, int f8, const int32_t* bsp) {
   return (bsp || bf || f8 == 2) ? not_built(what) : VMI_OK;
 }
 
-static int launch_pa_v1(void* out, const void* query, const void* key_cache,
+int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         const void* value_cache, int32_t num_seqs, int32_t num_heads,
                         int32_t head_size, int32_t num_kv_heads, float scale,
                         const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
                         int32_t max_seq_len, int32_t max_num_blocks_per_seq,
                         const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
                         int64_t kv_head_stride, int32_t device, void* stream, int32_t variant,
-                        bool bf = false, bool append = false, const void* key = nullptr,
-                        const void* value = nullptr, int64_t key_stride = 0, int64_t value_stride = 0,
-                        int f8 = false, float kv_scale = 1.0f, const int32_t* bsp = nullptr) {
+                        bool bf, bool append, const void* key, const void* value, int64_t key_stride,
+                        int64_t value_stride, int f8, float kv_scale, const int32_t* bsp) {
   // (an EMPTY batch — num_seqs == 0: the per-sequence tensors have no storage, torch hands out null data pointers — is
   //  a no-op below, not an error; the caches must exist either way)
   if (!key_cache || !value_cache || (num_seqs != 0 && (!out || !query || !block_tables || !seq_lens)))
@@ -1086,14 +1165,14 @@ static pa_reduce_t reduce_kernel_for(int head_size, bool bf) {
   return extra_reduce_kernel(head_size, false);
 }
 
-static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
+int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query,
                         const void* key_cache, const void* value_cache, int32_t num_seqs,
                         int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
                         const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
                         int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
                         int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                        int32_t device, void* stream, int32_t variant, bool bf = false, int f8 = false,
-                        float kv_scale = 1.0f, const int32_t* bsp = nullptr) {
+                        int32_t device, void* stream, int32_t variant, bool bf, int f8, float kv_scale,
+                        const int32_t* bsp) {
   if (int rc = extras_gate("paged_attention_v2", bf, f8, bsp)) return rc;
   if (bsp) {
     if (int rc = check_sparse("paged_attention_v2", bsp)) return rc;
@@ -1198,6 +1277,43 @@ static int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp
   return VMI_OK;
 }
 
+// the quantising scatter behind vmi_reshape_and_cache_fp8 (and, in the extras library, its bfloat16 / E5M2 forms)
+int reshape_and_cache_fp8_impl(const void* key, const void* value, void* key_cache, void* value_cache,
+                                      const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
+                                      int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
+                                      int64_t value_stride, float kv_scale, int32_t device, void* stream, bool bf,
+                                      bool e5) {
+  if (!key_cache || !value_cache || (num_tokens != 0 && (!key || !value || !slot_mapping)))
+    return fail(VMI_E_NULL_POINTER, "reshape_and_cache (fp8): NULL tensor pointer");
+  if (x != 16) return fail(VMI_E_X, "reshape_and_cache (fp8): key_cache.size(4) must be 16, got %d", x);
+  if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || (head_size & 15))
+    return fail(VMI_E_SHAPE, "reshape_and_cache (fp8): bad sizes (num_tokens=%d num_heads=%d head_size=%d)",
+                num_tokens, num_heads, head_size);
+  if (block_size <= 0) return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: %d", block_size);
+  if (!(kv_scale > 0.f)) return fail(VMI_E_SHAPE, "reshape_and_cache (fp8): kv_scale must be positive, got %g", (double)kv_scale);
+  if (!aligned16(key_cache)) return fail(VMI_E_ALIGNMENT, "reshape_and_cache (fp8): key_cache must be 16-byte aligned");
+  if (num_tokens == 0) return VMI_OK;
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  const bool vec = aligned16(key) && aligned16(value) && !(key_stride & 7) && !(value_stride & 7);
+  const int n16 = (num_heads * head_size) >> 4;
+  int threads = ((n16 + 63) / 64) * 64;
+  if (threads > 256) threads = 256;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const fp8_scatter_fn fn = (bf || e5) ? fp8_scatter_extra_kernel(vec, bf, e5)   // out-of-scope instantiations
+                            : vec      ? (fp8_scatter_fn)reshape_and_cache_fp8_kernel<true, false, false>
+                                       : (fp8_scatter_fn)reshape_and_cache_fp8_kernel<false, false, false>;
+  if (!fn) return not_built(e5 ? "reshape_and_cache over fp8-E5M2 pages" : "reshape_and_cache (fp8) over bfloat16 rows");
+  hipLaunchKernelGGL(fn, dim3(num_tokens), dim3(threads), 0, st, static_cast<const h16*>(key),
+                     static_cast<const h16*>(value), static_cast<uint8_t*>(key_cache),
+                     static_cast<uint8_t*>(value_cache), slot_mapping, key_stride, value_stride, num_heads, head_size,
+                     block_size, kv_scale);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "reshape_and_cache (fp8) launch");
+  return VMI_OK;
+}
+
 }  // namespace vmi
 
 // ----------------------------------------------------------------------------------------
@@ -1223,43 +1339,6 @@ int vmi_paged_attention_v1_f16(void* out, const void* query, const void* key_cac
                            kv_head_stride, device, stream, 0);
 }
 
-int vmi_paged_attention_v1_blocksparse(void* out, const void* query, const void* key_cache,
-                                       const void* value_cache, int32_t num_seqs, int32_t num_heads,
-                                       int32_t head_size, int32_t num_kv_heads, float scale,
-                                       const int32_t* block_tables, const int32_t* seq_lens,
-                                       int32_t block_size, int32_t max_seq_len,
-                                       int32_t max_num_blocks_per_seq, const float* alibi_slopes,
-                                       int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                                       int32_t device, void* stream, int32_t is_bf16, int32_t tp_rank,
-                                       int32_t blocksparse_local_blocks, int32_t blocksparse_vert_stride,
-                                       int32_t blocksparse_block_size, int32_t blocksparse_head_sliding_step) {
-  const int32_t bsp[5] = {tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
-                          blocksparse_head_sliding_step};
-  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
-                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
-                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
-                           kv_head_stride, device, stream, 0, is_bf16 != 0, false, nullptr, nullptr, 0, 0, false,
-                           1.0f, bsp);
-}
-
-int vmi_paged_attention_v2_blocksparse(void* out, float* exp_sums, float* max_logits, void* tmp_out,
-                                       const void* query, const void* key_cache, const void* value_cache,
-                                       int32_t num_seqs, int32_t num_heads, int32_t head_size,
-                                       int32_t num_kv_heads, float scale, const int32_t* block_tables,
-                                       const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
-                                       int32_t max_num_blocks_per_seq, const float* alibi_slopes,
-                                       int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                                       int32_t device, void* stream, int32_t is_bf16, int32_t tp_rank,
-                                       int32_t blocksparse_local_blocks, int32_t blocksparse_vert_stride,
-                                       int32_t blocksparse_block_size, int32_t blocksparse_head_sliding_step) {
-  const int32_t bsp[5] = {tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
-                          blocksparse_head_sliding_step};
-  return vmi::launch_pa_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs, num_heads,
-                           head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
-                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride, kv_head_stride,
-                           device, stream, 0, is_bf16 != 0, false, 1.0f, bsp);
-}
-
 int vmi_paged_attention_v1_f16_variant(void* out, const void* query, const void* key_cache,
                                        const void* value_cache, int32_t num_seqs,
                                        int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
@@ -1275,19 +1354,6 @@ int vmi_paged_attention_v1_f16_variant(void* out, const void* query, const void*
                            kv_head_stride, device, stream, variant);
 }
 
-int vmi_paged_attention_v1_bf16(void* out, const void* query, const void* key_cache,
-                                const void* value_cache, int32_t num_seqs, int32_t num_heads,
-                                int32_t head_size, int32_t num_kv_heads, float scale,
-                                const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
-                                int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-                                const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
-                                int64_t kv_head_stride, int32_t device, void* stream, int32_t variant) {
-  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
-                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
-                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
-                           kv_head_stride, device, stream, variant, true);
-}
-
 int vmi_paged_attention_v1_append_f16(void* out, const void* query, void* key_cache, void* value_cache,
                                       int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                       int32_t num_kv_heads, float scale, const int32_t* block_tables,
@@ -1300,21 +1366,6 @@ int vmi_paged_attention_v1_append_f16(void* out, const void* query, void* key_ca
                            num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
                            max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
                            kv_head_stride, device, stream, variant, false, true, key, value, key_stride,
-                           value_stride);
-}
-
-int vmi_paged_attention_v1_append_bf16(void* out, const void* query, void* key_cache, void* value_cache,
-                                       int32_t num_seqs, int32_t num_heads, int32_t head_size,
-                                       int32_t num_kv_heads, float scale, const int32_t* block_tables,
-                                       const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
-                                       int32_t max_num_blocks_per_seq, const float* alibi_slopes,
-                                       int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                                       int32_t device, void* stream, const void* key, const void* value,
-                                       int64_t key_stride, int64_t value_stride, int32_t variant) {
-  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
-                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
-                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
-                           kv_head_stride, device, stream, variant, true, true, key, value, key_stride,
                            value_stride);
 }
 
@@ -1334,22 +1385,6 @@ int vmi_paged_attention_v1_fp8(void* out, const void* query, const void* key_cac
                            true, kv_scale);
 }
 
-int vmi_paged_attention_v1_fp8_bf16(void* out, const void* query, const void* key_cache, const void* value_cache,
-                                    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-                                    float scale, const int32_t* block_tables, const int32_t* seq_lens,
-                                    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-                                    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
-                                    int64_t kv_head_stride, int32_t device, void* stream, float kv_scale,
-                                    int32_t variant) {
-  if (!(kv_scale > 0.f))
-    return vmi::fail(VMI_E_SHAPE, "paged_attention_v1 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
-  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
-                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
-                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
-                           kv_head_stride, device, stream, variant, true, false, nullptr, nullptr, 0, 0,
-                           true, kv_scale);
-}
-
 int vmi_paged_attention_v2_fp8(void* out, void* exp_sums, void* max_logits, void* tmp_out, const void* query,
                                const void* key_cache, const void* value_cache, int32_t num_seqs,
                                int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
@@ -1366,87 +1401,10 @@ int vmi_paged_attention_v2_fp8(void* out, void* exp_sums, void* max_logits, void
                            kv_scale);
 }
 
-// ---- fp8 E5M2 cache (kv_cache_dtype "fp8_e5m2"): the same operators over E5M2 bytes ----
-int vmi_paged_attention_v1_fp8_e5m2(void* out, const void* query, const void* key_cache, const void* value_cache,
-                                    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
-                                    float scale, const int32_t* block_tables, const int32_t* seq_lens,
-                                    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
-                                    const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
-                                    int64_t kv_head_stride, int32_t device, void* stream, float kv_scale,
-                                    int32_t variant, int32_t is_bf16) {
-  if (!(kv_scale > 0.f))
-    return vmi::fail(VMI_E_SHAPE, "paged_attention_v1 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
-  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
-                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
-                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
-                           kv_head_stride, device, stream, variant, is_bf16 != 0, false, nullptr, nullptr, 0, 0,
-                           2, kv_scale);
-}
-
-int vmi_paged_attention_v2_fp8_e5m2(void* out, void* exp_sums, void* max_logits, void* tmp_out, const void* query,
-                                    const void* key_cache, const void* value_cache, int32_t num_seqs,
-                                    int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
-                                    const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
-                                    int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
-                                    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                                    int32_t device, void* stream, float kv_scale, int32_t variant) {
-  if (!(kv_scale > 0.f))
-    return vmi::fail(VMI_E_SHAPE, "paged_attention_v2 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
-  return vmi::launch_pa_v2(out, static_cast<float*>(exp_sums), static_cast<float*>(max_logits), tmp_out, query,
-                           key_cache, value_cache, num_seqs, num_heads, head_size, num_kv_heads, scale,
-                           block_tables, seq_lens, block_size, max_seq_len, max_num_blocks_per_seq, alibi_slopes,
-                           q_stride, kv_block_stride, kv_head_stride, device, stream, variant, false, 2,
-                           kv_scale);
-}
-
-int vmi_paged_attention_v2_fp8_bf16(void* out, void* exp_sums, void* max_logits, void* tmp_out, const void* query,
-                                    const void* key_cache, const void* value_cache, int32_t num_seqs,
-                                    int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
-                                    const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,
-                                    int32_t max_seq_len, int32_t max_num_blocks_per_seq, const float* alibi_slopes,
-                                    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                                    int32_t device, void* stream, float kv_scale, int32_t variant, int32_t is_e5m2) {
-  if (!(kv_scale > 0.f))
-    return vmi::fail(VMI_E_SHAPE, "paged_attention_v2 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
-  return vmi::launch_pa_v2(out, static_cast<float*>(exp_sums), static_cast<float*>(max_logits), tmp_out, query,
-                           key_cache, value_cache, num_seqs, num_heads, head_size, num_kv_heads, scale,
-                           block_tables, seq_lens, block_size, max_seq_len, max_num_blocks_per_seq, alibi_slopes,
-                           q_stride, kv_block_stride, kv_head_stride, device, stream, variant, true, is_e5m2 ? 2 : 1,
-                           kv_scale);
-}
-
-int vmi_paged_attention_v1_pick_variant_fp8_e5m2(int32_t num_seqs, int32_t num_heads, int32_t head_size,
-                                                 int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len,
-                                                 int32_t is_bf16) {
-  if (!vmi::head_size_supported(head_size) || (block_size != 16 && block_size != 32)) return 0;
-  return vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, mean_seq_len, is_bf16 != 0, 2);
-}
-
 int vmi_paged_attention_v1_pick_variant_fp8(int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                             int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len) {
   if (!vmi::head_size_supported(head_size) || (block_size != 16 && block_size != 32)) return 0;
   return vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, mean_seq_len);
-}
-
-int vmi_paged_attention_v1_pick_variant_fp8_bf16(int32_t num_seqs, int32_t num_heads, int32_t head_size,
-                                                 int32_t block_size, int32_t max_seq_len, int32_t mean_seq_len) {
-  if (!vmi::head_size_supported(head_size) || (block_size != 16 && block_size != 32)) return 0;
-  return vmi::pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, mean_seq_len, true);
-}
-
-int vmi_paged_attention_v2_bf16(void* out, void* exp_sums, void* max_logits, void* tmp_out,
-                                const void* query, const void* key_cache, const void* value_cache,
-                                int32_t num_seqs, int32_t num_heads, int32_t head_size,
-                                int32_t num_kv_heads, float scale, const int32_t* block_tables,
-                                const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
-                                int32_t max_num_blocks_per_seq, const float* alibi_slopes,
-                                int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                                int32_t device, void* stream, int32_t variant) {
-  return vmi::launch_pa_v2(out, static_cast<float*>(exp_sums), static_cast<float*>(max_logits), tmp_out,
-                           query, key_cache, value_cache, num_seqs, num_heads, head_size, num_kv_heads,
-                           scale, block_tables, seq_lens, block_size, max_seq_len,
-                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
-                           kv_head_stride, device, stream, variant, true);
 }
 
 int vmi_paged_attention_v1_variant_count(void) { return vmi::nvariants_v1(); }
@@ -1588,65 +1546,12 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
   return VMI_OK;
 }
 
-static int reshape_and_cache_fp8_impl(const void* key, const void* value, void* key_cache, void* value_cache,
-                                      const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
-                                      int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
-                                      int64_t value_stride, float kv_scale, int32_t device, void* stream, bool bf,
-                                      bool e5 = false) {
-  using namespace vmi;
-  if (!key_cache || !value_cache || (num_tokens != 0 && (!key || !value || !slot_mapping)))
-    return fail(VMI_E_NULL_POINTER, "reshape_and_cache (fp8): NULL tensor pointer");
-  if (x != 16) return fail(VMI_E_X, "reshape_and_cache (fp8): key_cache.size(4) must be 16, got %d", x);
-  if (num_tokens < 0 || num_heads <= 0 || head_size <= 0 || (head_size & 15))
-    return fail(VMI_E_SHAPE, "reshape_and_cache (fp8): bad sizes (num_tokens=%d num_heads=%d head_size=%d)",
-                num_tokens, num_heads, head_size);
-  if (block_size <= 0) return fail(VMI_E_BLOCK_SIZE, "Unsupported block size: %d", block_size);
-  if (!(kv_scale > 0.f)) return fail(VMI_E_SHAPE, "reshape_and_cache (fp8): kv_scale must be positive, got %g", (double)kv_scale);
-  if (!aligned16(key_cache)) return fail(VMI_E_ALIGNMENT, "reshape_and_cache (fp8): key_cache must be 16-byte aligned");
-  if (num_tokens == 0) return VMI_OK;
-  DeviceGuard guard(device);
-  hipError_t e = guard.err;
-  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  const bool vec = aligned16(key) && aligned16(value) && !(key_stride & 7) && !(value_stride & 7);
-  const int n16 = (num_heads * head_size) >> 4;
-  int threads = ((n16 + 63) / 64) * 64;
-  if (threads > 256) threads = 256;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const fp8_scatter_fn fn = (bf || e5) ? fp8_scatter_extra_kernel(vec, bf, e5)   // out-of-scope instantiations
-                            : vec      ? (fp8_scatter_fn)reshape_and_cache_fp8_kernel<true, false, false>
-                                       : (fp8_scatter_fn)reshape_and_cache_fp8_kernel<false, false, false>;
-  if (!fn) return not_built(e5 ? "reshape_and_cache over fp8-E5M2 pages" : "reshape_and_cache (fp8) over bfloat16 rows");
-  hipLaunchKernelGGL(fn, dim3(num_tokens), dim3(threads), 0, st, static_cast<const h16*>(key),
-                     static_cast<const h16*>(value), static_cast<uint8_t*>(key_cache),
-                     static_cast<uint8_t*>(value_cache), slot_mapping, key_stride, value_stride, num_heads, head_size,
-                     block_size, kv_scale);
-  e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "reshape_and_cache (fp8) launch");
-  return VMI_OK;
-}
-
 int vmi_reshape_and_cache_fp8(const void* key, const void* value, void* key_cache, void* value_cache,
                               const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
                               int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
                               int64_t value_stride, float kv_scale, int32_t device, void* stream) {
-  return reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
+  return vmi::reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
                                     block_size, x, key_stride, value_stride, kv_scale, device, stream, false);
-}
-
-int vmi_reshape_and_cache_fp8_bf16(const void* key, const void* value, void* key_cache, void* value_cache,
-                                   const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
-                                   int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
-                                   int64_t value_stride, float kv_scale, int32_t device, void* stream) {
-  return reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
-                                    block_size, x, key_stride, value_stride, kv_scale, device, stream, true);
-}
-
-int vmi_reshape_and_cache_fp8_e5m2(const void* key, const void* value, void* key_cache, void* value_cache,
-                                   const int64_t* slot_mapping, int32_t num_tokens, int32_t num_heads,
-                                   int32_t head_size, int32_t block_size, int32_t x, int64_t key_stride,
-                                   int64_t value_stride, float kv_scale, int32_t device, void* stream, int32_t is_bf16) {
-  return reshape_and_cache_fp8_impl(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
-                                    block_size, x, key_stride, value_stride, kv_scale, device, stream, is_bf16 != 0, true);
 }
 
 int vmi_paged_attention_v2_f16(void* out, void* exp_sums, void* max_logits, void* tmp_out,
@@ -1781,6 +1686,16 @@ int vmi_diag_gather_read(const void* src, int64_t bytes, void* sink, int32_t chu
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "diag_gather_read launch");
   return VMI_OK;
+}
+
+// include/vmi_paged_attention_diag.h: where the core menu's pa_v1_kernel instantiations write their stage stamps
+int vmi_diag_set_stage_stamps(void* records, int32_t device) {
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return -1;
+  uint64_t* ptr = static_cast<uint64_t*>(records);
+  const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(vmi::g_stage_stamps), &ptr, sizeof(ptr));   // (synchronous)
+  (void)hipSetDevice(prev);
+  return e == hipSuccess ? 0 : -(int)e;
 }
 
 #endif  // VMI_DIAG

@@ -85,6 +85,12 @@ class GPT2PagedDecoder:
         assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
         assert pool.head_size == dims.head_size
         self.dims, self.sd, self.pool = dims, state_dict, pool
+        wdt = next(iter(state_dict.values())).dtype
+        if wdt != torch.float16 or pool.kv_cache_dtype == "fp8_e5m2":
+            # bfloat16 / float32 weights (hence q, k, v) and E5M2 pages are outside the hot path: the product library holds no
+            # kernel for them — fail in the constructor with the operators' message, not at the first launch
+            from . import _lib
+            _lib.require_extras(f"GPT2PagedDecoder over {wdt} weights / kv_cache_dtype='{pool.kv_cache_dtype}'")
         self.reference_off_by_one = reference_off_by_one
         # fused_append: one launch per layer (ops.paged_attention_v1_append) instead of the reference's call pair
         # reshape_and_cache + paged_attention_v1 (gpt2.py:44, :62); bit-identical caches and outputs.  It derives

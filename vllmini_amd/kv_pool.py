@@ -55,6 +55,10 @@ class PagedKVPool:
         # "auto": fp16 pages (kv_cache.py:13-14); "fp8" / "fp8_e5m2": E4M3 / E5M2 byte pages in the x = 16 layout, half the bytes
         # (the reference surface's kv_cache_dtype / kv_scale, passed through to both operators)
         self.kv_cache_dtype, self.kv_scale = kv_cache_dtype, float(kv_scale)
+        if allocate_tensors and kv_cache_dtype == "fp8_e5m2":
+            # E5M2 pages are outside the hot path (include/vmi_paged_attention_extras.h): say so HERE, not at the first launch
+            from . import _lib
+            _lib.require_extras("PagedKVPool(kv_cache_dtype='fp8_e5m2'): operators over fp8-E5M2 pages")
         if allocate_tensors:
             # kv_cache.py:13-14 — ONE pool shared by all layers
             x, dt = (16, torch.uint8) if kv_cache_dtype in ("fp8", "fp8_e4m3", "fp8_e5m2") else (X, torch.float16)

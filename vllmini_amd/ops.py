@@ -80,6 +80,9 @@ def _raise_native(code: int) -> None:
     raise RuntimeError(f"{_lib.last_error()} (vmi code {code})")
 
 
+_extras = _lib.require_extras      # the active library if it holds the out-of-scope operators, else RuntimeError("<what>: not in this build ...")
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -237,23 +240,27 @@ def paged_attention_v1(
                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
                       blocksparse_block_size, blocksparse_head_sliding_step)
     lib = _lib.load()
+    # (the first five branches are the out-of-scope corners of the reference's dispatch: they exist in the extras library
+    #  only, include/vmi_paged_attention_extras.h — on the product library _extras raises before any entry is touched)
     if query.dtype == torch.float32:               # the (float, float) dispatch branch: plain kernels, no variants
         if _variant:
             raise RuntimeError("_variant does not apply to float32 tensors")
-        rc = lib.vmi_paged_attention_v1_f32(*args)
+        rc = _extras("paged_attention_v1 over float32 tensors").vmi_paged_attention_v1_f32(*args)
     elif int(blocksparse_vert_stride) > 1:           # block-sparse attention: its own kernels, no tuning variants
         if _variant:
             raise RuntimeError("_variant does not apply to block-sparse attention")
-        rc = lib.vmi_paged_attention_v1_blocksparse(
+        rc = _extras("paged_attention_v1 with block-sparse attention").vmi_paged_attention_v1_blocksparse(
             *args, int(query.dtype == torch.bfloat16), int(tp_rank), int(blocksparse_local_blocks),
             int(blocksparse_vert_stride), int(blocksparse_block_size), int(blocksparse_head_sliding_step))
     elif _check_kv_cache_dtype(kv_cache_dtype) == 2:   # fp8 E5M2 cache
-        rc = lib.vmi_paged_attention_v1_fp8_e5m2(*args, float(kv_scale), int(_variant), int(query.dtype == torch.bfloat16))
+        rc = _extras("paged_attention_v1 over fp8-E5M2 pages").vmi_paged_attention_v1_fp8_e5m2(
+            *args, float(kv_scale), int(_variant), int(query.dtype == torch.bfloat16))
     elif _check_kv_cache_dtype(kv_cache_dtype):      # fp8 E4M3 cache, float16 or bfloat16 query
-        fn = lib.vmi_paged_attention_v1_fp8_bf16 if query.dtype == torch.bfloat16 else lib.vmi_paged_attention_v1_fp8
+        fn = _extras("paged_attention_v1 over bfloat16 tensors").vmi_paged_attention_v1_fp8_bf16 \
+            if query.dtype == torch.bfloat16 else lib.vmi_paged_attention_v1_fp8
         rc = fn(*args, float(kv_scale), int(_variant))
     elif query.dtype == torch.bfloat16:
-        rc = lib.vmi_paged_attention_v1_bf16(*args, int(_variant))
+        rc = _extras("paged_attention_v1 over bfloat16 tensors").vmi_paged_attention_v1_bf16(*args, int(_variant))
     elif _variant:
         rc = lib.vmi_paged_attention_v1_f16_variant(*args, int(_variant))
     else:
@@ -306,8 +313,8 @@ def paged_attention_v1_append(
             raise RuntimeError(f"{name} must be [num_seqs, num_kv_heads, head_size], got {tuple(t.shape)}")
         if t.stride(2) != 1 or t.stride(1) != head_size:
             raise RuntimeError(f"{name} must be contiguous in its last two dimensions")
-    lib = _lib.load()
-    fn = lib.vmi_paged_attention_v1_append_bf16 if query.dtype == torch.bfloat16 else lib.vmi_paged_attention_v1_append_f16
+    fn = _extras("paged_attention_v1_append over bfloat16 tensors").vmi_paged_attention_v1_append_bf16 \
+        if query.dtype == torch.bfloat16 else _lib.load().vmi_paged_attention_v1_append_f16
     rc = fn(*args, key.data_ptr(), value.data_ptr(), int(key.stride(0)), int(value.stride(0)), int(_variant))
     if rc != 0:
         _raise_native(rc)
@@ -365,20 +372,21 @@ def paged_attention_v2(
     if int(blocksparse_vert_stride) > 1:
         if _variant:
             raise RuntimeError("_variant does not apply to block-sparse attention")
-        rc = _lib.load().vmi_paged_attention_v2_blocksparse(
+        rc = _extras("paged_attention_v2 with block-sparse attention").vmi_paged_attention_v2_blocksparse(
             args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:],
             int(query.dtype == torch.bfloat16), int(tp_rank), int(blocksparse_local_blocks),
             int(blocksparse_vert_stride), int(blocksparse_block_size), int(blocksparse_head_sliding_step))
     elif fp8 and query.dtype == torch.bfloat16:
-        rc = _lib.load().vmi_paged_attention_v2_fp8_bf16(args[0], exp_sums.data_ptr(), max_logits.data_ptr(),
-                                                         tmp_out.data_ptr(), *args[1:], float(kv_scale), int(_variant),
-                                                         int(fp8 == 2))
+        rc = _extras("paged_attention_v2 over bfloat16 tensors").vmi_paged_attention_v2_fp8_bf16(
+            args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:], float(kv_scale), int(_variant),
+            int(fp8 == 2))
     elif fp8:
-        fn8 = _lib.load().vmi_paged_attention_v2_fp8_e5m2 if fp8 == 2 else _lib.load().vmi_paged_attention_v2_fp8
+        fn8 = _extras("paged_attention_v2 over fp8-E5M2 pages").vmi_paged_attention_v2_fp8_e5m2 if fp8 == 2 else \
+            _lib.load().vmi_paged_attention_v2_fp8
         rc = fn8(args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:],
                  float(kv_scale), int(_variant))
     else:
-        fn = _lib.load().vmi_paged_attention_v2_bf16 if query.dtype == torch.bfloat16 else \
+        fn = _extras("paged_attention_v2 over bfloat16 tensors").vmi_paged_attention_v2_bf16 if query.dtype == torch.bfloat16 else \
             _lib.load().vmi_paged_attention_v2_f16
         rc = fn(args[0], exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(), *args[1:], int(_variant))
     if rc != 0:
@@ -445,15 +453,16 @@ def reshape_and_cache(
               slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
               kst[0], vst[0], float(kv_scale), index, stream)
         if fp8 == 2:
-            rc = _lib.load().vmi_reshape_and_cache_fp8_e5m2(*a8, int(kdt == torch.bfloat16))
+            rc = _extras("reshape_and_cache over fp8-E5M2 pages").vmi_reshape_and_cache_fp8_e5m2(*a8, int(kdt == torch.bfloat16))
         else:
-            fn = _lib.load().vmi_reshape_and_cache_fp8_bf16 if kdt == torch.bfloat16 else \
+            fn = _extras("reshape_and_cache (fp8) over bfloat16 rows").vmi_reshape_and_cache_fp8_bf16 if kdt == torch.bfloat16 else \
                 _lib.load().vmi_reshape_and_cache_fp8
             rc = fn(*a8)
         if rc != 0:
             _raise_native(rc)
         return None
-    fn16 = _lib.load().vmi_reshape_and_cache_f32 if kdt == torch.float32 else _lib.load().vmi_reshape_and_cache_f16
+    fn16 = _extras("reshape_and_cache over float32 tensors").vmi_reshape_and_cache_f32 if kdt == torch.float32 else \
+        _lib.load().vmi_reshape_and_cache_f16
     rc = fn16(
         key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
         slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
@@ -520,6 +529,8 @@ def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int
     if num_kv_heads and num_kv_heads != num_heads:      # grouped-query attention: what the operators pick themselves
         return int(lib.vmi_paged_attention_v1_pick_variant_gqa(num_seqs, num_heads, int(num_kv_heads), head_size,
                                                                block_size, max_seq_len, int(bool(bf16)), fp8))
+    if (fp8 == 2 or (fp8 and bf16)) and not getattr(lib, "_vmi_has_extras", False):
+        return 0                                        # (the product library has no such kernel: what its menus answer for bf16)
     if fp8 == 2:
         return int(lib.vmi_paged_attention_v1_pick_variant_fp8_e5m2(num_seqs, num_heads, head_size, block_size,
                                                                     max_seq_len, int(mean_seq_len), int(bool(bf16))))

@@ -47,9 +47,14 @@ def barrier_sync(dist, sync: Optional[Callable[[], None]]) -> None:
         sync()
 
 
+TIMING_BRACKET = ("K steps between (device synchronise, barrier, device synchronise) on both sides; a rank's clock stops when ITS "
+                  "device has finished the K steps, in front of the closing barrier; the MAX over ranks is reported")
+TIMING_BRACKET_LEGACY = "the same bracket with the clock stopped BEHIND the closing barrier (rounds 1-2)"
+
+
 def timed_steps(step: Callable[[int], None], steps: int, warmup: int, dist=None,
                 sync: Optional[Callable[[], None]] = None,
-                timed_step: Optional[Callable[[int], None]] = None) -> float:
+                timed_step: Optional[Callable[[int], None]] = None, clock_behind_barrier: bool = False) -> float:
     """Run `warmup` untimed then exactly `steps` timed calls of step(i); returns local elapsed seconds.
     `sync` = device synchronise (torch.cuda.synchronize on GPU ranks, None on CPU).  `timed_step`, if
     given, replaces `step` inside the timed region (same work plus per-launch event records).
@@ -70,7 +75,20 @@ def timed_steps(step: Callable[[int], None], steps: int, warmup: int, dist=None,
         sync()
     elapsed = time.perf_counter() - t0
     barrier_sync(dist, sync)
+    if clock_behind_barrier:      # rounds 1-2: the closing barrier's own latency inside the reported time (TIMING_BRACKET_LEGACY)
+        elapsed = time.perf_counter() - t0
     return elapsed
+
+
+def all_ranks(value: float, dist=None, device: torch.device | str = "cpu") -> list:
+    """`value` of every rank, in rank order (a [world] all_gather of one float64): per-rank figures beside the max."""
+    if dist is None:
+        return [float(value)]
+    world = dist.get_world_size()
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    got = torch.empty(world, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(got, mine)
+    return [float(x) for x in got.cpu()]
 
 
 def max_over_ranks(value: float, dist=None, device: torch.device | str = "cpu") -> float:
