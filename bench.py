@@ -711,7 +711,7 @@ def rocprof_kernel_us(cfg_name: str, kernel_variant: str):
             d = json.load(f)
         if d.get("kernel_variant") and d["kernel_variant"] != kernel_variant:
             return None, None
-        return d["rocprofv3_kernel_us"]["mean"], os.path.relpath(path, REPO)
+        return d["pa_v1_dispatches"]["mean_us_after_warmup"], os.path.relpath(path, REPO)
     except (OSError, KeyError, ValueError, TypeError):
         return None, None
 
@@ -982,10 +982,15 @@ def main(argv=None):
                               "value": cfg.batch * n_g / g12, "unit": "tokens/s", "ms_per_step": g12 / n_g * 1e3,
                               "pairs_per_graph": 12,
                               "one_pair_per_graph_ms_per_step": g1 / args.steps * 1e3,
-                              "note": "level with plain launches (the call pair is not launch-bound: ms_per_step above); with ONE "
-                                      "pair per graph a step costs one_pair_per_graph_ms_per_step — a hipGraphLaunch costs "
-                                      f"{(g1 / args.steps - g12 / n_g) * 1e6:.1f} us more than the two kernel launches it replaces on this "
-                                      "ROCm, amortised over the 12 pairs here"}
+                              "plain_launches_ms_per_step": ms_per_step,
+                              "graph_minus_plain_us_per_step": (g12 / n_g * 1e3 - ms_per_step) * 1e3,
+                              "note": "graph_minus_plain_us_per_step is what replaying the pair from a hipGraph costs (+) or saves (-) "
+                                      "against plain launches: the call pair is NOT launch-bound (its two kernels run 125 us, the host "
+                                      "issues them in ~25), so a graph has no host time to hide here, and on this ROCm a graph's kernel "
+                                      "nodes are spaced a little wider than stream launches (a few us per pair); one pair per graph adds "
+                                      f"the graph launch itself: {(g1 / args.steps - g12 / n_g) * 1e6:.1f} us more per step than 12 pairs per "
+                                      "graph.  Where graphs pay is a step whose HOST work exceeds its kernels: the end-to-end decode "
+                                      "harness (e2e_step replays the whole token from one graph) and cfg2_step.graph_us_per_pair"}
     if plain and not args.no_ragged and not args.variant and not args.sequential_tables:
         # the same call pair, same default entry (no hint, no variant), on a RAGGED batch: seq_lens ~ U{1..seq_len}
         pools = (wl.key_cache, wl.value_cache)

@@ -1,0 +1,103 @@
+"""Does the work-decomposition heuristic (pick_variant, paged_attention.hip: the PickRules table) generalise beyond the head counts
+it was tuned on (12 x 64 and 32 x 128)?  For H in {8, 16, 20, 25, 40} x D in {64, 128} at the regime edges — 7/8 of the resident
+waves, exactly full (floor and ceiling), 1.1x, 1.5x, 2x, 3x full — and for equal and U{1..L} lengths: the DEFAULT entry against
+every enumerated fp16 multi-head variant of that head size that can serve the launch, same box, same tensors, launches back to
+back, median of 30 HIP-event pairs.  A cell passes when the default is within 5 % of the best variant.
+
+  python scripts/pick_generalisation.py [--heads 8,16,20,25,40] [--head-sizes 64,128] [--seq-len 1024] [out.json]"""
+import argparse
+import dataclasses
+import json
+import os
+import re
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllmini_amd import ops  # noqa: E402
+from vllmini_amd.workload import CONFIGS, make_workload  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--heads", default="8,16,20,25,40")
+ap.add_argument("--head-sizes", default="64,128")
+ap.add_argument("--seq-len", type=int, default=1024)
+ap.add_argument("--edges", default="0.875,1.0f,1.0c,1.1,1.5,2.0,3.0")
+ap.add_argument("out", nargs="?", default="gpurun_out/pick_generalisation.json")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+RESIDENT = 12 * cus
+names = ops.variant_names()
+L = args.seq_len
+res = []
+
+
+def candidates(D):
+    out = []
+    for i, n in enumerate(names):
+        if not re.match(rf"^(q_)?d{D}_", n) or any(t in n for t in ("_gq", "_pvm", "_nt0", "LOADSONLY", "_bs")):
+            continue
+        out.append((i + 1, n))
+    return out
+
+
+def timed(fn, n=30, warm=10):
+    for i in range(warm):
+        fn(i)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i, (a, b) in enumerate(ev):
+        a.record()
+        fn(i)
+        b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) * 1e3 for a, b in ev)[n // 2]
+
+
+for D in [int(x) for x in args.head_sizes.split(",")]:
+    cand = candidates(D)
+    for H in [int(x) for x in args.heads.split(",")]:
+        full = RESIDENT / H
+        batches = []
+        for e in args.edges.split(","):
+            b = int(full) if e == "1.0f" else -(-RESIDENT // H) if e == "1.0c" else int(round(float(e.rstrip("fc")) * full))
+            if b not in [x for x, _ in batches]:
+                batches.append((b, e))
+        for B, edge in batches:
+            if 4.0 * B * H * L * D * 2 > 40e9:
+                continue
+            cfg = dataclasses.replace(CONFIGS["cfg3"], name=f"h{H}_d{D}_b{B}", batch=B, num_heads=H, head_size=D, seq_len=L,
+                                      num_blocks=2 * B * (-(-L // 16)) + 8)
+            for ragged in (False, True):
+                wl = make_workload(cfg, dev, seed=B + H, table_sets=2, ragged=ragged)
+                out = torch.empty((B, H, D), dtype=torch.float16, device=dev)
+
+                def run(i, vid=0):
+                    ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, H, wl.scale, wl.tables[i % 2], wl.seq_lens,
+                                           16, L, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=vid)
+
+                d_us = timed(run)
+                d_label = ops.last_launch_label()
+                rows = []
+                for vid, n in cand:
+                    try:
+                        rows.append((timed(lambda i: run(i, vid), n=20, warm=6), n))
+                    except RuntimeError:
+                        continue          # (this variant cannot serve the launch: head count, LDS)
+                d_us = min(d_us, timed(run))          # the default once more, after the sweep (clock ramp)
+                rows.sort()
+                nbytes = int(wl.seq_lens.sum().item()) * H * D * 4
+                rec = {"heads": H, "head_size": D, "batch": B, "edge": edge, "units_over_resident": round(B * H / RESIDENT, 3),
+                       "lengths": "U{1..L}" if ragged else "equal", "seq_len": L, "default": d_label, "default_us": round(d_us, 1),
+                       "best": rows[0][1], "best_us": round(rows[0][0], 1), "default_over_best": round(d_us / rows[0][0], 3),
+                       "TBps_default": round(nbytes / d_us / 1e6, 2), "top3": [(n, round(u, 1)) for u, n in rows[:3]]}
+                res.append(rec)
+                print(json.dumps(rec), flush=True)
+                del wl, out
+                torch.cuda.empty_cache()
+os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+json.dump(res, open(args.out, "w"), indent=1)
+bad = [r for r in res if r["default_over_best"] > 1.05]
+print(f"{len(res)} cells, {len(bad)} with the default more than 5 % behind the best variant")
+for r in bad:
+    print("  ", r["heads"], r["head_size"], r["batch"], r["edge"], r["lengths"], r["default"], r["default_us"], "best", r["best"], r["best_us"])

@@ -27,7 +27,7 @@ def _median_attention_us(cfg_name: str, n: int = 40, warm: int = 25, kv: str = "
     from vllmini_amd.workload import CONFIGS, make_workload
 
     dev = torch.device("cuda:0")
-    cfg = CONFIGS[cfg_name]
+    cfg = CONFIGS[cfg_name] if isinstance(cfg_name, str) else cfg_name
     wl = make_workload(cfg, dev, seed=21, table_sets=2, ragged=ragged)
     out = torch.empty((cfg.batch, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
     kc, vc, esz = wl.key_cache, wl.value_cache, 2
@@ -87,4 +87,27 @@ def test_fp8_pages_and_ragged_lengths_keep_their_measured_fraction(kv, ragged, f
     us, nbytes, label = _median_attention_us("cfg3", kv=kv, ragged=ragged)
     frac = nbytes / (us * 1e-6) / HBM_PEAK
     assert frac >= floor, (f"cfg3 kv={kv} ragged={ragged}: {us:.1f} us = {frac:.3f} of the 8 TB/s HBM roofline "
+                           f"(floor {floor}); kernel: {label}")
+
+
+# The N = 1 anchor of the strong-scaling curve (BASELINE configs[4] on ONE GPU: 2048 sequences) and one sequence more.  2048 is
+# QSORT_MAX, the most sequences the balanced kernel ranks in LDS; beyond it that kernel serves a batch in index order.  Since
+# round 3 a batch with more items than resident waves takes eight waves per head instead (the hardware dispatcher hands the
+# workgroups out), so neither size reaches the unranked path by default — this floor keeps it that way: measured 0.83 at 2048
+# (`cfg5_strong_n1` in the bench line), the floor sits 10 % below for equal lengths and at the ragged figure of cfg3 for U{1..L}.
+@pytest.mark.parametrize("batch", [2048, 2049])
+@pytest.mark.parametrize("ragged,floor", [(False, 0.74), (True, 0.64)])
+def test_batch_at_and_above_the_ranking_limit_keeps_its_fraction(batch, ragged, floor):
+    import dataclasses
+
+    from vllmini_amd.workload import CONFIGS
+
+    if torch.cuda.get_device_properties(0).multi_processor_count < 200:
+        pytest.skip("the floors are stated for a whole MI355X (256 CUs)")
+    c5 = CONFIGS["cfg5"]
+    cfg = dataclasses.replace(c5, name=f"cfg5_b{batch}", batch=batch, num_blocks=2 * batch * c5.blocks_per_seq)
+    us, nbytes, label = _median_attention_us(cfg, n=24, warm=8, ragged=ragged)
+    frac = nbytes / (us * 1e-6) / HBM_PEAK
+    assert "q_d64" not in label, f"batch {batch}: the balanced kernel would serve {batch} sequences unranked; picked {label}"
+    assert frac >= floor, (f"batch {batch} ragged={ragged}: {us:.1f} us = {frac:.3f} of the 8 TB/s HBM roofline "
                            f"(floor {floor}); kernel: {label}")

@@ -228,8 +228,11 @@ struct PV8 {
       h16x2 c = h16x2{pr[0], pr[1]} + h16x2{pr[2], pr[3]};
       c = c + h16x2{pr[4], pr[5]};
       c = c + h16x2{pr[6], pr[7]};
-      // (fp32 add of the two halves, dtype_float16.cuh:439-443 — written as fma(c0, 1, c1): the same single rounding,
-      //  and v_fma_mix_f32 takes the fp16 operands directly instead of two conversions and an add)
+      // (fp32 add of the two halves, dtype_float16.cuh:439-443 — written as fma(c0, 1, c1): the same single rounding.  The
+      //  compiler folds it back into two conversions and an add; forcing ONE v_fma_mix_f32 with inline asm — a third of the
+      //  instructions, bit-identical — was measured in round 4: fp8 pages 66.3 -> 65.3 us on equal lengths, level on ragged
+      //  ones, and the fp16 headline kernels LOST 1 - 3 % (122.2 -> 123.6, ragged 70.8 -> 73.1: the asm pins the schedule of a
+      //  kernel that sits exactly on its 168-VGPR budget), so it is not used: profiles/r04_fp8_ragged_accounting.md)
       return __builtin_fmaf((float)c[0], 1.0f, (float)c[1]);
     }
   }

@@ -534,6 +534,11 @@ struct PickRules {
   double lock_min_waves_per_cu = 12.0;
   double lock_min_round_fill = 0.97; // only where the launch fills whole rounds of those slots: 129 x 32 heads ran 1120 us
                                      //   against 701: r03n_head_128_round_fit.md
+  int gate_max_seqs = 2048;          // the gated double launch behind it (launch_pa_v1): every wave of BOTH kernels reads all the
+                                     //   lengths for the verdict, bounded by what the balanced kernel ranks in LDS (QSORT_MAX)
+  // Head size 128 with MORE items than resident waves and no lockstep fit: eight waves per head as at head size 64 — over
+  // H in {8, 16, 20, 25, 40} at 1.0 - 2 x the resident waves the one-wave kernels of the gated double launch ran 3 - 12 %
+  // behind on equal lengths and 2 - 8 % on U{1..L} (r04_pick_generalisation.md); level from 3 x on.
 };
 static constexpr PickRules R{};
 static inline long full_chip_waves() { return (long)R.waves_per_cu_full * g_cus; }  // one (sequence, head) per resident wave
@@ -688,8 +693,19 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   // distributions (scripts/default_vs_waves_probe.py, r03z_eight_waves_per_head.md): equal lengths level, continuous
   // spreads 3 - 13 % faster, bimodal ones 3 - 9 %; behind only where nearly every sequence is very short.  The balanced
   // kernel keeps the chip it was built for: 7/8 ... 1 x the resident waves.
-  const bool over_full = units > full_chip_waves() && head_size == 64 && block_size == 16 && nblk >= R.many_min_blocks && lds_fits_q;
   const bool nt_by_bytes = kv_bytes > R.nt_kv_bytes;
+  // (the lockstep 4-heads-per-wave kernel needs the whole register file: ONE 16-head workgroup per CU, so it pays only
+  //  where the launch's workgroups fill whole rounds of those slots — 128 x 32 heads: 630 us against 641 for the
+  //  4-head workgroups; 129 sequences: 1120 against 701, 160: 1142 against 797, 96: 571 against 483 — and only as the front
+  //  half of a gated double launch, which is bounded in sequences)
+  const double lock_fill = (double)num_seqs * (num_heads / R.lock_heads_per_wg) / (double)g_cus;
+  const double lock_eff = lock_fill / (double)(long)(lock_fill + 0.999999);
+  const bool lock_ok = head_size == 128 && block_size == 16 && nt_by_bytes && num_heads % R.lock_heads_per_wg == 0 &&
+                       (double)units / (double)g_cus >= R.lock_min_waves_per_cu && lock_eff >= R.lock_min_round_fill &&
+                       num_seqs <= R.gate_max_seqs;
+  // (head size 128: from EXACTLY the resident waves on — there the one-wave kernels are level on equal lengths and 3 - 6 % behind on U{1..L})
+  const bool over_full = core && nblk >= R.many_min_blocks &&
+                         (head_size == 64 ? units > full_chip_waves() && lds_fits_q : units >= full_chip_waves() && !lock_ok);
   const bool balanced = allow_balanced && !over_full && (wph == 1 || near_full) && nt_by_bytes && block_size == 16 && head_size == 64 &&
                         lds_fits_q;
   const bool ragged = !balanced && mean_seq_len > 0 && (long)mean_seq_len * R.ragged_hint_den < (long)max_seq_len * R.ragged_hint_num;
@@ -728,13 +744,7 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
           return id;
       }
     }
-    // (the lockstep 4-heads-per-wave kernel needs the whole register file: ONE 16-head workgroup per CU, so it pays only
-    //  where the launch's workgroups fill whole rounds of those slots — 128 x 32 heads: 630 us against 641 for the
-    //  4-head workgroups; 129 sequences: 1120 against 701, 160: 1142 against 797, 96: 571 against 483)
-    const double lock_fill = (double)num_seqs * (num_heads / R.lock_heads_per_wg) / (double)g_cus;
-    const double lock_eff = lock_fill / (double)(long)(lock_fill + 0.999999);
-    if (wph == 1 && head_size == 128 && nt && num_heads % R.lock_heads_per_wg == 0 && waves_per_cu >= R.lock_min_waves_per_cu &&
-        lock_eff >= R.lock_min_round_fill) {
+    if (wph == 1 && lock_ok) {
       for (int id = 1; id <= nvariants_v1(); ++id) {  // d128_mh4_h4_u1_nt1_lock
         const Variant& c = variant_v1(id);
         if (c.BF == bf && c.D == 128 && c.HPT == 4 && c.HPW == 4 && c.U == 1 && !c.QUEUE) return id;
@@ -1038,7 +1048,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (gate_ok && v.D == 128 && v.BS == 16 && v.WPH == 1 && !v.GQS && !v.F8 && !v.SPARSE &&
       // (every wave of BOTH kernels reads all the lengths for the verdict — 4*B bytes per wave out of L2: bounded by 2048, the
       //  size the balanced kernel ranks in LDS; a larger batch runs the lockstep kernel alone, as a one-kernel launch)
-      num_seqs <= 2048 && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
+      num_seqs <= R.gate_max_seqs && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
     for (int i = 0; i < g_queue_nvariants; ++i)
       if (g_queue_variants[i].D == v.D && g_queue_variants[i].BF == v.BF && g_queue_variants[i].BS == v.BS &&
           g_queue_variants[i].F8 == v.F8 && !g_queue_variants[i].KM &&
