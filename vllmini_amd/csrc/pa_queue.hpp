@@ -215,7 +215,13 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   // workers, whose snake pairs a long item with a short one (67 us against 74).  profiles/r03c_heavy_tailed_batches.md
   bool team = false;
   if (queue && have_sum) {
-    const int wq0 = QF_WQ(flags) ? QF_WQ(flags) : 2;   // (the rule is calibrated on two workers, also where four run)
+    // (`share` is counted in TWO-worker shares also where four solo workers run (fp8 pages, head size 128) — deliberately, not
+    //  by oversight: it is the calibration of the 1.15 criterion, not a model of the schedule.  With the real worker count the
+    //  share halves and a plain U{1..L} batch (longest = 2 x mean) would be sent to teams, which is 25 % SLOWER there over fp8
+    //  pages: 51.2 against 41.0 us, profiles/r04_fp8_ragged_accounting.md.  Likewise nlong_est (4 * len > maxL) and the sort's
+    //  long / short split (buckets 0..47 of 64, scaled by maxL + 1) may differ by the sequences within 1/64 of maxL / 4 of the
+    //  boundary: the gate only asks "are at most 70 % long", the split decides who is — neither affects results.)
+    const int wq0 = QF_WQ(flags) ? QF_WQ(flags) : 2;
     const float share = sumL * (float)H / (float)(gridDim.x * wq0);  // tokens per solo worker
     team = (float)maxL > 1.15f * share || (ragged && rankable && nlong_est * 10 <= 7 * B);
   }
