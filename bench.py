@@ -414,11 +414,16 @@ def kernel_stats(kern_ms, dist, dev):
     return ks
 
 
-def graph_steps(wl, out, steps, variant, dev, per_graph=1):
+def graph_steps(wl, out, steps, variant, dev, per_graph=1, attend_only=False):
     """The reference's call pair captured ONCE into a hipGraph (one graph per table set) and replayed: the launch
     work the host does per step is one graph launch, so this is the step the GPU can do when the host is out of
     the way.  Returns seconds for `steps` replays."""
     graphs = []
+    if attend_only:      # (the attention launch alone, table sets alternating: the device's own time per launch)
+        def one_step(wl, out, i, variant):           # noqa: F811 — shadows the call pair for this measurement
+            attend(wl, out, i % len(wl.tables), variant)
+    else:
+        one_step = globals()["one_step"]
     side = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
@@ -730,18 +735,24 @@ def cfg2_record(args, dist, rank, world, dev):
     v2 = ops.variant_names()[ops.last_variant() - 1]
     n_g = 96
     g = graph_steps(wl2, out2, n_g, 0, dev, per_graph=48)
+    ga = graph_steps(wl2, out2, n_g, 0, dev, per_graph=48, attend_only=True)
     us, src = rocprof_kernel_us("cfg2", v2)
+    for k in ("kernel_us_median", "kernel_us_mean", "kernel_us_min"):      # not kernel times at this size: see the note
+        rec["event_pair_" + k[7:] + "_host_bound"] = rec.pop(k)
     return {"op": "reshape_and_cache + paged_attention_v1, BASELINE configs[1]: batch 32/GPU, seq_len 512, 12 heads x 64, "
                   "block_size 16, num_blocks 4096, fp16", **rec, "kernel_variant": v2,
             "algorithmic_bytes_per_launch": alg_bytes(c2, "auto"),
             "graph_us_per_pair": g / n_g * 1e6,
+            "graph_us_per_attention_launch": ga / n_g * 1e6,
             "rocprofv3_kernel_us": us, "rocprofv3_source": src,
             "regime": "Infinity-Cache-resident (50 MB per launch, two table sets = 100 MB of a 201 MB pool) and under-filled (384 "
                       "units on 256 CUs): a latency chain — launch, table + q, K pages, barrier, softmax, V pages, barrier, store "
                       "(profiles/r04_underfilled_chip.md) — not an HBM stream: no frac quoted",
-            "note": "ms_per_step is host-bound (the call pair's Python + launch work exceeds its 17 us of kernels); "
-                    "kernel_us_* include the event pair's own empty_event_pair_us; graph_us_per_pair = reshape_and_cache + "
-                    "paged_attention_v1 + gaps on the device, 48 pairs per graph"}
+            "note": "ms_per_step is host-bound (the call pair's Python + launch work exceeds its 15 us of kernels), and so are the "
+                    "event pairs around the attention launch (the GPU waits for the host between the two records): NOT kernel "
+                    "times at this size.  The device's own figures: graph_us_per_pair = reshape_and_cache + paged_attention_v1 + "
+                    "gaps, 48 pairs per hipGraph; graph_us_per_attention_launch = 48 attention launches per graph (kernel + "
+                    "~1 us of spacing); rocprofv3_kernel_us = the kernel alone, latest committed pass"}
 
 
 def strong_n1_record(args, dev):
