@@ -23,6 +23,7 @@ ap.add_argument("--heads", default="8,16,20,25,40")
 ap.add_argument("--head-sizes", default="64,128")
 ap.add_argument("--seq-len", type=int, default=1024)
 ap.add_argument("--edges", default="0.875,1.0f,1.0c,1.1,1.5,2.0,3.0")
+ap.add_argument("--kv", default="auto", choices=["auto", "fp8"], help="fp8: E4M3 pages, kv_scale 1 (the fp8_ menus)")
 ap.add_argument("out", nargs="?", default="gpurun_out/pick_generalisation.json")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -36,7 +37,10 @@ res = []
 def candidates(D):
     out = []
     for i, n in enumerate(names):
-        if not re.match(rf"^(q_)?d{D}_", n) or any(t in n for t in ("_gq", "_pvm", "_nt0", "LOADSONLY", "_bs")):
+        if args.kv == "fp8":
+            if not re.match(rf"^fp8_(q_)?d{D}_(bs16_)?", n) or any(t in n for t in ("_gq", "_pvm", "_nt0", "_bs32", "_bs8")):
+                continue
+        elif not re.match(rf"^(q_)?d{D}_", n) or any(t in n for t in ("_gq", "_pvm", "_nt0", "LOADSONLY", "_bs")):
             continue
         out.append((i + 1, n))
     return out
@@ -70,11 +74,15 @@ for D in [int(x) for x in args.head_sizes.split(",")]:
                                       num_blocks=2 * B * (-(-L // 16)) + 8)
             for ragged in (False, True):
                 wl = make_workload(cfg, dev, seed=B + H, table_sets=2, ragged=ragged)
+                if args.kv == "fp8":
+                    g8 = torch.Generator(device=dev).manual_seed(9)
+                    wl.key_cache = torch.randint(0, 64, (cfg.num_blocks, H, D // 16, 16, 16), dtype=torch.uint8, device=dev, generator=g8)
+                    wl.value_cache = torch.randint(0, 64, (cfg.num_blocks, H, D, 16), dtype=torch.uint8, device=dev, generator=g8)
                 out = torch.empty((B, H, D), dtype=torch.float16, device=dev)
 
                 def run(i, vid=0):
                     ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, H, wl.scale, wl.tables[i % 2], wl.seq_lens,
-                                           16, L, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=vid)
+                                           16, L, None, args.kv, 1.0, 0, 0, 1, 1, 0, _variant=vid)
 
                 d_us = timed(run)
                 d_label = ops.last_launch_label()
@@ -86,9 +94,9 @@ for D in [int(x) for x in args.head_sizes.split(",")]:
                         continue          # (this variant cannot serve the launch: head count, LDS)
                 d_us = min(d_us, timed(run))          # the default once more, after the sweep (clock ramp)
                 rows.sort()
-                nbytes = int(wl.seq_lens.sum().item()) * H * D * 4
+                nbytes = int(wl.seq_lens.sum().item()) * H * D * (2 if args.kv == "fp8" else 4)
                 rec = {"heads": H, "head_size": D, "batch": B, "edge": edge, "units_over_resident": round(B * H / RESIDENT, 3),
-                       "lengths": "U{1..L}" if ragged else "equal", "seq_len": L, "default": d_label, "default_us": round(d_us, 1),
+                       "lengths": "U{1..L}" if ragged else "equal", "seq_len": L, "kv": args.kv, "default": d_label, "default_us": round(d_us, 1),
                        "best": rows[0][1], "best_us": round(rows[0][0], 1), "default_over_best": round(d_us / rows[0][0], 3),
                        "TBps_default": round(nbytes / d_us / 1e6, 2), "top3": [(n, round(u, 1)) for u, n in rows[:3]]}
                 res.append(rec)

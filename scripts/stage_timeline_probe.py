@@ -43,11 +43,18 @@ def setup(case, dev):
     import dataclasses
     import torch
     from vllmini_amd.workload import CONFIGS, make_workload
-    name, b, L, var = case.split(":")
+    name, b, L, var = case.split(":")[:4]
+    kv = (case.split(":") + ["auto"])[4]            # optional fifth field: "fp8" = E4M3 pages, kv_scale 1
     b, L = int(b), int(L)
     per = -(-L // 16)
     cfg = dataclasses.replace(CONFIGS["cfg2"], name=name, batch=b, seq_len=L, num_blocks=max(4096, 2 * b * per))
     wl = make_workload(cfg, dev, seed=7, table_sets=2)
+    wl.kv = kv
+    if kv == "fp8":
+        g8 = torch.Generator(device=dev).manual_seed(9)
+        H, D = cfg.num_heads, cfg.head_size
+        wl.key_cache = torch.randint(0, 64, (cfg.num_blocks, H, D // 16, 16, 16), dtype=torch.uint8, device=dev, generator=g8)
+        wl.value_cache = torch.randint(0, 64, (cfg.num_blocks, H, D, 16), dtype=torch.uint8, device=dev, generator=g8)
     out = torch.empty((b, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)
     return cfg, wl, out, var
 
@@ -55,9 +62,9 @@ def setup(case, dev):
 def pair(ops, cache_ops, cfg, wl, out, i, vid, scatter=True):
     t = i % len(wl.tables)
     if scatter:
-        cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], "auto", 1.0)
+        cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache, wl.slots[t], wl.kv, 1.0)
     ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, cfg.kv_heads, wl.scale, wl.tables[t], wl.seq_lens,
-                           cfg.block_size, cfg.seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=vid)
+                           cfg.block_size, cfg.seq_len, None, wl.kv, 1.0, 0, 0, 1, 1, 0, _variant=vid)
 
 
 def run_plain():

@@ -5,7 +5,7 @@
 set -u
 TAG=${1:-r04}; OUT=gpurun_out/underfilled_$TAG; mkdir -p "$OUT/trace"
 export TMPDIR=/tmp
-CASES=$(cat scripts/underfilled_sweep_cases.txt)
+CASES=$(cat ${CASES_FILE:-scripts/underfilled_sweep_cases.txt})
 timeout 1500 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python scripts/stage_timeline_probe.py --plain --cases "$CASES" > "$OUT/trace/order.json.tmp" 2> "$OUT/trace.stderr"
 tail -1 "$OUT/trace/order.json.tmp" > "$OUT/trace/order.json"
 python scripts/stage_timeline_probe.py --summarize "$OUT/trace" "$OUT/rocprof.json" > "$OUT/rocprof.log" 2>&1

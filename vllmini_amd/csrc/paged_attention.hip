@@ -612,8 +612,13 @@ int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int block_size,
                      int mean_seq_len, bool bf, int fmt, bool unit_scale) {
   const long units = (long)num_seqs * num_heads;
   const int nblk = (max_seq_len + block_size - 1) / block_size;
+  const bool core = block_size == 16 && (head_size == 64 || head_size == 128);
   int wph = 1;
-  while (wph < R.max_waves_per_head && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
+  // (the tuned menu: the under-filled rules of the fp16 pages — every wave keeps two blocks, sixteen waves per head only while
+  //  units <= CUs — hold over fp8 pages too: 256 tokens 10 - 18 % faster on 8 waves x 2 blocks, batch 24 / 28 at 512 tokens
+  //  7.6 / 8.1 against 8.9 us; profiles/r04_underfilled_chip.md, r04z_underfilled_sweep_fp8.json)
+  if (core) wph = waves_to_fill_the_chip(units, nblk);
+  else while (wph < R.max_waves_per_head && units * wph < full_chip_waves() && wph * 2 <= (nblk > 0 ? nblk : 1)) wph *= 2;
   // A nearly full chip goes to the balanced kernel: since its solo workers are four per workgroup over fp8 pages (pa_queue.hpp,
   // WQ_SOLO) it is ahead of several waves per head there on equal lengths (batch 224: 61.4 against 64.4 - 66.7 us) and
   // level on ragged ones (39.7 / 39.9).
@@ -661,6 +666,9 @@ int pick_variant_fp8(int num_seqs, int num_heads, int head_size, int block_size,
     if (wph == 1) {
       v = find_variant(head_size, 16, (num_heads % 4 == 0) ? 4 : 1, 1, head_size == 64 ? 2 : 1, -1, bf, fmt);
     } else {
+      // (sixteen waves per head = a nearly empty chip: the temporal two-blocks-per-group kernel where the pages fit the
+      //  Infinity Cache — batch 1 ... 20 at 512 ... 2048 tokens 3 - 10 % ahead of the non-temporal one-block form)
+      if (wph == 16 && 2.0 * (double)units * max_seq_len * head_size <= R.nt_kv_bytes) v = find_variant(head_size, 16, 1, 16, 2, 0, bf, fmt);
       for (int ww = wph; ww >= 1 && !v; ww /= 2) v = find_variant(head_size, 16, 1, ww, -1, -1, bf, fmt);
     }
   }
