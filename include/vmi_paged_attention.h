@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMI_ABI_VERSION 20
+#define VMI_ABI_VERSION 21
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -55,6 +55,7 @@ enum {
   VMI_E_MAX_SEQ_LEN = 7,         /* logits for max_seq_len do not fit in the 160 KiB LDS of one CU    */
   VMI_E_VARIANT = 8,             /* unknown tuning variant id                                         */
   VMI_E_X = 9,                   /* key_cache innermost dimension is not 8 halves                     */
+  VMI_E_WORKSPACE = 11,          /* a split kernel was asked for by id without a (large enough, 16-byte aligned) workspace */
   VMI_E_NOT_BUILT = 10           /* internal guard: a kernel menu of this library is empty for the case asked; no entry of
                                     THIS header can return it (ABI 20: the out-of-scope entries left for
                                     vmi_paged_attention_extras.h and are not exported by the product library) */
@@ -113,6 +114,44 @@ int vmi_paged_attention_v1_f16_variant(
     const float* alibi_slopes,
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     int32_t device, void* stream, int32_t variant);
+
+/*
+ * The same operator with a CALLER-OWNED WORKSPACE (ABI 21).  The reference's launcher gives every (head, sequence) one
+ * workgroup (attention_kernels.cu:734-735); with fewer such items than the chip has CUs — the batch sizes the reference's
+ * scheduler runs (vllmini/scheduler.py:60) — most of the chip idles, and the reference's own remedy is the two-kernel
+ * paged_attention_v2 (:529-669, 828-990).  With a workspace, an under-filled launch spreads each item over several
+ * workgroups of ONE launch: they exchange (max, sum of exp) through the workspace between the K and the V pass, so every
+ * probability is normalised with the item's global values and rounded to fp16 exactly where the reference rounds it
+ * (:334-346, 398-400), and the item's last workgroup adds the fp32 partial rows in a fixed order.
+ *
+ *   workspace        device memory of >= vmi_paged_attention_v1_workspace_bytes(...) bytes, 16-byte aligned, whose control
+ *                    words are ZERO (vmi_paged_attention_v1_workspace_reset, or any memset) before its first use; a launch
+ *                    leaves them zero again.  One workspace serves one stream at a time (launches on one stream are
+ *                    ordered; concurrent launches need a workspace each).  Nothing is retained: the pointer is used by the
+ *                    kernels of this call only.
+ *   NULL / too small with variant 0: exactly vmi_paged_attention_v1_f16 (bit-identical — the same kernels).
+ *   variant          0 = heuristic (may pick a split kernel, names "d<head>_x<waves>_u<U>_nt<NT>"), else as _f16_variant;
+ *                    a split kernel asked for by id without a workspace is VMI_E_WORKSPACE.
+ * A launch that was killed in flight (device reset, aborted process) can leave control words non-zero: reset the workspace
+ * before using it again.  Word 0 of the workspace counts polls that gave up (bounded spins; stays 0 on a healthy launch).
+ */
+int vmi_paged_attention_v1_f16_ws(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream, void* workspace, int64_t workspace_bytes, int32_t variant);
+/* Bytes a workspace must have for these sizes (0: no kernel uses one for this head size). */
+int64_t vmi_paged_attention_v1_workspace_bytes(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                               int32_t max_seq_len);
+/* Zero the workspace's control words on `stream` (hipMemsetAsync): once after allocation, and after a launch that died. */
+int vmi_paged_attention_v1_workspace_reset(void* workspace, int64_t workspace_bytes, int32_t device, void* stream);
+/* What variant 0 of the _ws entry runs when a workspace is at hand (fp16 pages). */
+int vmi_paged_attention_v1_pick_variant_ws(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                           int32_t block_size, int32_t max_seq_len);
 
 /*
  * Fused decode step: cache_ops.reshape_and_cache + paged_attention_v1 in ONE launch (extension; the reference

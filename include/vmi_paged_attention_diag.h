@@ -59,6 +59,17 @@ int vmi_diag_set_wave_timeline(void* records, int32_t device);
  */
 int vmi_diag_set_stage_stamps(void* records, int32_t device);
 
+/*
+ * Diagnostic: stage stamps of the split kernels (vllmini_amd/csrc/pa_split.hpp).  `records` is device memory for 10 x uint64
+ * per wave of the launch, in workgroup order x wave: eight stamps in ticks of the constant 100 MHz clock — entry, lengths
+ * known, first K group consumed, K pass done, granule published, exchange complete, V pass done, end — then HW_REG_HW_ID
+ * and HW_REG_XCC_ID | (blocks of this wave << 8).  Synchronous.
+ */
+int vmi_diag_set_split_stamps(void* records, int32_t device);
+/* Test knob of the split kernels (per host thread; returns the previous value): bit 0 = an item's workgroups far apart
+ * in dispatch order instead of adjacent. */
+int vmi_debug_set_split_flags(int32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,8 @@ trips rather than a stream?
   python scripts/stage_timeline_probe.py --summarize DIR out.json    per case: the attention kernel's duration as rocprofv3
                                                                sees it (dispatch begin -> end, incl. what lies before the first
                                                                wave's first instruction and behind the last wave's last)
-Cases: `name:batch:seq_len:variant` ("auto" = the default entry); CASES below or --cases a,b,c."""
+Cases: `name:batch:seq_len:variant` ("auto" = the default entry, "auto_nows" = the default entry without a workspace);
+CASES below or --cases a,b,c."""
 import csv
 import glob
 import json
@@ -75,10 +76,12 @@ def run_plain():
     order = []
     for case in arg_cases():
         cfg, wl, out, var = setup(case, dev)
-        vid = 0 if var == "auto" else names[var]
+        ops.set_workspace_enabled(var != "auto_nows")      # "auto_nows": the default entry without a workspace (round 4's picks)
+        vid = 0 if var.startswith("auto") else names[var]
         for i in range(WARM + TIMED):
             pair(ops, cache_ops, cfg, wl, out, i, vid)
         torch.cuda.synchronize()
+        ops.set_workspace_enabled(True)
         order.append({"case": case, "kernel": ops.variant_names()[(vid or ops.last_variant()) - 1], "launches": WARM + TIMED})
         del wl, out
     print(json.dumps(order))
@@ -87,7 +90,8 @@ def run_plain():
 def summarize(trace_dir, out_path):
     order = json.loads(open(os.path.join(trace_dir, "order.json")).read().strip().splitlines()[-1])
     f = sorted(glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True))[0]
-    rows = [r for r in csv.DictReader(open(f)) if "pa_v1_kernel" in r["Kernel_Name"] or "pa_q_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "pa_v1_kernel" in r["Kernel_Name"] or "pa_q_kernel" in r["Kernel_Name"] or
+            "pa_split_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     res, k = [], 0
     for o in order:

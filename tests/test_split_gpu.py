@@ -1,0 +1,282 @@
+"""The split kernels (vllmini_amd/csrc/pa_split.hpp): paged_attention_v1 with one (sequence, head) spread over several
+workgroups of ONE launch that meet in a caller-owned workspace (C-ABI 21: vmi_paged_attention_v1_f16_ws).
+
+Checked here, through the drop-in surface -> C-ABI, against the CPU oracle (checker only):
+  * every split kernel of the menu, at the tight bound (2 fp16 ulp) — the probabilities are normalised with the item's
+    GLOBAL max / exp-sum before they are rounded to fp16, as the reference does (attention_kernels.cu:334-346, 398-400);
+  * the workspace contract: NULL / too small = yesterday's kernels bit for bit; a split kernel asked for by id without a
+    workspace is an error; a launch leaves every control word zero again; a poisoned workspace is healed by the reset entry;
+  * re-use: many launches back to back on one workspace, hipGraph replay, two streams, two host threads;
+  * run-to-run determinism (the partial rows are added in workgroup order, whatever the arrival order).
+
+Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_case
+from test_parity_gpu import _dev, assert_close, run_model
+
+pytestmark = pytest.mark.gpu
+
+LENS = [1, 16, 17, 100, 333, 1024, 47, 0, 700, 2, 513, 31]
+
+
+def _split_names(D=None):
+    from vllmini_amd import ops
+
+    return [(i + 1, n) for i, n in enumerate(ops.variant_names())
+            if "_x" in n and n.startswith("d") and (D is None or n.startswith(f"d{D}_"))]
+
+
+def _upload(case, dev):
+    S, H, D = case["q"].shape
+    qbuf = torch.from_numpy(case["qbuf"]).to(dev)
+    return dict(q=qbuf[:, : H * D].view(S, H, D), kc=torch.from_numpy(case["kc"]).to(dev),
+                vc=torch.from_numpy(case["vc"]).to(dev), tab=torch.from_numpy(case["tables"]).to(dev),
+                lens=torch.from_numpy(case["lens"]).to(dev), msl=max(int(case["lens"].max()), 1), _keep=qbuf)
+
+
+def _launch(case, t, variant=0, out=None):
+    from vllmini_amd import ops
+
+    S, H, D = case["q"].shape
+    if out is None:
+        out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=t["q"].device)
+    ops.paged_attention_v1(out, t["q"], t["kc"], t["vc"], case["num_kv_heads"], case["scale"], t["tab"], t["lens"], 16,
+                           t["msl"], None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=variant)
+    return out
+
+
+def _control_words_are_zero(index=0):
+    """status, arrival counters and granules of the current stream's workspace (everything in front of the partial rows)."""
+    from vllmini_amd import ops
+
+    ws = ops.workspace_for(index, create=False)
+    assert ws is not None
+    n = 256 + 8192 * 4 + 2048 * 4 * 8
+    torch.cuda.synchronize()
+    return int(ws[:n].view(torch.int64).ne(0).sum().item()) == 0
+
+
+@pytest.mark.parametrize("D,H", [(64, 12), (128, 8)])
+def test_every_split_kernel_matches_the_kernel_model(D, H):
+    from vllmini_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(500 + D)
+    case = make_case(rng, len(LENS), H, D, LENS, q_row_pad=2, poison_tail=True)
+    t = _upload(case, dev)
+    ref = run_model(case)
+    names = _split_names(D)
+    assert len(names) >= 12
+    ran = 0
+    for vid, name in names:
+        try:
+            got = _launch(case, t, vid).cpu().numpy()
+        except RuntimeError as e:     # more workgroups than are resident for this batch: refused, never a hang
+            assert "resident" in str(e), (name, str(e))
+            continue
+        assert_close(got, ref, name)
+        assert ops.workspace_status(0) == 0, name
+        ran += 1
+    assert ran >= 9
+    assert _control_words_are_zero()
+
+
+def test_grouped_query_and_alibi_through_a_split_kernel():
+    import oracle
+
+    dev = _dev()
+    rng = np.random.default_rng(77)
+    lens = [5, 64, 300, 129]
+    case = make_case(rng, len(lens), 8, 64, lens, num_kv_heads=2)
+    t = _upload(case, dev)
+    slopes = (0.5 ** np.arange(1, 9)).astype(np.float32)
+    from vllmini_amd import ops
+
+    vid = dict((n, i) for i, n in _split_names(64))["d64_x8_u1_nt0"]
+    out = torch.full((4, 8, 64), float("nan"), dtype=torch.float16, device=dev)
+    ops.paged_attention_v1(out, t["q"], t["kc"], t["vc"], 2, case["scale"], t["tab"], t["lens"], 16, t["msl"],
+                           torch.from_numpy(slopes).to(dev), "auto", 1.0, 0, 0, 1, 1, 0, _variant=vid)
+    ref = oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], 2, case["scale"], case["tables"], case["lens"], 16,
+                                    alibi_slopes=slopes, threads=8)
+    assert_close(out.cpu().numpy(), ref, "gqa + alibi", vmax=1.0)
+
+
+def test_without_a_workspace_the_entry_is_yesterdays_kernel_bit_for_bit():
+    """NULL workspace, a workspace that is too small, and the plain entries all run the same kernel."""
+    from vllmini_amd import _lib, ops
+
+    dev = _dev()
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    lens = [512] * 32
+    case = make_case(rng, 32, 12, 64, lens)
+    t = _upload(case, dev)
+    prev = ops.set_workspace_enabled(False)
+    try:
+        plain = _launch(case, t)
+        plain_kernel = ops.last_launch_label()
+    finally:
+        ops.set_workspace_enabled(prev)
+    args = ops._pa_common(torch.empty_like(plain), t["q"], t["kc"], t["vc"], 12, case["scale"], t["tab"], t["lens"], 16, 512,
+                          None, "auto", 1.0, 0, 0, 1, 1, 0)
+    small = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    for ws_ptr, ws_bytes in ((None, 0), (small.data_ptr(), small.numel()), (None, 1 << 30)):
+        out = torch.full_like(plain, float("nan"))
+        a = (out.data_ptr(),) + args[1:]
+        assert lib.vmi_paged_attention_v1_f16_ws(*a, ws_ptr, ws_bytes, 0) == 0
+        torch.cuda.synchronize()
+        assert ops.last_launch_label() == plain_kernel
+        assert torch.equal(out.view(torch.int16), plain.view(torch.int16))
+    # ... and a split kernel asked for by id without one is refused, with a message that names the remedy
+    vid = _split_names(64)[0][0]
+    out = torch.full_like(plain, float("nan"))
+    rc = lib.vmi_paged_attention_v1_f16_ws(*((out.data_ptr(),) + args[1:]), None, 0, vid)
+    assert rc == 11 and b"workspace" in lib.vmi_last_error_string()
+    with pytest.raises(RuntimeError, match="workspace"):
+        prev = ops.set_workspace_enabled(False)
+        try:
+            _launch(case, t, vid)
+        finally:
+            ops.set_workspace_enabled(prev)
+
+
+def test_with_a_workspace_the_default_entry_splits_an_underfilled_launch_and_agrees_with_the_model():
+    from vllmini_amd import ops
+
+    dev = _dev()
+    for S, L in ((1, 1024), (8, 1024), (32, 512)):
+        rng = np.random.default_rng(S + L)
+        case = make_case(rng, S, 12, 64, [L] * S)
+        t = _upload(case, dev)
+        got = _launch(case, t).cpu().numpy()
+        label = ops.last_launch_label()
+        assert_close(got, run_model(case), f"default entry, batch {S} x {L} ({label})")
+        assert ops.pick_variant(S, 12, 64, L, workspace=True) == ops.last_variant()
+    assert _control_words_are_zero()
+
+
+def test_a_workspace_is_reused_across_many_launches_and_shapes_and_results_do_not_depend_on_arrival_order():
+    from vllmini_amd import ops
+
+    dev = _dev()
+    names = dict((n, i) for i, n in _split_names(64))
+    rng = np.random.default_rng(11)
+    cases = []
+    for S, lens in ((8, [1024] * 8), (5, [100, 1000, 17, 512, 64]), (32, [512] * 32), (1, [2048])):
+        c = make_case(rng, S, 12, 64, lens)
+        cases.append((c, _upload(c, dev), run_model(c)))
+    first = {}
+    for rep in range(30):
+        for k, (c, t, ref) in enumerate(cases):
+            for name in ("d64_x8_u1_nt0", "d64_x16_u1_nt0"):
+                got = _launch(c, t, names[name])
+                if rep == 0:
+                    assert_close(got.cpu().numpy(), ref, f"{name} case {k}")
+                    first[(k, name)] = got.clone()
+                else:
+                    assert torch.equal(got.view(torch.int16), first[(k, name)].view(torch.int16)), (rep, k, name)
+    assert ops.workspace_status(0) == 0 and _control_words_are_zero()
+
+
+def test_a_poisoned_workspace_is_healed_by_the_reset_entry():
+    """A launch killed in flight can leave granules and counters behind; they make the next launch wrong (never hang:
+    every spin is bounded).  reset_workspaces() = vmi_paged_attention_v1_workspace_reset zeroes them."""
+    from vllmini_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    case = make_case(rng, 4, 12, 64, [700, 512, 64, 1000])
+    t = _upload(case, dev)
+    ref = run_model(case)
+    vid = dict((n, i) for i, n in _split_names(64))["d64_x16_u1_nt0"]
+    assert_close(_launch(case, t, vid).cpu().numpy(), ref, "clean")
+    ws = ops.workspace_for(0, create=False)
+    ws[256: 256 + 64].fill_(3)                    # arrival counters of the first items: "killed mid-flight"
+    ws[256 + 8192 * 4: 256 + 8192 * 4 + 512] = 0x3f  # ... and some of their granules
+    torch.cuda.synchronize()
+    ops.reset_workspaces(0)
+    assert _control_words_are_zero()
+    assert_close(_launch(case, t, vid).cpu().numpy(), ref, "after reset")
+    assert ops.workspace_status(0) == 0
+
+
+def test_graph_replay_two_streams_and_two_host_threads():
+    from vllmini_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(9)
+    case = make_case(rng, 6, 12, 64, [1024, 999, 512, 100, 17, 640])
+    t = _upload(case, dev)
+    ref = run_model(case)
+    vid = dict((n, i) for i, n in _split_names(64))["d64_x16_u1_nt0"]
+
+    # hipGraph: the capture stream's workspace must exist before the capture (nothing is allocated under capture)
+    s = torch.cuda.Stream()
+    out = torch.full((6, 12, 64), float("nan"), dtype=torch.float16, device=dev)
+    with torch.cuda.stream(s):
+        _launch(case, t, vid, out)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(4):
+                _launch(case, t, vid, out)
+        for _ in range(5):
+            out.fill_(float("nan"))
+            g.replay()
+            s.synchronize()
+            assert_close(out.cpu().numpy(), ref, "graph replay")
+
+    # a stream without a workspace under capture: yesterday's kernel is captured, not an error
+    s2 = torch.cuda.Stream()
+    out2 = torch.full_like(out, float("nan"))
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s2):
+        with torch.cuda.graph(g2, stream=s2):
+            _launch(case, t, 0, out2)
+        g2.replay()
+        s2.synchronize()
+    assert_close(out2.cpu().numpy(), ref, "captured without a workspace")
+
+    # two streams at once: a workspace each
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    oa, ob = torch.full_like(out, float("nan")), torch.full_like(out, float("nan"))
+    torch.cuda.synchronize()
+    for _ in range(20):
+        with torch.cuda.stream(sa):
+            _launch(case, t, vid, oa)
+        with torch.cuda.stream(sb):
+            _launch(case, t, vid, ob)
+    torch.cuda.synchronize()
+    assert_close(oa.cpu().numpy(), ref, "stream a")
+    assert_close(ob.cpu().numpy(), ref, "stream b")
+    assert ops.workspace_for(0, sa.cuda_stream, create=False).data_ptr() != ops.workspace_for(0, sb.cuda_stream, create=False).data_ptr()
+
+    # two host threads, each on its own stream
+    errs, outs = [], {}
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream()
+            o = torch.full_like(out, float("nan"))
+            with torch.cuda.stream(st):
+                for _ in range(20):
+                    _launch(case, t, vid, o)
+                st.synchronize()
+            outs[k] = o.cpu().numpy()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for k in range(2):
+        assert_close(outs[k], ref, f"thread {k}")

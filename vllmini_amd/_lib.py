@@ -36,6 +36,10 @@ SIGNATURES = {
     "vmi_target_arch": (ctypes.c_char_p, []),
     "vmi_paged_attention_v1_f16": (ctypes.c_int, list(_PA_ARGS)),
     "vmi_paged_attention_v1_f16_variant": (ctypes.c_int, list(_PA_ARGS) + [_i32]),
+    "vmi_paged_attention_v1_f16_ws": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _i64, _i32]),
+    "vmi_paged_attention_v1_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "vmi_paged_attention_v1_workspace_reset": (ctypes.c_int, [_c_void_p, _i64, _i32, _c_void_p]),
+    "vmi_paged_attention_v1_pick_variant_ws": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v1_append_f16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
     "vmi_paged_attention_v1_fp8": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32]),
     "vmi_paged_attention_v2_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32]),
@@ -100,9 +104,11 @@ DIAG_SIGNATURES = {
     "vmi_diag_stream_read": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "vmi_diag_set_wave_timeline": (ctypes.c_int, [_c_void_p, _i32]),
     "vmi_diag_set_stage_stamps": (ctypes.c_int, [_c_void_p, _i32]),
+    "vmi_diag_set_split_stamps": (ctypes.c_int, [_c_void_p, _i32]),
+    "vmi_debug_set_split_flags": (ctypes.c_int, [_i32]),
 }
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lock = threading.Lock()
 _product = None      # libvmi_paged_attention.so

@@ -53,23 +53,25 @@ SRC_SPARSE = [os.path.join(CSRC, f"pa_variants_sparse{t}.hip") for t in ("", "_b
 SRC_FP8_E5M2 = [os.path.join(CSRC, f"pa_variants_fp8_e5m2{t}.hip") for t in ("", "_bf16")]   # ... over E5M2 bytes
 SRC_F32 = os.path.join(CSRC, "pa_f32.hip")                    # float32 tensors (x = 4)
 SRC_QUEUE = os.path.join(CSRC, "pa_queue.hip")                # balanced (work-queue) kernels for ragged batches
+SRC_SPLIT = os.path.join(CSRC, "pa_split.hip")                # split kernels: one (sequence, head) over several workgroups + workspace
 SRC_STAGE = os.path.join(CSRC, "pa_stage.hip")                # experiment: pages staged through LDS (diagnostic library only)
 SRC_ABSENT = os.path.join(CSRC, "pa_extras_absent.hip")      # product library: empty out-of-scope menus, VMI_E_NOT_BUILT entries
 SRC_EXTRAS_CACHE = os.path.join(CSRC, "pa_extras_cache.hip")  # extras: convert_fp8, reshape_and_cache_flash, bf16 / E5M2 fp8 scatter
 SRC_EXTRAS_ABI = os.path.join(CSRC, "pa_extras_abi.hip")      # extras: the C-ABI entries of include/vmi_paged_attention_extras.h
 # (source, flavor): flavor "" = plain, "extras" = -DVMI_EXTRAS, "diag" = -DVMI_DIAG (+ -DVMI_EXTRAS)
-CORE = [SRC, SRC_EXTRA, SRC_APPEND[0], SRC_APPEND[1], SRC_FP8, SRC_QUEUE]          # the hot path
+CORE = [SRC, SRC_EXTRA, SRC_APPEND[0], SRC_APPEND[1], SRC_FP8, SRC_QUEUE, SRC_SPLIT]          # the hot path
 EXTRAS = [SRC_BF16, SRC_APPEND[2], SRC_FP8_BF16, *SRC_FP8_E5M2, *SRC_SPARSE, SRC_F32, SRC_EXTRAS_CACHE, SRC_EXTRAS_ABI]
 PRODUCT_UNITS = [(s, "") for s in CORE] + [(SRC_ABSENT, "")]
 EXTRAS_UNITS = [(s, "extras" if s == SRC_QUEUE else "") for s in CORE] + [(s, "") for s in EXTRAS]
 # the diagnostic library: these units are compiled again with -DVMI_DIAG (it changes their variant tables / entries),
 # pa_stage.hip exists only there, every other object is the extras library's
-DIAG_UNITS = [SRC, SRC_APPEND[0], SRC_QUEUE]
+DIAG_UNITS = [SRC, SRC_APPEND[0], SRC_QUEUE, SRC_SPLIT]
 DIAG_ONLY = [SRC_STAGE]
 DIAG_LIB_UNITS = [(s, "diag") if s in DIAG_UNITS else (s, f) for s, f in EXTRAS_UNITS] + [(s, "diag") for s in DIAG_ONLY]
 SOURCES = [*CORE, SRC_ABSENT, *EXTRAS]                        # every unit of the product and extras libraries
 HDR = os.path.join(CSRC, "pa_kernel.hpp")
 HDR_QUEUE = os.path.join(CSRC, "pa_queue.hpp")
+HDR_SPLIT = os.path.join(CSRC, "pa_split.hpp")
 HDRS_HOST = [os.path.join(CSRC, "pa_host.hpp"), os.path.join(CSRC, "pa_cache_fp8.hpp")]
 INCLUDE = os.path.join(REPO_ROOT, "include")
 OUT_DIR = os.path.join(PKG_DIR, "_C")
@@ -108,7 +110,7 @@ def _units_of(kind: str):
 
 
 def _deps(kind: str = "product") -> list[str]:
-    return [*(s for s, _ in _units_of(kind)), *TABLES, HDR, HDR_QUEUE, *HDRS_HOST,
+    return [*(s for s, _ in _units_of(kind)), *TABLES, HDR, HDR_QUEUE, HDR_SPLIT, *HDRS_HOST,
             os.path.join(INCLUDE, "vmi_paged_attention.h"), os.path.join(INCLUDE, "vmi_paged_attention_extras.h"),
             os.path.join(INCLUDE, "vmi_paged_attention_diag.h"),
             os.path.abspath(__file__)]

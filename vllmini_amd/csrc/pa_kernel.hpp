@@ -1418,6 +1418,8 @@ struct Variant {
   bool QUEUE;        // balanced kernel (pa_queue.hpp): persistent grid of 3 workgroups per CU, mode chosen on the device
   bool STAGE;        // experiment (pa_stage.hip): pages staged through an LDS ring of U slots by global_load_lds
   bool KM;           // balanced kernels: q.K^T of the K pass on the matrix cores (pa_queue.hpp); "m" names
+  int XW;            // split kernels (pa_split.hpp): waves per (sequence, head), spread over XW / WPH workgroups that meet in a
+                     //   caller-owned workspace; 0 = not a split kernel.  fn is a pa_split_kernel_t there
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);
@@ -1536,6 +1538,9 @@ pa_reduce_t bf16_reduce_kernel(int head_size);
 // balanced (work-queue) kernels, pa_queue.hip: v1 ids continue after every other menu
 extern Variant g_queue_variants[];
 extern const int g_queue_nvariants;
+// split kernels, pa_split.hip: behind the balanced ones; launched only through an entry that carries a workspace
+extern Variant g_split_variants[];
+extern const int g_split_nvariants;
 #ifdef VMI_DIAG
 // LDS-staged experiment kernels, pa_stage.hip (diagnostic library only): the last ids of all; never picked by a heuristic
 extern Variant g_stage_variants[];

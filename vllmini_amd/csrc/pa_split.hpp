@@ -1,0 +1,382 @@
+// pa_split.hpp — paged_attention_v1 with ONE (sequence, head) spread over several workgroups of one launch (round 5).
+//
+// Why.  The reference launches one workgroup per (head, sequence) (attention_kernels.cu:734-735) and so did every kernel
+// here until now: a head's partial results could only meet in LDS, i.e. on one CU.  With fewer (sequence, head) items
+// than the chip has CUs — batch 1 ... 16 at 12 heads, the regime the reference's own scheduler runs (scheduler.py:60) —
+// most CUs idle, and with 1.5 items per CU (BASELINE configs[1]: 384 items on 256 CUs) half the CUs carry twice the
+// load of the others.  The reference's own answer is paged_attention_v2 (:529-669, 828-990): 512-token partitions,
+// each normalised BY ITSELF and rounded to fp16, then merged by a second kernel — other rounding points than v1's, a
+// second launch, and no help below 1024 tokens.
+//
+// What.  An item is dealt to NW waves (block b -> wave b mod NW), NW / 4 workgroups of four waves, all resident.  Every
+// wave runs the K pass over its own blocks and publishes its (max, sum of exp) as ONE 8-byte granule in a caller-owned
+// workspace; every wave then polls the item's NW granules, and so knows the item's GLOBAL maximum and exp sum before it
+// rounds a single probability: p = half(exp(logit - max) * 1 / (sum + 1e-6)) is formed exactly where and how the
+// reference forms it (:334-346, 398-400).  V pass over the same blocks, fp32 partial outputs reduced in LDS per
+// workgroup, written through to the workspace; the LAST workgroup of the item to arrive (one counter per item) adds the
+// partials in workgroup order — a fixed order, whatever the arrival order — stores the row and puts the item's granules
+// and counter back to zero.  One launch, no zeroing launch in front, no merge kernel behind.
+//
+// Visibility (MI355X: 8 XCDs with private L2s, per-CU L1 never refreshed by other CUs): every shared word is written and
+// read with agent-scope relaxed atomics (global_store / global_load ... sc1: write-through, L1 bypassed), payload stores
+// are drained (s_waitcnt vmcnt(0)) in front of the arrival atomic, and the granule IS its own flag (sum of exp >= 1, so
+// its upper word is never zero once written).  Every spin is bounded: a poll that gives up sets status[0] and the
+// launch finishes with wrong numbers instead of hanging the device.
+//
+// The workspace belongs to the caller (ownership row: "if a split-KV path needs scratch, the
+// Python wrapper allocates it with torch on the same stream"); the library retains nothing.  Layout: pa_split_layout().
+#pragma once
+
+#include "pa_kernel.hpp"
+
+namespace vmi {
+
+struct PASplit {
+  unsigned long long* slots;  // [items][nw]      {float max, float exp_sum} granules; 0 = not published yet
+  float* partials;            // [items][nw / wpg][D]  fp32 partial outputs of the item's workgroups
+  unsigned int* counters;     // [items]          arrivals of the item's workgroups; back to 0 when the item is done
+  unsigned int* status;       // [0]: number of polls that gave up (must stay 0)
+  int32_t nw;                 // waves per item (<= 64, a multiple of the waves per workgroup)
+  int32_t wtok;               // logits per wave held in LDS: 16 * ceil(ceil(max_seq_len / 16) / nw)
+  int32_t flags;              // SPF_*
+};
+constexpr int SPF_GMAJOR = 1;        // workgroup index = g * items + item (an item's workgroups far apart in dispatch order)
+constexpr int SPLIT_MAX_WAVES = 64;  // one lane per granule in the poll
+constexpr unsigned SPLIT_SPIN_LIMIT = 1u << 20;
+
+#ifdef VMI_DIAG
+// diagnostic library: eight stamps per wave (100 MHz clock): entry, lengths known, first K group consumed, K pass done,
+// granule published, exchange complete, V pass done, end — then HW_ID, XCC_ID | blocks << 8
+static __device__ uint64_t* g_split_stamps = nullptr;
+#define VMI_SSTAMP(k) do { if (tl_) ts_[k] = wall_clock64(); } while (0)
+#else
+#define VMI_SSTAMP(k) ((void)0)
+#endif
+
+typedef unsigned long long __attribute__((address_space(1))) gu64_t;
+typedef unsigned int __attribute__((address_space(1))) gu32_t;
+typedef float __attribute__((address_space(1))) gf32_t;
+
+// D head size (64 | 128), U blocks per register group, NT non-temporal page loads, VA V groups requested in front of
+// the exchange (1 | 2).  Block size 16, fp16 query / pages.  grid = items * (nw / wpg), block = wpg * 64.
+// Launch bounds: six (head size 128: three) workgroups per CU — what the host counts as resident (split_resident_wgs).
+// LDS = wpg * (wtok * 4 (logits) + wtok * 2 (probabilities) + D * 4 (partial out)).
+template <int D, int U, bool NT, int VA>
+__global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PAParams p, const PASplit sp) {
+  constexpr int BS = 16;
+  constexpr int NL = D * BS / 8 / 64;  // 1-KiB loads per (block, head) tile: 2 | 4
+  constexpr int CPL = 4;               // K: 16-B chunks (8 dims) per load
+  constexpr int UPR = 2;               // V: 16-B units per dim row
+  constexpr int RPL = 32;              // V: rows per load
+  static_assert(D == 64 || D == 128, "head size 64 or 128");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+#ifdef VMI_DIAG
+  uint64_t* const tl_ = g_split_stamps;
+  uint64_t ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  VMI_SSTAMP(0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wpg = blockDim.x >> 6;
+  const int NW = sp.nw;
+  const int G = NW / wpg;
+  const int items = p.num_seqs * p.num_heads;
+  int item, g;
+  if (sp.flags & SPF_GMAJOR) {
+    g = blockIdx.x / items;
+    item = blockIdx.x - g * items;
+  } else {
+    item = blockIdx.x / G;
+    g = blockIdx.x - item * G;
+  }
+  const int seq = item / p.num_heads;
+  const int head = item - seq * p.num_heads;
+  const int w = g * wpg + wave;  // this wave's place among the item's NW
+
+  // requested before seq_len is known (any entry of the row is readable): my first 64 blocks' physical ids
+  const int32_t* bt = p.block_tables + (int64_t)seq * p.max_blocks_per_seq;
+  int bt_sg = 0;
+  int32_t bt_reg = (w + lane * NW < p.max_blocks_per_seq) ? bt[w + lane * NW] : 0;
+  int L = p.seq_lens[seq];
+  L = L > p.lpad ? p.lpad : L;  // (seq_len > max_seq_len: truncated to the LDS reserved, as pa_v1_kernel does)
+
+  const int c4 = lane >> 4;  // chunk within a K load
+  const int tk = lane & 15;  // token within the block
+  const int qpk = p.num_heads / p.num_kv_heads;
+  const int64_t hoff = (int64_t)(head / qpk) * p.kv_head_stride + lane * 8;
+  const float slope = p.alibi ? p.alibi[head] : 0.f;
+  u32x4 qreg[NL];
+  {
+    const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) qreg[i] = *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8);
+  }
+
+  uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + ((int64_t)seq * p.num_heads + head) * D;
+  if (L <= 0) {  // exp_sum = 0 -> the row is zero (reference: no tokens)
+    if (w == 0)
+      for (int d = lane; d < D; d += 64) outp[d] = 0;
+    return;
+  }
+  const int nblk = (L + BS - 1) / BS;
+  const int na = nblk < NW ? nblk : NW;     // waves of the item that own a block
+  const int ga = (na + wpg - 1) / wpg;      // workgroups of the item that hold such a wave
+  if (g >= ga) return;                      // the whole workgroup has nothing to do (uniform)
+  const int nmy = w < na ? (nblk - w + NW - 1) / NW : 0;  // my blocks: b = w + idx * NW
+  VMI_SSTAMP(1);
+
+  float* lg = reinterpret_cast<float*>(smem) + (size_t)wave * sp.wtok;                                   // my logits
+  uint16_t* ph = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(smem) + (size_t)wpg * sp.wtok) + (size_t)wave * sp.wtok;
+  float* osm = reinterpret_cast<float*>(smem + (size_t)wpg * sp.wtok * 6);                              // [wpg][D]
+
+  float acc[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc[i] = 0.f;
+  const int hf = lane % UPR;
+  const int rowl = lane / UPR;
+
+  if (nmy > 0) {
+    const int ngroups = (nmy + U - 1) / U;
+    auto table_for = [&](int gi) {
+      const int sg = (gi * U) >> 6;
+      if (sg != bt_sg) {
+        const int b = w + (sg * 64 + lane) * NW;
+        bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
+        bt_sg = sg;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bt_reg));  // (inside the branch: see pa_kernel.hpp table_for)
+      }
+    };
+    auto load_group = [&](u32x4(&r)[U][NL], const h16* cache, int gi) {
+      table_for(gi);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        int idx = gi * U + j;
+        idx = idx < nmy ? idx : nmy - 1;  // padding slots re-read my last block
+        const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
+        const h16* blk = cache + phys * p.kv_block_stride + hoff;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(blk + i * 512);
+      }
+    };
+    float qk_max = -FLT_MAX;
+    auto compute_k = [&](u32x4(&r)[U][NL], int gi) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int idx = gi * U + j;
+        if (idx < nmy) {
+          const int token = (w + idx * NW) * BS + tk;
+          const bool masked = token >= L;
+          float accv[NL];
+#pragma unroll
+          for (int i = 0; i < NL; ++i) accv[i] = dot8<false>(qreg[i], r[j][i]);
+          float a = accv[0];
+#pragma unroll
+          for (int i = 1; i < NL; ++i) a += accv[i];
+          a += __shfl_xor(a, 16);
+          a += __shfl_xor(a, 32);
+          float qk = p.scale * a;
+          qk += (slope != 0.f) ? slope * (float)(token - L + 1) : 0.f;
+          if (lane < BS) lg[idx * BS + tk] = masked ? 0.f : qk;
+          qk_max = masked ? qk_max : fmaxf(qk_max, qk);
+        }
+      }
+    };
+
+    u32x4 ra[U][NL], rb[U][NL];
+    const bool single = ngroups == 1;
+    if (single) {  // everything I own fits one register group: K and V pages in one round trip
+      load_group(ra, p.kc, 0);
+      load_group(rb, p.vc, 0);
+      compute_k(ra, 0);
+      VMI_SSTAMP(2);
+    } else {
+      load_group(ra, p.kc, 0);
+      int gi = 0;
+      for (; gi + 2 <= ngroups; gi += 2) {
+        load_group(rb, p.kc, gi + 1);
+        compute_k(ra, gi);
+#ifdef VMI_DIAG
+        if (gi == 0) VMI_SSTAMP(2);
+#endif
+        if (gi + 2 < ngroups) load_group(ra, p.kc, gi + 2);
+        compute_k(rb, gi + 1);
+      }
+      if (gi < ngroups) compute_k(ra, gi);
+      // the V pass walks my groups from the last one back (the sequence's last block was written a moment ago by
+      // reshape_and_cache: its wait hides behind the exchange); VA groups are requested in front of the exchange
+      load_group(ra, p.vc, ngroups - 1);
+      if constexpr (VA >= 2) load_group(rb, p.vc, ngroups - 2);
+    }
+    VMI_SSTAMP(3);
+
+    // ---- my share of the softmax statistics: max over my tokens, sum of exp relative to it ----
+    const float m_w = wave_max(qk_max);
+    float e_sum = 0.f;
+    for (int t = lane; t < nmy * BS; t += 64) {
+      const int token = (w + (t >> 4) * NW) * BS + (t & 15);
+      e_sum += token < L ? __expf(lg[t] - m_w) : 0.f;
+    }
+    const float s_w = wave_sum(e_sum);
+
+    float M = m_w, S = s_w;
+    if (na > 1) {
+      gu64_t* sl = (gu64_t*)sp.slots + (size_t)item * NW;
+      if (lane == 0) {
+        const unsigned long long g8 = (unsigned long long)__builtin_bit_cast(uint32_t, m_w) |
+                                      ((unsigned long long)__builtin_bit_cast(uint32_t, s_w) << 32);  // s_w >= 1: never 0
+        __hip_atomic_store(sl + w, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      VMI_SSTAMP(4);
+      unsigned long long x = 1ull << 32;
+      for (unsigned spins = 0;; ++spins) {
+        if (lane < na) x = __hip_atomic_load(sl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((x >> 32) != 0ull)) break;
+        if (spins >= SPLIT_SPIN_LIMIT) {  // never on a healthy launch; finish with wrong numbers rather than hang the device
+          if (lane == 0) atomicAdd(sp.status, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const float mj = lane < na ? __builtin_bit_cast(float, (uint32_t)x) : -FLT_MAX;
+      const float sj = lane < na ? __builtin_bit_cast(float, (uint32_t)(x >> 32)) : 0.f;
+      M = wave_max(mj);
+      S = wave_sum(sj * __expf(mj - M));  // the same values in the same lanes in every wave of the item: one S for all
+    }
+    VMI_SSTAMP(5);
+    const float inv = __builtin_amdgcn_rcpf(S + 1e-6f);  // :342
+
+    // ---- probabilities of my tokens, rounded to fp16 once (:398-400); positions past the context become 0 ----
+    for (int t = lane; t < nmy * BS; t += 64) {
+      const int token = (w + (t >> 4) * NW) * BS + (t & 15);
+      ph[t] = token < L ? to_elem<false>(__expf(lg[t] - M) * inv) : (uint16_t)0;
+    }
+
+    // ---- V pass ----
+    auto compute_v = [&](auto masked, u32x4(&r)[U][NL], int gi) {
+      constexpr bool MASK = decltype(masked)::value;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int idx = gi * U + j;
+        if (idx < nmy) {
+          const int b = w + idx * NW;
+          const int token0 = b * BS + hf * 8;
+          const bool last = (b == nblk - 1);
+          PV8<false> pv;
+          pv.load(*reinterpret_cast<const u32x4_alias*>(ph + idx * BS + hf * 8));
+#pragma unroll
+          for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
+        }
+      }
+    };
+    if (single) {
+      compute_v(std::true_type{}, rb, 0);
+    } else {
+      const int last = ngroups - 1;
+      if constexpr (VA < 2) load_group(rb, p.vc, last - 1);
+      compute_v(std::true_type{}, ra, last);
+      int s = 1;
+      for (; s + 1 < ngroups; s += 2) {
+        load_group(ra, p.vc, last - (s + 1));
+        compute_v(std::false_type{}, rb, last - s);
+        if (s + 2 < ngroups) load_group(rb, p.vc, last - (s + 2));
+        compute_v(std::false_type{}, ra, last - (s + 1));
+      }
+      if (s < ngroups) compute_v(std::false_type{}, rb, last - s);
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc[i] += __shfl_xor(acc[i], 1);  // the two 8-token halves of a row
+  }
+  VMI_SSTAMP(6);
+
+  // ---- partial outputs: the workgroup's waves meet in LDS, the item's workgroups in the workspace ----
+  const int nwa = (na - g * wpg) < wpg ? (na - g * wpg) : wpg;  // waves of this workgroup that own blocks
+  if (hf == 0) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) osm[wave * D + RPL * i + rowl] = acc[i];
+  }
+  lds_barrier();
+  if (wave == 0) {
+    float part[D / 64];
+#pragma unroll
+    for (int k = 0; k < D / 64; ++k) {
+      float ssum = 0.f;
+      for (int wv = 0; wv < nwa; ++wv) ssum += osm[wv * D + lane + 64 * k];
+      part[k] = ssum;
+    }
+    if (ga == 1) {
+#pragma unroll
+      for (int k = 0; k < D / 64; ++k) outp[lane + 64 * k] = to_elem<false>(part[k]);
+      if (na > 1 && lane < na)  // my own waves exchanged through the workspace (all of them are past the barrier: they have read)
+        __hip_atomic_store((gu64_t*)sp.slots + (size_t)item * NW + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      gf32_t* mine = (gf32_t*)sp.partials + ((size_t)item * G + g) * D;
+#pragma unroll
+      for (int k = 0; k < D / 64; ++k) __hip_atomic_store(mine + lane + 64 * k, part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the payload has left before the arrival is counted
+      unsigned old = 0;
+      if (lane == 0)
+        old = __hip_atomic_fetch_add((gu32_t*)sp.counters + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old == (unsigned)(ga - 1)) {  // the item's last workgroup: add the partials in workgroup order, store, reset
+        const gf32_t* all = (const gf32_t*)sp.partials + (size_t)item * G * D;
+        float o[D / 64];
+#pragma unroll
+        for (int k = 0; k < D / 64; ++k) o[k] = 0.f;
+        for (int g0 = 0; g0 < ga; g0 += 8) {
+          float t8[8][D / 64];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int k = 0; k < D / 64; ++k)
+              t8[q][k] = (g0 + q < ga) ? __hip_atomic_load(all + (size_t)(g0 + q) * D + lane + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int k = 0; k < D / 64; ++k) o[k] += t8[q][k];
+        }
+#pragma unroll
+        for (int k = 0; k < D / 64; ++k) outp[lane + 64 * k] = to_elem<false>(o[k]);
+        // every wave of the item has read the granules (its workgroup arrived after that): back to "not published"
+        gu64_t* sl = (gu64_t*)sp.slots + (size_t)item * NW;
+        if (lane < na) __hip_atomic_store(sl + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store((gu32_t*)sp.counters + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+#ifdef VMI_DIAG
+  if (tl_) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ts_[7] = wall_clock64();
+    if (lane == 0) {
+      uint64_t* rec = tl_ + ((size_t)blockIdx.x * wpg + wave) * 10;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) rec[k] = ts_[k];
+      rec[8] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);                          // HW_REG_HW_ID
+      rec[9] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((uint64_t)nmy << 8);  // HW_REG_XCC_ID
+    }
+  }
+#endif
+}
+
+// Bytes of workspace and where its parts lie.  Sized for any launch the split kernels take: at most `max_wgs` workgroups
+// (they must all be resident) of four waves.
+struct SplitLayout {
+  size_t status_off, counters_off, slots_off, partials_off, bytes;
+};
+constexpr int SPLIT_MAX_WGS = 2048;    // 8 resident 256-thread workgroups per CU x 256 CUs
+constexpr int SPLIT_MAX_ITEMS = 8192;  // = waves of SPLIT_MAX_WGS: an item has at least one wave
+static inline SplitLayout pa_split_layout(int head_size) {
+  SplitLayout l;
+  l.status_off = 0;                                                         // 256 B header
+  l.counters_off = 256;
+  l.slots_off = l.counters_off + (size_t)SPLIT_MAX_ITEMS * 4;
+  l.partials_off = l.slots_off + (size_t)SPLIT_MAX_WGS * 4 * 8;
+  l.bytes = l.partials_off + (size_t)SPLIT_MAX_WGS * (size_t)head_size * 4;
+  return l;
+}
+
+typedef void (*pa_split_kernel_t)(const PAParams, const PASplit);
+
+}  // namespace vmi

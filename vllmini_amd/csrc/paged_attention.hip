@@ -47,6 +47,7 @@
 #include "vmi_paged_attention_diag.h"
 #endif
 #include "pa_kernel.hpp"
+#include "pa_split.hpp"
 #include "pa_host.hpp"
 #include "pa_cache_fp8.hpp"
 
@@ -351,7 +352,7 @@ static const int g_stage_nvariants = 0;
 #endif
 static int nvariants_v1() {
   return g_ncore + g_extra_nvariants_v1 + g_bf16_nvariants_v1 + g_fp8_nvariants_v1 + g_fp8bf_nvariants_v1 +
-         g_fp8_nvariants_v1_e5m2 + g_fp8bf_nvariants_v1_e5m2 + g_queue_nvariants + g_stage_nvariants;
+         g_fp8_nvariants_v1_e5m2 + g_fp8bf_nvariants_v1_e5m2 + g_queue_nvariants + g_split_nvariants + g_stage_nvariants;
 }
 static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf16][fp8 cache]
   if (id <= g_ncore) return g_variants[id - 1];
@@ -368,7 +369,9 @@ static Variant& variant_v1(int id) {  // 1-based over [core fp16][extra fp16][bf
   if (id <= f3 + g_fp8bf_nvariants_v1_e5m2) return g_fp8bf_variants_v1_e5m2[id - 1 - f3];
   const int f4 = f3 + g_fp8bf_nvariants_v1_e5m2;
   if (id <= f4 + g_queue_nvariants) return g_queue_variants[id - 1 - f4];  // balanced kernels (pa_queue.hip)
-  return g_stage_variants[id - 1 - f4 - g_queue_nvariants];                 // LDS-staged experiment (pa_stage.hip)
+  const int f5 = f4 + g_queue_nvariants;
+  if (id <= f5 + g_split_nvariants) return g_split_variants[id - 1 - f5];  // split kernels (pa_split.hip): need a workspace
+  return g_stage_variants[id - 1 - f5 - g_split_nvariants];                 // LDS-staged experiment (pa_stage.hip)
 }
 
 static bool is_diag(const Variant& v) { return strstr(v.name, "LOADSONLY") != nullptr; }
@@ -379,7 +382,7 @@ static int find_variant(int D, int BS, int HPW, int WPH, int U, int NT /* -1 = a
   for (int id = 1; id <= nvariants_v1(); ++id) {
     const Variant& v = variant_v1(id);
     if (v.F8 == f8 && v.BF == bf && v.D == D && v.BS == BS && v.HPW == HPW && v.WPH == WPH && (U < 0 || v.U == U) &&
-        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0 && !v.GQS && !v.QUEUE && !v.STAGE)
+        (NT < 0 || v.NT == (bool)NT) && !is_diag(v) && !is_lock(v) && v.UMAX == 0 && !v.GQS && !v.QUEUE && !v.STAGE && !v.XW)
       return id;
   }
   return 0;
@@ -534,6 +537,9 @@ struct PickRules {
   double lock_min_waves_per_cu = 12.0;
   double lock_min_round_fill = 0.97; // only where the launch fills whole rounds of those slots: 129 x 32 heads ran 1120 us
                                      //   against 701: r03n_head_128_round_fit.md
+  // ---- split kernels (pa_split.hpp; a workspace is at hand): r05_split_kernels.md ----
+  int split_wgs_per_cu = 3;          // workgroups per CU a split launch may have (all resident)
+  int split_min_blocks_per_wave = 1; // an item is cut into at most blocks / this many waves
   int gate_max_seqs = 2048;          // the gated double launch behind it (launch_pa_v1): every wave of BOTH kernels reads all the
                                      //   lengths for the verdict, bounded by what the balanced kernel ranks in LDS (QSORT_MAX)
   // Head size 128 with MORE items than resident waves and no lockstep fit: eight waves per head as at head size 64 — over
@@ -777,6 +783,44 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   return v;
 }
 
+// ---- split kernels (pa_split.hpp): a (sequence, head) over XW waves = XW / 4 workgroups of one launch ----
+// Every workgroup of the launch must be resident (an item's waves wait for one another): the kernels' launch bounds hold
+// them to six 4-wave workgroups per CU at head size 64 and three at 128; the picks below ask for at most split_wgs_per_cu.
+static inline int split_resident_wgs(int head_size) {
+  const int n = (head_size == 64 ? 6 : 3) * g_cus;
+  return n < SPLIT_MAX_WGS ? n : SPLIT_MAX_WGS;
+}
+static int find_split(int D, int xw, int U, int nt) {
+  for (int i = 0; i < g_split_nvariants; ++i) {
+    const Variant& c = g_split_variants[i];
+    if (c.D == D && c.XW == xw && c.U == U && c.NT == (bool)nt)
+      return nvariants_v1() - g_stage_nvariants - g_split_nvariants + i + 1;
+  }
+  return 0;
+}
+// Which split kernel, if any, serves a launch the plain heuristic gave `plain` to.  0 = keep the plain pick.
+static int pick_split(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len, int plain) {
+  if (block_size != 16 || (head_size != 64 && head_size != 128) || g_split_nvariants == 0) return 0;
+  if (plain >= 1 && plain <= nvariants_v1()) {
+    const Variant& pv = variant_v1(plain);
+    if (pv.GQS || pv.QUEUE || pv.WPH == 1) return 0;   // only where the plain pick already cuts heads into waves: an under-filled chip
+  }
+  const long units = (long)num_seqs * num_heads;
+  const int nblk = (max_seq_len + 15) / 16;
+  const long cap = (long)R.split_wgs_per_cu * g_cus;   // workgroups the launch may have
+  int xw = 0;
+  for (int x = 64; x >= 8; x /= 2)
+    if (units * (x / 4) <= cap && x * R.split_min_blocks_per_wave <= nblk) { xw = x; break; }
+  if (!xw) return 0;
+  const double kv_bytes = 4.0 * (double)units * (double)max_seq_len * head_size;
+  const int nt = kv_bytes > R.nt_kv_bytes ? 1 : 0;
+  const int bpw = (nblk + xw - 1) / xw;
+  int v = 0;
+  if (!nt && bpw >= 4 && bpw % 2 == 0) v = find_split(head_size, xw, 2, 0);
+  if (!v) v = find_split(head_size, xw, 1, nt);
+  return v;
+}
+
 // ---- per-device facts, guarded by one mutex (several host threads may drive several GPUs through this library) ----
 constexpr int MAX_DEVICES = 64;
 struct DeviceState {
@@ -795,8 +839,11 @@ static int clamp_queue_flags(int flags) { return ((flags >> 2) & 7) > 4 ? (flags
 // test / bench knob for the balanced kernels (pa_queue.hpp QF_*), diagnostic library only; initial value from
 // VMI_QUEUE_FLAGS.  The product library always passes 0: the kernel decides everything from seq_lens.
 static thread_local int g_queue_flags = clamp_queue_flags(env_int("VMI_QUEUE_FLAGS"));
+// ... and for the split kernels (pa_split.hpp SPF_*); initial value from VMI_SPLIT_FLAGS
+static thread_local int g_split_flags = env_int("VMI_SPLIT_FLAGS");
 #else
 static constexpr int g_queue_flags = 0;
+static constexpr int g_split_flags = 0;
 #endif
 static thread_local int g_last_variant = 0;  // what this thread's last paged_attention_v1 launch ran (0: none yet / block-sparse)
 static thread_local int g_last_partner = 0;  // ... and the balanced kernel launched behind it in a gated double launch (0: none)
@@ -813,7 +860,10 @@ static int device_cus(int device) {  // caller holds the device current
 }
 
 // dynamic LDS a kernel needs for logits rows of `lpad` floats (max_seq_len padded to 32)
+static inline int split_wtok(int lpad, int xw) { return 16 * ((lpad / 16 + xw - 1) / xw); }   // logits per wave of a split kernel
 static size_t variant_lds_bytes(const Variant& c, int lpad) {
+  if (c.XW)     // per wave: its share of the logits (fp32) and probabilities (fp16) + one partial output row
+    return (size_t)c.WPH * ((size_t)split_wtok(lpad, c.XW) * 6 + (size_t)c.D * 4);
   if (c.STAGE)  // per wave: the logits + a ring of U slots, each one (block, head) tile
     return (size_t)4 * ((size_t)lpad * 4 + (size_t)c.U * (c.D * 16 * (c.F8 ? 1 : 2)));
   if (c.QUEUE)  // 4 waves' logits + the ranking, its bucket counts and masks + a team's exchange buffers (pa_queue.hpp)
@@ -877,7 +927,8 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
                         int64_t kv_head_stride, int32_t device, void* stream, int32_t variant,
                         bool bf, bool append, const void* key, const void* value, int64_t key_stride,
-                        int64_t value_stride, int f8, float kv_scale, const int32_t* bsp) {
+                        int64_t value_stride, int f8, float kv_scale, const int32_t* bsp, void* workspace,
+                        int64_t workspace_bytes) {
   // (an EMPTY batch — num_seqs == 0: the per-sequence tensors have no storage, torch hands out null data pointers — is
   //  a no-op below, not an error; the caches must exist either way)
   if (!key_cache || !value_cache || (num_seqs != 0 && (!out || !query || !block_tables || !seq_lens)))
@@ -922,6 +973,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   const bool gate_ok = variant == 0 && !append && !bsp && !f8;  // an explicit variant is run as asked
   g_cus = device_cus(device);  // the heuristics size the launch for THIS device
   Variant* sparse_v = nullptr;
+  bool picked = false;  // the library chose the variant (the caller passed 0)
   if (bsp) {  // one or four waves per head, by how many (seq, head) units there are to fill the chip with
     const int nblk = (max_seq_len + block_size - 1) / block_size;
     const bool many = (long)num_seqs * num_heads >= full_chip_waves() || nblk < 4;
@@ -929,6 +981,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
     if (sparse_v && lds_of(*sparse_v) > 160 * 1024) sparse_v = find_sparse(head_size, block_size, 1, bf, false);
     if (!sparse_v) return fail(VMI_E_VARIANT, "paged_attention_v1: no block-sparse kernel for head size %d / block size %d", head_size, block_size);
   } else if (variant == 0) {
+    picked = true;
     variant = pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size, max_seq_len, bf, f8);
     if (!variant || (append && !app_variant_v1(variant)))
       variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf, f8,
@@ -942,6 +995,12 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
       if (!alt || lds_of(variant_v1(alt)) > 160 * 1024) alt = find_variant(head_size, block_size, 1, 1, -1, -1, bf, f8);
       if (alt) variant = alt;
     }
+  }
+  const bool have_ws = workspace != nullptr && aligned16(workspace) &&
+                       workspace_bytes >= (int64_t)pa_split_layout(head_size).bytes;
+  if (!sparse_v && picked && have_ws && !append && !f8 && !bf) {
+    // a caller-owned workspace lets an under-filled launch spread each (sequence, head) over several workgroups
+    if (const int sv = pick_split(num_seqs, num_heads, head_size, block_size, max_seq_len, variant)) variant = sv;
   }
   if (!sparse_v && (variant < 1 || variant > nvariants_v1()))
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
@@ -975,6 +1034,19 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
     return fail(VMI_E_SHAPE, "paged_attention_v1: num_seqs * num_heads = %lld items exceed 2^31",
                 (long long)num_seqs * num_heads);
 
+  if (v.XW) {
+    if (append || bsp || f8 || bf)
+      return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (split kernel) takes fp16 tensors over fp16 pages, without the "
+                  "fused append or block-sparse attention", v.name);
+    if (!have_ws)
+      return fail(VMI_E_WORKSPACE, "paged_attention_v1: variant %s spreads a (sequence, head) over several workgroups and needs a "
+                  "16-byte aligned workspace of vmi_paged_attention_v1_workspace_bytes() = %zu bytes (got %p, %lld)", v.name,
+                  pa_split_layout(head_size).bytes, workspace, (long long)workspace_bytes);
+    const int64_t wgs = (int64_t)num_seqs * num_heads * (v.XW / v.WPH);
+    if (wgs > split_resident_wgs(head_size))
+      return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s would launch %lld workgroups; the split kernels need every "
+                  "workgroup resident (at most %d on this device)", v.name, (long long)wgs, split_resident_wgs(head_size));
+  }
   const size_t lds = lds_of(v);
   if (lds > 160 * 1024)
     return fail(VMI_E_MAX_SEQ_LEN, "paged_attention_v1: max_seq_len=%d needs %zu B of LDS per "
@@ -1045,6 +1117,24 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
     return VMI_OK;
   };
   if (v.QUEUE) return launch_balanced(v, 0);
+  if (v.XW) {  // split kernel (pa_split.hpp): items x (XW / 4) workgroups, all resident, meeting in the caller's workspace
+    const SplitLayout lay = pa_split_layout(head_size);
+    char* wsb = static_cast<char*>(workspace);
+    PASplit sp;
+    sp.status = reinterpret_cast<unsigned int*>(wsb + lay.status_off);
+    sp.counters = reinterpret_cast<unsigned int*>(wsb + lay.counters_off);
+    sp.slots = reinterpret_cast<unsigned long long*>(wsb + lay.slots_off);
+    sp.partials = reinterpret_cast<float*>(wsb + lay.partials_off);
+    sp.nw = v.XW;
+    sp.wtok = split_wtok(lpad, v.XW);
+    sp.flags = g_split_flags;
+    const unsigned grid = (unsigned)((int64_t)num_seqs * num_heads * (v.XW / v.WPH));
+    hipLaunchKernelGGL(reinterpret_cast<pa_split_kernel_t>(v.fn), dim3(grid), dim3(v.WPH * 64), lds,
+                       static_cast<hipStream_t>(stream), p, sp);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 (split) launch");
+    return VMI_OK;
+  }
 
   // Head size 128 on a full chip: the fastest kernel for equal lengths reads 4 adjacent heads per wave in lockstep
   // (d128_mh4_*_lock, 0.87 of the roofline) and is the slowest on ragged ones (cfg4 U{1..2048}: 469 us against 325 us
@@ -1065,7 +1155,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   }
   if (partner) {
     p.q_flags |= QF_GATE_UNIFORM;
-    g_last_partner = nvariants_v1() - g_stage_nvariants - g_queue_nvariants + (int)(partner - g_queue_variants) + 1;
+    g_last_partner = nvariants_v1() - g_stage_nvariants - g_split_nvariants - g_queue_nvariants + (int)(partner - g_queue_variants) + 1;
   }
 
   dim3 block(v.HPW * v.WPH * 64);
@@ -1372,6 +1462,48 @@ int vmi_paged_attention_v1_f16_variant(void* out, const void* query, const void*
                            kv_head_stride, device, stream, variant);
 }
 
+int vmi_paged_attention_v1_f16_ws(void* out, const void* query, const void* key_cache, const void* value_cache,
+                                  int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+                                  float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                                  int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+                                  const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                                  int64_t kv_head_stride, int32_t device, void* stream, void* workspace,
+                                  int64_t workspace_bytes, int32_t variant) {
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, false, false, nullptr, nullptr, 0, 0, 0, 1.0f,
+                           nullptr, workspace, workspace_bytes);
+}
+
+int64_t vmi_paged_attention_v1_workspace_bytes(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                               int32_t max_seq_len) {
+  (void)num_seqs; (void)num_heads; (void)max_seq_len;   // (sized for any launch the split kernels take: they are bounded
+  if (head_size != 64 && head_size != 128) return 0;    //  by what is resident, not by the batch)
+  return (int64_t)vmi::pa_split_layout(head_size).bytes;
+}
+
+int vmi_paged_attention_v1_workspace_reset(void* workspace, int64_t workspace_bytes, int32_t device, void* stream) {
+  using namespace vmi;
+  if (!workspace || workspace_bytes <= 0) return fail(VMI_E_NULL_POINTER, "workspace_reset: NULL workspace");
+  DeviceGuard guard(device);
+  if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+  // only the words a launch polls have to be zero: status, counters, granules (the partial rows are written before read)
+  const size_t n = pa_split_layout(128).partials_off;
+  const hipError_t e = hipMemsetAsync(workspace, 0, (size_t)workspace_bytes < n ? (size_t)workspace_bytes : n,
+                                      static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail(e, "workspace_reset hipMemsetAsync");
+  return VMI_OK;
+}
+
+int vmi_paged_attention_v1_pick_variant_ws(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                           int32_t block_size, int32_t max_seq_len) {
+  if (!vmi::head_size_supported(head_size) || !vmi::block_size_supported(block_size)) return 0;
+  const int plain = vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len);
+  const int sv = vmi::pick_split(num_seqs, num_heads, head_size, block_size, max_seq_len, plain);
+  return sv ? sv : plain;
+}
+
 int vmi_paged_attention_v1_append_f16(void* out, const void* query, void* key_cache, void* value_cache,
                                       int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                       int32_t num_kv_heads, float scale, const int32_t* block_tables,
@@ -1451,6 +1583,11 @@ int vmi_paged_attention_v1_last_partner(void) { return vmi::g_last_partner; }
 int vmi_debug_set_queue_flags(int flags) {
   const int prev = vmi::g_queue_flags;
   vmi::g_queue_flags = vmi::clamp_queue_flags(flags);
+  return prev;
+}
+int vmi_debug_set_split_flags(int flags) {
+  const int prev = vmi::g_split_flags;
+  vmi::g_split_flags = flags;
   return prev;
 }
 #endif

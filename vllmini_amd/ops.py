@@ -34,6 +34,8 @@ __all__ = [
     "paged_attention_v2",
     "reshape_and_cache",
     "pick_variant",
+    "workspace_for",
+    "reset_workspaces",
     "variant_fits",
     "variant_names",
 ]
@@ -208,6 +210,62 @@ def _pa_common(out, query, key_cache, value_cache, num_kv_heads, scale, block_ta
     )
 
 
+# ---- the wrapper-owned workspace of paged_attention_v1 (ownership row: "if a split-KV path needs
+# scratch, the Python wrapper allocates it with torch on the same stream").  One tensor per (device, stream): launches on
+# one stream are ordered, so they can share it; launches on different streams get one each.  The native library keeps
+# nothing — the pointer travels with every call.  Under stream capture nothing is allocated (an allocation would belong
+# to the graph's private pool): a stream that has no workspace yet captures today's kernels; call workspace_for() before
+# capturing to let the graph hold the split kernels.
+_WS: dict = {}
+_WS_HEAD_SIZES = (64, 128)
+_ws_enabled = True
+
+
+def _capturing() -> bool:
+    try:
+        return torch.cuda.is_current_stream_capturing()
+    except Exception:
+        return False
+
+
+def workspace_for(index: int, stream: Optional[int] = None, create: bool = True) -> Optional[torch.Tensor]:
+    """The workspace the operators hand to the library for launches on (device `index`, its current stream) — allocated
+    and zeroed on first use (never during stream capture)."""
+    if stream is None:
+        stream = _stream_of(index)
+    ws = _WS.get((index, stream))
+    if ws is None and create and not _capturing():
+        lib = _lib.load()
+        nbytes = max(int(lib.vmi_paged_attention_v1_workspace_bytes(1, 1, d, 16)) for d in _WS_HEAD_SIZES)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", index))   # zeroed on the current stream
+        _WS[(index, stream)] = ws
+    return ws
+
+
+def reset_workspaces(index: Optional[int] = None) -> None:
+    """Zero the control words of every cached workspace (of device `index`): after a launch that died in flight."""
+    lib = _lib.load()
+    for (i, st), ws in list(_WS.items()):
+        if index is None or i == index:
+            rc = lib.vmi_paged_attention_v1_workspace_reset(ws.data_ptr(), ws.numel(), i, st)
+            if rc != 0:
+                _raise_native(rc)
+
+
+def workspace_status(index: int, stream: Optional[int] = None) -> int:
+    """Polls that gave up in launches on this workspace (0 on a healthy run).  Synchronises."""
+    ws = workspace_for(index, stream, create=False)
+    return 0 if ws is None else int(ws[:4].view(torch.int32).item())
+
+
+def set_workspace_enabled(on: bool) -> bool:
+    """Process-wide switch (default on): off = the operators pass no workspace, i.e. yesterday's kernels.  Returns the
+    previous setting."""
+    global _ws_enabled
+    prev, _ws_enabled = _ws_enabled, bool(on)
+    return prev
+
+
 def paged_attention_v1(
     out: torch.Tensor,
     query: torch.Tensor,
@@ -261,10 +319,14 @@ def paged_attention_v1(
         rc = fn(*args, float(kv_scale), int(_variant))
     elif query.dtype == torch.bfloat16:
         rc = _extras("paged_attention_v1 over bfloat16 tensors").vmi_paged_attention_v1_bf16(*args, int(_variant))
-    elif _variant:
-        rc = lib.vmi_paged_attention_v1_f16_variant(*args, int(_variant))
     else:
-        rc = lib.vmi_paged_attention_v1_f16(*args)
+        ws = workspace_for(args[18], args[19]) if (_ws_enabled and args[6] in _WS_HEAD_SIZES) else None
+        if ws is not None:
+            rc = lib.vmi_paged_attention_v1_f16_ws(*args, ws.data_ptr(), ws.numel(), int(_variant))
+        elif _variant:
+            rc = lib.vmi_paged_attention_v1_f16_variant(*args, int(_variant))
+        else:
+            rc = lib.vmi_paged_attention_v1_f16(*args)
     if rc != 0:
         _raise_native(rc)
     return None
@@ -520,10 +582,13 @@ def last_launch_label() -> str:
 
 
 def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int, block_size: int = 16,
-                 mean_seq_len: int = 0, bf16: bool = False, fp8=False, num_kv_heads: int = 0) -> int:
+                 mean_seq_len: int = 0, bf16: bool = False, fp8=False, num_kv_heads: int = 0,
+                 workspace: bool = False) -> int:
     """The library's work-decomposition heuristic (what `_variant=0` runs).  A caller that knows the batch's
     lengths on the host may pass their mean: a ragged batch (mean well below max_seq_len) then gets the
-    many-waves-per-head decomposition; pass the result as `_variant`.  fp8: False / True (E4M3) / "e5m2"."""
+    many-waves-per-head decomposition; pass the result as `_variant`.  fp8: False / True (E4M3) / "e5m2".
+    workspace=True: what the operators run when they hand the library a workspace (fp16 pages; the default of
+    paged_attention_v1 outside stream capture)."""
     lib = _lib.load()
     fp8 = 2 if fp8 in (2, "e5m2", "fp8_e5m2") else int(bool(fp8))
     if num_kv_heads and num_kv_heads != num_heads:      # grouped-query attention: what the operators pick themselves
@@ -537,6 +602,8 @@ def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int
     if fp8:
         fn = lib.vmi_paged_attention_v1_pick_variant_fp8_bf16 if bf16 else lib.vmi_paged_attention_v1_pick_variant_fp8
         return int(fn(num_seqs, num_heads, head_size, block_size, max_seq_len, int(mean_seq_len)))
+    if workspace and not (mean_seq_len or bf16):
+        return int(lib.vmi_paged_attention_v1_pick_variant_ws(num_seqs, num_heads, head_size, block_size, max_seq_len))
     if mean_seq_len or bf16:
         return int(lib.vmi_paged_attention_v1_pick_variant_hint(num_seqs, num_heads, head_size, block_size,
                                                                 max_seq_len, int(mean_seq_len), int(bool(bf16))))
