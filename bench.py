@@ -200,6 +200,10 @@ def init_dist(args):
 
         if world != n_gpus:
             raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
+        # one rank = one GPU = the host cores next to it (before RCCL / gloo start their threads: they inherit the mask)
+        global _PLACEMENT
+        _PLACEMENT = shard.place_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), None if cpu else local_rank,
+                                      bind=os.environ.get("VMI_BENCH_NO_BIND") != "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # RCCL prints a banner on STDOUT — when the communicator is created and again, with the lazily created
@@ -226,6 +230,7 @@ def init_dist(args):
 
 
 _REAL_STDOUT = None
+_PLACEMENT = None      # shard.place_rank() of this rank (N > 1)
 
 
 def emit_line(line: dict) -> None:
@@ -649,7 +654,7 @@ def standin_main(args, dist, rank, world, dev):
     """--standin-cpu: everything around the kernels — self-launch, rendezvous, barrier-bracketed timing, max over ranks,
     token exchange, one JSON line on rank 0's stdout — with a stand-in step on CPU tensors over gloo.  No product
     kernel runs and the line says so: it exists for tests/test_bench_launch.py, never as a measurement."""
-    batch = 8
+    batch = 256 if args.scaling == "weak" else 2048 // world      # the sequences per rank of the real run (BASELINE configs[4])
     x = torch.ones(batch, 64)
     setup_exchange(batch, dist, dev)
 
@@ -665,6 +670,7 @@ def standin_main(args, dist, rank, world, dev):
         _EXCHANGE["work"] = [None, None]
     per_rank = shard.all_ranks(elapsed / args.steps * 1e3, dist, dev)     # the N > 1 line's per-rank figures, same code path
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    placement = shard.gather_objects(_PLACEMENT, dist) if dist is not None else None
     legacy = None
     if dist is not None:     # the rounds-1-2 method beside it: blocking exchange on every step, clock behind the barrier
 
@@ -685,9 +691,10 @@ def standin_main(args, dist, rank, world, dev):
                    "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                    "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                    "vs_baseline": None, "dtype": "f32", "data": "stand-in",
-                   "config": {"workload": "stand-in step on CPU over gloo", "global_batch": batch * world},
+                   "config": {"workload": "stand-in step on CPU over gloo", "global_batch": batch * world, "batch_per_rank": batch},
                    "roofline": None, "cpu_baseline": None,
                    "method_version": 3, "timing_bracket": shard.TIMING_BRACKET, "ms_per_step_per_rank": per_rank,
+                   "rank_placement": placement, "token_exchange_every_steps": EXCHANGE_EVERY,
                    "legacy_method_step": legacy,
                    "self_launched": os.environ.get("VMI_BENCH_SELF_LAUNCHED") == "1"})
 
@@ -956,6 +963,7 @@ def main(argv=None):
                                   "and waited for one token later and before the closing synchronise; token_exchange_us = median "
                                   f"of {args.kernel_samples} BLOCKING exchanges alone, by HIP events")
         line["token_exchange_every_steps"] = EXCHANGE_EVERY
+        line["rank_placement"] = shard.gather_objects(_PLACEMENT, dist)     # per rank: device uuid / PCI id, NUMA node, bound cores
         # the SAME K steps the way rounds 1-2 measured them: blocking exchange on every step, clock behind the barrier
         l_elapsed = shard.max_over_ranks(time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op, legacy=True),
                                          dist, dev)

@@ -40,6 +40,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the entries declared here are all it exports */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define VMI_ABI_VERSION 21
 
@@ -362,6 +366,9 @@ int vmi_is_diag_build(void);
  */
 int vmi_has_extras(void);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the entries declared here are all it exports */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /*
  * Test / benchmark knob of the balanced ("q_*") kernels (per host thread, default 0 = automatic; returns the previous
@@ -70,6 +74,9 @@ int vmi_diag_set_split_stamps(void* records, int32_t device);
  * in dispatch order instead of adjacent. */
 int vmi_debug_set_split_flags(int32_t flags);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the entries declared here are all it exports */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /*
  * Block-sparse attention: paged_attention_v1 / paged_attention_v2 called with blocksparse_vert_stride > 1
@@ -207,6 +211,9 @@ int vmi_reshape_and_cache_f32(
 int vmi_convert_fp8(void* dst, const void* src, int64_t num_elements, float kv_scale, int32_t kind, int32_t to_fp8,
                     int32_t device, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,6 @@ python scripts/stage_timeline_probe.py --summarize "$OUT/trace" "$OUT/rocprof.js
 python - "$OUT/rocprof.json" <<'PY'
 import json, sys
 for r in json.load(open(sys.argv[1])):
-    print(f"{r['case']:44s} {r['kernel']:22s} med {r['rocprofv3_us_median']:7.2f} min {r['rocprofv3_us_min']:7.2f} grid {r['grid']}")
+    print(f"{r['case']:44s} {r['kernel']:22s} med {r['rocprofv3_us_median']:7.2f} min {r['rocprofv3_us_min']:7.2f} grid {r['grid']}  scatter {r.get('scatter_us_median', 0):5.2f} {r.get('scatter_grid', '')}")
 PY
 find "$OUT/trace" -name "*kernel_trace.csv" -size +8M -delete

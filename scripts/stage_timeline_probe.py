@@ -30,7 +30,7 @@ CASES = [
 ]
 STAGES = ["entry", "seq_len known", "first pages requested", "first K group consumed", "K pass done", "maxima exchanged",
           "probabilities written", "V pass done", "partial outputs exchanged", "out stored"]
-WARM, TIMED = 10, 50
+WARM, TIMED = 10, (50 if "--few" not in sys.argv else 12)
 
 
 def arg_cases():
@@ -46,9 +46,11 @@ def setup(case, dev):
     from vllmini_amd.workload import CONFIGS, make_workload
     name, b, L, var = case.split(":")[:4]
     kv = (case.split(":") + ["auto"])[4]            # optional fifth field: "fp8" = E4M3 pages, kv_scale 1
+    hd = (case.split(":") + ["auto", "12x64"])[5]   # optional sixth field: heads x head size
     b, L = int(b), int(L)
     per = -(-L // 16)
-    cfg = dataclasses.replace(CONFIGS["cfg2"], name=name, batch=b, seq_len=L, num_blocks=max(4096, 2 * b * per))
+    cfg = dataclasses.replace(CONFIGS["cfg2"], name=name, batch=b, seq_len=L, num_blocks=max(4096, 2 * b * per),
+                              num_heads=int(hd.split("x")[0]), head_size=int(hd.split("x")[1]))
     wl = make_workload(cfg, dev, seed=7, table_sets=2)
     wl.kv = kv
     if kv == "fp8":
@@ -90,17 +92,24 @@ def run_plain():
 def summarize(trace_dir, out_path):
     order = json.loads(open(os.path.join(trace_dir, "order.json")).read().strip().splitlines()[-1])
     f = sorted(glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True))[0]
-    rows = [r for r in csv.DictReader(open(f)) if "pa_v1_kernel" in r["Kernel_Name"] or "pa_q_kernel" in r["Kernel_Name"] or
+    every = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    rows = [r for r in every if "pa_v1_kernel" in r["Kernel_Name"] or "pa_q_kernel" in r["Kernel_Name"] or
             "pa_split_kernel" in r["Kernel_Name"]]
-    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    scat = [r for r in every if "reshape_and_cache" in r["Kernel_Name"]]      # the other half of the call pair
     res, k = [], 0
+    us = lambda chunk: np.array([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in chunk])   # noqa: E731
     for o in order:
         chunk = rows[k: k + o["launches"]][WARM:]
+        d = us(chunk)
+        rec = {**o, "rocprofv3_us_mean": round(float(d.mean()), 2), "rocprofv3_us_median": round(float(np.median(d)), 2),
+               "rocprofv3_us_min": round(float(d.min()), 2), "grid": chunk[0].get("Grid_Size_X", "") + "x" + chunk[0].get("Grid_Size_Y", ""),
+               "workgroup": chunk[0].get("Workgroup_Size_X", "")}
+        if len(scat) == len(rows):
+            ds = us(scat[k: k + o["launches"]][WARM:])
+            rec["scatter_us_median"] = round(float(np.median(ds)), 2)
+            rec["scatter_grid"] = scat[k + WARM].get("Grid_Size_X", "") + "x" + scat[k + WARM].get("Grid_Size_Y", "")
         k += o["launches"]
-        d = np.array([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in chunk])
-        res.append({**o, "rocprofv3_us_mean": round(float(d.mean()), 2), "rocprofv3_us_median": round(float(np.median(d)), 2),
-                    "rocprofv3_us_min": round(float(d.min()), 2), "grid": chunk[0].get("Grid_Size_X", "") + "x" + chunk[0].get("Grid_Size_Y", ""),
-                    "workgroup": chunk[0].get("Workgroup_Size_X", "")})
+        res.append(rec)
         print(json.dumps(res[-1]), flush=True)
     assert k == len(rows), (k, len(rows))
     json.dump(res, open(out_path, "w"), indent=1)

@@ -19,6 +19,9 @@ Fixtures written:
                     (tests/kernels/paged_attention.py:7-24: 1 seq, 3 tokens, H12, D64) and for
                     multi-block / multi-sequence scenarios -> pins oracle.eager and bounds
                     oracle.kernel_model at the reference test's own tolerance (atol 1e-2, :138).
+  ref_eager_long.npz  (round 5) the same reference expression at the lengths the bench runs: 300 ... 1024 tokens at 12 x 64,
+                    1999 / 2048 at 4 x 128, fp32 and fp16 outputs.  The input rows come from numpy's PCG64 stream
+                    (long_rows below: bit-stable everywhere), so the fixture holds their SHA-256 and the outputs only.
   seam_trace.npz    every (reshape_and_cache | paged_attention_v1) call the reference's
                     Scheduler/BlockManager/GPT-2 make for config 1 (B=1, 5-token prompt ->
                     32 tokens, block 16, max_blocks_per_seq 4), with strides, plus the allocator state
@@ -175,6 +178,64 @@ def gen_ref_eager(out_path: str):
             fixtures[f"{name}/{s}/scale"] = np.float64(attn.scale)
     np.savez_compressed(out_path, **fixtures)
     print(f"wrote {out_path}: {len(fixtures)} arrays")
+
+
+# ------------------------------------------------------------------------------------------------
+# fixture 1b (round 5): the reference's eager attention AT THE LENGTHS THE BENCH RUNS
+# ------------------------------------------------------------------------------------------------
+LONG_SCENARIOS = [
+    # name, context lengths, H, D, numpy seed — BASELINE.json configs[1..3]: 512 / 1024 tokens at 12 x 64, 2048 at head size 128
+    ("long512_h12_d64", [512, 513, 300], 12, 64, 5120),
+    ("long1024_h12_d64", [1023, 1024, 513, 700], 12, 64, 10240),
+    ("long2048_h4_d128", [2048, 1999], 4, 128, 20480),
+]
+
+
+def long_rows(seed: int, s: int, L: int, H: int, D: int):
+    """The inputs of sequence `s` of a LONG_SCENARIO: float16 rows from numpy's PCG64 stream (bit-stable across platforms
+    and numpy versions) — so the fixture only has to hold their checksums and the reference's outputs (14 MB of
+    incompressible rows otherwise).  Used by this generator AND by the tests that replay the fixture."""
+    rng = np.random.default_rng([seed, s])
+    key = rng.standard_normal((L, H, D), dtype=np.float32).astype(np.float16)
+    value = rng.standard_normal((L, H, D), dtype=np.float32).astype(np.float16)
+    query = rng.standard_normal((1, H, D), dtype=np.float32).astype(np.float16)
+    return key, value, query
+
+
+def rows_checksum(key, value, query) -> np.ndarray:
+    import hashlib
+    h = hashlib.sha256()
+    for a in (key, value, query):
+        h.update(np.ascontiguousarray(a).view(np.uint8).tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8).copy()
+
+
+def gen_ref_eager_long(out_path: str):
+    """`GPT2Attention._vanilla_attention` (gpt2.py:71-78 = tests/kernels/paged_attention.py:102-110) in fp32 and fp16 on
+    contexts of 300 ... 2048 tokens: the oracle and the HIP kernels are pinned against the REFERENCE where the bench runs,
+    not only on the short contexts of ref_eager.npz."""
+    from transformers import GPT2Config
+    from vllmini.model.gpt2 import GPT2Attention  # reference code, imported in place
+
+    fixtures = {}
+    for name, lens, H, D, seed in LONG_SCENARIOS:
+        attn = GPT2Attention(GPT2Config(n_embd=H * D, n_head=H))
+        assert abs(attn.scale - D ** -0.5) < 1e-12
+        for s, L in enumerate(lens):
+            key, value, query = long_rows(seed, s, L, H, D)
+            q4 = torch.from_numpy(query).view(1, 1, H, D).transpose(1, 2)
+            k4 = torch.from_numpy(key).view(1, L, H, D).transpose(1, 2)
+            v4 = torch.from_numpy(value).view(1, L, H, D).transpose(1, 2)
+            with torch.no_grad():
+                out32 = attn._vanilla_attention(q4.float(), k4.float(), v4.float(), None)
+                out16 = attn._vanilla_attention(q4, k4, v4, None)
+            fixtures[f"{name}/{s}/len"] = np.int64(L)
+            fixtures[f"{name}/{s}/rows_sha256"] = rows_checksum(key, value, query)
+            fixtures[f"{name}/{s}/ref_eager_fp32"] = out32.reshape(H, D).numpy()
+            fixtures[f"{name}/{s}/ref_eager_fp16"] = out16.reshape(H, D).numpy()
+        fixtures[f"{name}/meta"] = np.array(json.dumps({"lens": lens, "H": H, "D": D, "seed": seed, "scale": float(attn.scale)}))
+    np.savez_compressed(out_path, **fixtures)
+    print(f"wrote {out_path}: {len(fixtures)} arrays, {os.path.getsize(out_path)} bytes")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -419,6 +480,8 @@ def main():
     with CudaToCpu():
         if only in ("", "eager"):
             gen_ref_eager(os.path.join(HERE, "ref_eager.npz"))
+        if only in ("", "eager_long"):
+            gen_ref_eager_long(os.path.join(HERE, "ref_eager_long.npz"))
         if only in ("", "seam"):
             gen_seam_trace(os.path.join(HERE, "seam_trace.npz"), rec)
         if only in ("", "capacity"):

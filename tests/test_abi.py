@@ -45,9 +45,74 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 20
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 21
     assert typed.vmi_target_arch() == b"gfx950"
     assert typed.vmi_is_diag_build() == 0 and typed.vmi_has_extras() == 0
+
+
+def test_libraries_export_the_c_abi_and_nothing_else_that_can_be_called():
+    """Built with -fvisibility=hidden: the dynamic symbol table of each library holds the extern "C" entries of include/*.h
+    (visibility pushed to default there) and no other FUNCTION — none of the ~900 vmi:: launchers / pick functions that used
+    to leak (round-4 advisor finding: the extras library's wrappers reached them through the PLT, so loading two libraries
+    RTLD_GLOBAL could bind one's entries to the other's menus).  What remains besides `vmi_*` are the weak data handles the HIP
+    runtime registers kernels by (type V)."""
+    from vllmini_amd import build
+
+    build.build()
+    for path in (build.LIB_PATH, build.EXTRAS_LIB_PATH, build.DIAG_LIB_PATH):
+        if not os.path.exists(path):
+            continue
+        r = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True)
+        rows = [ln.split() for ln in r.stdout.splitlines() if ln.strip()]
+        funcs = [x[-1] for x in rows if x[-2] in "TtWw"]
+        assert funcs and all(f.startswith("vmi_") for f in funcs), [f for f in funcs if not f.startswith("vmi_")][:5]
+        assert not [x[-1] for x in rows if "launch_pa" in x[-1] or "pick_variant" in x[-1] and not x[-1].startswith("vmi_")]
+
+
+def test_head_128_long_context_picks_fit_their_lds():
+    """Round-4 advisor finding: `lock_ok` had no LDS term, so head size 128 x 16 / 32 heads at 3400 ... 16384 tokens was handed
+    the 16-heads-per-workgroup lockstep kernel, whose logits do not fit there (the launcher then fell back to one wave per
+    head).  Every pick over that grid must fit its LDS."""
+    from vllmini_amd import ops
+
+    names = ops.variant_names()
+    for H in (16, 32):
+        for B in (128, 256, 1024, 2048):
+            for L in (2048, 2560, 3400, 4096, 8192, 16384):
+                v = ops.pick_variant(B, H, 128, L)
+                assert v and ops.variant_fits(v, L), (H, B, L, names[v - 1])
+                if L >= 3400:
+                    assert "_lock" not in names[v - 1], (H, B, L, names[v - 1])
+
+
+def test_a_worker_thread_starts_on_the_product_library_and_can_opt_in_for_itself():
+    """`_lib.use_extras()` / `use_diag()` switch the library of the calling CONTEXT (a ContextVar since round 4): a thread
+    started inside the `with` runs on the product library unless it opts in itself or is started through
+    contextvars.copy_context().run (INTEGRATION.md)."""
+    import contextvars
+    import threading
+
+    from vllmini_amd import _lib, build
+
+    if not os.path.exists(build.EXTRAS_LIB_PATH):
+        pytest.skip("extras library not built")
+    seen = {}
+
+    def worker(tag):
+        seen[tag] = _lib.load().vmi_has_extras()
+
+    def opting_in():
+        with _lib.use_extras():
+            seen["opted"] = _lib.load().vmi_has_extras()
+
+    with _lib.use_extras():
+        assert _lib.load().vmi_has_extras() == 1
+        t = [threading.Thread(target=worker, args=("plain",)), threading.Thread(target=opting_in),
+             threading.Thread(target=contextvars.copy_context().run, args=(worker, "copied"))]
+        [x.start() for x in t]
+        [x.join() for x in t]
+    assert seen == {"plain": 0, "opted": 1, "copied": 1}
+    assert _lib.load().vmi_has_extras() == 0
 
 
 OUT_OF_SCOPE = re.compile(r"bf16|e5m2|_sp_|sparse|f32_kernel|convert_fp8_kernel|flash_kernel", re.I)

@@ -37,7 +37,7 @@ def test_plain_python_bench_gpus_n_launches_its_own_ranks(n):
     line = _one_json_line(r.stdout)
     assert line["n_gpus"] == n and line["steps"] == 7 and line["warmup"] == 2
     assert line["self_launched"] is True
-    assert line["config"]["global_batch"] == 8 * n
+    assert line["config"]["global_batch"] == 256 * n
     assert line["value"] > 0 and line["ms_per_step"] > 0
     assert "STAND-IN" in line["metric"]          # can never be mistaken for a measurement
     # the N > 1 line says how it was timed and carries every rank's figure, not only the max; and the same K steps the
@@ -46,6 +46,49 @@ def test_plain_python_bench_gpus_n_launches_its_own_ranks(n):
     assert len(line["ms_per_step_per_rank"]) == n and max(line["ms_per_step_per_rank"]) == pytest.approx(line["ms_per_step"])
     leg = line["legacy_method_step"]
     assert leg["method_version"] == 2 and leg["ms_per_step"] > 0 and "BEHIND" in leg["timing_bracket"]
+
+
+@pytest.mark.parametrize("scaling,per_rank", [("weak", 256), ("strong", 256)])
+def test_world_8_stand_in_of_the_scaling_curve(scaling, per_rank):
+    """The shape of the driver's 8-GPU run, on CPU over gloo: `python bench.py --gpus 8 [--scaling strong]` starts eight ranks,
+    each bound to its own slice of the host's cores, 256 sequences per rank either way (weak: 8 x 256; strong: 2048 / 8), the
+    token exchange once per token (every 12th layer step), one line with every rank's figure and placement."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "25", "--warmup", "2", "--standin-cpu", "--scaling", scaling],
+                       capture_output=True, text=True, timeout=600, env=_clean_env(), cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _one_json_line(r.stdout)
+    assert line["n_gpus"] == 8 and line["scaling"] == scaling and line["self_launched"] is True
+    assert line["config"]["batch_per_rank"] == per_rank and line["config"]["global_batch"] == 2048
+    assert line["token_exchange_every_steps"] == 12
+    per = line["ms_per_step_per_rank"]
+    assert len(per) == 8 and all(x > 0 for x in per) and max(per) == pytest.approx(line["ms_per_step"])
+    assert line["value"] == pytest.approx(2048 * 25 / (line["ms_per_step"] * 25 / 1e3), rel=1e-6)
+    place = line["rank_placement"]
+    assert [p["local_rank"] for p in place] == list(range(8))
+    cores = [p["cores"] for p in place]
+    if len(os.sched_getaffinity(0)) >= 8:        # every rank has its own cores
+        assert len(set(cores)) == 8 and all(p["bound"] and p["n_cores"] >= 1 for p in place), place
+
+
+def test_rank_placement_follows_the_gpus_numa_node(tmp_path):
+    """shard.cores_for_rank / gpu_numa_node against a fake /sys: a rank runs on the cores of its GPU's NUMA node, sliced among
+    the local ranks; an unknown node (-1, or no /sys) deals all allowed cores evenly."""
+    sys.path.insert(0, REPO)
+    from vllmini_amd import shard
+
+    (tmp_path / "bus/pci/devices/0000:05:00.0").mkdir(parents=True)
+    (tmp_path / "bus/pci/devices/0000:05:00.0/numa_node").write_text("1\n")
+    (tmp_path / "devices/system/node/node1").mkdir(parents=True)
+    (tmp_path / "devices/system/node/node1/cpulist").write_text("64-127,192-255\n")
+    assert shard.gpu_numa_node("0000:05:00.0", str(tmp_path)) == 1
+    assert shard.gpu_numa_node("0000:99:00.0", str(tmp_path)) == -1
+    allowed = set(range(256))
+    got = [shard.cores_for_rank(r, 8, 1, allowed, str(tmp_path)) for r in range(8)]
+    assert all(len(g) == 16 for g in got) and got[0][0] == 64 and got[7][-1] == 255
+    assert sorted(c for g in got for c in g) == list(range(64, 128)) + list(range(192, 256))
+    even = [shard.cores_for_rank(r, 8, -1, allowed, str(tmp_path)) for r in range(8)]
+    assert [len(g) for g in even] == [32] * 8 and even[3][0] == 96
+    assert shard.cores_for_rank(5, 8, -1, {3}, str(tmp_path)) == [3]              # fewer cores than ranks: never empty
 
 
 def test_bench_under_an_external_launcher_does_not_relaunch():

@@ -138,6 +138,47 @@ def test_oracle_pinned_against_reference_eager_golden(golden_dir):
     assert worst_model <= 2.5e-3, worst_model   # fp16 rounding of p and p*v (1.95e-3 @ L=3)
 
 
+def _long_cases(golden_dir):
+    """tests/golden/ref_eager_long.npz: the reference's eager attention at the lengths the bench runs.  The input rows are
+    regenerated from the seeded numpy stream the generator used (gen_golden.long_rows) and checked against the fixture's
+    SHA-256 before anything is compared."""
+    import sys
+
+    sys.path.insert(0, golden_dir)
+    import gen_golden as g
+
+    z = np.load(os.path.join(golden_dir, "ref_eager_long.npz"))
+    for name, lens, H, D, seed in g.LONG_SCENARIOS:
+        meta = json.loads(str(z[f"{name}/meta"]))
+        assert meta["lens"] == lens and meta["H"] == H and meta["D"] == D and meta["seed"] == seed
+        rows = []
+        for s, L in enumerate(lens):
+            key, value, query = g.long_rows(seed, s, L, H, D)
+            assert np.array_equal(g.rows_checksum(key, value, query), z[f"{name}/{s}/rows_sha256"]), (name, s)
+            rows.append((key, value, query))
+        yield name, z, rows, H, D, float(meta["scale"])
+
+
+def test_oracle_pinned_against_reference_eager_at_bench_lengths(golden_dir):
+    """Round 5: the kernel model against the REFERENCE's eager attention at 300 ... 2048 tokens (BASELINE.json configs[1..3]
+    run 512 / 1024 / 2048).  Bound: 5e-4 — SURVEY.md A.3 measured 2.4e-4 at 512 tokens and 1.2e-4 at 1024 for this
+    restatement against exact arithmetic; the short-context fixture's 2.5e-3 is the L = 3 figure."""
+    rng = np.random.default_rng(8)
+    worst = {}
+    for name, z, rows, H, D, scale in _long_cases(golden_dir):
+        kc, vc, tables, lens = _paged_from_rows(rng, [r[0] for r in rows], [r[1] for r in rows], H, D)
+        q = np.stack([r[2][0] for r in rows])
+        eager64 = oracle.eager_paged_attention(q, kc, vc, H, scale, tables, lens)
+        model = oracle.paged_attention_v1(q, kc, vc, H, scale, tables, lens, BS, threads=8).astype(np.float64)
+        for s in range(len(rows)):
+            ref32 = z[f"{name}/{s}/ref_eager_fp32"].astype(np.float64)
+            ref16 = z[f"{name}/{s}/ref_eager_fp16"].astype(np.float64)
+            assert np.abs(eager64[s] - ref32).max() <= 2e-6, (name, s)
+            assert np.abs(model[s] - ref16).max() <= 1e-2, (name, s)           # the reference test's own bar
+            worst[name] = max(worst.get(name, 0.0), np.abs(model[s] - ref32).max())
+    assert len(worst) == 3 and max(worst.values()) <= 5e-4, worst
+
+
 def test_reference_own_unittest_passed_against_oracle(golden_dir):
     with open(os.path.join(golden_dir, "ref_selftest.json")) as f:
         r = json.load(f)

@@ -2,7 +2,7 @@
 
 `ops.variant_names()` / `ops.variant_names_v2()` list every (kernel, work decomposition) the library holds; a variant id
 reaches each of them through the C-ABI (`vmi_paged_attention_v1_f16_variant` and friends).  This test walks ALL of them —
-no filter by name — builds a case of the shape the name describes (element type, KV-cache type, head size, block size,
+no filter by name (the split kernels, "_x<waves>", get the wrapper's workspace like any call through ops) — builds a case of the shape the name describes (element type, KV-cache type, head size, block size,
 query heads per KV head), runs the variant and compares with the kernel model.  A name the walker cannot parse, a variant
 that is refused for every shape tried, or a library that still carries a diagnostic kernel fails the test: nothing that
 ships is untested or wrong by design (the diagnostic build, -DVMI_DIAG, is where "loads only" and the LDS-staging
@@ -25,7 +25,7 @@ from test_parity_gpu import _bf16_tensor, _dev, _e5m2_case, _fp8_case, assert_cl
 pytestmark = pytest.mark.gpu
 
 NAME = re.compile(r"^(?P<bf>bf16_)?(?P<kv>fp8e5m2_|fp8_)?(?P<v2>v2_)?(?P<q>q_)?d(?P<D>\d+)(?:_bs(?P<bs>\d+))?"
-                  r"(?:_mh(?P<mh>\d+))?(?:_gq(?P<gq>\d+))?(?:_h(?P<h>\d+))?(?:_w(?P<w>\d+))?(?:_s(?P<s>\d+)q(?P<uq>\d+)(?P<km>m)?)?"
+                  r"(?:_mh(?P<mh>\d+))?(?:_gq(?P<gq>\d+))?(?:_h(?P<h>\d+))?(?:_w(?P<w>\d+))?(?:_x(?P<x>\d+))?(?:_s(?P<s>\d+)q(?P<uq>\d+)(?P<km>m)?)?"
                   r"(?:_u(?P<u>\d+)(?:a(?P<a>\d+))?)?(?:_nt(?P<nt>\d))?(?P<pvm>_pvm)?(?P<lock>_lock)?$")
 
 
@@ -35,13 +35,14 @@ class Cases:
     def __init__(self):
         self.cache = {}
 
-    def get(self, bf, kv, D, bs, H, hkv, v2):
-        key = (bf, kv, D, bs, H, hkv, v2)
+    def get(self, bf, kv, D, bs, H, hkv, v2, nseq=9):
+        key = (bf, kv, D, bs, H, hkv, v2, nseq)
         if key in self.cache:
             return self.cache[key]
         dev = _dev()
         rng = np.random.default_rng(hash(key) % (2 ** 32))
-        lens = [1, bs, bs + 1, 100, 333, 47, 700, 0, 2 * bs - 1]
+        # (nseq < 9: the widest split kernels — every workgroup of a launch must be resident — get the first few of a reordering)
+        lens = [1, bs, bs + 1, 100, 333, 47, 700, 0, 2 * bs - 1] if nseq == 9 else [700, 1, 333, 0, bs + 1, 100, 47, bs][:nseq]
         msl = 1024 if v2 else max(lens)
         scale = 0.75 if kv else 1.0                   # kv_scale (the balanced fp8 kernels: 1.0, set by the caller)
         if kv == "fp8_":
@@ -124,7 +125,10 @@ def _walk(names, v2, cases):
         errors = []
         for hkv in (4, 6, 8, 3):                             # H_kv a multiple of what a workgroup takes
             H = hkv * g
-            case = cases.get(bf, kv, D, bs, H, hkv, v2)
+            nseq = 9
+            if m["x"]:      # split kernel: sequences x heads x (waves / 4) workgroups, all resident (6 per CU at head size 64, 3 at 128)
+                nseq = max(1, min(9, (1536 if D == 64 else 768) * 4 // (int(m["x"]) * H)))
+            case = cases.get(bf, kv, D, bs, H, hkv, v2, nseq)
             try:
                 got = _launch(case, vid, v2, kvd, kv_scale, bf)
             except RuntimeError as e:

@@ -55,7 +55,7 @@ SRC_F32 = os.path.join(CSRC, "pa_f32.hip")                    # float32 tensors 
 SRC_QUEUE = os.path.join(CSRC, "pa_queue.hip")                # balanced (work-queue) kernels for ragged batches
 SRC_SPLIT = os.path.join(CSRC, "pa_split.hip")                # split kernels: one (sequence, head) over several workgroups + workspace
 SRC_STAGE = os.path.join(CSRC, "pa_stage.hip")                # experiment: pages staged through LDS (diagnostic library only)
-SRC_ABSENT = os.path.join(CSRC, "pa_extras_absent.hip")      # product library: empty out-of-scope menus, VMI_E_NOT_BUILT entries
+SRC_ABSENT = os.path.join(CSRC, "pa_extras_absent.hip")      # product library: empty out-of-scope menus, no out-of-scope entry
 SRC_EXTRAS_CACHE = os.path.join(CSRC, "pa_extras_cache.hip")  # extras: convert_fp8, reshape_and_cache_flash, bf16 / E5M2 fp8 scatter
 SRC_EXTRAS_ABI = os.path.join(CSRC, "pa_extras_abi.hip")      # extras: the C-ABI entries of include/vmi_paged_attention_extras.h
 # (source, flavor): flavor "" = plain, "extras" = -DVMI_EXTRAS, "diag" = -DVMI_DIAG (+ -DVMI_EXTRAS)
@@ -89,6 +89,7 @@ HIPCC_FLAGS = [
     "-std=c++17",
     "-ffp-contract=off",
     "-fPIC",
+    "-fvisibility=hidden",          # only the extern "C" entries (VMI_API in the headers) leave the library
     "-fno-gpu-rdc", *os.environ.get("VMI_EXTRA_FLAGS", "").split(),
     f"-I{INCLUDE}",
 ]

@@ -1,7 +1,7 @@
 // pa_extras_cache.hip — cache operators OUTSIDE the hot-path scope, linked into
 // libvmi_paged_attention_extras.so only: convert_fp8, reshape_and_cache_flash, and the bfloat16-row / E5M2 instantiations
-// of the fp8 reshape_and_cache kernel.  The product library links pa_extras_absent.hip instead, whose entries of the same
-// names return VMI_E_NOT_BUILT.
+// of the fp8 reshape_and_cache kernel.  The product library links pa_extras_absent.hip instead: empty kernel menus, and none of
+// these entries.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -5,7 +5,7 @@
 // straightforward kernel per (head size, block size), not a tuned menu: one workgroup of four waves per (sequence, head),
 // the blocks dealt round-robin to the waves, a (block, head) tile fetched as 1-KiB wave loads in the layout's own order.
 // Out of the hot-path scope: linked into libvmi_paged_attention_extras.so only (kernels AND their two C-ABI entries; the
-// product library's entries of the same names, pa_extras_absent.hip, return VMI_E_NOT_BUILT).
+// product library has neither — pa_extras_absent.hip holds empty menus and no entry).
 #include "vmi_paged_attention_extras.h"
 #include "pa_kernel.hpp"
 #include "pa_host.hpp"

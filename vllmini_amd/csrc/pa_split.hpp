@@ -36,12 +36,13 @@ struct PASplit {
   float* partials;            // [items][nw / wpg][D]  fp32 partial outputs of the item's workgroups
   unsigned int* counters;     // [items]          arrivals of the item's workgroups; back to 0 when the item is done
   unsigned int* status;       // [0]: number of polls that gave up (must stay 0)
-  int32_t nw;                 // waves per item (<= 64, a multiple of the waves per workgroup)
-  int32_t wtok;               // logits per wave held in LDS: 16 * ceil(ceil(max_seq_len / 16) / nw)
+  int32_t nw;                 // waves per item (<= 256, a multiple of the waves per workgroup)
+  int32_t wtok;               // logits per wave held in LDS: 16 * max(8, ceil(ceil(max_seq_len / 16) / nw)) (split_wtok)
   int32_t flags;              // SPF_*
 };
 constexpr int SPF_GMAJOR = 1;        // workgroup index = g * items + item (an item's workgroups far apart in dispatch order)
-constexpr int SPLIT_MAX_WAVES = 64;  // one lane per granule in the poll
+constexpr int SLOTS_PER_LANE = 4;     // granules a lane reads in the poll
+constexpr int SPLIT_MAX_WAVES = 64 * SLOTS_PER_LANE;
 constexpr unsigned SPLIT_SPIN_LIMIT = 1u << 20;
 
 #ifdef VMI_DIAG
@@ -60,7 +61,7 @@ typedef float __attribute__((address_space(1))) gf32_t;
 // D head size (64 | 128), U blocks per register group, NT non-temporal page loads, VA V groups requested in front of
 // the exchange (1 | 2).  Block size 16, fp16 query / pages.  grid = items * (nw / wpg), block = wpg * 64.
 // Launch bounds: six (head size 128: three) workgroups per CU — what the host counts as resident (split_resident_wgs).
-// LDS = wpg * (wtok * 4 (logits) + wtok * 2 (probabilities) + D * 4 (partial out)).
+// LDS = wpg * (wtok * 4 (logits) + wtok * 2 (probabilities) + D * 4 (partial out)) + 16 (the "I am last" flag).
 template <int D, int U, bool NT, int VA>
 __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PAParams p, const PASplit sp) {
   constexpr int BS = 16;
@@ -121,10 +122,17 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
     return;
   }
   const int nblk = (L + BS - 1) / BS;
-  const int na = nblk < NW ? nblk : NW;     // waves of the item that own a block
+  // The host sized NW for max_seq_len — which the reference's scheduler sets to the CAPACITY of a block table
+  // (scheduler.py:97), not to the lengths at hand.  A wave wants at least four blocks (r05_split_kernels.md: 1 - 2 blocks per
+  // wave lose to the exchange they pay for), so this item uses NWe = 4 * floor(blocks / 16) of its NW waves (>= one
+  // workgroup); every wave of the item derives the same NWe from the same seq_len.
+  int NWe = nblk / (4 * wpg) * wpg;
+  NWe = NWe < wpg ? wpg : (NWe > NW ? NW : NWe);
+  if (NWe != NW) bt_sg = -1;                 // the table entries requested above were dealt for NW waves
+  const int na = nblk < NWe ? nblk : NWe;   // waves of the item that own a block
   const int ga = (na + wpg - 1) / wpg;      // workgroups of the item that hold such a wave
   if (g >= ga) return;                      // the whole workgroup has nothing to do (uniform)
-  const int nmy = w < na ? (nblk - w + NW - 1) / NW : 0;  // my blocks: b = w + idx * NW
+  const int nmy = w < na ? (nblk - w + NWe - 1) / NWe : 0;  // my blocks: b = w + idx * NWe
   VMI_SSTAMP(1);
 
   float* lg = reinterpret_cast<float*>(smem) + (size_t)wave * sp.wtok;                                   // my logits
@@ -142,7 +150,7 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
     auto table_for = [&](int gi) {
       const int sg = (gi * U) >> 6;
       if (sg != bt_sg) {
-        const int b = w + (sg * 64 + lane) * NW;
+        const int b = w + (sg * 64 + lane) * NWe;
         bt_reg = (b < p.max_blocks_per_seq) ? bt[b] : 0;
         bt_sg = sg;
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bt_reg));  // (inside the branch: see pa_kernel.hpp table_for)
@@ -166,7 +174,7 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
       for (int j = 0; j < U; ++j) {
         const int idx = gi * U + j;
         if (idx < nmy) {
-          const int token = (w + idx * NW) * BS + tk;
+          const int token = (w + idx * NWe) * BS + tk;
           const bool masked = token >= L;
           float accv[NL];
 #pragma unroll
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
     const float m_w = wave_max(qk_max);
     float e_sum = 0.f;
     for (int t = lane; t < nmy * BS; t += 64) {
-      const int token = (w + (t >> 4) * NW) * BS + (t & 15);
+      const int token = (w + (t >> 4) * NWe) * BS + (t & 15);
       e_sum += token < L ? __expf(lg[t] - m_w) : 0.f;
     }
     const float s_w = wave_sum(e_sum);
@@ -229,27 +237,44 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
         __hip_atomic_store(sl + w, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       VMI_SSTAMP(4);
-      unsigned long long x = 1ull << 32;
+      // one lane per granule, up to SLOTS_PER_LANE passes of 64: every wave of the item reads all na granules
+      unsigned long long x[SLOTS_PER_LANE];
+#pragma unroll
+      for (int q = 0; q < SLOTS_PER_LANE; ++q) x[q] = 1ull << 32;
       for (unsigned spins = 0;; ++spins) {
-        if (lane < na) x = __hip_atomic_load(sl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all((x >> 32) != 0ull)) break;
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < SLOTS_PER_LANE; ++q) {
+          if (lane + 64 * q < na) x[q] = __hip_atomic_load(sl + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (x[q] >> 32) != 0ull;
+        }
+        if (__all(ok)) break;
         if (spins >= SPLIT_SPIN_LIMIT) {  // never on a healthy launch; finish with wrong numbers rather than hang the device
           if (lane == 0) atomicAdd(sp.status, 1u);
           break;
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      const float mj = lane < na ? __builtin_bit_cast(float, (uint32_t)x) : -FLT_MAX;
-      const float sj = lane < na ? __builtin_bit_cast(float, (uint32_t)(x >> 32)) : 0.f;
-      M = wave_max(mj);
-      S = wave_sum(sj * __expf(mj - M));  // the same values in the same lanes in every wave of the item: one S for all
+      float mj[SLOTS_PER_LANE], sj[SLOTS_PER_LANE], mloc = -FLT_MAX;
+#pragma unroll
+      for (int q = 0; q < SLOTS_PER_LANE; ++q) {
+        const bool has = lane + 64 * q < na;
+        mj[q] = has ? __builtin_bit_cast(float, (uint32_t)x[q]) : -FLT_MAX;
+        sj[q] = has ? __builtin_bit_cast(float, (uint32_t)(x[q] >> 32)) : 0.f;
+        mloc = fmaxf(mloc, mj[q]);
+      }
+      M = wave_max(mloc);
+      float sloc = 0.f;
+#pragma unroll
+      for (int q = 0; q < SLOTS_PER_LANE; ++q) sloc += sj[q] * __expf(mj[q] - M);
+      S = wave_sum(sloc);  // the same values in the same lanes in every wave of the item: one S for all
     }
     VMI_SSTAMP(5);
     const float inv = __builtin_amdgcn_rcpf(S + 1e-6f);  // :342
 
     // ---- probabilities of my tokens, rounded to fp16 once (:398-400); positions past the context become 0 ----
     for (int t = lane; t < nmy * BS; t += 64) {
-      const int token = (w + (t >> 4) * NW) * BS + (t & 15);
+      const int token = (w + (t >> 4) * NWe) * BS + (t & 15);
       ph[t] = token < L ? to_elem<false>(__expf(lg[t] - M) * inv) : (uint16_t)0;
     }
 
@@ -260,7 +285,7 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
       for (int j = 0; j < U; ++j) {
         const int idx = gi * U + j;
         if (idx < nmy) {
-          const int b = w + idx * NW;
+          const int b = w + idx * NWe;
           const int token0 = b * BS + hf * 8;
           const bool last = (b == nblk - 1);
           PV8<false> pv;
@@ -297,6 +322,13 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
     for (int i = 0; i < NL; ++i) osm[wave * D + RPL * i + rowl] = acc[i];
   }
   lds_barrier();
+  int* last_flag = reinterpret_cast<int*>(osm + wpg * D);
+  gu64_t* my_slots = (gu64_t*)sp.slots + (size_t)item * NW;
+  auto reset_slots = [&]() {  // every wave of the item has read the granules by now: back to "not published"
+#pragma unroll
+    for (int q = 0; q < SLOTS_PER_LANE; ++q)
+      if (lane + 64 * q < na) __hip_atomic_store(my_slots + lane + 64 * q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   if (wave == 0) {
     float part[D / 64];
 #pragma unroll
@@ -308,39 +340,51 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
     if (ga == 1) {
 #pragma unroll
       for (int k = 0; k < D / 64; ++k) outp[lane + 64 * k] = to_elem<false>(part[k]);
-      if (na > 1 && lane < na)  // my own waves exchanged through the workspace (all of them are past the barrier: they have read)
-        __hip_atomic_store((gu64_t*)sp.slots + (size_t)item * NW + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (na > 1) reset_slots();  // (my own waves exchanged through the workspace; all of them are past the barrier)
     } else {
       gf32_t* mine = (gf32_t*)sp.partials + ((size_t)item * G + g) * D;
 #pragma unroll
       for (int k = 0; k < D / 64; ++k) __hip_atomic_store(mine + lane + 64 * k, part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the payload has left before the arrival is counted
       unsigned old = 0;
-      if (lane == 0)
+      if (lane == 0) {
         old = __hip_atomic_fetch_add((gu32_t*)sp.counters + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      old = __builtin_amdgcn_readfirstlane(old);
-      if (old == (unsigned)(ga - 1)) {  // the item's last workgroup: add the partials in workgroup order, store, reset
-        const gf32_t* all = (const gf32_t*)sp.partials + (size_t)item * G * D;
-        float o[D / 64];
+        *last_flag = old == (unsigned)(ga - 1);
+      }
+    }
+  }
+  if (ga > 1) {
+    lds_barrier();
+    if (*last_flag) {
+      // The item's last workgroup adds the partial rows — its four waves a quarter each (wave k: workgroups k, k + 4, ...),
+      // then wave 0 the four sums: an order fixed by ga alone, whatever the arrival order.
+      const gf32_t* all = (const gf32_t*)sp.partials + (size_t)item * G * D;
+      float o[D / 64];
 #pragma unroll
-        for (int k = 0; k < D / 64; ++k) o[k] = 0.f;
-        for (int g0 = 0; g0 < ga; g0 += 8) {
-          float t8[8][D / 64];
+      for (int k = 0; k < D / 64; ++k) o[k] = 0.f;
+      for (int g0 = wave; g0 < ga; g0 += 8 * wpg) {
+        float t8[8][D / 64];
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < 8; ++q)
 #pragma unroll
-            for (int k = 0; k < D / 64; ++k)
-              t8[q][k] = (g0 + q < ga) ? __hip_atomic_load(all + (size_t)(g0 + q) * D + lane + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          for (int k = 0; k < D / 64; ++k)
+            t8[q][k] = (g0 + q * wpg < ga) ? __hip_atomic_load(all + (size_t)(g0 + q * wpg) * D + lane + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < 8; ++q)
 #pragma unroll
-            for (int k = 0; k < D / 64; ++k) o[k] += t8[q][k];
+          for (int k = 0; k < D / 64; ++k) o[k] += t8[q][k];
+      }
+#pragma unroll
+      for (int k = 0; k < D / 64; ++k) osm[wave * D + lane + 64 * k] = o[k];
+      lds_barrier();
+      if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < D / 64; ++k) {
+          float ssum = 0.f;
+          for (int wv = 0; wv < wpg; ++wv) ssum += osm[wv * D + lane + 64 * k];
+          outp[lane + 64 * k] = to_elem<false>(ssum);
         }
-#pragma unroll
-        for (int k = 0; k < D / 64; ++k) outp[lane + 64 * k] = to_elem<false>(o[k]);
-        // every wave of the item has read the granules (its workgroup arrived after that): back to "not published"
-        gu64_t* sl = (gu64_t*)sp.slots + (size_t)item * NW;
-        if (lane < na) __hip_atomic_store(sl + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reset_slots();
         if (lane == 0) __hip_atomic_store((gu32_t*)sp.counters + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256)
     reshape_and_cache_blocks_kernel(const h16* __restrict__ key, const h16* __restrict__ value,
                                     h16* __restrict__ kc, h16* __restrict__ vc,
                                     const int64_t* __restrict__ slot_mapping, int64_t key_stride,
-                                    int64_t value_stride, int T, int H, int D, int DW) {
+                                    int64_t value_stride, int T, int H, int D, int DW, int spec) {
   // A wave owns DW dims of one head for a run of BS tokens (DW = 32 when D % 32 == 0 — with BS = 16 that is one
   // 16-byte unit per lane, the same parallelism as the per-token kernel — else the whole head).  A dim range is
   // self-contained in both layouts: chunks d/8 of the K tile, rows d of the V tile.
@@ -162,12 +162,25 @@ __global__ void __launch_bounds__(256)
   extern __shared__ __attribute__((aligned(16))) char blk_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wph = D / DW;                      // waves per head
-  const int gw = blockIdx.y * 4 + wave;
+  const int gw = blockIdx.y * (blockDim.x >> 6) + wave;   // (decode-sized calls come as one-wave workgroups: more CUs share the scatter)
   const int h = gw / wph, d0 = (gw % wph) * DW;
   if (h >= H) return;  // waves are independent: no workgroup barrier below
   const int t0 = blockIdx.x * BS;
   const int nt = (T - t0) < BS ? (T - t0) : BS;
   const long long mine = (lane < nt) ? (long long)slot_mapping[t0 + lane] : -1;
+  // spec (decode-sized calls, 32-dim slices): this lane's piece of the token-by-token form below — 16 bytes of a key row,
+  // eight halves of a value row — is requested NOW, next to the slots, instead of behind them: the rows do not depend on
+  // the slots, only the stores do (one memory round trip instead of two in a row; rows of padding tokens are valid memory)
+  u32x4 kv_pre = {0u, 0u, 0u, 0u};
+  h16 ve_pre[8];
+  const bool pre = spec && DW == 32 && lane < nt * 4;
+  if (pre) {
+    const int tok = lane >> 2, c = lane & 3;
+    kv_pre = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + h * D + d0 + c * 8);
+    const h16* vsrc = value + (int64_t)(t0 + tok) * value_stride + h * D + d0 + c;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ve_pre[e] = vsrc[4 * e];
+  }
   const long long s0 = __shfl(mine, 0);
   const bool in_order = lane >= BS || mine == s0 + lane;
   const bool whole = nt == BS && s0 >= 0 && (s0 % BS) == 0 && __all(in_order);
@@ -213,7 +226,8 @@ __global__ void __launch_bounds__(256)
     if (slot >= 0) {  // padding tokens (slot < 0) are skipped (ref cache_kernels.cu:165-169)
       const int64_t blk = slot / BS, off = slot % BS;
       const int i = h * D + d0 + c * 8;
-      const u32x4 kv = *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + i);
+      const bool use_pre = pre && u0 == 0;   // (wave-uniform: with 32-dim slices a run of <= 16 tokens is one trip)
+      const u32x4 kv = use_pre ? kv_pre : *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride + i);
       h16* kdst = kc + (((blk * H + h) * (int64_t)(D >> 3) + (d0 >> 3) + c) * BS + off) * 8;
       // NON-TEMPORAL stores.  A decode batch writes 16-byte and 2-byte pieces into 24 different cache lines per
       // (token, head); left dirty in L2 by plain stores they are evicted piecemeal by the attention launch that follows
@@ -228,7 +242,7 @@ __global__ void __launch_bounds__(256)
         const h16* vsrc = value + (int64_t)(t0 + tok) * value_stride + h * D + d0 + c;
         h16 ve[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ve[e] = vsrc[4 * e];
+        for (int e = 0; e < 8; ++e) ve[e] = use_pre ? ve_pre[e] : vsrc[4 * e];
         h16* vdst = vc + ((blk * H + h) * (int64_t)D + d0 + c) * BS + off;
 #pragma unroll
         for (int e = 0; e < 8; ++e) __builtin_nontemporal_store(ve[e], vdst + (int64_t)(4 * e) * BS);
@@ -473,8 +487,9 @@ static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_si
 // ----------------------------------------------------------------------------------------
 // THE MEASURED THRESHOLDS OF THE WORK-DECOMPOSITION HEURISTICS, IN ONE PLACE (round 4).
 //
-// pick_variant / pick_variant_fp8 / waves_per_head_without_balancing below are control flow over this table and nothing
-// else: no number in them that is not a field here.  Thresholds are expressed in RESIDENT WAVES, WORKGROUP SLOTS and
+// pick_variant / pick_variant_fp8 / waves_per_head_without_balancing below are control flow over this table: every MEASURED
+// threshold is a field here (what remains in the functions are properties of the kernel menu — which U / waves-per-head
+// values have rows — and of the hardware: 160 KiB of LDS, 2 / 3 resident workgroups of the balanced kernels).  Thresholds are expressed in RESIDENT WAVES, WORKGROUP SLOTS and
 // BYTES, not in batch sizes, so they carry over to other head counts: profiles/r04_pick_generalisation.md compares the
 // default pick with the best enumerated variant over H in {8, 16, 20, 25, 40} x D in {64, 128} at the regime edges.
 // Each field names the file under profiles/ that holds its measurement.
@@ -539,7 +554,13 @@ struct PickRules {
                                      //   against 701: r03n_head_128_round_fit.md
   // ---- split kernels (pa_split.hpp; a workspace is at hand): r05_split_kernels.md ----
   int split_wgs_per_cu = 3;          // workgroups per CU a split launch may have (all resident)
-  int split_min_blocks_per_wave = 1; // an item is cut into at most blocks / this many waves
+  int split_min_blocks_per_wave = 4; // an item is cut into at most blocks / 4 waves (the kernel trims likewise by seq_len)
+  int split_min_blocks_per_wave_loaded = 16;  // ... blocks / 16 once the launch has more workgroups than CUs
+  int split_max_units_num = 1, split_max_units_den = 2;   // only while (sequence, head) items <= half the CUs (batch 8 at 12 heads;
+                                     //   192 items lost in every cell, 96 won from 8192 tokens on)
+  long split_min_item_bytes_per_unit = 20480;   // ... and an item's pages >= 20 KiB x items (head size 64: max_seq_len >= 80 x
+                                     //   items — batch 2 from 2048 tokens, batch 4 from 4096, batch 8 from 8192)
+  long split_min_item_bytes = 384 * 1024;   // ... and >= 384 KiB (1536 tokens at head size 64: batch 1 at 1024 tokens is level)
   int gate_max_seqs = 2048;          // the gated double launch behind it (launch_pa_v1): every wave of BOTH kernels reads all the
                                      //   lengths for the verdict, bounded by what the balanced kernel ranks in LDS (QSORT_MAX)
   // Head size 128 with MORE items than resident waves and no lockstep fit: eight waves per head as at head size 64 — over
@@ -714,9 +735,13 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   //  half of a gated double launch, which is bounded in sequences)
   const double lock_fill = (double)num_seqs * (num_heads / R.lock_heads_per_wg) / (double)g_cus;
   const double lock_eff = lock_fill / (double)(long)(lock_fill + 0.999999);
+  // (... and only while the 16 heads' logits fit the workgroup's LDS — 4 bytes per token and head: up to ~2500 tokens.  Without
+  //  this term contexts of 3400 ... 16384 tokens at 16 / 32 heads were handed a kernel that launch_pa_v1 then had to replace by
+  //  one wave per head, and the eight-waves-per-head rule for a full chip never saw them: round-4 advisor finding)
+  const bool lock_lds_fits = (size_t)R.lock_heads_per_wg * (lpad32(max_seq_len) * 4 + 2 * 4 + (size_t)head_size * 4) <= R.lds_per_cu;
   const bool lock_ok = head_size == 128 && block_size == 16 && nt_by_bytes && num_heads % R.lock_heads_per_wg == 0 &&
                        (double)units / (double)g_cus >= R.lock_min_waves_per_cu && lock_eff >= R.lock_min_round_fill &&
-                       num_seqs <= R.gate_max_seqs;
+                       num_seqs <= R.gate_max_seqs && lock_lds_fits;
   // (head size 128: from EXACTLY the resident waves on — there the one-wave kernels are level on equal lengths and 3 - 6 % behind on U{1..L})
   const bool over_full = core && nblk >= R.many_min_blocks &&
                          (head_size == 64 ? units > full_chip_waves() && lds_fits_q : units >= full_chip_waves() && !lock_ok);
@@ -783,6 +808,25 @@ static int pick_variant(int num_seqs, int num_heads, int head_size, int block_si
   return v;
 }
 
+// a long max_seq_len may not leave room for several heads' logits in one workgroup's LDS: fall back to one head per
+// workgroup, then to one wave per head (no second copy of the probabilities) before giving up
+// logits per wave of a split kernel: its share of max_seq_len's blocks, or the 8 blocks a wave can meet when the kernel uses
+// fewer waves for a shorter context (pa_split.hpp, NWe)
+static inline int split_wtok(int lpad, int xw) {
+  const int b = (lpad / 16 + xw - 1) / xw;
+  return 16 * (b > 8 ? b : 8);
+}
+static size_t variant_lds_bytes(const Variant& c, int lpad);
+static int fit_lds(int variant, int head_size, int block_size, int lpad, bool bf, int f8) {
+  if (variant >= 1 && variant <= nvariants_v1() && variant_lds_bytes(variant_v1(variant), lpad) > R.lds_per_cu) {
+    const int wph0 = variant_v1(variant).WPH;
+    int alt = find_variant(head_size, block_size, 1, wph0, -1, -1, bf, f8);
+    if (!alt || variant_lds_bytes(variant_v1(alt), lpad) > R.lds_per_cu) alt = find_variant(head_size, block_size, 1, 1, -1, -1, bf, f8);
+    if (alt) variant = alt;
+  }
+  return variant;
+}
+
 // ---- split kernels (pa_split.hpp): a (sequence, head) over XW waves = XW / 4 workgroups of one launch ----
 // Every workgroup of the launch must be resident (an item's waves wait for one another): the kernels' launch bounds hold
 // them to six 4-wave workgroups per CU at head size 64 and three at 128; the picks below ask for at most split_wgs_per_cu.
@@ -799,24 +843,49 @@ static int find_split(int D, int xw, int U, int nt) {
   return 0;
 }
 // Which split kernel, if any, serves a launch the plain heuristic gave `plain` to.  0 = keep the plain pick.
+// Measured (profiles/r05_split_kernels.md, rocprofv3, 12 heads x 64, batch 1 ... 16 x 1024 ... 16384 tokens): an item's waves
+// pay two trips through memory (exchange of max / exp-sum: 1.5 us on an idle chip, 2.5 - 2.9 us under load; partial rows and
+// the last arriver's merge: 1.7 - 2.4 us), so spreading an item pays where its work on ONE CU lasts much longer than that:
+// few items, long contexts — batch 1 at 16384 tokens 53.4 -> 19.0 us, batch 4 at 8192 30.2 -> 22.0, batch 8 at 16384
+// 98.4 -> 70.5 — and loses below (batch 1 at 1024 tokens 8.5 -> 8.8, BASELINE configs[1] 10.5 -> 17.0).
 static int pick_split(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len, int plain) {
   if (block_size != 16 || (head_size != 64 && head_size != 128) || g_split_nvariants == 0) return 0;
+  const long units = (long)num_seqs * num_heads;
+  bool starved = false;
   if (plain >= 1 && plain <= nvariants_v1()) {
     const Variant& pv = variant_v1(plain);
-    if (pv.GQS || pv.QUEUE || pv.WPH == 1) return 0;   // only where the plain pick already cuts heads into waves: an under-filled chip
+    if (pv.GQS || pv.QUEUE || pv.XW) return 0;
+    // ONE wave per head on a chip those waves do not fill: the plain pick fell back there because several waves' logits and
+    // probabilities (6 bytes per token) no longer fit a workgroup's LDS — from ~27 000 tokens on; batch 1 at 32768 tokens ran
+    // 1487 us that way, 24.5 us split (a wave of a split kernel holds its own blocks' logits only)
+    starved = pv.WPH == 1 && units * 2 < full_chip_waves();
+    if (pv.WPH == 1 && !starved) return 0;   // a full chip
   }
-  const long units = (long)num_seqs * num_heads;
+  const bool few = units * R.split_max_units_den <= (long)g_cus * R.split_max_units_num;
+  const long item_bytes = 4L * max_seq_len * head_size;   // K and V pages of one (sequence, head)
+  if (!starved && (!few || item_bytes < R.split_min_item_bytes_per_unit * units || item_bytes < R.split_min_item_bytes)) return 0;
   const int nblk = (max_seq_len + 15) / 16;
-  const long cap = (long)R.split_wgs_per_cu * g_cus;   // workgroups the launch may have
+  const long cap = (long)R.split_wgs_per_cu * g_cus;   // workgroups the launch may have (all resident)
+  // the most waves per item such that the launch's workgroups fit the CUs once with >= 4 blocks per wave, or up to
+  // split_wgs_per_cu times with >= 16 (a loaded chip's exchange is slower: batch 4 at 4096 tokens 21.3 us on 768 workgroups of
+  // 4-block waves, 16.3 on 384 of 8-block ones, 19.0 unsplit; batch 2 at 16384 tokens 27.3 us on 768 workgroups, 22.8 on 384)
+  const int lpad = (int)lpad32(max_seq_len);
+  auto lds_fits = [&](int x) { return (size_t)4 * ((size_t)split_wtok(lpad, x) * 6 + (size_t)head_size * 4) + 16 <= R.lds_per_cu; };
   int xw = 0;
-  for (int x = 64; x >= 8; x /= 2)
-    if (units * (x / 4) <= cap && x * R.split_min_blocks_per_wave <= nblk) { xw = x; break; }
+  for (int x = SPLIT_MAX_WAVES; x >= 8; x /= 2) {
+    const long wgs = units * (x / 4);
+    const int bpw = nblk / x;
+    if (lds_fits(x) &&
+        ((wgs <= g_cus && bpw >= R.split_min_blocks_per_wave) || (wgs <= cap && bpw >= R.split_min_blocks_per_wave_loaded))) { xw = x; break; }
+  }
+  if (!xw && starved) {   // more items than that: the widest form that is resident
+    for (int x = 64; x >= 8; x /= 2)
+      if (units * (x / 4) <= split_resident_wgs(head_size) && lds_fits(x)) { xw = x; break; }
+  }
   if (!xw) return 0;
   const double kv_bytes = 4.0 * (double)units * (double)max_seq_len * head_size;
   const int nt = kv_bytes > R.nt_kv_bytes ? 1 : 0;
-  const int bpw = (nblk + xw - 1) / xw;
-  int v = 0;
-  if (!nt && bpw >= 4 && bpw % 2 == 0) v = find_split(head_size, xw, 2, 0);
+  int v = find_split(head_size, xw, 2, nt);   // (two blocks per register group: ahead of one in 23 of 25 cells)
   if (!v) v = find_split(head_size, xw, 1, nt);
   return v;
 }
@@ -860,10 +929,9 @@ static int device_cus(int device) {  // caller holds the device current
 }
 
 // dynamic LDS a kernel needs for logits rows of `lpad` floats (max_seq_len padded to 32)
-static inline int split_wtok(int lpad, int xw) { return 16 * ((lpad / 16 + xw - 1) / xw); }   // logits per wave of a split kernel
 static size_t variant_lds_bytes(const Variant& c, int lpad) {
   if (c.XW)     // per wave: its share of the logits (fp32) and probabilities (fp16) + one partial output row
-    return (size_t)c.WPH * ((size_t)split_wtok(lpad, c.XW) * 6 + (size_t)c.D * 4);
+    return (size_t)c.WPH * ((size_t)split_wtok(lpad, c.XW) * 6 + (size_t)c.D * 4) + 16;   // + the "I am last" flag
   if (c.STAGE)  // per wave: the logits + a ring of U slots, each one (block, head) tile
     return (size_t)4 * ((size_t)lpad * 4 + (size_t)c.U * (c.D * 16 * (c.F8 ? 1 : 2)));
   if (c.QUEUE)  // 4 waves' logits + the ranking, its bucket counts and masks + a team's exchange buffers (pa_queue.hpp)
@@ -987,14 +1055,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
       variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf, f8,
                                       kv_scale == 1.0f && !append)
                    : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, 0, !append);
-    // a long max_seq_len may not leave room for several heads' logits in one workgroup's LDS: fall back to one
-    // head per workgroup, then to one wave per head (no second copy of the probabilities) before giving up
-    if (variant >= 1 && variant <= nvariants_v1() && lds_of(variant_v1(variant)) > 160 * 1024) {
-      const int wph0 = variant_v1(variant).WPH;
-      int alt = find_variant(head_size, block_size, 1, wph0, -1, -1, bf, f8);
-      if (!alt || lds_of(variant_v1(alt)) > 160 * 1024) alt = find_variant(head_size, block_size, 1, 1, -1, -1, bf, f8);
-      if (alt) variant = alt;
-    }
+    variant = fit_lds(variant, head_size, block_size, lpad, bf, f8);
   }
   const bool have_ws = workspace != nullptr && aligned16(workspace) &&
                        workspace_bytes >= (int64_t)pa_split_layout(head_size).bytes;
@@ -1005,7 +1066,8 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (!sparse_v && (variant < 1 || variant > nvariants_v1()))
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
   Variant* vp = sparse_v ? sparse_v : (append ? app_variant_v1(variant) : &variant_v1(variant));
-  if (!vp) return fail(VMI_E_VARIANT, "paged_attention_v1_append: kernel menus out of step (build error)");
+  if (!vp) return fail(VMI_E_VARIANT, "paged_attention_v1_append: variant %d (%s) has no fused-append twin", variant,
+                       variant_v1(variant).name);
   Variant& v = *vp;
   if (append && is_diag(v))
     return fail(VMI_E_VARIANT, "paged_attention_v1_append: %s is a bandwidth diagnostic", v.name);
@@ -1043,7 +1105,10 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
                   "16-byte aligned workspace of vmi_paged_attention_v1_workspace_bytes() = %zu bytes (got %p, %lld)", v.name,
                   pa_split_layout(head_size).bytes, workspace, (long long)workspace_bytes);
     const int64_t wgs = (int64_t)num_seqs * num_heads * (v.XW / v.WPH);
-    if (wgs > split_resident_wgs(head_size))
+    if (wgs > 0x7fffffff || (int64_t)num_seqs * num_heads * v.XW > (int64_t)SPLIT_MAX_WGS * 4)
+      return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s would launch %lld workgroups (the workspace holds the granules "
+                  "of %d waves)", v.name, (long long)wgs, SPLIT_MAX_WGS * 4);
+    if (v.XW > v.WPH && wgs > split_resident_wgs(head_size))   // (one workgroup per item: nothing waits across workgroups)
       return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s would launch %lld workgroups; the split kernels need every "
                   "workgroup resident (at most %d on this device)", v.name, (long long)wgs, split_resident_wgs(head_size));
   }
@@ -1145,7 +1210,8 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   Variant* partner = nullptr;
   if (gate_ok && v.D == 128 && v.BS == 16 && v.WPH == 1 && !v.GQS && !v.F8 && !v.SPARSE &&
       // (every wave of BOTH kernels reads all the lengths for the verdict — 4*B bytes per wave out of L2: bounded by 2048, the
-      //  size the balanced kernel ranks in LDS; a larger batch runs the lockstep kernel alone, as a one-kernel launch)
+      //  size the balanced kernel ranks in LDS; pick_variant never hands a larger batch the lockstep kernel — lock_ok — so
+      //  beyond that bound whatever kernel was picked runs alone)
       num_seqs <= R.gate_max_seqs && (int64_t)num_seqs * num_heads >= (int64_t)device_cus(device) * 8) {
     for (int i = 0; i < g_queue_nvariants; ++i)
       if (g_queue_variants[i].D == v.D && g_queue_variants[i].BF == v.BF && g_queue_variants[i].BS == v.BS &&
@@ -1499,7 +1565,8 @@ int vmi_paged_attention_v1_workspace_reset(void* workspace, int64_t workspace_by
 int vmi_paged_attention_v1_pick_variant_ws(int32_t num_seqs, int32_t num_heads, int32_t head_size,
                                            int32_t block_size, int32_t max_seq_len) {
   if (!vmi::head_size_supported(head_size) || !vmi::block_size_supported(block_size)) return 0;
-  const int plain = vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len);
+  const int plain = vmi::fit_lds(vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len), head_size,
+                                 block_size, ((max_seq_len + 31) / 32) * 32, false, 0);
   const int sv = vmi::pick_split(num_seqs, num_heads, head_size, block_size, max_seq_len, plain);
   return sv ? sv : plain;
 }
@@ -1658,26 +1725,32 @@ int vmi_reshape_and_cache_f16(const void* key, const void* value, void* key_cach
   dim3 grid(num_tokens), block(threads);
   // prefill-sized calls with 16-B aligned rows: whole-block form (falls back per run inside the kernel)
   if (vec && num_tokens >= 2 * block_size && (block_size == 8 || block_size == 16 || block_size == 32)) {
-    typedef void (*blocks_fn)(const h16*, const h16*, h16*, h16*, const int64_t*, int64_t, int64_t, int, int, int, int);
+    typedef void (*blocks_fn)(const h16*, const h16*, h16*, h16*, const int64_t*, int64_t, int64_t, int, int, int, int, int);
     // dims per wave: 32-dim slices while whole-head waves would not fill the chip (decode batches: cfg3 6.8 us instead
     // of 8.5), whole heads for prompt-sized calls (16384 tokens x 32 x 128: 118 us vs 133 with slices)
     const long whole_head_waves = (long)((num_tokens + block_size - 1) / block_size) * num_heads;
     const int dw = (head_size % 32 == 0 && whole_head_waves < 4096) ? 32 : head_size;
+    // decode-sized calls (round 5): the launch is a latency chain, not a stream — slots, rows, scattered 2-byte stores — so
+    // (a) ONE wave per workgroup while that still leaves fewer workgroups than 4 per CU: cfg2 48 workgroups instead of 12,
+    // cfg3 384 instead of 96, i.e. that many CUs' store paths share the scatter; (b) the rows are requested next to the slots
+    const long waves = (long)((num_tokens + block_size - 1) / block_size) * num_heads * (head_size / dw);
+    const bool small = dw == 32 && waves <= 4L * device_cus(device);
+    const int wpb = small ? 1 : 4;
     const blocks_fn fn = block_size == 8    ? (blocks_fn)reshape_and_cache_blocks_kernel<8>
                          : block_size == 16 ? (blocks_fn)reshape_and_cache_blocks_kernel<16>
                                             : (blocks_fn)reshape_and_cache_blocks_kernel<32>;
-    const size_t lds = (size_t)4 * block_size * (dw + 8) * 2;
+    const size_t lds = (size_t)wpb * block_size * (dw + 8) * 2;
     if (lds <= 160 * 1024) {
       if (lds > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(reshape_and_cache_blocks)");
       }
-      hipLaunchKernelGGL(fn, dim3((num_tokens + block_size - 1) / block_size, (num_heads * (head_size / dw) + 3) / 4), dim3(256), lds,
+      hipLaunchKernelGGL(fn, dim3((num_tokens + block_size - 1) / block_size, (num_heads * (head_size / dw) + wpb - 1) / wpb), dim3(64 * wpb), lds,
                          static_cast<hipStream_t>(stream), static_cast<const h16*>(key),
                          static_cast<const h16*>(value), static_cast<h16*>(key_cache),
                          static_cast<h16*>(value_cache), slot_mapping, key_stride, value_stride, num_tokens,
-                         num_heads, head_size, dw);
+                         num_heads, head_size, dw, small ? 1 : 0);
       e = hipGetLastError();
       if (e != hipSuccess) return hip_fail(e, "reshape_and_cache (blocks) launch");
       return VMI_OK;

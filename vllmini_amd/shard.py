@@ -145,6 +145,91 @@ def gather_token_ids_async(local_ids: torch.Tensor, global_batch: int, dist, out
     return out, dist.all_gather_into_tensor(out, local_ids, async_op=True)
 
 
+# ---- where a rank runs: host cores near its GPU ------------------------------------------------------------------------
+# A decode loop spends ~25 us of host time per 128-us call pair; eight such loops on a 2-socket host whose scheduler is free
+# to move them across sockets is where "linear by construction" fails first.  One process per GPU, bound to cores of the NUMA
+# node its GPU hangs off (the driver's /sys tree names it); where the node is unknown (containers that hide /sys, the CPU
+# stand-in) the process's current core set is dealt evenly to the local ranks.
+
+def _parse_cpulist(text: str) -> list:
+    cores = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cores.extend(range(int(a), int(b or a) + 1))
+    return cores
+
+
+def gpu_numa_node(pci_bus_id: str, sysfs: str = "/sys") -> int:
+    """NUMA node of the PCI function `dddd:bb:dd.f` (-1: unknown)."""
+    try:
+        with open(f"{sysfs}/bus/pci/devices/{pci_bus_id.lower()}/numa_node") as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def cores_for_rank(local_rank: int, local_world: int, numa_node: int = -1, allowed=None, sysfs: str = "/sys") -> list:
+    """Host cores rank `local_rank` of `local_world` should run on: the allowed cores of its GPU's NUMA node, dealt evenly to
+    the ranks whose GPUs share that node as far as this function can know — i.e. sliced by local_rank among local_world —
+    or, with the node unknown, an even slice of all allowed cores.  Never empty."""
+    import os
+
+    allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    pool = allowed
+    if numa_node >= 0:
+        try:
+            with open(f"{sysfs}/devices/system/node/node{numa_node}/cpulist") as f:
+                node = set(_parse_cpulist(f.read()))
+            near = [c for c in allowed if c in node]
+            if near:
+                pool = near
+        except OSError:
+            pass
+    lo, hi = shard_range(len(pool), local_rank % max(local_world, 1), max(local_world, 1))
+    mine = pool[lo:hi]
+    return mine or pool
+
+
+def place_rank(local_rank: int, local_world: int, device_index=None, bind: bool = True) -> dict:
+    """Bind this process to the cores cores_for_rank() gives it and describe where it runs: what the N > 1 bench line
+    carries per rank (device UUID, PCI bus id, NUMA node, cores)."""
+    import os
+
+    info = {"local_rank": local_rank, "pci_bus_id": None, "uuid": None, "numa_node": -1}
+    if device_index is not None and torch.cuda.is_available():
+        p = torch.cuda.get_device_properties(device_index)
+        bus = getattr(p, "pci_bus_id", None)
+        if isinstance(bus, int):        # torch exposes domain / bus / device as integers
+            bus = f"{getattr(p, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(p, 'pci_device_id', 0):02x}.0"
+        info["pci_bus_id"] = bus
+        info["uuid"] = str(getattr(p, "uuid", "")) or None
+        if bus:
+            info["numa_node"] = gpu_numa_node(bus)
+    cores = cores_for_rank(local_rank, local_world, info["numa_node"])
+    if bind:
+        try:
+            os.sched_setaffinity(0, cores)
+            info["bound"] = True
+        except OSError:
+            info["bound"] = False
+    else:
+        info["bound"] = False
+    info["cores"] = f"{cores[0]}-{cores[-1]}" if cores == list(range(cores[0], cores[-1] + 1)) else ",".join(map(str, cores))
+    info["n_cores"] = len(cores)
+    return info
+
+
+def gather_objects(obj, dist=None) -> list:
+    """`obj` of every rank in rank order (outside any timed region)."""
+    if dist is None:
+        return [obj]
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, obj)
+    return got
+
+
 def shard_rows(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     lo, hi = shard_range(x.shape[0], rank, world)
     return x[lo:hi]
