@@ -1642,9 +1642,22 @@ def test_pa_v1_long_max_seq_len_falls_back_to_one_head_per_workgroup():
     lens = [5, 300, 1000]
     case = make_case(rng, len(lens), 8, 64, lens)
     ref = run_model(case)
+    from vllmini_amd import ops
+
     assert_close(run_hip(case, max_seq_len=32768), ref, "max_seq_len 32768")
-    with pytest.raises(RuntimeError, match="paged_attention_v2"):
-        run_hip(case, max_seq_len=50000)
+    # Round 5: with the wrapper's workspace at hand the split kernels take over where one wave per head would be all that
+    # fits — a workgroup holds its own waves' logits only, so 50 000 (and 500 000) tokens of capacity are served ...
+    for msl in (50000, 500000):
+        assert_close(run_hip(case, max_seq_len=msl), ref, f"max_seq_len {msl} (split kernel)")
+        assert "_x" in ops.last_launch_label()
+    # ... and without a workspace (the plain C entry) the limit and its message are what they were
+    prev = ops.set_workspace_enabled(False)
+    try:
+        assert_close(run_hip(case, max_seq_len=32768), ref, "max_seq_len 32768, no workspace")
+        with pytest.raises(RuntimeError, match="paged_attention_v2"):
+            run_hip(case, max_seq_len=50000)
+    finally:
+        ops.set_workspace_enabled(prev)
 
 
 # ------------------------------------------------------------------------------------------------

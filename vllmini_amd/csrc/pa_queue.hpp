@@ -761,7 +761,20 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       }
       return;
     }
-    if (wq >= N) return;  // more workers than items (forced modes only)
+    // ONE ROUND of four solo workers per workgroup on a 256-CU chip (fp8 pages, head size 128: as many workers as items) —
+    // which ranks share a CU?  Workgroup b runs on XCD b mod 8, the j-th workgroup of an XCD on CU slot j mod 32
+    // (profiles/r04_underfilled_chip.md), so in rank order the three workgroups of CU u would hold places u, 256 + u, 512 + u
+    // of the ranking (in quads of ranks): the first CUs twice the bytes of the last.  Instead they take places u,
+    // 256 + (u + 128) mod 256 and 512 + (254 - 2u | 511 - 2u): every CU's — hence every SIMD's — places add up to 382 / 383.
+    // Only WHICH worker runs an item changes (results bit-identical); cfg3 fp8 U{1..L} 42.1 -> 40.5 us by events on one box,
+    // 39.53 -> 39.35 by rocprofv3 on another (profiles/r04_fp8_ragged_accounting.md section 4; adopted in round 5).
+    int wqe = wq;
+    if (WQ == 4 && !late && G == 768 && N <= nworkers) {
+      const int j = g >> 3, u = (g & 7) * 32 + (j & 31), kk = j >> 5;
+      const int pl = kk == 0 ? u : (kk == 1 ? 256 + ((u + 128) & 255) : 512 + (u < 128 ? 254 - 2 * u : 511 - 2 * u));
+      wqe = pl * 4 + wave;
+    }
+    if (wqe >= N) return;  // more workers than items
     if (late) {
       hmode = 0;
       first = firstq;  // first item = item wq in index order: asked for at the top of the kernel
@@ -775,7 +788,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       vrank = a * H + hq0;
     } else {  // first item of worker wq = rank order position wq
       int s0, h0;
-      ids_of(wq, s0, h0);
+      ids_of(wqe, s0, h0);
       meta_issue(first, s0, h0, 1, 0);
     }
   }
