@@ -104,6 +104,7 @@ def build_parser():
     ap.add_argument("--no-cfg2", action="store_true", help="skip the extra BASELINE configs[1] measurement")
     ap.add_argument("--no-strong", action="store_true", help="skip the N = 1 anchor of the strong-scaling curve (batch 2048 on one GPU)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the extra end-to-end GPT-2 measurement")
+    ap.add_argument("--no-long", action="store_true", help="skip the extra few-sequences-x-long-context measurement (workspace on / off)")
     ap.add_argument("--noop-instead-of-reshape", action="store_true",
                     help="diagnostic: a 4-byte fill kernel takes reshape_and_cache's place in the step")
     ap.add_argument("--reshape-other-set", action="store_true",
@@ -135,7 +136,7 @@ def parse_args(argv=None):
     args = build_parser().parse_args(argv)
     if args.headline_only:
         args.no_cpu_baseline = args.no_fused = args.no_fp8 = args.no_ragged = args.no_graph = True
-        args.no_cfg4 = args.no_e2e = args.no_cfg2 = args.no_strong = True
+        args.no_cfg4 = args.no_e2e = args.no_cfg2 = args.no_strong = args.no_long = True
     args.kernel_samples = max(50, args.kernel_samples)
     return args
 
@@ -389,17 +390,6 @@ def kernel_pass(wl, out, n, variant, dev, op="v1", warm=5):
     return [a.elapsed_time(b) for a, b in ev]
 
 
-def empty_event_pair_us(dev, n=40):
-    """What an event pair reads with NOTHING between its two records (median, us): the part of every kernel_pass sample
-    that is instrumentation, not kernel — for reconciling the event figures with rocprofv3's kernel durations."""
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-    for a, b in ev:
-        a.record()
-        b.record()
-    torch.cuda.synchronize(dev)
-    return statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
-
-
 def exchange_pass(n, dist, dev):
     """Median duration of the token all_gather alone (event pair around each of n exchanges), us."""
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -438,13 +428,13 @@ def graph_steps(wl, out, steps, variant, dev, per_graph=1, attend_only=False):
     if per_graph <= 1:
         for t in range(len(wl.tables)):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=side):      # (the stream the warm-up ran on: its workspace exists, ops.workspace_for)
                 one_step(wl, out, t, variant)
             graphs.append(g)
         per_graph = 1
     else:   # `per_graph` consecutive steps (table sets in the loop's order) in ONE graph
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=side):
             for t in range(per_graph):
                 one_step(wl, out, t % len(wl.tables), variant)
         graphs.append(g)
@@ -459,21 +449,52 @@ def graph_steps(wl, out, steps, variant, dev, per_graph=1, attend_only=False):
     return (time.perf_counter() - t0) * steps / (replays * per_graph)
 
 
+_LIB_SHA = None
+
+
+def library_sha16() -> str:
+    """First 16 hex digits of the SHA-256 of the product library this process loads: ties a bench line to its binary, and a
+    committed rocprofv3 pass (profiles/pmc_*_latest.json carry the same field) to the binary it profiled."""
+    global _LIB_SHA
+    if _LIB_SHA is None:
+        import hashlib
+        from vllmini_amd import build as _b
+        h = hashlib.sha256()
+        with open(_b.LIB_PATH, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        _LIB_SHA = h.hexdigest()[:16]
+    return _LIB_SHA
+
+
+def _committed_pass(cfg_name: str, kernel_variant: str):
+    """profiles/pmc_<cfg>_latest.json if it describes THIS kernel variant of THIS binary, else (None, why)."""
+    path = os.path.join(REPO, "profiles", f"pmc_{cfg_name}_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, "no committed pass"
+    if d.get("kernel_variant") and d["kernel_variant"] != kernel_variant:
+        return None, f"committed pass is of kernel {d.get('kernel_variant')}"
+    if d.get("library_sha16") and d["library_sha16"] != library_sha16():
+        return None, f"committed pass is of library {d['library_sha16']}, this run loads {library_sha16()}"
+    d["_path"] = os.path.relpath(path, REPO)
+    return d, None
+
+
 def pmc_traffic(cfg_name: str, kernel_variant: str):
     """HBM bytes per launch of the attention kernel from the rocprofv3 PMC passes committed under
     profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE x1024 x2 per the
     gfx950 correction in MI355X_MICROARCH.md §HBM).  bench.py cannot run a profiler around itself, so
     the figure comes from the latest recorded pass for this workload and kernel variant, else None."""
-    cfg_name = cfg_name.replace("cfg5", "cfg3")   # cfg5 = the cfg3 launch over a larger pool (N > 1 runs)
-    path = os.path.join(REPO, "profiles", f"pmc_{cfg_name}_latest.json")
+    if cfg_name == "cfg5":
+        cfg_name = "cfg3"   # cfg5 = the cfg3 launch over a larger pool (N > 1 runs)
+    d, why = _committed_pass(cfg_name, kernel_variant)
     try:
-        with open(path) as f:
-            d = json.load(f)
-        if d.get("kernel_variant") and d["kernel_variant"] != kernel_variant:
-            return None, None
-        return d["traffic_bytes_corrected"]["total"], os.path.relpath(path, REPO)
-    except (OSError, KeyError, ValueError):
-        return None, None
+        return (d["traffic_bytes_corrected"]["total"], d["_path"]) if d else (None, why)
+    except (KeyError, TypeError):
+        return None, "committed pass holds no traffic figure"
 
 
 # ---- the CPU baseline -------------------------------------------------------------------------------------------------
@@ -717,22 +738,18 @@ def pair_record(wl, out, args, variant, dist, dev, tokens, nbytes, op="v1"):
 def rocprof_kernel_us(cfg_name: str, kernel_variant: str):
     """The attention kernel's average duration in the latest committed rocprofv3 --kernel-trace --stats pass for this workload
     and kernel (profiles/pmc_<cfg>_latest.json), or None — bench.py cannot run a profiler around itself."""
-    path = os.path.join(REPO, "profiles", f"pmc_{cfg_name}_latest.json")
+    d, why = _committed_pass(cfg_name, kernel_variant)
     try:
-        with open(path) as f:
-            d = json.load(f)
-        if d.get("kernel_variant") and d["kernel_variant"] != kernel_variant:
-            return None, None
-        return d["pa_v1_dispatches"]["mean_us_after_warmup"], os.path.relpath(path, REPO)
-    except (OSError, KeyError, ValueError, TypeError):
-        return None, None
+        return (d["pa_v1_dispatches"]["mean_us_after_warmup"], f"{d['_path']} (pass {d.get('profile_tag', '?')})") if d else (None, why)
+    except (KeyError, TypeError):
+        return None, "committed pass holds no kernel duration"
 
 
 def cfg2_record(args, dist, rank, world, dev):
     """BASELINE configs[1]: batch 32, seq_len 512, 12 heads x 64, num_blocks 4096 — 50 MB per launch, resident in the 256 MiB
     Infinity Cache, 384 (sequence, head) units on 256 CUs: a LATENCY chain, not a stream, so no fraction of the HBM peak is
     quoted.  The launch is shorter than the host's work per call, so three figures: the plain call pair (host-bound), the
-    attention kernel between HIP events (reads empty_event_pair_us high), and the pair replayed from a hipGraph of 48 pairs
+    attention kernel between HIP events (host-bound at this size), and the pair replayed from a hipGraph of 48 pairs
     (the device's own time per pair)."""
     from vllmini_amd import ops
     c2 = CONFIGS["cfg2"]
@@ -751,7 +768,7 @@ def cfg2_record(args, dist, rank, world, dev):
             "algorithmic_bytes_per_launch": alg_bytes(c2, "auto"),
             "graph_us_per_pair": g / n_g * 1e6,
             "graph_us_per_attention_launch": ga / n_g * 1e6,
-            "rocprofv3_kernel_us": us, "rocprofv3_source": src,
+            "committed_profile_kernel_us": us, "committed_profile_source": src,
             "regime": "Infinity-Cache-resident (50 MB per launch, two table sets = 100 MB of a 201 MB pool) and under-filled (384 "
                       "units on 256 CUs): a latency chain — launch, table + q, K pages, barrier, softmax, V pages, barrier, store "
                       "(profiles/r04_underfilled_chip.md) — not an HBM stream: no frac quoted",
@@ -759,7 +776,38 @@ def cfg2_record(args, dist, rank, world, dev):
                     "event pairs around the attention launch (the GPU waits for the host between the two records): NOT kernel "
                     "times at this size.  The device's own figures: graph_us_per_pair = reshape_and_cache + paged_attention_v1 + "
                     "gaps, 48 pairs per hipGraph; graph_us_per_attention_launch = 48 attention launches per graph (kernel + "
-                    "~1 us of spacing); rocprofv3_kernel_us = the kernel alone, latest committed pass"}
+                    "~1 us of spacing); committed_profile_kernel_us = the kernel alone in the rocprofv3 pass committed under profiles/ — NOT measured by this run, and null unless that pass profiled this kernel variant of this very binary (library_sha16)"}
+
+
+def long_context_record(args, dev):
+    """Few sequences x long contexts (batch 1 x 16384 tokens and batch 4 x 8192, 12 heads x 64): the regime the reference's
+    scheduler runs (one sequence at a time, scheduler.py:60) at today's context lengths.  The same default entry with and
+    without the wrapper's workspace (round 5: with one, paged_attention_v1 spreads each (sequence, head) over up to 64 waves on
+    as many CUs — vmi_paged_attention_v1_f16_ws, pa_split.hpp).  Device time per attention launch, 24 launches per hipGraph."""
+    from vllmini_amd import ops
+    out = {"op": "paged_attention_v1, default entry, fp16, 12 heads x 64, block_size 16", "unit": "us per attention launch (hipGraph of 24)"}
+    for name in ("long_b1", "long_b4"):
+        c = CONFIGS[name]
+        wl = make_workload(c, dev, seed=17, table_sets=2)
+        o = torch.empty((c.batch, c.num_heads, c.head_size), dtype=torch.float16, device=dev)
+        rec = {"batch": c.batch, "seq_len": c.seq_len, "algorithmic_bytes_per_launch": alg_bytes(c, "auto")}
+        for key, on in (("with_workspace", True), ("without_workspace", False)):
+            prev = ops.set_workspace_enabled(on)
+            try:
+                attend(wl, o, 0, 0)
+                torch.cuda.synchronize(dev)
+                v = ops.variant_names()[ops.last_variant() - 1]
+                us = graph_steps(wl, o, 96, 0, dev, per_graph=24, attend_only=True) / 96 * 1e6
+            finally:
+                ops.set_workspace_enabled(prev)
+            rec[key] = {"us": us, "kernel_variant": v, "achieved_GBps": rec["algorithmic_bytes_per_launch"] / us / 1e3}
+        rec["speedup"] = rec["without_workspace"]["us"] / rec["with_workspace"]["us"]
+        us_p, src = rocprof_kernel_us(name, rec["with_workspace"]["kernel_variant"])
+        rec["committed_profile_kernel_us"], rec["committed_profile_source"] = us_p, src
+        out[name] = rec
+        del wl, o
+        torch.cuda.empty_cache()
+    return out
 
 
 def strong_n1_record(args, dev):
@@ -777,8 +825,11 @@ def strong_n1_record(args, dev):
     v5 = ops.variant_names()[ops.last_variant() - 1]
     del wl5, out5
     torch.cuda.empty_cache()
+    t5, t5src = pmc_traffic("cfg5_strong", v5)
+    us5, us5src = rocprof_kernel_us("cfg5_strong", v5)
     return {"op": "reshape_and_cache + paged_attention_v1, BASELINE configs[4] on ONE GPU: batch 2048, seq_len 1024, 12 heads x 64, "
                   f"block_size 16, num_blocks {c5.num_blocks}, fp16", **rec, "kernel_variant": v5,
+            "traffic": t5, "traffic_source": t5src, "committed_profile_kernel_us": us5, "committed_profile_source": us5src,
             "note": "N = 1 point of `--scaling strong` (2048 sequences in all, 2048/N per GPU); batch 2048 = QSORT_MAX; "
                     "the weak-scaling N = 1 point is the headline itself (256 sequences per GPU)"}
 
@@ -857,7 +908,7 @@ def main(argv=None):
         KV_DTYPE = args.kv
         if args.op != "v1":
             raise SystemExit("--kv fp8 is built for --op v1")
-        args.no_fused = args.no_cpu_baseline = args.no_cfg4 = args.no_e2e = args.no_cfg2 = args.no_strong = True
+        args.no_fused = args.no_cpu_baseline = args.no_cfg4 = args.no_e2e = args.no_cfg2 = args.no_strong = args.no_long = True
         gk = torch.Generator(device=dev).manual_seed(99 + rank)
         kshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size // 16, cfg.block_size, 16)
         vshape = (cfg.num_blocks, cfg.kv_heads, cfg.head_size, cfg.block_size)
@@ -928,7 +979,8 @@ def main(argv=None):
         "paged_attention_v1_us_min": ks["min"],
         "paged_attention_v1_us_median_per_rank": ks["median_per_rank"],
         "kernel_event_samples": args.kernel_samples,
-        "empty_event_pair_us": empty_event_pair_us(dev),
+        "library_sha16": library_sha16(),
+        "committed_profile_kernel_us": rocprof_kernel_us(cfg.name if cfg.name != "cfg5" else "cfg3", vname)[0] if args.op == "v1" and args.kv == "auto" and not args.ragged else None,
         "method_version": 3,
         "method": "v3 (round 3 on): event-free timed region; " + shard.TIMING_BRACKET + "; for N > 1 the token all_gather runs "
                   f"once per token (every {EXCHANGE_EVERY}th layer step), asynchronously on the process group's stream.  v2 (rounds "
@@ -954,6 +1006,10 @@ def main(argv=None):
                                         "issues no MFMA (SQ_INSTS_MFMA = 0, profiles/pmc_cfg3_latest.json)"}),
         },
     }
+    if line.get("committed_profile_kernel_us"):
+        # what the HIP event pair around a launch reads above the kernel's own duration in the committed rocprofv3 pass of this
+        # binary (dispatch-to-dispatch spacing, event records): the instrumentation share of roofline.achieved's denominator
+        line["event_minus_rocprof_us"] = ks["median"] - line["committed_profile_kernel_us"]
     if dist is not None:
         line["token_exchange_us"] = shard.max_over_ranks(exchange_pass(args.kernel_samples, dist, dev), dist, dev)
         line["token_exchange"] = (f"all_gather of {cfg.batch} int64 ids per rank ({cfg.batch * world * 8} B in all), backend nccl "
@@ -1055,6 +1111,12 @@ def main(argv=None):
         res = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context)
         line["e2e_step"] = {k: res[k] for k in ("metric", "value", "unit", "ms_per_step", "context", "batch_per_gpu", "note",
                                                 "operators_ms_per_step", "operators_share_of_step", "operators_note")}
+        # the same model with the harness's own fused step (one launch instead of the reference's call pair per layer — bit-
+        # identical, tests/test_parity_gpu.py): the reference surface stays the pair, the harness may use what is faster
+        resf = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, fused=True, operator_share=False)
+        line["e2e_step"]["fused_append"] = {k: resf[k] for k in ("value", "unit", "ms_per_step", "note")}
+    if plain and not args.no_long and args.config == "cfg3" and not args.variant and dist is None:
+        line["long_context_step"] = long_context_record(args, dev)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

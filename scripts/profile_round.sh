@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round evidence (run on the GPU box via gpurun): the five rocprofv3 passes of scripts/profile_bench.sh for every tracked
-# configuration with the round's last binary.  Usage: scripts/profile_round.sh <round tag, e.g. r04z>
+# configuration with the round's last binary.  Usage: scripts/profile_round.sh <round tag, e.g. r05z>
 T=${1:-r04z}
 scripts/profile_bench.sh ${T}_cfg3 > /dev/null 2>&1
 scripts/profile_bench.sh ${T}_cfg3_ragged --ragged > /dev/null 2>&1
@@ -9,7 +9,10 @@ scripts/profile_bench.sh ${T}_cfg3_fp8_ragged --kv fp8 --ragged > /dev/null 2>&1
 scripts/profile_bench.sh ${T}_cfg4 --config cfg4 > /dev/null 2>&1
 scripts/profile_bench.sh ${T}_cfg4_ragged --config cfg4 --ragged > /dev/null 2>&1
 scripts/profile_bench.sh ${T}_cfg2 --config cfg2 > /dev/null 2>&1
-for c in cfg3 cfg3_ragged cfg3_fp8 cfg3_fp8_ragged cfg4 cfg4_ragged cfg2; do
+scripts/profile_bench.sh ${T}_cfg5_strong --config cfg5_strong > /dev/null 2>&1     # BASELINE configs[4] on one GPU (N = 1 of the strong curve)
+scripts/profile_bench.sh ${T}_long_b1 --config long_b1 > /dev/null 2>&1             # batch 1 x 16384 tokens: a split kernel (workspace)
+scripts/profile_bench.sh ${T}_long_b4 --config long_b4 > /dev/null 2>&1             # batch 4 x 8192 tokens
+for c in cfg3 cfg3_ragged cfg3_fp8 cfg3_fp8_ragged cfg4 cfg4_ragged cfg2 cfg5_strong long_b1 long_b4; do
   python - "$T" "$c" <<'PY'
 import json, sys, glob, shutil, os
 t, c = sys.argv[1], sys.argv[2]

@@ -17,7 +17,7 @@ for f in find("trace/**/*kernel_stats.csv"):
 # per-dispatch durations of the attention kernel (skip warm-up dispatches).  A gated double launch (head size 128)
 # runs two attention kernels per call: the one that does the work is reported, the one that leaves at once beside it
 for f in find("trace/**/*kernel_trace.csv"):
-    rows = [r for r in csv.DictReader(open(f)) if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_", "pa_stage_"))]
+    rows = [r for r in csv.DictReader(open(f)) if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_", "pa_stage_", "pa_split_"))]
     groups = {}
     for r in rows:
         groups.setdefault(r["Kernel_Name"], []).append(r)
@@ -65,6 +65,8 @@ try:
     res["kernel_variant"] = b["config"]["kernel_variant"]
     res["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_launch"]
     res["bench_event_us_under_trace"] = b["paged_attention_v1_us_per_step"]
+    res["library_sha16"] = b.get("library_sha16")     # the binary this pass profiled (bench.py drops a figure taken from another)
+    res["profile_tag"] = os.path.basename(out.rstrip("/")).replace("prof_", "")
 except Exception as e:  # noqa: BLE001
     res["bench_json_error"] = str(e)
 for k in res.get("kernel_stats", []):

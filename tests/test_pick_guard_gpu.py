@@ -1,0 +1,101 @@
+"""Guard of the work-decomposition heuristic: in seven cells that span its regimes the DEFAULT pick must stay within 8 % of the
+best of a handful of named kernels — so that a kernel or threshold change that silently invalidates the offline sweeps
+(profiles/r04_pick_generalisation.md, r04_underfilled_chip.md, r05_split_kernels.md) fails a test instead.
+
+Timing: the attention launch alone, replayed from a hipGraph of 12 launches over two disjoint table sets (device time, no host
+in the loop); every candidate is read twice, the default first AND last (the first kernel of a cell reads high), the better
+reading counts.  Whole file < 20 s on an MI355X.  Nothing here reads /root/reference; results are not checked here (the
+parity tests do that for every kernel named).
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOLERANCE = 1.08
+PER_GRAPH = 12
+
+# name, batch, heads, head_size, seq_len, ragged, candidates
+CELLS = [
+    ("underfilled_b16", 16, 12, 64, 1024, False,
+     ["d64_h1_w16_u1_nt0", "d64_h1_w16_u2_nt0", "d64_h1_w8_u1_nt0", "d64_h1_w8_u2_nt0", "d64_x8_u2_nt0"]),
+    ("cfg2_b32_l512", 32, 12, 64, 512, False,
+     ["d64_h1_w8_u1_nt0", "d64_h1_w8_u1_nt1", "d64_h1_w4_u2_nt0", "d64_h1_w16_u1_nt0", "d64_x8_u1_nt0"]),
+    ("seven_eighths_b224", 224, 12, 64, 1024, False,
+     ["q_d64_s1q2", "d64_h1_w8_u1_nt1", "d64_h1_w4_u1_nt1", "d64_h1_w2_u1_nt1"]),
+    ("full_cfg3", 256, 12, 64, 1024, False,
+     ["q_d64_s1q2", "d64_h4_w1_u1_nt1", "d64_h1_w8_u1_nt1"]),
+    ("over_full_b384_ragged", 384, 12, 64, 1024, True,
+     ["q_d64_s1q2", "d64_h1_w8_u1_nt1", "d64_h1_w4_u1_nt1"]),
+    ("d128_full_b64x32", 64, 32, 128, 2048, False,
+     ["d128_h4_w1_u1_nt1", "d128_h1_w8_u1_nt1", "q_d128_s1q1", "d128_h1_w4_u1_nt1"]),
+    ("long_b1_l16384", 1, 12, 64, 16384, False,
+     ["d64_x64_u2_nt0", "d64_x32_u2_nt0", "d64_h1_w16_u2_nt0", "d64_x64_u1_nt0"]),
+]
+
+
+def _graph_us(wl, out, vid, dev):
+    """Device microseconds per attention launch of variant `vid` (0 = the default entry), hipGraph of PER_GRAPH launches."""
+    from vllmini_amd import ops
+
+    cfg = wl.cfg
+
+    def launch(t):
+        ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, cfg.kv_heads, wl.scale, wl.tables[t], wl.seq_lens,
+                               cfg.block_size, cfg.seq_len, None, "auto", 1.0, 0, 0, 1, 1, 0, _variant=vid)
+
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for t in range(len(wl.tables)):
+            launch(t)                       # warm-up outside capture; creates this stream's workspace (ops.workspace_for)
+        side.synchronize()
+        label = ops.last_launch_label()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for i in range(PER_GRAPH):
+                launch(i % len(wl.tables))
+        g.replay()
+        side.synchronize()
+        best = float("inf")
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            g.replay()
+            g.replay()
+            b.record()
+            b.synchronize()
+            best = min(best, a.elapsed_time(b) * 1e3 / (2 * PER_GRAPH))
+    torch.cuda.current_stream(dev).wait_stream(side)
+    return best, label
+
+
+@pytest.mark.parametrize("cell", CELLS, ids=[c[0] for c in CELLS])
+def test_default_pick_is_within_8_percent_of_the_best_named_kernel(cell):
+    from vllmini_amd import ops
+    from vllmini_amd.workload import CONFIGS, make_workload
+
+    if torch.cuda.get_device_properties(0).multi_processor_count < 200:
+        pytest.skip("the regimes are stated for a whole MI355X (256 CUs)")
+    name, batch, heads, head_size, seq_len, ragged, candidates = cell
+    dev = torch.device("cuda:0")
+    per = -(-seq_len // 16)
+    cfg = dataclasses.replace(CONFIGS["cfg3"], name=name, batch=batch, num_heads=heads, head_size=head_size, seq_len=seq_len,
+                              num_blocks=2 * batch * per + 8)
+    wl = make_workload(cfg, dev, seed=21, table_sets=2, ragged=ragged)
+    out = torch.empty((batch, heads, head_size), dtype=torch.float16, device=dev)
+    ids = {n: i + 1 for i, n in enumerate(ops.variant_names())}
+    default_a, label = _graph_us(wl, out, 0, dev)
+    times = {}
+    for c in candidates:
+        times[c] = min(_graph_us(wl, out, ids[c], dev)[0] for _ in range(2))
+    default_b, _ = _graph_us(wl, out, 0, dev)
+    default = min(default_a, default_b)
+    best_name = min(times, key=times.get)
+    assert default <= TOLERANCE * times[best_name], (
+        f"{name}: the default entry ({label}) takes {default:.2f} us, {best_name} {times[best_name]:.2f} us "
+        f"(> {TOLERANCE:.2f} x); all: " + ", ".join(f"{k} {v:.2f}" for k, v in sorted(times.items(), key=lambda kv: kv[1])))

@@ -226,6 +226,14 @@ class GPT2PagedDecoder:
                                          self.pool.block_size, mean_seq_len=max(int(lens.mean()), 1),
                                          bf16=self.pool.key_cache.dtype == torch.bfloat16,
                                          fp8={"auto": False, "fp8_e5m2": "e5m2"}.get(self.pool.kv_cache_dtype, True))
+        # few sequences x long contexts: with the wrapper's workspace the library spreads a head over several workgroups
+        # (ops.pick_variant(workspace=True) names a split kernel, "_x<waves>", exactly where the default entry would run one)
+        if st["variant"] and not self.fused_append and self.pool.kv_cache_dtype == "auto" and \
+                self.pool.key_cache.dtype == torch.float16:
+            ws_pick = ops.pick_variant(B, self.dims.n_head, self.dims.head_size, max(int(lens.max()), 1),
+                                       self.pool.block_size, workspace=True)
+            if ws_pick and "_x" in ops.variant_names()[ws_pick - 1]:
+                st["variant"] = ws_pick
         # ... but the launch reserves LDS for self.max_seq_len (the pool's capacity, as the reference's scheduler passes
         # it, scheduler.py:97) and may be the fused append: a hinted variant that cannot serve that is dropped
         if not ops.variant_fits(st["variant"], self.max_seq_len, for_append=self.fused_append):
@@ -252,7 +260,7 @@ class GPT2PagedDecoder:
                 self._forward_decode(st)
             torch.cuda.current_stream(self.device).wait_stream(s)
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, stream=s):   # (the warm-up's stream: its paged_attention_v1 workspace exists)
                 self._graph_out = self._forward_decode(st)
             self._graph_variant = st["variant"]
         self._graph.replay()

@@ -56,6 +56,11 @@ CONFIGS = {
     # not in BASELINE.json: long context, small batch — the shape split-KV (paged_attention_v2) exists for
     "long": DecodeConfig("long", 4, 32, 128, 16384, 8192),
     "b1": DecodeConfig("b1", 1, 12, 64, 1024, 256),
+    # BASELINE configs[4] on ONE GPU (the N = 1 point of the strong-scaling curve): all 2048 sequences, two table sets
+    "cfg5_strong": DecodeConfig("cfg5_strong", 2048, 12, 64, 1024, 262144),
+    # few sequences x long contexts: where a caller-owned workspace lets paged_attention_v1 spread a head over many CUs
+    "long_b1": DecodeConfig("long_b1", 1, 12, 64, 16384, 4096),
+    "long_b4": DecodeConfig("long_b4", 4, 12, 64, 8192, 8192),
 }
 
 
