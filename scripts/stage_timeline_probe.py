@@ -94,7 +94,7 @@ def summarize(trace_dir, out_path):
     f = sorted(glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True))[0]
     every = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     rows = [r for r in every if "pa_v1_kernel" in r["Kernel_Name"] or "pa_q_kernel" in r["Kernel_Name"] or
-            "pa_split_kernel" in r["Kernel_Name"]]
+            "pa_split" in r["Kernel_Name"]]
     scat = [r for r in every if "reshape_and_cache" in r["Kernel_Name"]]      # the other half of the call pair
     res, k = [], 0
     us = lambda chunk: np.array([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in chunk])   # noqa: E731

@@ -17,7 +17,7 @@ for f in find("trace/**/*kernel_stats.csv"):
 # per-dispatch durations of the attention kernel (skip warm-up dispatches).  A gated double launch (head size 128)
 # runs two attention kernels per call: the one that does the work is reported, the one that leaves at once beside it
 for f in find("trace/**/*kernel_trace.csv"):
-    rows = [r for r in csv.DictReader(open(f)) if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_", "pa_stage_", "pa_split_"))]
+    rows = [r for r in csv.DictReader(open(f)) if any(k in r.get("Kernel_Name", "") for k in ("pa_v1_", "pa_q_", "pa_stage_", "pa_split"))]
     groups = {}
     for r in rows:
         groups.setdefault(r["Kernel_Name"], []).append(r)
