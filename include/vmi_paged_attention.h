@@ -153,8 +153,8 @@ int64_t vmi_paged_attention_v1_workspace_bytes(int32_t num_seqs, int32_t num_hea
                                                int32_t max_seq_len);
 /* Zero the workspace's control words on `stream` (hipMemsetAsync): once after allocation, and after a launch that died. */
 int vmi_paged_attention_v1_workspace_reset(void* workspace, int64_t workspace_bytes, int32_t device, void* stream);
-/* What variant 0 of the _ws entry runs when a workspace is at hand (fp16 pages). */
-int vmi_paged_attention_v1_pick_variant_ws(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+/* What variant 0 of the _ws entry runs when a workspace is at hand (fp16 pages; num_kv_heads <= 0 = num_heads). */
+int vmi_paged_attention_v1_pick_variant_ws(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads, int32_t head_size,
                                            int32_t block_size, int32_t max_seq_len);
 
 /*

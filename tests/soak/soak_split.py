@@ -1,0 +1,94 @@
+"""Soak run of the SPLIT kernels (vllmini_amd/csrc/pa_split.hpp) on the PRODUCT library: one (sequence, head) over several
+workgroups of one launch that meet in the wrapper's workspace.  What the unit tests do not vary: random batches of 1 .. 12
+sequences, 1 .. 16 heads (grouped KV heads sometimes), head size 64 / 128, contexts up to 20 000 tokens with every length
+distribution of soak_auto (equal, uniform, one long among one-token sequences, empty ones), max_seq_len at the longest length
+or a capacity far above it, ALiBi sometimes — and, as the hand-off rules demand (MI355X_MICROARCH.md: "test every hand-off
+under UNEVEN load, consumer L1-warm"), HALF the cases run while another stream streams through a 1 GiB buffer, and every case
+is launched three times back to back on the same workspace.  Each case: an explicit split kernel (random waves per item, U,
+nt) or the default entry; all rows against the CPU kernel model (checker only) at the tight bound, the three launches
+bit-identical, the workspace's control words zero and its give-up counter 0 afterwards.
+`PYTHONPATH=.:tests python tests/soak/soak_split.py [n_cases] [first_seed]`; exit code 1 if anything failed."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "tests")
+import oracle  # noqa: E402  (checker)
+from helpers import make_case, ulp16  # noqa: E402
+from vllmini_amd import _lib, ops  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 70000
+dev = torch.device("cuda:0")
+assert _lib.load().vmi_is_diag_build() == 0
+names = {n: i + 1 for i, n in enumerate(ops.variant_names())}
+load_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()     # 1 GiB
+load_stream = torch.cuda.Stream()
+fails, t0, ran, refused, picked = 0, time.time(), 0, 0, {}
+for seed in range(first, first + n_cases):
+    rng = np.random.default_rng(seed)
+    D = int(rng.choice([64, 64, 128]))
+    qpk = int(rng.choice([1, 1, 2, 4]))
+    hkv = int(rng.choice([1, 2, 3, 4]))
+    H = hkv * qpk
+    B = int(rng.choice([1, 1, 2, 3, 4, 8, 12]))
+    top = int(rng.choice([40, 700, 2048, 4096, 9000, 20000], p=[.1, .15, .2, .25, .2, .1]))
+    if B * H * top > 1.2e6:
+        top = max(64, int(1.2e6 / (B * H)))
+    kind = int(rng.integers(0, 5))
+    lens = (np.full(B, top) if kind == 0 else rng.integers(0, top + 1, B) if kind == 1 else
+            np.where(np.arange(B) == int(rng.integers(0, B)), top, 1) if kind == 2 else
+            np.minimum((rng.exponential(1.0, B) * top / 3).astype(np.int64), top) if kind == 3 else
+            rng.choice([0, 1, 15, 16, 17, top], B))
+    lens = np.asarray(lens, dtype=np.int64)
+    case = make_case(rng, B, H, D, lens.tolist(), num_kv_heads=hkv, q_row_pad=int(rng.integers(0, 3)), poison_tail=True)
+    msl = max(int(lens.max()), 1)
+    if seed % 3 == 0:
+        msl = int(msl * rng.choice([1.5, 4, 16])) + 5          # capacity-style max_seq_len (scheduler.py:97)
+    slopes = (rng.uniform(0.01, 0.5, H).astype(np.float32) if seed % 4 == 0 else None)
+    x = int(rng.choice([8, 16, 32, 64, 128, 256]))
+    vname = f"d{D}_x{x}_u{int(rng.choice([1, 2]))}_nt{int(rng.choice([0, 1]))}"
+    vid = 0 if seed % 5 == 0 else names[vname]
+    S = B
+    qbuf = torch.from_numpy(case["qbuf"]).to(dev)
+    q = qbuf[:, : H * D].view(S, H, D)
+    kc, vc = torch.from_numpy(case["kc"]).to(dev), torch.from_numpy(case["vc"]).to(dev)
+    tab, ln = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
+    al = None if slopes is None else torch.from_numpy(slopes).to(dev)
+    busy = seed % 2 == 0
+    outs = []
+    try:
+        for rep in range(3):
+            if busy:
+                with torch.cuda.stream(load_stream):
+                    load_buf.mul_(1.0000001)
+            out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=dev)
+            ops.paged_attention_v1(out, q, kc, vc, hkv, case["scale"], tab, ln, 16, msl, al, "auto", 1.0, 0, 0, 1, 1, 0, _variant=vid)
+            outs.append(out)
+        torch.cuda.synchronize()
+    except RuntimeError as e:
+        if "would launch" in str(e) or "LDS" in str(e):      # not all resident / LDS of this shape: refused, never wrong
+            refused += 1
+            continue
+        raise
+    ran += 1
+    label = ops.last_launch_label()
+    picked[label] = picked.get(label, 0) + 1
+    ref = oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], hkv, case["scale"], case["tables"], case["lens"], 16,
+                                    alibi_slopes=slopes, threads=8).astype(np.float64)
+    got = outs[0].cpu().numpy().astype(np.float64)
+    d = np.abs(got - ref)
+    ok = np.isfinite(got).all() and bool((d <= np.maximum(2 * ulp16(ref), 5e-4)).all())
+    same = all(torch.equal(outs[0].view(torch.int16), o.view(torch.int16)) for o in outs[1:])
+    ws = ops.workspace_for(0, create=False)
+    n_ctl = 256 + 8192 * 4 + 2048 * 4 * 8
+    clean = ws is None or int(ws[:n_ctl].view(torch.int64).ne(0).sum().item()) == 0
+    if not (ok and same and clean):
+        fails += 1
+        print(f"FAIL seed {seed}: {label} D{D} H{H}/{hkv} B{B} lens {lens.tolist()} msl {msl} busy {busy}: "
+              f"max|d| {d.max() if np.isfinite(d).all() else 'nan'} ok {ok} identical {same} workspace clean {clean}", flush=True)
+print(f"{ran} cases run, {refused} refused (not resident), {fails} failures, {time.time() - t0:.0f} s; kernels: "
+      + ", ".join(f"{k} x{v}" for k, v in sorted(picked.items(), key=lambda kv: -kv[1])[:12]))
+sys.exit(1 if fails else 0)

@@ -185,6 +185,15 @@ def test_with_a_workspace_the_default_entry_splits_an_underfilled_launch_and_agr
         assert_close(got, run_model(case), f"default entry, batch {S} x {L} ({label})")
         assert ops.pick_variant(S, 12, 64, L, workspace=True) == ops.last_variant()
     assert _control_words_are_zero()
+    # grouped-query heads (8 query heads on 2 KV heads, head size 128): the split kernels replace the gq kernels from 1024
+    # tokens on — a query head's waves read their KV head's tiles themselves
+    rng = np.random.default_rng(99)
+    case = make_case(rng, 2, 8, 128, [2048, 1500], num_kv_heads=2)
+    t = _upload(case, dev)
+    got = _launch(case, t).cpu().numpy()
+    assert "_x" in ops.last_launch_label(), ops.last_launch_label()
+    assert ops.pick_variant(2, 8, 128, 2048, workspace=True, num_kv_heads=2) == ops.last_variant()
+    assert_close(got, run_model(case), f"default entry, grouped-query ({ops.last_launch_label()})")
 
 
 def test_a_workspace_is_reused_across_many_launches_and_shapes_and_results_do_not_depend_on_arrival_order():

@@ -560,6 +560,7 @@ struct PickRules {
                                      //   192 items lost in every cell, 96 won from 8192 tokens on)
   long split_min_item_bytes_per_unit = 20480;   // ... and an item's pages >= 20 KiB x items (head size 64: max_seq_len >= 80 x
                                      //   items — batch 2 from 2048 tokens, batch 4 from 4096, batch 8 from 8192)
+  int split_gqa_min_tokens = 1024;   // grouped-query heads: from 1024 tokens on (r05i_split_gqa_sweep_rocprof.json)
   long split_min_item_bytes = 384 * 1024;   // ... and >= 384 KiB (1536 tokens at head size 64: batch 1 at 1024 tokens is level)
   int gate_max_seqs = 2048;          // the gated double launch behind it (launch_pa_v1): every wave of BOTH kernels reads all the
                                      //   lengths for the verdict, bounded by what the balanced kernel ranks in LDS (QSORT_MAX)
@@ -848,22 +849,35 @@ static int find_split(int D, int xw, int U, int nt) {
 // the last arriver's merge: 1.7 - 2.4 us), so spreading an item pays where its work on ONE CU lasts much longer than that:
 // few items, long contexts — batch 1 at 16384 tokens 53.4 -> 19.0 us, batch 4 at 8192 30.2 -> 22.0, batch 8 at 16384
 // 98.4 -> 70.5 — and loses below (batch 1 at 1024 tokens 8.5 -> 8.8, BASELINE configs[1] 10.5 -> 17.0).
-static int pick_split(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len, int plain) {
+static int pick_split(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len, int plain, int qpk = 1) {
   if (block_size != 16 || (head_size != 64 && head_size != 128) || g_split_nvariants == 0) return 0;
   const long units = (long)num_seqs * num_heads;
   bool starved = false;
   if (plain >= 1 && plain <= nvariants_v1()) {
     const Variant& pv = variant_v1(plain);
-    if (pv.GQS || pv.QUEUE || pv.XW) return 0;
+    // (grouped-query picks included: with few items the gq kernels — one tile load for several query heads, but a KV head's
+    //  whole context on ONE CU — lose to the split kernels by 2 - 6 x although those read a tile once per QUERY head (the
+    //  repeats hit L2): 32 / 8 heads x 128, batch 1 x 4096 tokens 56 -> 17 us, x 16 384 164 -> 26, batch 4 x 8192 159 -> 43;
+    //  16 / 4 heads x 64, batch 4 x 8192 130 -> 20: profiles/r05h_split_gqa_rocprof.json)
+    if (pv.QUEUE || pv.XW) return 0;
     // ONE wave per head on a chip those waves do not fill: the plain pick fell back there because several waves' logits and
     // probabilities (6 bytes per token) no longer fit a workgroup's LDS — from ~27 000 tokens on; batch 1 at 32768 tokens ran
     // 1487 us that way, 24.5 us split (a wave of a split kernel holds its own blocks' logits only)
     starved = pv.WPH == 1 && units * 2 < full_chip_waves();
     if (pv.WPH == 1 && !starved) return 0;   // a full chip
   }
-  const bool few = units * R.split_max_units_den <= (long)g_cus * R.split_max_units_num;
   const long item_bytes = 4L * max_seq_len * head_size;   // K and V pages of one (sequence, head)
-  if (!starved && (!few || item_bytes < R.split_min_item_bytes_per_unit * units || item_bytes < R.split_min_item_bytes)) return 0;
+  bool few = units * R.split_max_units_den <= (long)g_cus * R.split_max_units_num;
+  bool big = item_bytes >= R.split_min_item_bytes_per_unit * units && item_bytes >= R.split_min_item_bytes;
+  if (qpk > 1) {
+    // Grouped-query heads: the alternative is a gq kernel that keeps a KV head's whole context on one CU, and it loses from
+    // 1024 tokens on wherever the split launch stays within the resident workgroups (r05i_split_gqa_sweep_rocprof.json:
+    // 32 / 8 heads x 128, batch 1 ... 4 x 1024 ... 8192 tokens 0.60 ... 0.13 of the gq kernel's time; 16 / 4 x 64 up to batch
+    // 16: 0.96 ... 0.14) — except with as many query heads as CUs at head size 128 (two workgroups per item: 1.1 - 1.2 x)
+    few = units * (head_size == 128 ? 2 : 1) <= (long)g_cus;
+    big = max_seq_len >= R.split_gqa_min_tokens;
+  }
+  if (!starved && !(few && big)) return 0;
   const int nblk = (max_seq_len + 15) / 16;
   const long cap = (long)R.split_wgs_per_cu * g_cus;   // workgroups the launch may have (all resident)
   // the most waves per item such that the launch's workgroups fit the CUs once with >= 4 blocks per wave, or up to
@@ -883,7 +897,7 @@ static int pick_split(int num_seqs, int num_heads, int head_size, int block_size
       if (units * (x / 4) <= split_resident_wgs(head_size) && lds_fits(x)) { xw = x; break; }
   }
   if (!xw) return 0;
-  const double kv_bytes = 4.0 * (double)units * (double)max_seq_len * head_size;
+  const double kv_bytes = 4.0 * (double)units / (double)(qpk > 0 ? qpk : 1) * (double)max_seq_len * head_size;
   const int nt = kv_bytes > R.nt_kv_bytes ? 1 : 0;
   int v = find_split(head_size, xw, 2, nt);   // (two blocks per register group: ahead of one in 23 of 25 cells)
   if (!v) v = find_split(head_size, xw, 1, nt);
@@ -1061,7 +1075,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
                        workspace_bytes >= (int64_t)pa_split_layout(head_size).bytes;
   if (!sparse_v && picked && have_ws && !append && !f8 && !bf) {
     // a caller-owned workspace lets an under-filled launch spread each (sequence, head) over several workgroups
-    if (const int sv = pick_split(num_seqs, num_heads, head_size, block_size, max_seq_len, variant)) variant = sv;
+    if (const int sv = pick_split(num_seqs, num_heads, head_size, block_size, max_seq_len, variant, num_heads / num_kv_heads)) variant = sv;
   }
   if (!sparse_v && (variant < 1 || variant > nvariants_v1()))
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
@@ -1562,12 +1576,15 @@ int vmi_paged_attention_v1_workspace_reset(void* workspace, int64_t workspace_by
   return VMI_OK;
 }
 
-int vmi_paged_attention_v1_pick_variant_ws(int32_t num_seqs, int32_t num_heads, int32_t head_size,
+int vmi_paged_attention_v1_pick_variant_ws(int32_t num_seqs, int32_t num_heads, int32_t num_kv_heads, int32_t head_size,
                                            int32_t block_size, int32_t max_seq_len) {
   if (!vmi::head_size_supported(head_size) || !vmi::block_size_supported(block_size)) return 0;
-  const int plain = vmi::fit_lds(vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len), head_size,
-                                 block_size, ((max_seq_len + 31) / 32) * 32, false, 0);
-  const int sv = vmi::pick_split(num_seqs, num_heads, head_size, block_size, max_seq_len, plain);
+  if (num_kv_heads <= 0) num_kv_heads = num_heads;
+  if (num_heads % num_kv_heads) return 0;
+  int plain = vmi::pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size, max_seq_len, false, 0);
+  if (!plain) plain = vmi::pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len);
+  plain = vmi::fit_lds(plain, head_size, block_size, ((max_seq_len + 31) / 32) * 32, false, 0);
+  const int sv = vmi::pick_split(num_seqs, num_heads, head_size, block_size, max_seq_len, plain, num_heads / num_kv_heads);
   return sv ? sv : plain;
 }
 

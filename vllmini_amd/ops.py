@@ -591,6 +591,9 @@ def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int
     paged_attention_v1 outside stream capture)."""
     lib = _lib.load()
     fp8 = 2 if fp8 in (2, "e5m2", "fp8_e5m2") else int(bool(fp8))
+    if workspace and not (mean_seq_len or bf16 or fp8):
+        return int(lib.vmi_paged_attention_v1_pick_variant_ws(num_seqs, num_heads, int(num_kv_heads or 0), head_size, block_size,
+                                                              max_seq_len))
     if num_kv_heads and num_kv_heads != num_heads:      # grouped-query attention: what the operators pick themselves
         return int(lib.vmi_paged_attention_v1_pick_variant_gqa(num_seqs, num_heads, int(num_kv_heads), head_size,
                                                                block_size, max_seq_len, int(bool(bf16)), fp8))
@@ -602,8 +605,6 @@ def pick_variant(num_seqs: int, num_heads: int, head_size: int, max_seq_len: int
     if fp8:
         fn = lib.vmi_paged_attention_v1_pick_variant_fp8_bf16 if bf16 else lib.vmi_paged_attention_v1_pick_variant_fp8
         return int(fn(num_seqs, num_heads, head_size, block_size, max_seq_len, int(mean_seq_len)))
-    if workspace and not (mean_seq_len or bf16):
-        return int(lib.vmi_paged_attention_v1_pick_variant_ws(num_seqs, num_heads, head_size, block_size, max_seq_len))
     if mean_seq_len or bf16:
         return int(lib.vmi_paged_attention_v1_pick_variant_hint(num_seqs, num_heads, head_size, block_size,
                                                                 max_seq_len, int(mean_seq_len), int(bool(bf16))))
