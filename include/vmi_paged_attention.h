@@ -204,6 +204,18 @@ int vmi_paged_attention_v1_fp8(
     int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     int32_t device, void* stream,
     float kv_scale, int32_t variant);
+/* ... with a caller-owned workspace (see vmi_paged_attention_v1_f16_ws: the same contract; split kernels "fp8_d<head>_x<waves>_..."). */
+int vmi_paged_attention_v1_fp8_ws(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+    float scale,
+    const int32_t* block_tables, const int32_t* seq_lens,
+    int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+    const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream,
+    float kv_scale,
+    void* workspace, int64_t workspace_bytes, int32_t variant);
 int vmi_paged_attention_v2_fp8(
     void* out, void* exp_sums, void* max_logits, void* tmp_out,
     const void* query, const void* key_cache, const void* value_cache,

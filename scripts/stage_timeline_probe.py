@@ -46,7 +46,7 @@ def setup(case, dev):
     from vllmini_amd.workload import CONFIGS, make_workload
     name, b, L, var = case.split(":")[:4]
     kv = (case.split(":") + ["auto"])[4]            # optional fifth field: "fp8" = E4M3 pages, kv_scale 1
-    hd = (case.split(":") + ["auto", "12x64"])[5]   # optional sixth field: heads x head size
+    hd = (case.split(":") + ["auto", "12x64"])[5] if len(case.split(":")) > 5 else "12x64"   # optional sixth field: heads x head size [x KV heads]
     b, L = int(b), int(L)
     per = -(-L // 16)
     cfg = dataclasses.replace(CONFIGS["cfg2"], name=name, batch=b, seq_len=L, num_blocks=max(4096, 2 * b * per),

@@ -113,6 +113,34 @@ def test_long_contexts_use_every_wave_of_the_widest_split_kernels(D):
     assert ops.workspace_status(0) == 0 and _control_words_are_zero()
 
 
+@pytest.mark.parametrize("D", [64, 128])
+def test_fp8_pages_through_the_split_kernels(D):
+    """fp8 E4M3 pages ("fp8_d<head>_x<waves>_..."): every element becomes half(float(fp8) * kv_scale) first, then the fp16
+    arithmetic of the fp16 kernels — against the oracle's fp8 restatement, kv_scale 1 and 0.6, long and short contexts, and the
+    default entry (vmi_paged_attention_v1_fp8_ws) where it picks one."""
+    import oracle
+    from test_parity_gpu import _fp8_case, _run_fp8
+    from vllmini_amd import ops
+
+    rng = np.random.default_rng(40 + D)
+    lens = [9000, 1, 700, 0, 4097, 33]
+    H, hkv = 4, 2
+    case = _fp8_case(rng, len(lens), H, D, lens, 16, num_kv_heads=hkv)
+    names = {n: i + 1 for i, n in enumerate(ops.variant_names())}
+    mine = [n for n in names if n.startswith(f"fp8_d{D}_x")]
+    assert len(mine) >= 10
+    for kv_scale in (1.0, 0.6):
+        ref = oracle.paged_attention_v1_fp8(case["q"], case["kq"], case["vq"], hkv, case["scale"], case["tables"], case["lens"], 16,
+                                            kv_scale=kv_scale, threads=8)
+        for n in mine:
+            got = _run_fp8(case, kv_scale, variant=names[n])
+            assert_close(got, ref, f"{n} kv_scale {kv_scale}", vmax=2 * kv_scale)
+        got = _run_fp8(case, kv_scale)                          # default entry: 24 items x 9000 tokens -> a split kernel
+        assert ops.last_launch_label().startswith(f"fp8_d{D}_x"), ops.last_launch_label()
+        assert_close(got, ref, f"default entry kv_scale {kv_scale}", vmax=2 * kv_scale)
+    assert ops.workspace_status(0) == 0 and _control_words_are_zero()
+
+
 def test_grouped_query_and_alibi_through_a_split_kernel():
     import oracle
 

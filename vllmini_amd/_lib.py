@@ -42,6 +42,7 @@ SIGNATURES = {
     "vmi_paged_attention_v1_pick_variant_ws": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v1_append_f16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
     "vmi_paged_attention_v1_fp8": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32]),
+    "vmi_paged_attention_v1_fp8_ws": (ctypes.c_int, list(_PA_ARGS) + [_f32, _c_void_p, _i64, _i32]),
     "vmi_paged_attention_v2_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32]),
     "vmi_reshape_and_cache_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                                  _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _i32, _c_void_p]),

@@ -48,22 +48,17 @@ __global__ void __launch_bounds__(256)
                                  const int64_t* __restrict__ slot_mapping, int64_t key_stride,
                                  int64_t value_stride, int H, int D, int BS, float kv_scale) {
   const int64_t token = blockIdx.x;
-  const int64_t slot = slot_mapping[token];
-  if (slot < 0) return;  // padding token (ref cache_kernels.cu:165-169)
-  const int64_t blk = slot / BS, off = slot % BS;
   const h16* ksrc = key + token * key_stride;
   const h16* vsrc = value + token * value_stride;
   const int n16 = (H * D) >> 4;
   const int cph = D >> 4;  // 16-dim chunks (lanes) per head
-  for (int c = threadIdx.x; c < n16; c += blockDim.x) {
-    const int i = c << 4, h = i / D, d = i - h * D;
-    const int cc = d >> 4;  // this lane's chunk within its head
-    // K: the lane's 16 consecutive dims are one 16-byte unit of the tile.
-    // V: the lanes of a head take the rows e*cph + cc (not 16*cc + e), so that store instruction e writes cph CONSECUTIVE
-    // rows of the tile — one 64- or 128-byte piece of a line per token instead of cph pieces of cph lines; and both are
-    // stored NON-TEMPORALLY: dirty partial lines left in L2 are paid for by the attention launch behind this one
-    // (profiles/r02b_call_pair_aftermath.md).
-    h16 kv[16], vv[16];
+  // K: the lane's 16 consecutive dims are one 16-byte unit of the tile.
+  // V: the lanes of a head take the rows e*cph + cc (not 16*cc + e), so that store instruction e writes cph CONSECUTIVE
+  // rows of the tile — one 64- or 128-byte piece of a line per token instead of cph pieces of cph lines; and both are
+  // stored NON-TEMPORALLY: dirty partial lines left in L2 are paid for by the attention launch behind this one
+  // (profiles/r02b_call_pair_aftermath.md).
+  auto load_rows = [&](int c, h16(&kv)[16], h16(&vv)[16]) {
+    const int i = c << 4, h = i / D, d = i - h * D, cc = d >> 4;
     if constexpr (VEC) {
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
@@ -77,6 +72,28 @@ __global__ void __launch_bounds__(256)
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) vv[e] = vsrc[h * D + e * cph + cc];
+  };
+  // (round 5) this lane's first chunk of the rows is requested BEFORE the slot is consumed: the rows do not depend on the
+  // slot, only the stores do — one memory round trip instead of two in a row (rows of padding tokens are valid memory too)
+  h16 kv0[16], vv0[16];
+  const int c0 = threadIdx.x;
+  if (c0 < n16) load_rows(c0, kv0, vv0);
+  const int64_t slot = slot_mapping[token];
+  if (slot < 0) return;  // padding token (ref cache_kernels.cu:165-169)
+  const int64_t blk = slot / BS, off = slot % BS;
+  for (int c = c0; c < n16; c += blockDim.x) {
+    const int i = c << 4, h = i / D, d = i - h * D;
+    const int cc = d >> 4;  // this lane's chunk within its head
+    h16 kv[16], vv[16];
+    if (c == c0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        kv[e] = kv0[e];
+        vv[e] = vv0[e];
+      }
+    } else {
+      load_rows(c, kv, vv);
+    }
     u32x4 kq = {0u, 0u, 0u, 0u};
     uint8_t* vdst = vc + ((blk * H + h) * (int64_t)D + cc) * BS + off;
 #pragma unroll

@@ -59,16 +59,21 @@ typedef unsigned int __attribute__((address_space(1))) gu32_t;
 typedef float __attribute__((address_space(1))) gf32_t;
 
 // D head size (64 | 128), U blocks per register group, NT non-temporal page loads, VA V groups requested in front of
-// the exchange (1 | 2).  Block size 16, fp16 query / pages.  grid = items * (nw / wpg), block = wpg * 64.
+// the exchange (1 | 2), F8 = 1: the pages hold fp8 E4M3 bytes (K [NB, H, D/16, 16, 16], V [NB, H, D, 16]; every element becomes
+// half(float(fp8) * kv_scale) first, reference quant_utils.cuh:295-300, then the fp16 arithmetic applies unchanged).
+// Block size 16, fp16 query.  grid = items * (nw / wpg), block = wpg * 64.
 // Launch bounds: six (head size 128: three) workgroups per CU — what the host counts as resident (split_resident_wgs).
 // LDS = wpg * (wtok * 4 (logits) + wtok * 2 (probabilities) + D * 4 (partial out)) + 16 (the "I am last" flag).
-template <int D, int U, bool NT, int VA>
+template <int D, int U, bool NT, int VA, int F8 = 0>
 __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PAParams p, const PASplit sp) {
   constexpr int BS = 16;
-  constexpr int NL = D * BS / 8 / 64;  // 1-KiB loads per (block, head) tile: 2 | 4
-  constexpr int CPL = 4;               // K: 16-B chunks (8 dims) per load
-  constexpr int UPR = 2;               // V: 16-B units per dim row
-  constexpr int RPL = 32;              // V: rows per load
+  constexpr int EPU = F8 ? 16 : 8;       // cache elements per 16-byte unit
+  constexpr int ES = F8 ? 1 : 2;         // bytes per cache element
+  constexpr int NL = D * BS / EPU / 64;  // 1-KiB loads per (block, head) tile: 2 | 4 (fp8 pages: 1 | 2)
+  constexpr int CPL = 4;                 // K: 16-B chunks (EPU dims) per load
+  constexpr int UPR = BS / EPU;          // V: 16-B units per dim row
+  constexpr int RPL = 64 / UPR;          // V: rows per load
+  constexpr int QW = F8 ? 2 : 1;         // 16-byte pieces of q facing one K unit
   static_assert(D == 64 || D == 128, "head size 64 or 128");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -106,13 +111,15 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
   const int c4 = lane >> 4;  // chunk within a K load
   const int tk = lane & 15;  // token within the block
   const int qpk = p.num_heads / p.num_kv_heads;
-  const int64_t hoff = (int64_t)(head / qpk) * p.kv_head_stride + lane * 8;
+  const int64_t hoff = (int64_t)(head / qpk) * p.kv_head_stride + lane * EPU;   // cache strides are in elements
   const float slope = p.alibi ? p.alibi[head] : 0.f;
-  u32x4 qreg[NL];
+  u32x4 qreg[NL][QW];
   {
     const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) qreg[i] = *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8);
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+      for (int qw = 0; qw < QW; ++qw) qreg[i][qw] = *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * EPU + 8 * qw);
   }
 
   uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + ((int64_t)seq * p.num_heads + head) * D;
@@ -163,9 +170,9 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
         int idx = gi * U + j;
         idx = idx < nmy ? idx : nmy - 1;  // padding slots re-read my last block
         const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
-        const h16* blk = cache + phys * p.kv_block_stride + hoff;
+        const char* blk = reinterpret_cast<const char*>(cache) + (phys * p.kv_block_stride + hoff) * ES;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(blk + i * 512);
+        for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(blk + i * 1024);
       }
     };
     float qk_max = -FLT_MAX;
@@ -178,7 +185,10 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
           const bool masked = token >= L;
           float accv[NL];
 #pragma unroll
-          for (int i = 0; i < NL; ++i) accv[i] = dot8<false>(qreg[i], r[j][i]);
+          for (int i = 0; i < NL; ++i) {
+            if constexpr (F8) accv[i] = dot16_f8<false, false, false>(qreg[i][0], qreg[i][QW - 1], r[j][i], p.kv_scale);
+            else accv[i] = dot8<false>(qreg[i][0], r[j][i]);
+          }
           float a = accv[0];
 #pragma unroll
           for (int i = 1; i < NL; ++i) a += accv[i];
@@ -286,12 +296,22 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
         const int idx = gi * U + j;
         if (idx < nmy) {
           const int b = w + idx * NWe;
-          const int token0 = b * BS + hf * 8;
+          const int token0 = b * BS + hf * EPU;
           const bool last = (b == nblk - 1);
           PV8<false> pv;
-          pv.load(*reinterpret_cast<const u32x4_alias*>(ph + idx * BS + hf * 8));
+          pv.load(*reinterpret_cast<const u32x4_alias*>(ph + idx * BS + hf * EPU));
+          if constexpr (F8) {  // a 16-byte unit is a whole 16-token row: two of the reference's 8-token groups
+            PV8<false> pw;
+            pw.load(*reinterpret_cast<const u32x4_alias*>(ph + idx * BS + 8));
 #pragma unroll
-          for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
+            for (int i = 0; i < NL; ++i) {
+              acc[i] += pv.template dot<MASK>(deq8<false>(r[j][i][0], r[j][i][1], p.kv_scale), last, token0, L);
+              acc[i] += pw.template dot<MASK>(deq8<false>(r[j][i][2], r[j][i][3], p.kv_scale), last, token0 + 8, L);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
+          }
         }
       }
     };
@@ -311,7 +331,9 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
       if (s < ngroups) compute_v(std::false_type{}, rb, last - s);
     }
 #pragma unroll
-    for (int i = 0; i < NL; ++i) acc[i] += __shfl_xor(acc[i], 1);  // the two 8-token halves of a row
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+      for (int mm = 1; mm < UPR; mm <<= 1) acc[i] += __shfl_xor(acc[i], mm);  // the 8-token groups of a row held by other lanes
   }
   VMI_SSTAMP(6);
 

@@ -835,10 +835,10 @@ static inline int split_resident_wgs(int head_size) {
   const int n = (head_size == 64 ? 6 : 3) * g_cus;
   return n < SPLIT_MAX_WGS ? n : SPLIT_MAX_WGS;
 }
-static int find_split(int D, int xw, int U, int nt) {
+static int find_split(int D, int xw, int U, int nt, int f8 = 0) {
   for (int i = 0; i < g_split_nvariants; ++i) {
     const Variant& c = g_split_variants[i];
-    if (c.D == D && c.XW == xw && c.U == U && c.NT == (bool)nt)
+    if (c.D == D && c.XW == xw && c.U == U && c.NT == (bool)nt && c.F8 == f8)
       return nvariants_v1() - g_stage_nvariants - g_split_nvariants + i + 1;
   }
   return 0;
@@ -849,7 +849,8 @@ static int find_split(int D, int xw, int U, int nt) {
 // the last arriver's merge: 1.7 - 2.4 us), so spreading an item pays where its work on ONE CU lasts much longer than that:
 // few items, long contexts — batch 1 at 16384 tokens 53.4 -> 19.0 us, batch 4 at 8192 30.2 -> 22.0, batch 8 at 16384
 // 98.4 -> 70.5 — and loses below (batch 1 at 1024 tokens 8.5 -> 8.8, BASELINE configs[1] 10.5 -> 17.0).
-static int pick_split(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len, int plain, int qpk = 1) {
+static int pick_split(int num_seqs, int num_heads, int head_size, int block_size, int max_seq_len, int plain, int qpk = 1,
+                      int f8 = 0) {
   if (block_size != 16 || (head_size != 64 && head_size != 128) || g_split_nvariants == 0) return 0;
   const long units = (long)num_seqs * num_heads;
   bool starved = false;
@@ -897,10 +898,12 @@ static int pick_split(int num_seqs, int num_heads, int head_size, int block_size
       if (units * (x / 4) <= split_resident_wgs(head_size) && lds_fits(x)) { xw = x; break; }
   }
   if (!xw) return 0;
-  const double kv_bytes = 4.0 * (double)units / (double)(qpk > 0 ? qpk : 1) * (double)max_seq_len * head_size;
+  const double kv_bytes = (f8 ? 2.0 : 4.0) * (double)units / (double)(qpk > 0 ? qpk : 1) * (double)max_seq_len * head_size;
   const int nt = kv_bytes > R.nt_kv_bytes ? 1 : 0;
-  int v = find_split(head_size, xw, 2, nt);   // (two blocks per register group: ahead of one in 23 of 25 cells)
-  if (!v) v = find_split(head_size, xw, 1, nt);
+  int v = f8 ? find_split(head_size, xw, 4, nt, f8) : 0;   // (fp8 pages, half-size tiles: four blocks per group 3 - 5 % ahead of two)
+  if (!v) v = find_split(head_size, xw, 2, nt, f8);   // (two blocks per register group: ahead of one in 23 of 25 cells)
+  if (!v) v = find_split(head_size, xw, 1, nt, f8);
+  if (!v && xw > 128) v = find_split(head_size, 128, 2, nt, f8);   // (the fp8 menu ends at 128 waves per item)
   return v;
 }
 
@@ -1073,9 +1076,9 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   }
   const bool have_ws = workspace != nullptr && aligned16(workspace) &&
                        workspace_bytes >= (int64_t)pa_split_layout(head_size).bytes;
-  if (!sparse_v && picked && have_ws && !append && !f8 && !bf) {
+  if (!sparse_v && picked && have_ws && !append && f8 != 2 && !bf) {
     // a caller-owned workspace lets an under-filled launch spread each (sequence, head) over several workgroups
-    if (const int sv = pick_split(num_seqs, num_heads, head_size, block_size, max_seq_len, variant, num_heads / num_kv_heads)) variant = sv;
+    if (const int sv = pick_split(num_seqs, num_heads, head_size, block_size, max_seq_len, variant, num_heads / num_kv_heads, f8)) variant = sv;
   }
   if (!sparse_v && (variant < 1 || variant > nvariants_v1()))
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
@@ -1111,9 +1114,9 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
                 (long long)num_seqs * num_heads);
 
   if (v.XW) {
-    if (append || bsp || f8 || bf)
-      return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (split kernel) takes fp16 tensors over fp16 pages, without the "
-                  "fused append or block-sparse attention", v.name);
+    if (append || bsp || f8 == 2 || bf)
+      return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (split kernel) takes fp16 tensors over fp16 or fp8-E4M3 pages, "
+                  "without the fused append or block-sparse attention", v.name);
     if (!have_ws)
       return fail(VMI_E_WORKSPACE, "paged_attention_v1: variant %s spreads a (sequence, head) over several workgroups and needs a "
                   "16-byte aligned workspace of vmi_paged_attention_v1_workspace_bytes() = %zu bytes (got %p, %lld)", v.name,
@@ -1617,6 +1620,22 @@ int vmi_paged_attention_v1_fp8(void* out, const void* query, const void* key_cac
                            max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
                            kv_head_stride, device, stream, variant, false, false, nullptr, nullptr, 0, 0,
                            true, kv_scale);
+}
+
+int vmi_paged_attention_v1_fp8_ws(void* out, const void* query, const void* key_cache, const void* value_cache,
+                                  int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
+                                  float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                                  int32_t block_size, int32_t max_seq_len, int32_t max_num_blocks_per_seq,
+                                  const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                                  int64_t kv_head_stride, int32_t device, void* stream, float kv_scale, void* workspace,
+                                  int64_t workspace_bytes, int32_t variant) {
+  if (!(kv_scale > 0.f) || kv_scale != kv_scale)
+    return vmi::fail(VMI_E_SHAPE, "paged_attention_v1 (fp8 cache): kv_scale must be positive, got %g", (double)kv_scale);
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, false, false, nullptr, nullptr, 0, 0,
+                           true, kv_scale, nullptr, workspace, workspace_bytes);
 }
 
 int vmi_paged_attention_v2_fp8(void* out, void* exp_sums, void* max_logits, void* tmp_out, const void* query,

@@ -314,9 +314,13 @@ def paged_attention_v1(
         rc = _extras("paged_attention_v1 over fp8-E5M2 pages").vmi_paged_attention_v1_fp8_e5m2(
             *args, float(kv_scale), int(_variant), int(query.dtype == torch.bfloat16))
     elif _check_kv_cache_dtype(kv_cache_dtype):      # fp8 E4M3 cache, float16 or bfloat16 query
-        fn = _extras("paged_attention_v1 over bfloat16 tensors").vmi_paged_attention_v1_fp8_bf16 \
-            if query.dtype == torch.bfloat16 else lib.vmi_paged_attention_v1_fp8
-        rc = fn(*args, float(kv_scale), int(_variant))
+        ws = workspace_for(args[18], args[19]) if (_ws_enabled and query.dtype == torch.float16 and args[6] in _WS_HEAD_SIZES) else None
+        if ws is not None:
+            rc = lib.vmi_paged_attention_v1_fp8_ws(*args, float(kv_scale), ws.data_ptr(), ws.numel(), int(_variant))
+        else:
+            fn = _extras("paged_attention_v1 over bfloat16 tensors").vmi_paged_attention_v1_fp8_bf16 \
+                if query.dtype == torch.bfloat16 else lib.vmi_paged_attention_v1_fp8
+            rc = fn(*args, float(kv_scale), int(_variant))
     elif query.dtype == torch.bfloat16:
         rc = _extras("paged_attention_v1 over bfloat16 tensors").vmi_paged_attention_v1_bf16(*args, int(_variant))
     else:
