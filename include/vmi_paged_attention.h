@@ -168,6 +168,7 @@ int vmi_paged_attention_v1_pick_variant_ws(int32_t num_seqs, int32_t num_heads, 
  * (vllmini/block_manager.py decode_step) — and the attention over positions 0..seq_lens[i]-1 takes that token
  * from the rows themselves.  Caches and `out` end up bit-identical to
  *   vmi_reshape_and_cache_f16(key, value, ..., slot_mapping = those slots) ; vmi_paged_attention_v1_f16(...)
+ * (the plain entry: the _ws entry with a workspace may run a split kernel there — the same up to fp32 summation order).
  * A sequence must own its last block (no two sequences append into one block; the reference never shares blocks).
  * Rows with seq_lens[i] <= 0 append nothing.  key rows must be 16-byte aligned.  variant: 0 = heuristic.
  * The first 20 arguments are those of vmi_paged_attention_v1_f16 (caches mutable here).

@@ -1257,10 +1257,23 @@ def _append_vs_two_ops(case, variant, dtype=torch.float16, seed=0, what=""):
     out_a = torch.full((S, H, D), float("nan"), dtype=dtype, device=dev)
     out_b = torch.full((S, H, D), float("nan"), dtype=dtype, device=dev)
     cache_ops.reshape_and_cache(key, value, kc_a, vc_a, slots, "auto", 1.0)
-    ops.paged_attention_v1(out_a, q, kc_a, vc_a, Hkv, case["scale"], tab, lens, bs, msl, None, "auto", 1.0,
-                           _variant=variant)
+    # The fused entry takes no workspace, so "bit-identical to the call pair" means the pair WITHOUT one: the same kernel on
+    # both sides.  (With a workspace the pair may run a split kernel — other fp32 summation order, <= 1 fp16 ulp: checked
+    # against the oracle in tests/test_split_gpu.py, and against the fused entry at the tight bound here.)
+    prev = ops.set_workspace_enabled(False)
+    try:
+        ops.paged_attention_v1(out_a, q, kc_a, vc_a, Hkv, case["scale"], tab, lens, bs, msl, None, "auto", 1.0,
+                               _variant=variant)
+    finally:
+        ops.set_workspace_enabled(prev)
     ops.paged_attention_v1_append(out_b, q, key, value, kc_b, vc_b, Hkv, case["scale"], tab, lens, bs, msl,
                                   _variant=variant)
+    if dtype == torch.float16 and not variant:
+        out_w = torch.full((S, H, D), float("nan"), dtype=dtype, device=dev)
+        ops.paged_attention_v1(out_w, q, kc_a, vc_a, Hkv, case["scale"], tab, lens, bs, msl, None, "auto", 1.0)
+        torch.cuda.synchronize()
+        assert_close(out_w.cpu().numpy(), out_b.cpu().numpy(), f"{what}: pair with a workspace vs fused",
+                     vmax=float(vc_a.float().abs().max()))
     torch.cuda.synchronize()
     i16 = torch.int16
     assert torch.equal(kc_a.view(i16), kc_b.view(i16)), f"{what}: key cache differs"

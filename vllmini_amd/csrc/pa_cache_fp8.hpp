@@ -26,6 +26,19 @@ __device__ __forceinline__ uint32_t f32_to_fp8e4m3_satfinite(float f) {
   return sign | ((u >> 20) - ((127u - 7u) << 3));
 }
 
+// The same conversion on the gfx950 converter (round 5): v_cvt_pk_fp8_f32 rounds two floats to OCP E4M3 (RNE, subnormals
+// included); what it does past the largest finite value is not what __NV_SATFINITE asks for, so magnitudes are clamped to
+// 448 first (448 < |x| < 464 rounds to 448 either way) and a NaN keeps its sign with code 0x7f.  Checked bit for bit against
+// the integer form above over all 65 536 half values x two scales (tests/test_parity_gpu.py::test_reshape_and_cache_fp8_
+// every_half_value_bit_exact) — the integer form stays the definition, this is the fast path of the scatter.
+__device__ __forceinline__ uint32_t f32x2_to_fp8e4m3_satfinite_hw(float a, float b) {
+  const float ca = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f), cb = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+  uint32_t r = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(ca, cb, 0, false) & 0xffffu;
+  if (a != a) r = (r & 0xff00u) | ((__builtin_bit_cast(uint32_t, a) >> 24) & 0x80u) | 0x7fu;
+  if (b != b) r = (r & 0x00ffu) | ((((__builtin_bit_cast(uint32_t, b) >> 24) & 0x80u) | 0x7fu) << 8);
+  return r;
+}
+
 // fp8 E5M2 (kv_cache_dtype "fp8_e5m2"): the upper byte of an IEEE half.  RNE on 2 mantissa bits, saturating at +-57344
 // (__NV_SATFINITE: infinities saturate too), NaN kept as a NaN code.  Integer arithmetic on the fp32 bit pattern.
 __device__ __forceinline__ uint32_t f32_to_fp8e5m2_satfinite(float f) {
@@ -96,15 +109,34 @@ __global__ void __launch_bounds__(256)
     }
     u32x4 kq = {0u, 0u, 0u, 0u};
     uint8_t* vdst = vc + ((blk * H + h) * (int64_t)D + cc) * BS + off;
+    // kv_scale == 1 (the reference's callers): x / 1.0f is x, and 32 IEEE divisions per lane were half of this kernel's time —
+    // one wave per token is instruction-bound, not memory-bound (round 5: 5.2 us for a one-token call)
+    auto quantise = [&](auto unit_scale) {
+      constexpr bool S1 = decltype(unit_scale)::value;
+      auto widen = [&](h16 x) -> float {   // bfloat16 rows (quant_utils.cuh:468-478) widen by a 16-bit shift; float16 rows by v_cvt_f32_f16
+        float f = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, x) << 16) : (float)x;
+        if constexpr (!S1) f = f / kv_scale;
+        return f;
+      };
+      if constexpr (!E5) {   // E4M3: two values per v_cvt_pk_fp8_f32
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      // bfloat16 rows (quant_utils.cuh:468-478) widen by a 16-bit shift; float16 rows by v_cvt_f32_f16
-      const float kf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, kv[e]) << 16) : (float)kv[e];
-      const float vf = BF ? __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, vv[e]) << 16) : (float)vv[e];
-      kq[e >> 2] |= (E5 ? f32_to_fp8e5m2_satfinite(kf / kv_scale) : f32_to_fp8e4m3_satfinite(kf / kv_scale)) << (8 * (e & 3));
-      __builtin_nontemporal_store((uint8_t)(E5 ? f32_to_fp8e5m2_satfinite(vf / kv_scale) : f32_to_fp8e4m3_satfinite(vf / kv_scale)),
-                                  vdst + (int64_t)(e * cph) * BS);
-    }
+        for (int e = 0; e < 16; e += 2) {
+          const uint32_t k2 = f32x2_to_fp8e4m3_satfinite_hw(widen(kv[e]), widen(kv[e + 1]));
+          const uint32_t v2 = f32x2_to_fp8e4m3_satfinite_hw(widen(vv[e]), widen(vv[e + 1]));
+          kq[e >> 2] |= k2 << (8 * (e & 3));
+          __builtin_nontemporal_store((uint8_t)(v2 & 0xffu), vdst + (int64_t)(e * cph) * BS);
+          __builtin_nontemporal_store((uint8_t)(v2 >> 8), vdst + (int64_t)((e + 1) * cph) * BS);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          kq[e >> 2] |= f32_to_fp8e5m2_satfinite(widen(kv[e])) << (8 * (e & 3));
+          __builtin_nontemporal_store((uint8_t)f32_to_fp8e5m2_satfinite(widen(vv[e])), vdst + (int64_t)(e * cph) * BS);
+        }
+      }
+    };
+    if (kv_scale == 1.0f) quantise(std::true_type{});
+    else quantise(std::false_type{});
     __builtin_nontemporal_store(kq, reinterpret_cast<u32x4*>(kc + (((blk * H + h) * (D >> 4) + (d >> 4)) * BS + off) * 16));
   }
 }
