@@ -31,7 +31,7 @@ def _split_names(D=None):
     from vllmini_amd import ops
 
     return [(i + 1, n) for i, n in enumerate(ops.variant_names())
-            if "_x" in n and n.startswith("d") and (D is None or n.startswith(f"d{D}_"))]
+            if "_x" in n and "_gq" not in n and n.startswith("d") and (D is None or n.startswith(f"d{D}_"))]
 
 
 def _upload(case, dev):
@@ -138,6 +138,47 @@ def test_fp8_pages_through_the_split_kernels(D):
         got = _run_fp8(case, kv_scale)                          # default entry: 24 items x 9000 tokens -> a split kernel
         assert ops.last_launch_label().startswith(f"fp8_d{D}_x"), ops.last_launch_label()
         assert_close(got, ref, f"default entry kv_scale {kv_scale}", vmax=2 * kv_scale)
+    assert ops.workspace_status(0) == 0 and _control_words_are_zero()
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_four_query_heads_of_a_kv_head_per_item(D):
+    """The "gq4" split kernels: an item is four query heads of one KV head — every K / V tile of a wave's blocks loaded once,
+    q.K^T on the matrix cores (exact fp16 products, fp32 accumulation), every head with its own granules, probabilities and
+    partial rows.  Against the kernel model at the tight bound; ragged, empty, ALiBi, 4 and 8 query heads per KV head; the
+    same bits on a second launch; and the default entry where it picks this form."""
+    import oracle
+    from vllmini_amd import ops
+
+    dev = _dev()
+    names = {n: i + 1 for i, n in enumerate(ops.variant_names())}
+    mine = [n for n in names if n.startswith(f"d{D}_gq4_x")]
+    assert len(mine) >= 8
+    for (S, hkv, qpk, lens) in ((3, 2, 4, [4096, 100, 0]), (2, 1, 8, [1500, 17]), (1, 2, 4, [9000]), (5, 1, 4, [1, 16, 33, 700, 2048])):
+        H = hkv * qpk
+        rng = np.random.default_rng(D + S + H)
+        case = make_case(rng, S, H, D, lens, num_kv_heads=hkv, q_row_pad=1, poison_tail=True)
+        slopes = rng.uniform(0.01, 0.3, H).astype(np.float32) if S == 2 else None
+        ref = oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], hkv, case["scale"], case["tables"], case["lens"], 16,
+                                        alibi_slopes=slopes, threads=8)
+        t = _upload(case, dev)
+        al = None if slopes is None else torch.from_numpy(slopes).to(dev)
+        for n in mine:
+            outs = []
+            for _ in range(2):
+                out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=dev)
+                ops.paged_attention_v1(out, t["q"], t["kc"], t["vc"], hkv, case["scale"], t["tab"], t["lens"], 16, t["msl"], al,
+                                       "auto", 1.0, 0, 0, 1, 1, 0, _variant=names[n])
+                outs.append(out)
+            assert_close(outs[0].cpu().numpy(), ref, f"{n} S{S} H{H}/{hkv} lens {lens}")
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), n
+    # the default entry: 8 sequences x 32 / 8 heads = 256 query heads -> four per item
+    rng = np.random.default_rng(7 + D)
+    case = make_case(rng, 8, 32, D, [2048] * 8, num_kv_heads=8)
+    t = _upload(case, dev)
+    got = _launch(case, t).cpu().numpy()
+    assert f"d{D}_gq4_x" in ops.last_launch_label(), ops.last_launch_label()
+    assert_close(got, run_model(case), f"default entry ({ops.last_launch_label()})")
     assert ops.workspace_status(0) == 0 and _control_words_are_zero()
 
 

@@ -20,9 +20,16 @@ namespace vmi {
 #define VMI_ROWS_X8(D, U, NT, VA) \
   VMI_ROW_X8(D, 8, U, NT, VA) VMI_ROW_X8(D, 16, U, NT, VA) VMI_ROW_X8(D, 32, U, NT, VA) VMI_ROW_X8(D, 64, U, NT, VA) VMI_ROW_X8(D, 128, U, NT, VA)
 
+#define VMI_ROW_XG(D, X, U, NT, VA) /* grouped-query: four query heads of one KV head per item, every tile loaded once */ \
+  {"d" #D "_gq4_x" #X "_u" #U "_nt" #NT, D, 16, 1, 4, U, (bool)(NT), 4, false,                                       \
+   (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 0, 4>, 0, 0, 0, 0, true, false, false, false, false, false, X},
+#define VMI_ROWS_XG(D, U, NT, VA) VMI_ROW_XG(D, 8, U, NT, VA) VMI_ROW_XG(D, 16, U, NT, VA) VMI_ROW_XG(D, 32, U, NT, VA) VMI_ROW_XG(D, 64, U, NT, VA)
+
 Variant g_split_variants[] = {
     VMI_ROWS_X(64, 1, 0, 2) VMI_ROWS_X(64, 2, 0, 2) VMI_ROWS_X(64, 1, 1, 1) VMI_ROWS_X(64, 2, 1, 1)
     VMI_ROWS_X(128, 1, 0, 2) VMI_ROWS_X(128, 2, 0, 2) VMI_ROWS_X(128, 1, 1, 1) VMI_ROWS_X(128, 2, 1, 1)
+    // grouped-query attention (num_heads / num_kv_heads a multiple of 4)
+    VMI_ROWS_XG(64, 2, 0, 2) VMI_ROWS_XG(64, 2, 1, 1) VMI_ROWS_XG(128, 1, 0, 2) VMI_ROWS_XG(128, 1, 1, 1) VMI_ROWS_XG(128, 2, 0, 2)
     // fp8 E4M3 pages (any kv_scale): half the bytes per tile, so two / four blocks per register group
     VMI_ROWS_X8(64, 2, 0, 2) VMI_ROWS_X8(64, 4, 0, 2) VMI_ROWS_X8(64, 2, 1, 1) VMI_ROWS_X8(128, 2, 0, 2) VMI_ROWS_X8(128, 2, 1, 1)
 };

@@ -61,11 +61,15 @@ typedef float __attribute__((address_space(1))) gf32_t;
 // D head size (64 | 128), U blocks per register group, NT non-temporal page loads, VA V groups requested in front of
 // the exchange (1 | 2), F8 = 1: the pages hold fp8 E4M3 bytes (K [NB, H, D/16, 16, 16], V [NB, H, D, 16]; every element becomes
 // half(float(fp8) * kv_scale) first, reference quant_utils.cuh:295-300, then the fp16 arithmetic applies unchanged).
+// HPT > 1 (grouped-query attention): an item is HPT query heads of ONE KV head (num_heads / num_kv_heads a multiple of HPT) —
+// a wave loads each K / V tile of its blocks ONCE and uses it for the HPT heads (the reference re-reads it per query head,
+// attention_kernels.cu:153); every head keeps its own logits, granules, probabilities and partial rows, so a head's
+// arithmetic is what HPT = 1 computes.  Up to 64 waves per item there (one granule per lane and head in the poll).
 // Block size 16, fp16 query.  grid = items * (nw / wpg), block = wpg * 64.
-// Launch bounds: six (head size 128: three) workgroups per CU — what the host counts as resident (split_resident_wgs).
-// LDS = wpg * (wtok * 4 (logits) + wtok * 2 (probabilities) + D * 4 (partial out)) + 16 (the "I am last" flag).
-template <int D, int U, bool NT, int VA, int F8 = 0>
-__global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PAParams p, const PASplit sp) {
+// Launch bounds: six (head size 128: three; grouped: four / two) workgroups per CU — what the host counts as resident.
+// LDS = wpg * HPT * (wtok * 4 (logits) + wtok * 2 (probabilities) + D * 4 (partial out)) + 16 (the "I am last" flag).
+template <int D, int U, bool NT, int VA, int F8 = 0, int HPT = 1>
+__global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 6 : 3)) pa_split_kernel(const PAParams p, const PASplit sp) {
   constexpr int BS = 16;
   constexpr int EPU = F8 ? 16 : 8;       // cache elements per 16-byte unit
   constexpr int ES = F8 ? 1 : 2;         // bytes per cache element
@@ -74,6 +78,7 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
   constexpr int UPR = BS / EPU;          // V: 16-B units per dim row
   constexpr int RPL = 64 / UPR;          // V: rows per load
   constexpr int QW = F8 ? 2 : 1;         // 16-byte pieces of q facing one K unit
+  constexpr int SPL = HPT > 1 ? 1 : SLOTS_PER_LANE;  // granules a lane reads per head in the poll
   static_assert(D == 64 || D == 128, "head size 64 or 128");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -88,7 +93,8 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
   const int wpg = blockDim.x >> 6;
   const int NW = sp.nw;
   const int G = NW / wpg;
-  const int items = p.num_seqs * p.num_heads;
+  const int hgroups = p.num_heads / HPT;     // items per sequence
+  const int items = p.num_seqs * hgroups;
   int item, g;
   if (sp.flags & SPF_GMAJOR) {
     g = blockIdx.x / items;
@@ -97,8 +103,8 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
     item = blockIdx.x / G;
     g = blockIdx.x - item * G;
   }
-  const int seq = item / p.num_heads;
-  const int head = item - seq * p.num_heads;
+  const int seq = item / hgroups;
+  const int head0 = (item - seq * hgroups) * HPT;
   const int w = g * wpg + wave;  // this wave's place among the item's NW
 
   // requested before seq_len is known (any entry of the row is readable): my first 64 blocks' physical ids
@@ -111,21 +117,41 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
   const int c4 = lane >> 4;  // chunk within a K load
   const int tk = lane & 15;  // token within the block
   const int qpk = p.num_heads / p.num_kv_heads;
-  const int64_t hoff = (int64_t)(head / qpk) * p.kv_head_stride + lane * EPU;   // cache strides are in elements
-  const float slope = p.alibi ? p.alibi[head] : 0.f;
-  u32x4 qreg[NL][QW];
-  {
-    const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)head * D;
+  const int64_t hoff = (int64_t)(head0 / qpk) * p.kv_head_stride + lane * EPU;   // cache strides are in elements
+  // HPT = 1: this lane's EPU dims of q facing each K load (fp32 FMA chains on the VALU, the reference's arithmetic).
+  // HPT > 1: q.K^T of a block is a (16 tokens) x (HPT heads, padded to 16) x (D dims) product on the matrix cores — the K tile as
+  // loaded IS the A operand of v_mfma_f32_16x16x32_f16 (lane = chunk * 16 + token holds 8 dims of one token), B is q with
+  // lane & 15 = head; products of fp16 operands are exact in fp32 and the accumulation is fp32: the reference's arithmetic up to
+  // summation order (as in pa_v1_kernel's grouped-query kernels, pa_kernel.hpp QK_MFMA).
+  constexpr bool QKM = HPT > 1;
+  static_assert(!(QKM && F8), "grouped-query split kernels: 16-bit pages");
+  float slope[QKM ? 1 : HPT];
+  u32x4 qreg[QKM ? 1 : HPT][NL][QW];
+  u32x4 qB[QKM ? NL : 1];
+  if constexpr (QKM) {
+    const int n = lane & 15;
+    const bool has = n < HPT;
+    const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + (has ? n : 0)) * D;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
+    for (int i = 0; i < NL; ++i) qB[i] = has ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8) : zero4;
+    slope[0] = (has && p.alibi) ? p.alibi[head0 + n] : 0.f;   // of head (lane & 15)
+  } else {
 #pragma unroll
-      for (int qw = 0; qw < QW; ++qw) qreg[i][qw] = *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * EPU + 8 * qw);
+    for (int hh = 0; hh < HPT; ++hh) {
+      slope[hh] = p.alibi ? p.alibi[head0 + hh] : 0.f;
+      const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + hh) * D;
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int qw = 0; qw < QW; ++qw) qreg[hh][i][qw] = *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * EPU + 8 * qw);
+    }
   }
 
-  uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + ((int64_t)seq * p.num_heads + head) * D;
-  if (L <= 0) {  // exp_sum = 0 -> the row is zero (reference: no tokens)
+  uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + ((int64_t)seq * p.num_heads + head0) * D;  // HPT adjacent rows
+  if (L <= 0) {  // exp_sum = 0 -> the rows are zero (reference: no tokens)
     if (w == 0)
-      for (int d = lane; d < D; d += 64) outp[d] = 0;
+      for (int d = lane; d < HPT * D; d += 64) outp[d] = 0;
     return;
   }
   const int nblk = (L + BS - 1) / BS;
@@ -142,13 +168,16 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
   const int nmy = w < na ? (nblk - w + NWe - 1) / NWe : 0;  // my blocks: b = w + idx * NWe
   VMI_SSTAMP(1);
 
-  float* lg = reinterpret_cast<float*>(smem) + (size_t)wave * sp.wtok;                                   // my logits
-  uint16_t* ph = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(smem) + (size_t)wpg * sp.wtok) + (size_t)wave * sp.wtok;
-  float* osm = reinterpret_cast<float*>(smem + (size_t)wpg * sp.wtok * 6);                              // [wpg][D]
+  const int wtok = sp.wtok;
+  float* lg0 = reinterpret_cast<float*>(smem) + (size_t)wave * HPT * wtok;                               // my logits, + hh * wtok
+  uint16_t* ph0 = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(smem) + (size_t)wpg * HPT * wtok) + (size_t)wave * HPT * wtok;
+  float* osm = reinterpret_cast<float*>(smem + (size_t)wpg * HPT * wtok * 6);                            // [wpg][HPT][D]
 
-  float acc[NL];
+  float acc[HPT][NL];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) acc[i] = 0.f;
+  for (int hh = 0; hh < HPT; ++hh)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc[hh][i] = 0.f;
   const int hf = lane % UPR;
   const int rowl = lane / UPR;
 
@@ -175,29 +204,54 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
         for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(blk + i * 1024);
       }
     };
-    float qk_max = -FLT_MAX;
+    float qk_max[HPT];
+#pragma unroll
+    for (int hh = 0; hh < HPT; ++hh) qk_max[hh] = -FLT_MAX;
+    float qmaxB = -FLT_MAX;  // QKM: running max of head (lane & 15) over this lane's token rows
     auto compute_k = [&](u32x4(&r)[U][NL], int gi) {
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         const int idx = gi * U + j;
         if (idx < nmy) {
-          const int token = (w + idx * NWe) * BS + tk;
-          const bool masked = token >= L;
-          float accv[NL];
+          if constexpr (QKM) {
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int i = 0; i < NL; ++i) {
-            if constexpr (F8) accv[i] = dot16_f8<false, false, false>(qreg[i][0], qreg[i][QW - 1], r[j][i], p.kv_scale);
-            else accv[i] = dot8<false>(qreg[i][0], r[j][i]);
+            for (int i = 0; i < NL; ++i)
+              d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, r[j][i]), __builtin_bit_cast(h16x8, qB[i]), d4, 0, 0, 0);
+            // C/D layout: column = lane & 15 (head), rows 4 * (lane >> 4) + reg (tokens of this block)
+            const int tok4 = (w + idx * NWe) * BS + 4 * c4;
+            f32x4 lg4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float qk = p.scale * d4[e];
+              qk += (slope[0] != 0.f) ? slope[0] * (float)(tok4 + e - L + 1) : 0.f;
+              const bool m = tok4 + e >= L;
+              lg4[e] = m ? 0.f : qk;
+              qmaxB = m ? qmaxB : fmaxf(qmaxB, qk);
+            }
+            if ((lane & 15) < HPT) *reinterpret_cast<f32x4_alias*>(lg0 + (lane & 15) * wtok + idx * BS + 4 * c4) = lg4;
+          } else {
+            const int token = (w + idx * NWe) * BS + tk;
+            const bool masked = token >= L;
+#pragma unroll
+            for (int hh = 0; hh < HPT; ++hh) {
+              float accv[NL];
+#pragma unroll
+              for (int i = 0; i < NL; ++i) {
+                if constexpr (F8) accv[i] = dot16_f8<false, false, false>(qreg[hh][i][0], qreg[hh][i][QW - 1], r[j][i], p.kv_scale);
+                else accv[i] = dot8<false>(qreg[hh][i][0], r[j][i]);
+              }
+              float a = accv[0];
+#pragma unroll
+              for (int i = 1; i < NL; ++i) a += accv[i];
+              a += __shfl_xor(a, 16);
+              a += __shfl_xor(a, 32);
+              float qk = p.scale * a;
+              qk += (slope[hh] != 0.f) ? slope[hh] * (float)(token - L + 1) : 0.f;
+              if (lane < BS) lg0[hh * wtok + idx * BS + tk] = masked ? 0.f : qk;
+              qk_max[hh] = masked ? qk_max[hh] : fmaxf(qk_max[hh], qk);
+            }
           }
-          float a = accv[0];
-#pragma unroll
-          for (int i = 1; i < NL; ++i) a += accv[i];
-          a += __shfl_xor(a, 16);
-          a += __shfl_xor(a, 32);
-          float qk = p.scale * a;
-          qk += (slope != 0.f) ? slope * (float)(token - L + 1) : 0.f;
-          if (lane < BS) lg[idx * BS + tk] = masked ? 0.f : qk;
-          qk_max = masked ? qk_max : fmaxf(qk_max, qk);
         }
       }
     };
@@ -229,35 +283,52 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
     }
     VMI_SSTAMP(3);
 
-    // ---- my share of the softmax statistics: max over my tokens, sum of exp relative to it ----
-    const float m_w = wave_max(qk_max);
-    float e_sum = 0.f;
-    for (int t = lane; t < nmy * BS; t += 64) {
-      const int token = (w + (t >> 4) * NWe) * BS + (t & 15);
-      e_sum += token < L ? __expf(lg[t] - m_w) : 0.f;
+    if constexpr (QKM) {  // per-head maxima live in lanes (lane & 15) = head: fold the four row groups, then hand out
+      qmaxB = fmaxf(qmaxB, __shfl_xor(qmaxB, 16));
+      qmaxB = fmaxf(qmaxB, __shfl_xor(qmaxB, 32));
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) qk_max[hh] = __shfl(qmaxB, hh);
     }
-    const float s_w = wave_sum(e_sum);
+    // ---- my share of the softmax statistics, per head: max over my tokens, sum of exp relative to it ----
+    float M[HPT], S[HPT];
+#pragma unroll
+    for (int hh = 0; hh < HPT; ++hh) {
+      const float m_w = wave_max(qk_max[hh]);
+      float e_sum = 0.f;
+      for (int t = lane; t < nmy * BS; t += 64) {
+        const int token = (w + (t >> 4) * NWe) * BS + (t & 15);
+        e_sum += token < L ? __expf(lg0[hh * wtok + t] - m_w) : 0.f;
+      }
+      M[hh] = m_w;
+      S[hh] = wave_sum(e_sum);
+    }
 
-    float M = m_w, S = s_w;
     if (na > 1) {
-      gu64_t* sl = (gu64_t*)sp.slots + (size_t)item * NW;
-      if (lane == 0) {
-        const unsigned long long g8 = (unsigned long long)__builtin_bit_cast(uint32_t, m_w) |
-                                      ((unsigned long long)__builtin_bit_cast(uint32_t, s_w) << 32);  // s_w >= 1: never 0
-        __hip_atomic_store(sl + w, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gu64_t* sl = (gu64_t*)sp.slots + (size_t)item * HPT * NW;   // + hh * NW
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        if (lane == hh) {
+          const unsigned long long g8 = (unsigned long long)__builtin_bit_cast(uint32_t, M[hh]) |
+                                        ((unsigned long long)__builtin_bit_cast(uint32_t, S[hh]) << 32);  // sum >= 1: never 0
+          __hip_atomic_store(sl + hh * NW + w, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       VMI_SSTAMP(4);
-      // one lane per granule, up to SLOTS_PER_LANE passes of 64: every wave of the item reads all na granules
-      unsigned long long x[SLOTS_PER_LANE];
+      // one lane per granule (and head), up to SPL passes of 64: every wave of the item reads all na granules of every head
+      unsigned long long x[HPT][SPL];
 #pragma unroll
-      for (int q = 0; q < SLOTS_PER_LANE; ++q) x[q] = 1ull << 32;
+      for (int hh = 0; hh < HPT; ++hh)
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) x[hh][q] = 1ull << 32;
       for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
-        for (int q = 0; q < SLOTS_PER_LANE; ++q) {
-          if (lane + 64 * q < na) x[q] = __hip_atomic_load(sl + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && (x[q] >> 32) != 0ull;
-        }
+        for (int hh = 0; hh < HPT; ++hh)
+#pragma unroll
+          for (int q = 0; q < SPL; ++q) {
+            if (lane + 64 * q < na) x[hh][q] = __hip_atomic_load(sl + hh * NW + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (x[hh][q] >> 32) != 0ull;
+          }
         if (__all(ok)) break;
         if (spins >= SPLIT_SPIN_LIMIT) {  // never on a healthy launch; finish with wrong numbers rather than hang the device
           if (lane == 0) atomicAdd(sp.status, 1u);
@@ -265,27 +336,33 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      float mj[SLOTS_PER_LANE], sj[SLOTS_PER_LANE], mloc = -FLT_MAX;
 #pragma unroll
-      for (int q = 0; q < SLOTS_PER_LANE; ++q) {
-        const bool has = lane + 64 * q < na;
-        mj[q] = has ? __builtin_bit_cast(float, (uint32_t)x[q]) : -FLT_MAX;
-        sj[q] = has ? __builtin_bit_cast(float, (uint32_t)(x[q] >> 32)) : 0.f;
-        mloc = fmaxf(mloc, mj[q]);
+      for (int hh = 0; hh < HPT; ++hh) {
+        float mj[SPL], sj[SPL], mloc = -FLT_MAX;
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+          const bool has = lane + 64 * q < na;
+          mj[q] = has ? __builtin_bit_cast(float, (uint32_t)x[hh][q]) : -FLT_MAX;
+          sj[q] = has ? __builtin_bit_cast(float, (uint32_t)(x[hh][q] >> 32)) : 0.f;
+          mloc = fmaxf(mloc, mj[q]);
+        }
+        M[hh] = wave_max(mloc);
+        float sloc = 0.f;
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) sloc += sj[q] * __expf(mj[q] - M[hh]);
+        S[hh] = wave_sum(sloc);  // the same values in the same lanes in every wave of the item: one S for all
       }
-      M = wave_max(mloc);
-      float sloc = 0.f;
-#pragma unroll
-      for (int q = 0; q < SLOTS_PER_LANE; ++q) sloc += sj[q] * __expf(mj[q] - M);
-      S = wave_sum(sloc);  // the same values in the same lanes in every wave of the item: one S for all
     }
     VMI_SSTAMP(5);
-    const float inv = __builtin_amdgcn_rcpf(S + 1e-6f);  // :342
 
     // ---- probabilities of my tokens, rounded to fp16 once (:398-400); positions past the context become 0 ----
-    for (int t = lane; t < nmy * BS; t += 64) {
-      const int token = (w + (t >> 4) * NWe) * BS + (t & 15);
-      ph[t] = token < L ? to_elem<false>(__expf(lg[t] - M) * inv) : (uint16_t)0;
+#pragma unroll
+    for (int hh = 0; hh < HPT; ++hh) {
+      const float inv = __builtin_amdgcn_rcpf(S[hh] + 1e-6f);  // :342
+      for (int t = lane; t < nmy * BS; t += 64) {
+        const int token = (w + (t >> 4) * NWe) * BS + (t & 15);
+        ph0[hh * wtok + t] = token < L ? to_elem<false>(__expf(lg0[hh * wtok + t] - M[hh]) * inv) : (uint16_t)0;
+      }
     }
 
     // ---- V pass ----
@@ -298,19 +375,31 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
           const int b = w + idx * NWe;
           const int token0 = b * BS + hf * EPU;
           const bool last = (b == nblk - 1);
-          PV8<false> pv;
-          pv.load(*reinterpret_cast<const u32x4_alias*>(ph + idx * BS + hf * EPU));
-          if constexpr (F8) {  // a 16-byte unit is a whole 16-token row: two of the reference's 8-token groups
-            PV8<false> pw;
-            pw.load(*reinterpret_cast<const u32x4_alias*>(ph + idx * BS + 8));
+          u32x4 vd[F8 ? NL : 1][2];  // fp8 pages: the tile decoded once, whatever the number of heads
+          if constexpr (F8) {
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
-              acc[i] += pv.template dot<MASK>(deq8<false>(r[j][i][0], r[j][i][1], p.kv_scale), last, token0, L);
-              acc[i] += pw.template dot<MASK>(deq8<false>(r[j][i][2], r[j][i][3], p.kv_scale), last, token0 + 8, L);
+              vd[i][0] = deq8<false>(r[j][i][0], r[j][i][1], p.kv_scale);
+              vd[i][1] = deq8<false>(r[j][i][2], r[j][i][3], p.kv_scale);
             }
-          } else {
+          }
 #pragma unroll
-            for (int i = 0; i < NL; ++i) acc[i] += pv.template dot<MASK>(r[j][i], last, token0, L);
+          for (int hh = 0; hh < HPT; ++hh) {
+            const uint16_t* php = ph0 + hh * wtok + idx * BS;
+            PV8<false> pv;
+            pv.load(*reinterpret_cast<const u32x4_alias*>(php + hf * EPU));
+            if constexpr (F8) {  // a 16-byte unit is a whole 16-token row: two of the reference's 8-token groups
+              PV8<false> pw;
+              pw.load(*reinterpret_cast<const u32x4_alias*>(php + 8));
+#pragma unroll
+              for (int i = 0; i < NL; ++i) {
+                acc[hh][i] += pv.template dot<MASK>(vd[F8 ? i : 0][0], last, token0, L);
+                acc[hh][i] += pw.template dot<MASK>(vd[F8 ? i : 0][1], last, token0 + 8, L);
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < NL; ++i) acc[hh][i] += pv.template dot<MASK>(r[j][i], last, token0, L);
+            }
           }
         }
       }
@@ -331,42 +420,49 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
       if (s < ngroups) compute_v(std::false_type{}, rb, last - s);
     }
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
+    for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
-      for (int mm = 1; mm < UPR; mm <<= 1) acc[i] += __shfl_xor(acc[i], mm);  // the 8-token groups of a row held by other lanes
+      for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int mm = 1; mm < UPR; mm <<= 1) acc[hh][i] += __shfl_xor(acc[hh][i], mm);  // the 8-token groups of a row held by other lanes
   }
   VMI_SSTAMP(6);
 
   // ---- partial outputs: the workgroup's waves meet in LDS, the item's workgroups in the workspace ----
+  constexpr int HD = HPT * D;   // floats of an item's output rows
   const int nwa = (na - g * wpg) < wpg ? (na - g * wpg) : wpg;  // waves of this workgroup that own blocks
   if (hf == 0) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) osm[wave * D + RPL * i + rowl] = acc[i];
+    for (int hh = 0; hh < HPT; ++hh)
+#pragma unroll
+      for (int i = 0; i < NL; ++i) osm[(wave * HPT + hh) * D + RPL * i + rowl] = acc[hh][i];
   }
   lds_barrier();
-  int* last_flag = reinterpret_cast<int*>(osm + wpg * D);
-  gu64_t* my_slots = (gu64_t*)sp.slots + (size_t)item * NW;
+  int* last_flag = reinterpret_cast<int*>(osm + wpg * HD);
+  gu64_t* my_slots = (gu64_t*)sp.slots + (size_t)item * HPT * NW;
   auto reset_slots = [&]() {  // every wave of the item has read the granules by now: back to "not published"
 #pragma unroll
-    for (int q = 0; q < SLOTS_PER_LANE; ++q)
-      if (lane + 64 * q < na) __hip_atomic_store(my_slots + lane + 64 * q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int hh = 0; hh < HPT; ++hh)
+#pragma unroll
+      for (int q = 0; q < SPL; ++q)
+        if (lane + 64 * q < na) __hip_atomic_store(my_slots + hh * NW + lane + 64 * q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   if (wave == 0) {
-    float part[D / 64];
+    float part[HD / 64];
 #pragma unroll
-    for (int k = 0; k < D / 64; ++k) {
+    for (int k = 0; k < HD / 64; ++k) {
       float ssum = 0.f;
-      for (int wv = 0; wv < nwa; ++wv) ssum += osm[wv * D + lane + 64 * k];
+      for (int wv = 0; wv < nwa; ++wv) ssum += osm[wv * HD + lane + 64 * k];
       part[k] = ssum;
     }
     if (ga == 1) {
 #pragma unroll
-      for (int k = 0; k < D / 64; ++k) outp[lane + 64 * k] = to_elem<false>(part[k]);
+      for (int k = 0; k < HD / 64; ++k) outp[lane + 64 * k] = to_elem<false>(part[k]);
       if (na > 1) reset_slots();  // (my own waves exchanged through the workspace; all of them are past the barrier)
     } else {
-      gf32_t* mine = (gf32_t*)sp.partials + ((size_t)item * G + g) * D;
+      gf32_t* mine = (gf32_t*)sp.partials + ((size_t)item * G + g) * HD;
 #pragma unroll
-      for (int k = 0; k < D / 64; ++k) __hip_atomic_store(mine + lane + 64 * k, part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < HD / 64; ++k) __hip_atomic_store(mine + lane + 64 * k, part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the payload has left before the arrival is counted
       unsigned old = 0;
       if (lane == 0) {
@@ -380,30 +476,31 @@ __global__ void __launch_bounds__(256, D == 64 ? 6 : 3) pa_split_kernel(const PA
     if (*last_flag) {
       // The item's last workgroup adds the partial rows — its four waves a quarter each (wave k: workgroups k, k + 4, ...),
       // then wave 0 the four sums: an order fixed by ga alone, whatever the arrival order.
-      const gf32_t* all = (const gf32_t*)sp.partials + (size_t)item * G * D;
-      float o[D / 64];
+      const gf32_t* all = (const gf32_t*)sp.partials + (size_t)item * G * HD;
+      float o[HD / 64];
 #pragma unroll
-      for (int k = 0; k < D / 64; ++k) o[k] = 0.f;
-      for (int g0 = wave; g0 < ga; g0 += 8 * wpg) {
-        float t8[8][D / 64];
+      for (int k = 0; k < HD / 64; ++k) o[k] = 0.f;
+      constexpr int QB = HPT > 1 ? 2 : 8;   // workgroups' rows in flight per trip
+      for (int g0 = wave; g0 < ga; g0 += QB * wpg) {
+        float t8[QB][HD / 64];
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < QB; ++q)
 #pragma unroll
-          for (int k = 0; k < D / 64; ++k)
-            t8[q][k] = (g0 + q * wpg < ga) ? __hip_atomic_load(all + (size_t)(g0 + q * wpg) * D + lane + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          for (int k = 0; k < HD / 64; ++k)
+            t8[q][k] = (g0 + q * wpg < ga) ? __hip_atomic_load(all + (size_t)(g0 + q * wpg) * HD + lane + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < QB; ++q)
 #pragma unroll
-          for (int k = 0; k < D / 64; ++k) o[k] += t8[q][k];
+          for (int k = 0; k < HD / 64; ++k) o[k] += t8[q][k];
       }
 #pragma unroll
-      for (int k = 0; k < D / 64; ++k) osm[wave * D + lane + 64 * k] = o[k];
+      for (int k = 0; k < HD / 64; ++k) osm[wave * HD + lane + 64 * k] = o[k];
       lds_barrier();
       if (wave == 0) {
 #pragma unroll
-        for (int k = 0; k < D / 64; ++k) {
+        for (int k = 0; k < HD / 64; ++k) {
           float ssum = 0.f;
-          for (int wv = 0; wv < wpg; ++wv) ssum += osm[wv * D + lane + 64 * k];
+          for (int wv = 0; wv < wpg; ++wv) ssum += osm[wv * HD + lane + 64 * k];
           outp[lane + 64 * k] = to_elem<false>(ssum);
         }
         reset_slots();

@@ -463,7 +463,7 @@ static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_si
     int best = 0;
     for (int id = 1; id <= nvariants_v1(); ++id) {
       const Variant& c = variant_v1(id);
-      if (!c.GQS || c.FPV != fpv || c.BF != bf || c.F8 != f8 || c.D != head_size || c.BS != block_size || c.HPT != g ||
+      if (!c.GQS || c.XW || c.FPV != fpv || c.BF != bf || c.F8 != f8 || c.D != head_size || c.BS != block_size || c.HPT != g ||
           !fits(c))
         continue;
       if (wph == 1 ? (c.WPH == 1 && (num_heads / g) % c.HPW == 0)
@@ -476,7 +476,7 @@ static int pick_variant_gqa_of(int num_seqs, int num_heads, int qpk, int head_si
     if (best) return best;
     for (int id = 1; id <= nvariants_v1(); ++id) {  // no kernel of the wanted shape: any kernel of this group size
       const Variant& c = variant_v1(id);
-      if (c.GQS && c.FPV == fpv && c.BF == bf && c.F8 == f8 && c.D == head_size && c.BS == block_size && c.HPT == g &&
+      if (c.GQS && !c.XW && c.FPV == fpv && c.BF == bf && c.F8 == f8 && c.D == head_size && c.BS == block_size && c.HPT == g &&
           (num_heads / g) % c.HPW == 0 && fits(c) && units * c.WPH * 4 >= units * wph)  // at most 4x fewer waves than wanted
         return id;
     }
@@ -831,14 +831,14 @@ static int fit_lds(int variant, int head_size, int block_size, int lpad, bool bf
 // ---- split kernels (pa_split.hpp): a (sequence, head) over XW waves = XW / 4 workgroups of one launch ----
 // Every workgroup of the launch must be resident (an item's waves wait for one another): the kernels' launch bounds hold
 // them to six 4-wave workgroups per CU at head size 64 and three at 128; the picks below ask for at most split_wgs_per_cu.
-static inline int split_resident_wgs(int head_size) {
-  const int n = (head_size == 64 ? 6 : 3) * g_cus;
+static inline int split_resident_wgs(int head_size, int hpt = 1) {
+  const int n = (hpt > 1 ? (head_size == 64 ? 4 : 2) : (head_size == 64 ? 6 : 3)) * g_cus;   // the kernels' launch bounds
   return n < SPLIT_MAX_WGS ? n : SPLIT_MAX_WGS;
 }
-static int find_split(int D, int xw, int U, int nt, int f8 = 0) {
+static int find_split(int D, int xw, int U, int nt, int f8 = 0, int hpt = 1) {
   for (int i = 0; i < g_split_nvariants; ++i) {
     const Variant& c = g_split_variants[i];
-    if (c.D == D && c.XW == xw && c.U == U && c.NT == (bool)nt && c.F8 == f8)
+    if (c.D == D && c.XW == xw && c.U == U && c.NT == (bool)nt && c.F8 == f8 && c.HPT == hpt)
       return nvariants_v1() - g_stage_nvariants - g_split_nvariants + i + 1;
   }
   return 0;
@@ -870,36 +870,58 @@ static int pick_split(int num_seqs, int num_heads, int head_size, int block_size
   const long item_bytes = 4L * max_seq_len * head_size;   // K and V pages of one (sequence, head)
   bool few = units * R.split_max_units_den <= (long)g_cus * R.split_max_units_num;
   bool big = item_bytes >= R.split_min_item_bytes_per_unit * units && item_bytes >= R.split_min_item_bytes;
+  int hpt = 1;   // query heads per item
   if (qpk > 1) {
     // Grouped-query heads: the alternative is a gq kernel that keeps a KV head's whole context on one CU, and it loses from
     // 1024 tokens on wherever the split launch stays within the resident workgroups (r05i_split_gqa_sweep_rocprof.json:
     // 32 / 8 heads x 128, batch 1 ... 4 x 1024 ... 8192 tokens 0.60 ... 0.13 of the gq kernel's time; 16 / 4 x 64 up to batch
-    // 16: 0.96 ... 0.14) — except with as many query heads as CUs at head size 128 (two workgroups per item: 1.1 - 1.2 x)
-    few = units * (head_size == 128 ? 2 : 1) <= (long)g_cus;
+    // 16: 0.96 ... 0.14).  Two forms (r05l_split_gq4_rocprof.json): ONE query head per item — every query head's waves read
+    // their KV head's tiles themselves, the repeats hit L2 — is ahead while query heads < CUs / 2 (32 / 8 x 128, batch 1 x 8192:
+    // 19.7 against 22.8 us); FOUR query heads of a KV head per item — every tile loaded once, q.K^T on the matrix cores — from
+    // CUs / 2 query heads on (batch 4 x 8192: 43 -> 35 us; batch 8 x 4096 / 8192, where the first form no longer fits: 64 / 164
+    // -> 34 / 58), up to CUs / 2 such items.
     big = max_seq_len >= R.split_gqa_min_tokens;
+    if (qpk % 4 == 0 && !f8 && units * 2 >= (long)g_cus) {
+      hpt = 4;
+      few = (units / 4) * 2 <= (long)g_cus;
+      if ((units / 4) * 4 > (long)g_cus) big = max_seq_len >= 2 * R.split_gqa_min_tokens;   // (128 such items at 1024 tokens: 23.9 against 22.9 us)
+    } else {
+      few = units * (head_size == 128 ? 2 : 1) <= (long)g_cus;
+    }
   }
   if (!starved && !(few && big)) return 0;
+  const long nitems = units / hpt;
   const int nblk = (max_seq_len + 15) / 16;
-  const long cap = (long)R.split_wgs_per_cu * g_cus;   // workgroups the launch may have (all resident)
+  // workgroups the launch may have (all resident; four heads per item: their partial rows bound it too)
+  long cap = (long)R.split_wgs_per_cu * g_cus;
+  if (hpt > 1) cap = cap < split_resident_wgs(head_size, hpt) ? cap : split_resident_wgs(head_size, hpt);
+  if (hpt > 1 && cap > SPLIT_MAX_WGS / hpt) cap = SPLIT_MAX_WGS / hpt;
   // the most waves per item such that the launch's workgroups fit the CUs once with >= 4 blocks per wave, or up to
   // split_wgs_per_cu times with >= 16 (a loaded chip's exchange is slower: batch 4 at 4096 tokens 21.3 us on 768 workgroups of
   // 4-block waves, 16.3 on 384 of 8-block ones, 19.0 unsplit; batch 2 at 16384 tokens 27.3 us on 768 workgroups, 22.8 on 384)
   const int lpad = (int)lpad32(max_seq_len);
-  auto lds_fits = [&](int x) { return (size_t)4 * ((size_t)split_wtok(lpad, x) * 6 + (size_t)head_size * 4) + 16 <= R.lds_per_cu; };
+  auto lds_fits = [&](int x) { return (size_t)4 * hpt * ((size_t)split_wtok(lpad, x) * 6 + (size_t)head_size * 4) + 16 <= R.lds_per_cu; };
   int xw = 0;
-  for (int x = SPLIT_MAX_WAVES; x >= 8; x /= 2) {
-    const long wgs = units * (x / 4);
+  for (int x = hpt > 1 ? 64 : SPLIT_MAX_WAVES; x >= 8; x /= 2) {
+    const long wgs = nitems * (x / 4);
     const int bpw = nblk / x;
     if (lds_fits(x) &&
         ((wgs <= g_cus && bpw >= R.split_min_blocks_per_wave) || (wgs <= cap && bpw >= R.split_min_blocks_per_wave_loaded))) { xw = x; break; }
   }
   if (!xw && starved) {   // more items than that: the widest form that is resident
     for (int x = 64; x >= 8; x /= 2)
-      if (units * (x / 4) <= split_resident_wgs(head_size) && lds_fits(x)) { xw = x; break; }
+      if (nitems * (x / 4) <= split_resident_wgs(head_size, hpt) && nitems * (x / 4) * hpt <= SPLIT_MAX_WGS && lds_fits(x)) { xw = x; break; }
   }
   if (!xw) return 0;
   const double kv_bytes = (f8 ? 2.0 : 4.0) * (double)units / (double)(qpk > 0 ? qpk : 1) * (double)max_seq_len * head_size;
-  const int nt = kv_bytes > R.nt_kv_bytes ? 1 : 0;
+  // (one query head per item over grouped-query heads: the other query heads' reads of a tile must HIT L2 — never non-temporal:
+  //  32 / 8 x 128, batch 4 x 8192 tokens 43.2 us with temporal loads, 62.8 with non-temporal ones)
+  const int nt = (kv_bytes > R.nt_kv_bytes && !(qpk > 1 && hpt == 1)) ? 1 : 0;
+  if (hpt > 1) {
+    int vg = find_split(head_size, xw, head_size == 64 ? 2 : 1, nt, 0, hpt);
+    if (!vg) vg = find_split(head_size, xw, head_size == 64 ? 1 : 2, nt, 0, hpt);
+    return vg;
+  }
   int v = f8 ? find_split(head_size, xw, 4, nt, f8) : 0;   // (fp8 pages, half-size tiles: four blocks per group 3 - 5 % ahead of two)
   if (!v) v = find_split(head_size, xw, 2, nt, f8);   // (two blocks per register group: ahead of one in 23 of 25 cells)
   if (!v) v = find_split(head_size, xw, 1, nt, f8);
@@ -948,7 +970,7 @@ static int device_cus(int device) {  // caller holds the device current
 // dynamic LDS a kernel needs for logits rows of `lpad` floats (max_seq_len padded to 32)
 static size_t variant_lds_bytes(const Variant& c, int lpad) {
   if (c.XW)     // per wave: its share of the logits (fp32) and probabilities (fp16) + one partial output row
-    return (size_t)c.WPH * ((size_t)split_wtok(lpad, c.XW) * 6 + (size_t)c.D * 4) + 16;   // + the "I am last" flag
+    return (size_t)c.WPH * c.HPT * ((size_t)split_wtok(lpad, c.XW) * 6 + (size_t)c.D * 4) + 16;   // + the "I am last" flag
   if (c.STAGE)  // per wave: the logits + a ring of U slots, each one (block, head) tile
     return (size_t)4 * ((size_t)lpad * 4 + (size_t)c.U * (c.D * 16 * (c.F8 ? 1 : 2)));
   if (c.QUEUE)  // 4 waves' logits + the ranking, its bucket counts and masks + a team's exchange buffers (pa_queue.hpp)
@@ -1121,13 +1143,16 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
       return fail(VMI_E_WORKSPACE, "paged_attention_v1: variant %s spreads a (sequence, head) over several workgroups and needs a "
                   "16-byte aligned workspace of vmi_paged_attention_v1_workspace_bytes() = %zu bytes (got %p, %lld)", v.name,
                   pa_split_layout(head_size).bytes, workspace, (long long)workspace_bytes);
-    const int64_t wgs = (int64_t)num_seqs * num_heads * (v.XW / v.WPH);
-    if (wgs > 0x7fffffff || (int64_t)num_seqs * num_heads * v.XW > (int64_t)SPLIT_MAX_WGS * 4)
+    if (num_heads % v.HPT)
+      return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s takes %d query heads of one KV head per item, got num_heads = %d",
+                  v.name, v.HPT, num_heads);
+    const int64_t wgs = (int64_t)num_seqs * (num_heads / v.HPT) * (v.XW / v.WPH);
+    if (wgs > 0x7fffffff || (int64_t)num_seqs * num_heads * v.XW > (int64_t)SPLIT_MAX_WGS * 4 || wgs * v.HPT > SPLIT_MAX_WGS)
       return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s would launch %lld workgroups (the workspace holds the granules "
                   "of %d waves)", v.name, (long long)wgs, SPLIT_MAX_WGS * 4);
-    if (v.XW > v.WPH && wgs > split_resident_wgs(head_size))   // (one workgroup per item: nothing waits across workgroups)
+    if (v.XW > v.WPH && wgs > split_resident_wgs(head_size, v.HPT))   // (one workgroup per item: nothing waits across workgroups)
       return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s would launch %lld workgroups; the split kernels need every "
-                  "workgroup resident (at most %d on this device)", v.name, (long long)wgs, split_resident_wgs(head_size));
+                  "workgroup resident (at most %d on this device)", v.name, (long long)wgs, split_resident_wgs(head_size, v.HPT));
   }
   const size_t lds = lds_of(v);
   if (lds > 160 * 1024)
@@ -1210,7 +1235,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
     sp.nw = v.XW;
     sp.wtok = split_wtok(lpad, v.XW);
     sp.flags = g_split_flags;
-    const unsigned grid = (unsigned)((int64_t)num_seqs * num_heads * (v.XW / v.WPH));
+    const unsigned grid = (unsigned)((int64_t)num_seqs * (num_heads / v.HPT) * (v.XW / v.WPH));
     hipLaunchKernelGGL(reinterpret_cast<pa_split_kernel_t>(v.fn), dim3(grid), dim3(v.WPH * 64), lds,
                        static_cast<hipStream_t>(stream), p, sp);
     e = hipGetLastError();
