@@ -780,17 +780,19 @@ def cfg2_record(args, dist, rank, world, dev):
 
 
 def long_context_record(args, dev):
-    """Few sequences x long contexts (batch 1 x 16384 tokens and batch 4 x 8192, 12 heads x 64): the regime the reference's
+    """Few sequences x long contexts (batch 1 x 16384 tokens and batch 4 x 8192 at 12 heads x 64; batch 4 x 8192 at 32 / 8
+    grouped-query heads x 128): the regime the reference's
     scheduler runs (one sequence at a time, scheduler.py:60) at today's context lengths.  The same default entry with and
     without the wrapper's workspace (round 5: with one, paged_attention_v1 spreads each (sequence, head) over up to 64 waves on
     as many CUs — vmi_paged_attention_v1_f16_ws, pa_split.hpp).  Device time per attention launch, 24 launches per hipGraph."""
     from vllmini_amd import ops
-    out = {"op": "paged_attention_v1, default entry, fp16, 12 heads x 64, block_size 16", "unit": "us per attention launch (hipGraph of 24)"}
-    for name in ("long_b1", "long_b4"):
+    out = {"op": "paged_attention_v1, default entry, fp16, block_size 16", "unit": "us per attention launch (hipGraph of 24)"}
+    for name in ("long_b1", "long_b4", "long_gqa"):
         c = CONFIGS[name]
         wl = make_workload(c, dev, seed=17, table_sets=2)
         o = torch.empty((c.batch, c.num_heads, c.head_size), dtype=torch.float16, device=dev)
-        rec = {"batch": c.batch, "seq_len": c.seq_len, "algorithmic_bytes_per_launch": alg_bytes(c, "auto")}
+        rec = {"batch": c.batch, "seq_len": c.seq_len, "heads": f"{c.num_heads} / {c.kv_heads} x {c.head_size}",
+               "algorithmic_bytes_per_launch": alg_bytes(c, "auto")}
         for key, on in (("with_workspace", True), ("without_workspace", False)):
             prev = ops.set_workspace_enabled(on)
             try:

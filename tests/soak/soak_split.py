@@ -1,6 +1,6 @@
 """Soak run of the SPLIT kernels (vllmini_amd/csrc/pa_split.hpp) on the PRODUCT library: one (sequence, head) over several
-workgroups of one launch that meet in the wrapper's workspace.  What the unit tests do not vary: random batches of 1 .. 12
-sequences, 1 .. 16 heads (grouped KV heads sometimes), head size 64 / 128, contexts up to 20 000 tokens with every length
+workgroups of one launch that meet in the wrapper's workspace.  What the unit tests do not vary: random batches of 1 .. 48
+sequences (the larger ones in rounds), 1 .. 16 heads (grouped KV heads sometimes), head size 64 / 128, contexts up to 20 000 tokens with every length
 distribution of soak_auto (equal, uniform, one long among one-token sequences, empty ones), max_seq_len at the longest length
 or a capacity far above it, ALiBi sometimes — and, as the hand-off rules demand (MI355X_MICROARCH.md: "test every hand-off
 under UNEVEN load, consumer L1-warm"), HALF the cases run while another stream streams through a 1 GiB buffer, and every case
@@ -33,7 +33,7 @@ for seed in range(first, first + n_cases):
     qpk = int(rng.choice([1, 1, 2, 4]))
     hkv = int(rng.choice([1, 2, 3, 4]))
     H = hkv * qpk
-    B = int(rng.choice([1, 1, 2, 3, 4, 8, 12]))
+    B = int(rng.choice([1, 1, 2, 3, 4, 8, 12, 24, 48]))      # (24 / 48: more workgroups than are resident -> in rounds)
     top = int(rng.choice([40, 700, 2048, 4096, 9000, 20000], p=[.1, .15, .2, .25, .2, .1]))
     if B * H * top > 1.2e6:
         top = max(64, int(1.2e6 / (B * H)))

@@ -1420,6 +1420,7 @@ struct Variant {
   bool KM;           // balanced kernels: q.K^T of the K pass on the matrix cores (pa_queue.hpp); "m" names
   int XW;            // split kernels (pa_split.hpp): waves per (sequence, head), spread over XW / WPH workgroups that meet in a
                      //   caller-owned workspace; 0 = not a split kernel.  fn is a pa_split_kernel_t there
+  pa_kernel_t fn_rounds;  // split kernels: the same kernel serving more items than are resident in rounds (nullptr: none)
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);

@@ -4,25 +4,28 @@
 // The waves per item are a launch parameter, so the rows of one (head, u, nt) share a kernel.  A workgroup holds the logits
 // and probabilities of ITS waves' blocks only (6 bytes per token / workgroups per item), so max_seq_len is bounded by
 // 27 000 tokens x workgroups per item — where the plain kernels stop at ~27 000 and fall back to one wave per head.
+// Every row has a twin (Variant::fn_rounds) that serves more items than fit the chip at once in rounds.
 #include "pa_split.hpp"
 
 namespace vmi {
 
 #define VMI_ROW_X(D, X, U, NT, VA)                                                                                  \
   {"d" #D "_x" #X "_u" #U "_nt" #NT, D, 16, 1, 4, U, (bool)(NT), 1, false, (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA>, \
-   0, 0, 0, 0, false, false, false, false, false, false, X},
+   0, 0, 0, 0, false, false, false, false, false, false, X, (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 0, 1, true>},
 #define VMI_ROWS_X(D, U, NT, VA) \
   VMI_ROW_X(D, 8, U, NT, VA) VMI_ROW_X(D, 16, U, NT, VA) VMI_ROW_X(D, 32, U, NT, VA) VMI_ROW_X(D, 64, U, NT, VA) VMI_ROW_X(D, 128, U, NT, VA) VMI_ROW_X(D, 256, U, NT, VA)
 
 #define VMI_ROW_X8(D, X, U, NT, VA) /* fp8 E4M3 pages */                                                             \
   {"fp8_d" #D "_x" #X "_u" #U "_nt" #NT, D, 16, 1, 4, U, (bool)(NT), 1, false,                                       \
-   (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 1>, 0, 0, 0, 1, false, false, false, false, false, false, X},
+   (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 1>, 0, 0, 0, 1, false, false, false, false, false, false, X,    \
+   (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 1, 1, true>},
 #define VMI_ROWS_X8(D, U, NT, VA) \
   VMI_ROW_X8(D, 8, U, NT, VA) VMI_ROW_X8(D, 16, U, NT, VA) VMI_ROW_X8(D, 32, U, NT, VA) VMI_ROW_X8(D, 64, U, NT, VA) VMI_ROW_X8(D, 128, U, NT, VA)
 
 #define VMI_ROW_XG(D, X, U, NT, VA) /* grouped-query: four query heads of one KV head per item, every tile loaded once */ \
   {"d" #D "_gq4_x" #X "_u" #U "_nt" #NT, D, 16, 1, 4, U, (bool)(NT), 4, false,                                       \
-   (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 0, 4>, 0, 0, 0, 0, true, false, false, false, false, false, X},
+   (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 0, 4>, 0, 0, 0, 0, true, false, false, false, false, false, X,  \
+   (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 0, 4, true>},
 #define VMI_ROWS_XG(D, U, NT, VA) VMI_ROW_XG(D, 8, U, NT, VA) VMI_ROW_XG(D, 16, U, NT, VA) VMI_ROW_XG(D, 32, U, NT, VA) VMI_ROW_XG(D, 64, U, NT, VA)
 
 Variant g_split_variants[] = {

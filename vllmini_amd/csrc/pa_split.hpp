@@ -44,6 +44,7 @@ constexpr int SPF_GMAJOR = 1;        // workgroup index = g * items + item (an i
 constexpr int SLOTS_PER_LANE = 4;     // granules a lane reads in the poll
 constexpr int SPLIT_MAX_WAVES = 64 * SLOTS_PER_LANE;
 constexpr unsigned SPLIT_SPIN_LIMIT = 1u << 20;
+constexpr int SPLIT_MAX_ITEMS = 8192;  // arrival counters in the workspace: [0, 4096) by item / place-and-round, [4096, 8192) rounds finished by place
 
 #ifdef VMI_DIAG
 // diagnostic library: eight stamps per wave (100 MHz clock): entry, lengths known, first K group consumed, K pass done,
@@ -58,6 +59,13 @@ typedef unsigned long long __attribute__((address_space(1))) gu64_t;
 typedef unsigned int __attribute__((address_space(1))) gu32_t;
 typedef float __attribute__((address_space(1))) gf32_t;
 
+// Workgroups per CU the kernels are compiled for (launch bounds; what the host counts as resident).  The kernels that go in
+// rounds run where LDS, not registers, bounds the occupancy (long contexts): half the workgroups, twice the registers.
+__host__ __device__ constexpr int split_wgs_per_cu(int D, int HPT, bool rounds) {
+  const int n = HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 6 : 3);
+  return rounds ? (n + 1) / 2 : n;
+}
+
 // D head size (64 | 128), U blocks per register group, NT non-temporal page loads, VA V groups requested in front of
 // the exchange (1 | 2), F8 = 1: the pages hold fp8 E4M3 bytes (K [NB, H, D/16, 16, 16], V [NB, H, D, 16]; every element becomes
 // half(float(fp8) * kv_scale) first, reference quant_utils.cuh:295-300, then the fp16 arithmetic applies unchanged).
@@ -68,8 +76,8 @@ typedef float __attribute__((address_space(1))) gf32_t;
 // Block size 16, fp16 query.  grid = items * (nw / wpg), block = wpg * 64.
 // Launch bounds: six (head size 128: three; grouped: four / two) workgroups per CU — what the host counts as resident.
 // LDS = wpg * HPT * (wtok * 4 (logits) + wtok * 2 (probabilities) + D * 4 (partial out)) + 16 (the "I am last" flag).
-template <int D, int U, bool NT, int VA, int F8 = 0, int HPT = 1>
-__global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 6 : 3)) pa_split_kernel(const PAParams p, const PASplit sp) {
+template <int D, int U, bool NT, int VA, int F8 = 0, int HPT = 1, bool ROUNDS = false>
+__global__ void __launch_bounds__(256, split_wgs_per_cu(D, HPT, ROUNDS)) pa_split_kernel(const PAParams p, const PASplit sp) {
   constexpr int BS = 16;
   constexpr int EPU = F8 ? 16 : 8;       // cache elements per 16-byte unit
   constexpr int ES = F8 ? 1 : 2;         // bytes per cache element
@@ -95,13 +103,21 @@ __global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 
   const int G = NW / wpg;
   const int hgroups = p.num_heads / HPT;     // items per sequence
   const int items = p.num_seqs * hgroups;
+  // Workgroup vb of the launch's items * G serves workgroup vb % G of item vb / G.  Usually the grid IS that many workgroups (all
+  // resident).  With more items than are resident the grid is a multiple of G that is, and a workgroup serves vb = blockIdx.x,
+  // blockIdx.x + gridDim.x, ... in ROUNDS: the G workgroups of an item sit at the same places of the grid in the same round, so
+  // an item's waves always run together.  The workspace is indexed by the PLACE in the grid (not by the item), two regions
+  // alternating by round (see the loop at the end).
+  const int total = items * G;
+  constexpr bool looped = ROUNDS;   // (a kernel of its own: the loop costs the one-round kernels registers)
+  auto process = [&](int vb, int wsi) {
   int item, g;
   if (sp.flags & SPF_GMAJOR) {
-    g = blockIdx.x / items;
-    item = blockIdx.x - g * items;
+    g = vb / items;
+    item = vb - g * items;
   } else {
-    item = blockIdx.x / G;
-    g = blockIdx.x - item * G;
+    item = vb / G;
+    g = vb - item * G;
   }
   const int seq = item / hgroups;
   const int head0 = (item - seq * hgroups) * HPT;
@@ -304,7 +320,7 @@ __global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 
     }
 
     if (na > 1) {
-      gu64_t* sl = (gu64_t*)sp.slots + (size_t)item * HPT * NW;   // + hh * NW
+      gu64_t* sl = (gu64_t*)sp.slots + (size_t)wsi * HPT * NW;   // + hh * NW
 #pragma unroll
       for (int hh = 0; hh < HPT; ++hh) {
         if (lane == hh) {
@@ -439,7 +455,7 @@ __global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 
   }
   lds_barrier();
   int* last_flag = reinterpret_cast<int*>(osm + wpg * HD);
-  gu64_t* my_slots = (gu64_t*)sp.slots + (size_t)item * HPT * NW;
+  gu64_t* my_slots = (gu64_t*)sp.slots + (size_t)wsi * HPT * NW;
   auto reset_slots = [&]() {  // every wave of the item has read the granules by now: back to "not published"
 #pragma unroll
     for (int hh = 0; hh < HPT; ++hh)
@@ -459,14 +475,15 @@ __global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 
 #pragma unroll
       for (int k = 0; k < HD / 64; ++k) outp[lane + 64 * k] = to_elem<false>(part[k]);
       if (na > 1) reset_slots();  // (my own waves exchanged through the workspace; all of them are past the barrier)
+      if (looped) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-      gf32_t* mine = (gf32_t*)sp.partials + ((size_t)item * G + g) * HD;
+      gf32_t* mine = (gf32_t*)sp.partials + ((size_t)wsi * G + g) * HD;
 #pragma unroll
       for (int k = 0; k < HD / 64; ++k) __hip_atomic_store(mine + lane + 64 * k, part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the payload has left before the arrival is counted
       unsigned old = 0;
       if (lane == 0) {
-        old = __hip_atomic_fetch_add((gu32_t*)sp.counters + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __hip_atomic_fetch_add((gu32_t*)sp.counters + wsi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *last_flag = old == (unsigned)(ga - 1);
       }
     }
@@ -476,7 +493,7 @@ __global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 
     if (*last_flag) {
       // The item's last workgroup adds the partial rows — its four waves a quarter each (wave k: workgroups k, k + 4, ...),
       // then wave 0 the four sums: an order fixed by ga alone, whatever the arrival order.
-      const gf32_t* all = (const gf32_t*)sp.partials + (size_t)item * G * HD;
+      const gf32_t* all = (const gf32_t*)sp.partials + (size_t)wsi * G * HD;
       float o[HD / 64];
 #pragma unroll
       for (int k = 0; k < HD / 64; ++k) o[k] = 0.f;
@@ -504,7 +521,8 @@ __global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 
           outp[lane + 64 * k] = to_elem<false>(ssum);
         }
         reset_slots();
-        if (lane == 0) __hip_atomic_store((gu32_t*)sp.counters + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store((gu32_t*)sp.counters + wsi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (looped) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the words are zero before this workgroup moves on
       }
     }
   }
@@ -513,7 +531,7 @@ __global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     ts_[7] = wall_clock64();
     if (lane == 0) {
-      uint64_t* rec = tl_ + ((size_t)blockIdx.x * wpg + wave) * 10;
+      uint64_t* rec = tl_ + ((size_t)vb * wpg + wave) * 10;
 #pragma unroll
       for (int k = 0; k < 8; ++k) rec[k] = ts_[k];
       rec[8] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);                          // HW_REG_HW_ID
@@ -521,6 +539,43 @@ __global__ void __launch_bounds__(256, HPT > 1 ? (D == 64 ? 4 : 2) : (D == 64 ? 
     }
   }
 #endif
+  };  // process
+
+  if constexpr (!ROUNDS) {
+    process((int)blockIdx.x, (int)blockIdx.x / G);
+  } else {
+    // The G workgroups at one place of the grid go through the rounds together, but not in step: one that has nothing to do in
+    // a round (an empty sequence, a context too short for its waves) is through it at once.  Round r + 2 uses the words of
+    // round r again, so nobody starts it before all G have FINISHED round r.  Two running counts per place, of the (workgroup,
+    // round)s finished in even and in odd rounds: before round r a workgroup waits for G * (r / 2) in the count of r's parity
+    // — so many can only come from rounds r - 2, r - 4, ..., complete: nobody adds to that count from round r or later before
+    // somebody has entered round r.  Almost always there already.  The last arrival of a count zeroes it.
+    const int places = (int)gridDim.x / G;  // items in flight per round
+    const int place = (int)blockIdx.x / G;
+    gu32_t* done = (gu32_t*)sp.counters + SPLIT_MAX_ITEMS / 2 + 2 * place;   // [parity]
+    const unsigned nrounds = (unsigned)((total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);   // (the same for all G)
+    unsigned round = 0;
+    for (int vb = (int)blockIdx.x; vb < total; vb += (int)gridDim.x, ++round) {
+      if (round >= 2) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(done + (round & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G * (round >> 1)) {
+          if (++spins >= SPLIT_SPIN_LIMIT) {
+            if (lane == 0) atomicAdd(sp.status, 1u);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      process(vb, place + (int)(round & 1) * places);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my words of this round are where they belong
+      lds_barrier();  // ... for all four waves; and the workgroup's LDS (partial rows, the "I am last" flag) is free again
+      if (wave == 0 && lane == 0) {
+        const unsigned all = (unsigned)G * ((nrounds + 1 - (round & 1)) >> 1);   // this parity's (workgroup, round)s of the launch
+        const unsigned old = __hip_atomic_fetch_add(done + (round & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == all) __hip_atomic_store(done + (round & 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 // Bytes of workspace and where its parts lie.  Sized for any launch the split kernels take: at most `max_wgs` workgroups
@@ -529,7 +584,6 @@ struct SplitLayout {
   size_t status_off, counters_off, slots_off, partials_off, bytes;
 };
 constexpr int SPLIT_MAX_WGS = 2048;    // 8 resident 256-thread workgroups per CU x 256 CUs
-constexpr int SPLIT_MAX_ITEMS = 8192;  // = waves of SPLIT_MAX_WGS: an item has at least one wave
 static inline SplitLayout pa_split_layout(int head_size) {
   SplitLayout l;
   l.status_off = 0;                                                         // 256 B header

@@ -908,9 +908,18 @@ static int pick_split(int num_seqs, int num_heads, int head_size, int block_size
     if (lds_fits(x) &&
         ((wgs <= g_cus && bpw >= R.split_min_blocks_per_wave) || (wgs <= cap && bpw >= R.split_min_blocks_per_wave_loaded))) { xw = x; break; }
   }
-  if (!xw && starved) {   // more items than that: the widest form that is resident
-    for (int x = 64; x >= 8; x /= 2)
-      if (nitems * (x / 4) <= split_resident_wgs(head_size, hpt) && nitems * (x / 4) * hpt <= SPLIT_MAX_WGS && lds_fits(x)) { xw = x; break; }
+  if (starved) {
+    // Contexts too long for several waves' logits in one workgroup's LDS: at least the narrowest form of which three workgroups
+    // fit a CU's LDS — in ROUNDS (Variant::fn_rounds) where that is more workgroups than are resident
+    // (r05n_split_rounds_rocprof.json, 12 heads x 64: batch 64 x 32768 tokens 4574 us one wave per head, 1131 at 8 waves per
+    // item in one round, 959 at 16 in rounds; batch 32: 8 waves 566, 16 waves 484; batch 80: 6073 -> 1229 (8 / 32 / 64 waves:
+    // 1476 / 1240 / 1306); batch 40 x 65536: 16 waves — one workgroup per CU — 1487, 32: 1236, 64: 1268)
+    int x3 = 0;
+    for (int x = 16; x <= (hpt > 1 ? 64 : 128); x *= 2) {
+      const size_t lds = (size_t)4 * hpt * ((size_t)split_wtok(lpad, x) * 6 + (size_t)head_size * 4) + 16;
+      if (3 * (lds + 1024) <= R.lds_per_cu) { x3 = x; break; }
+    }
+    if (x3 > xw) xw = x3;
   }
   if (!xw) return 0;
   const double kv_bytes = (f8 ? 2.0 : 4.0) * (double)units / (double)(qpk > 0 ? qpk : 1) * (double)max_seq_len * head_size;
@@ -1135,6 +1144,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
     return fail(VMI_E_SHAPE, "paged_attention_v1: num_seqs * num_heads = %lld items exceed 2^31",
                 (long long)num_seqs * num_heads);
 
+  bool split_rounds = false;
   if (v.XW) {
     if (append || bsp || f8 == 2 || bf)
       return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (split kernel) takes fp16 tensors over fp16 or fp8-E4M3 pages, "
@@ -1147,10 +1157,14 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
       return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s takes %d query heads of one KV head per item, got num_heads = %d",
                   v.name, v.HPT, num_heads);
     const int64_t wgs = (int64_t)num_seqs * (num_heads / v.HPT) * (v.XW / v.WPH);
-    if (wgs > 0x7fffffff || (int64_t)num_seqs * num_heads * v.XW > (int64_t)SPLIT_MAX_WGS * 4 || wgs * v.HPT > SPLIT_MAX_WGS)
-      return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s would launch %lld workgroups (the workspace holds the granules "
-                  "of %d waves)", v.name, (long long)wgs, SPLIT_MAX_WGS * 4);
-    if (v.XW > v.WPH && wgs > split_resident_wgs(head_size, v.HPT))   // (one workgroup per item: nothing waits across workgroups)
+    if (wgs > 0x7fffffff)
+      return fail(VMI_E_SHAPE, "paged_attention_v1: variant %s would launch %lld workgroups", v.name, (long long)wgs);
+    // more workgroups than are resident (or than the workspace holds words for): the kernel's twin that goes in rounds
+    split_rounds = v.XW > v.WPH && (wgs > split_resident_wgs(head_size, v.HPT) || wgs * v.HPT > SPLIT_MAX_WGS);
+    if (v.XW == v.WPH && wgs * v.HPT > SPLIT_MAX_WGS)   // (one workgroup per item: nothing waits across workgroups)
+      return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s would launch %lld workgroups (the workspace holds the rows of %d)",
+                  v.name, (long long)wgs, SPLIT_MAX_WGS / v.HPT);
+    if (split_rounds && !v.fn_rounds)
       return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s would launch %lld workgroups; the split kernels need every "
                   "workgroup resident (at most %d on this device)", v.name, (long long)wgs, split_resident_wgs(head_size, v.HPT));
   }
@@ -1166,7 +1180,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (lds > 48 * 1024) {
     // (set on every such launch: the attribute is per device and the library may be driven from several host threads —
     //  remembering "already granted" in the variant table was a data race; the call costs about a microsecond)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_rounds ? v.fn_rounds : v.fn),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   }
@@ -1235,8 +1249,24 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
     sp.nw = v.XW;
     sp.wtok = split_wtok(lpad, v.XW);
     sp.flags = g_split_flags;
-    const unsigned grid = (unsigned)((int64_t)num_seqs * (num_heads / v.HPT) * (v.XW / v.WPH));
-    hipLaunchKernelGGL(reinterpret_cast<pa_split_kernel_t>(v.fn), dim3(grid), dim3(v.WPH * 64), lds,
+    unsigned grid = (unsigned)((int64_t)num_seqs * (num_heads / v.HPT) * (v.XW / v.WPH));
+    if (split_rounds) {
+      // As many whole items as are truly resident — by the twin's launch bounds and by LDS — and as half the workspace holds
+      // words for (its two halves alternate by round): a workgroup serves grid-strided items, an item's workgroups always
+      // together (pa_split.hpp).
+      const int G = v.XW / v.WPH;
+      int per_cu = split_wgs_per_cu(head_size, v.HPT, true);
+      const int by_lds = (int)(((size_t)160 * 1024) / (lds + 1024));
+      per_cu = per_cu < by_lds ? per_cu : by_lds;
+      int64_t res = (int64_t)per_cu * device_cus(device);
+      const int64_t by_ws = SPLIT_MAX_WGS / (2 * v.HPT);
+      res = res < by_ws ? res : by_ws;
+      if (res < G)
+        return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s: not even one item's %d workgroups are resident at %zu B of "
+                    "LDS each", v.name, G, lds);
+      grid = (unsigned)(res / G * G);
+    }
+    hipLaunchKernelGGL(reinterpret_cast<pa_split_kernel_t>(split_rounds ? v.fn_rounds : v.fn), dim3(grid), dim3(v.WPH * 64), lds,
                        static_cast<hipStream_t>(stream), p, sp);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "paged_attention_v1 (split) launch");

@@ -61,6 +61,7 @@ CONFIGS = {
     # few sequences x long contexts: where a caller-owned workspace lets paged_attention_v1 spread a head over many CUs
     "long_b1": DecodeConfig("long_b1", 1, 12, 64, 16384, 4096),
     "long_b4": DecodeConfig("long_b4", 4, 12, 64, 8192, 8192),
+    "long_gqa": DecodeConfig("long_gqa", 4, 32, 128, 8192, 8192, num_kv_heads=8),   # Llama-3-8B-shaped heads (grouped-query)
 }
 
 
