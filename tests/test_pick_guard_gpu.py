@@ -1,4 +1,4 @@
-"""Guard of the work-decomposition heuristic: in seven cells that span its regimes the DEFAULT pick must stay within 8 % of the
+"""Guard of the work-decomposition heuristic: in nine cells that span its regimes the DEFAULT pick must stay within 8 % of the
 best of a handful of named kernels — so that a kernel or threshold change that silently invalidates the offline sweeps
 (profiles/r04_pick_generalisation.md, r04_underfilled_chip.md, r05_split_kernels.md) fails a test instead.
 
@@ -35,6 +35,14 @@ CELLS = [
      ["d128_h4_w1_u1_nt1", "d128_h1_w8_u1_nt1", "q_d128_s1q1", "d128_h1_w4_u1_nt1"]),
     ("long_b1_l16384", 1, 12, 64, 16384, False,
      ["d64_x64_u2_nt0", "d64_x32_u2_nt0", "d64_h1_w16_u2_nt0", "d64_x64_u1_nt0"]),
+    # contexts past the plain kernels' LDS: split kernels, 32 sequences' workgroups no longer all resident at 16 waves per item
+    ("past_lds_b32_l32768", 32, 12, 64, 32768, False,
+     ["d64_x8_u2_nt1", "d64_x16_u2_nt1", "d64_x32_u2_nt1", "d64_x16_u1_nt1", "d64_h1_w1_u1_nt1"]),
+    # grouped-query heads (32 query / 8 KV heads x 128), few sequences x long contexts: four query heads of a KV head per item
+    # (6 sequences = 201 MB of pages: batch 4 = 134 MB sits ON the 128 MB line between temporal and non-temporal page loads,
+    #  where two alternating table sets half fit the 256 MiB Infinity Cache and the temporal form is 6 % ahead — r05p_split_nt_rocprof.json)
+    ("gqa_b6_l8192", 6, (32, 8), 128, 8192, False,
+     ["d128_gq4_x32_u1_nt1", "d128_gq4_x32_u1_nt0", "d128_gq4_x64_u1_nt1", "d128_gq4_x16_u1_nt1", "d128_x32_u2_nt0"]),
 ]
 
 
@@ -84,8 +92,9 @@ def test_default_pick_is_within_8_percent_of_the_best_named_kernel(cell):
     name, batch, heads, head_size, seq_len, ragged, candidates = cell
     dev = torch.device("cuda:0")
     per = -(-seq_len // 16)
+    heads, kv_heads = heads if isinstance(heads, tuple) else (heads, 0)
     cfg = dataclasses.replace(CONFIGS["cfg3"], name=name, batch=batch, num_heads=heads, head_size=head_size, seq_len=seq_len,
-                              num_blocks=2 * batch * per + 8)
+                              num_blocks=2 * batch * per + 8, num_kv_heads=kv_heads)
     wl = make_workload(cfg, dev, seed=21, table_sets=2, ragged=ragged)
     out = torch.empty((batch, heads, head_size), dtype=torch.float16, device=dev)
     ids = {n: i + 1 for i, n in enumerate(ops.variant_names())}
