@@ -1159,8 +1159,11 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
     const int64_t wgs = (int64_t)num_seqs * (num_heads / v.HPT) * (v.XW / v.WPH);
     if (wgs > 0x7fffffff)
       return fail(VMI_E_SHAPE, "paged_attention_v1: variant %s would launch %lld workgroups", v.name, (long long)wgs);
-    // more workgroups than are resident (or than the workspace holds words for): the kernel's twin that goes in rounds
-    split_rounds = v.XW > v.WPH && (wgs > split_resident_wgs(head_size, v.HPT) || wgs * v.HPT > SPLIT_MAX_WGS);
+    // more workgroups than are resident — by the launch bounds and by LDS — or than the workspace holds words for: the kernel's
+    // twin that goes in rounds (waiting for a workgroup that is not on the chip yet works only as long as workgroups are
+    // dispatched in index order; the twin does not lean on that)
+    const int64_t by_lds = (int64_t)(((size_t)160 * 1024) / (lds_of(v) + 1024)) * g_cus;
+    split_rounds = v.XW > v.WPH && (wgs > split_resident_wgs(head_size, v.HPT) || wgs > by_lds || wgs * v.HPT > SPLIT_MAX_WGS);
     if (v.XW == v.WPH && wgs * v.HPT > SPLIT_MAX_WGS)   // (one workgroup per item: nothing waits across workgroups)
       return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s would launch %lld workgroups (the workspace holds the rows of %d)",
                   v.name, (long long)wgs, SPLIT_MAX_WGS / v.HPT);
