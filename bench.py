@@ -781,13 +781,13 @@ def cfg2_record(args, dist, rank, world, dev):
 
 def long_context_record(args, dev):
     """Few sequences x long contexts (batch 1 x 16384 tokens and batch 4 x 8192 at 12 heads x 64; batch 4 x 8192 at 32 / 8
-    grouped-query heads x 128): the regime the reference's
+    grouped-query heads x 128; batch 48 x 32768 — past the plain kernels' LDS, in rounds): the regime the reference's
     scheduler runs (one sequence at a time, scheduler.py:60) at today's context lengths.  The same default entry with and
     without the wrapper's workspace (round 5: with one, paged_attention_v1 spreads each (sequence, head) over up to 64 waves on
     as many CUs — vmi_paged_attention_v1_f16_ws, pa_split.hpp).  Device time per attention launch, 24 launches per hipGraph."""
     from vllmini_amd import ops
     out = {"op": "paged_attention_v1, default entry, fp16, block_size 16", "unit": "us per attention launch (hipGraph of 24)"}
-    for name in ("long_b1", "long_b4", "long_gqa"):
+    for name in ("long_b1", "long_b4", "long_gqa", "long_32k"):
         c = CONFIGS[name]
         wl = make_workload(c, dev, seed=17, table_sets=2)
         o = torch.empty((c.batch, c.num_heads, c.head_size), dtype=torch.float16, device=dev)
@@ -799,7 +799,8 @@ def long_context_record(args, dev):
                 attend(wl, o, 0, 0)
                 torch.cuda.synchronize(dev)
                 v = ops.variant_names()[ops.last_variant() - 1]
-                us = graph_steps(wl, o, 96, 0, dev, per_graph=24, attend_only=True) / 96 * 1e6
+                n = 96 if c.seq_len * c.batch < (1 << 18) else 24        # (long_32k without a workspace: 3.4 ms per launch)
+                us = graph_steps(wl, o, n, 0, dev, per_graph=min(n, 24), attend_only=True) / n * 1e6
             finally:
                 ops.set_workspace_enabled(prev)
             rec[key] = {"us": us, "kernel_variant": v, "achieved_GBps": rec["algorithmic_bytes_per_launch"] / us / 1e3}

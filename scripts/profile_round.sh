@@ -13,7 +13,8 @@ scripts/profile_bench.sh ${T}_cfg5_strong --config cfg5_strong > /dev/null 2>&1 
 scripts/profile_bench.sh ${T}_long_b1 --config long_b1 > /dev/null 2>&1             # batch 1 x 16384 tokens: a split kernel (workspace)
 scripts/profile_bench.sh ${T}_long_b4 --config long_b4 > /dev/null 2>&1             # batch 4 x 8192 tokens
 scripts/profile_bench.sh ${T}_long_gqa --config long_gqa > /dev/null 2>&1           # batch 4 x 8192 tokens, 32 / 8 heads x 128: four query heads per item
-for c in cfg3 cfg3_ragged cfg3_fp8 cfg3_fp8_ragged cfg4 cfg4_ragged cfg2 cfg5_strong long_b1 long_b4 long_gqa; do
+scripts/profile_bench.sh ${T}_long_32k --config long_32k > /dev/null 2>&1           # batch 48 x 32768 tokens: past the plain kernels' LDS, in rounds
+for c in cfg3 cfg3_ragged cfg3_fp8 cfg3_fp8_ragged cfg4 cfg4_ragged cfg2 cfg5_strong long_b1 long_b4 long_gqa long_32k; do
   python - "$T" "$c" <<'PY'
 import json, sys, glob, shutil, os
 t, c = sys.argv[1], sys.argv[2]

@@ -62,6 +62,8 @@ CONFIGS = {
     "long_b1": DecodeConfig("long_b1", 1, 12, 64, 16384, 4096),
     "long_b4": DecodeConfig("long_b4", 4, 12, 64, 8192, 8192),
     "long_gqa": DecodeConfig("long_gqa", 4, 32, 128, 8192, 8192, num_kv_heads=8),   # Llama-3-8B-shaped heads (grouped-query)
+    # contexts past what several waves' logits fit in one workgroup's LDS (~27 000 tokens), more items than are resident: in rounds
+    "long_32k": DecodeConfig("long_32k", 48, 12, 64, 32768, 196608),
 }
 
 
