@@ -5,7 +5,7 @@ distribution of soak_auto (equal, uniform, one long among one-token sequences, e
 or a capacity far above it, ALiBi sometimes — and, as the hand-off rules demand (MI355X_MICROARCH.md: "test every hand-off
 under UNEVEN load, consumer L1-warm"), HALF the cases run while another stream streams through a 1 GiB buffer, and every case
 is launched three times back to back on the same workspace.  Each case: an explicit split kernel (random waves per item, U,
-nt) or the default entry; all rows against the CPU kernel model (checker only) at the tight bound, the three launches
+nt; four query heads per item where the grouping allows; fp8 E4M3 pages every seventh case) or the default entry; all rows against the CPU kernel model (checker only) at the tight bound, the three launches
 bit-identical, the workspace's control words zero and its give-up counter 0 afterwards.
 `PYTHONPATH=.:tests python tests/soak/soak_split.py [n_cases] [first_seed]`; exit code 1 if anything failed."""
 import sys
@@ -50,11 +50,26 @@ for seed in range(first, first + n_cases):
     slopes = (rng.uniform(0.01, 0.5, H).astype(np.float32) if seed % 4 == 0 else None)
     x = int(rng.choice([8, 16, 32, 64, 128, 256]))
     vname = f"d{D}_x{x}_u{int(rng.choice([1, 2]))}_nt{int(rng.choice([0, 1]))}"
+    fp8 = seed % 7 == 3                                       # fp8 E4M3 pages (random codes, kv_scale 1 or 0.7)
+    if fp8:
+        pool = [n for n in names if n.startswith(f"fp8_d{D}_x")]
+        vname = pool[int(rng.integers(0, len(pool)))]
+    elif qpk % 4 == 0 and seed % 3 == 1:                      # four query heads of a KV head per item
+        pool = [n for n in names if n.startswith(f"d{D}_gq4_x")]
+        vname = pool[int(rng.integers(0, len(pool)))]
     vid = 0 if seed % 5 == 0 else names[vname]
+    kv_scale = 1.0
+    if fp8:
+        kv_scale = float(rng.choice([1.0, 0.7]))
+        NB = case["kc"].shape[0]
+        kq = rng.integers(0, 256, (NB, hkv, D // 16, 16, 16), dtype=np.uint8)
+        vq = rng.integers(0, 256, (NB, hkv, D, 16), dtype=np.uint8)
+        case["kq"] = np.where((kq & 0x7f) >= 0x40, (kq & 0x80) | 0x30 | (kq & 7), kq).astype(np.uint8)   # |x| < 2, no NaN codes
+        case["vq"] = np.where((vq & 0x7f) >= 0x40, (vq & 0x80) | 0x30 | (vq & 7), vq).astype(np.uint8)
     S = B
     qbuf = torch.from_numpy(case["qbuf"]).to(dev)
     q = qbuf[:, : H * D].view(S, H, D)
-    kc, vc = torch.from_numpy(case["kc"]).to(dev), torch.from_numpy(case["vc"]).to(dev)
+    kc, vc = torch.from_numpy(case["kq" if fp8 else "kc"]).to(dev), torch.from_numpy(case["vq" if fp8 else "vc"]).to(dev)
     tab, ln = torch.from_numpy(case["tables"]).to(dev), torch.from_numpy(case["lens"]).to(dev)
     al = None if slopes is None else torch.from_numpy(slopes).to(dev)
     busy = seed % 2 == 0
@@ -65,7 +80,8 @@ for seed in range(first, first + n_cases):
                 with torch.cuda.stream(load_stream):
                     load_buf.mul_(1.0000001)
             out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=dev)
-            ops.paged_attention_v1(out, q, kc, vc, hkv, case["scale"], tab, ln, 16, msl, al, "auto", 1.0, 0, 0, 1, 1, 0, _variant=vid)
+            ops.paged_attention_v1(out, q, kc, vc, hkv, case["scale"], tab, ln, 16, msl, al, "fp8" if fp8 else "auto", kv_scale, 0, 0, 1, 1,
+                                   0, _variant=vid)
             outs.append(out)
         torch.cuda.synchronize()
     except RuntimeError as e:
@@ -76,11 +92,15 @@ for seed in range(first, first + n_cases):
     ran += 1
     label = ops.last_launch_label()
     picked[label] = picked.get(label, 0) + 1
-    ref = oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], hkv, case["scale"], case["tables"], case["lens"], 16,
-                                    alibi_slopes=slopes, threads=8).astype(np.float64)
+    if fp8:
+        ref = oracle.paged_attention_v1_fp8(case["q"], case["kq"], case["vq"], hkv, case["scale"], case["tables"], case["lens"], 16,
+                                            kv_scale=kv_scale, alibi_slopes=slopes, threads=8).astype(np.float64)
+    else:
+        ref = oracle.paged_attention_v1(case["q"], case["kc"], case["vc"], hkv, case["scale"], case["tables"], case["lens"], 16,
+                                        alibi_slopes=slopes, threads=8).astype(np.float64)
     got = outs[0].cpu().numpy().astype(np.float64)
     d = np.abs(got - ref)
-    ok = np.isfinite(got).all() and bool((d <= np.maximum(2 * ulp16(ref), 5e-4)).all())
+    ok = np.isfinite(got).all() and bool((d <= np.maximum(2 * ulp16(ref), 5e-4 * max(1.0, 2 * kv_scale))).all())
     same = all(torch.equal(outs[0].view(torch.int16), o.view(torch.int16)) for o in outs[1:])
     ws = ops.workspace_for(0, create=False)
     n_ctl = 256 + 8192 * 4 + 2048 * 4 * 8
