@@ -56,7 +56,7 @@ def setup(case, dev):
     wl.kv = kv
     if kv == "fp8":
         g8 = torch.Generator(device=dev).manual_seed(9)
-        H, D = cfg.num_heads, cfg.head_size
+        H, D = cfg.kv_heads, cfg.head_size
         wl.key_cache = torch.randint(0, 64, (cfg.num_blocks, H, D // 16, 16, 16), dtype=torch.uint8, device=dev, generator=g8)
         wl.value_cache = torch.randint(0, 64, (cfg.num_blocks, H, D, 16), dtype=torch.uint8, device=dev, generator=g8)
     out = torch.empty((b, cfg.num_heads, cfg.head_size), dtype=torch.float16, device=dev)

@@ -52,7 +52,7 @@ for seed in range(first, first + n_cases):
     vname = f"d{D}_x{x}_u{int(rng.choice([1, 2]))}_nt{int(rng.choice([0, 1]))}"
     fp8 = seed % 7 == 3                                       # fp8 E4M3 pages (random codes, kv_scale 1 or 0.7)
     if fp8:
-        pool = [n for n in names if n.startswith(f"fp8_d{D}_x")]
+        pool = [n for n in names if n.startswith(f"fp8_d{D}_x") or (qpk % 4 == 0 and n.startswith(f"fp8_d{D}_gq4_x"))]
         vname = pool[int(rng.integers(0, len(pool)))]
     elif qpk % 4 == 0 and seed % 3 == 1:                      # four query heads of a KV head per item
         pool = [n for n in names if n.startswith(f"d{D}_gq4_x")]

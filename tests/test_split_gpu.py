@@ -232,6 +232,41 @@ def test_four_query_heads_of_a_kv_head_per_item(D):
     assert ops.workspace_status(0) == 0 and _control_words_are_zero()
 
 
+@pytest.mark.parametrize("D", [64, 128])
+def test_four_query_heads_per_item_over_fp8_pages(D):
+    """"fp8_d<head>_gq4_x...": the fp8 tile of a wave's block decoded ONCE for the four query heads of its KV head (q.K^T on the
+    matrix cores from half(float(fp8) * kv_scale) operands, V decoded once per tile).  Against the oracle's fp8 restatement;
+    kv_scale 1 and 0.6; ragged, empty; 4 and 8 query heads per KV head; ALiBi; the default entry where it picks this form."""
+    import oracle
+    from test_parity_gpu import _fp8_case, _run_fp8
+    from vllmini_amd import ops
+
+    names = {n: i + 1 for i, n in enumerate(ops.variant_names())}
+    mine = [n for n in names if n.startswith(f"fp8_d{D}_gq4_x")]
+    assert len(mine) >= 8
+    for (S, hkv, qpk, lens) in ((3, 2, 4, [4096, 100, 0]), (2, 1, 8, [1500, 17]), (5, 1, 4, [1, 16, 33, 700, 2048])):
+        H = hkv * qpk
+        rng = np.random.default_rng(3 * D + S + H)
+        case = _fp8_case(rng, S, H, D, lens, 16, num_kv_heads=hkv)
+        slopes = rng.uniform(0.01, 0.3, H).astype(np.float32) if S == 2 else None
+        for kv_scale in (1.0, 0.6):
+            ref = oracle.paged_attention_v1_fp8(case["q"], case["kq"], case["vq"], hkv, case["scale"], case["tables"], case["lens"], 16,
+                                                kv_scale=kv_scale, alibi_slopes=slopes, threads=8)
+            for n in mine:
+                got = _run_fp8(case, kv_scale, variant=names[n], alibi=slopes)
+                assert_close(got, ref, f"{n} S{S} H{H}/{hkv} kv_scale {kv_scale}", vmax=2 * kv_scale)
+                assert np.array_equal(_run_fp8(case, kv_scale, variant=names[n], alibi=slopes).view(np.int16), got.view(np.int16)), n
+    # the default entry: 8 sequences x 32 / 8 heads = 256 query heads -> four per item
+    rng = np.random.default_rng(11 + D)
+    case = _fp8_case(rng, 8, 32, D, [2048] * 8, 16, num_kv_heads=8)
+    ref = oracle.paged_attention_v1_fp8(case["q"], case["kq"], case["vq"], 8, case["scale"], case["tables"], case["lens"], 16,
+                                        kv_scale=0.8, threads=8)
+    got = _run_fp8(case, 0.8)
+    assert f"fp8_d{D}_gq4_x" in ops.last_launch_label(), ops.last_launch_label()
+    assert_close(got, ref, f"default entry ({ops.last_launch_label()})", vmax=1.6)
+    assert ops.workspace_status(0) == 0 and _control_words_are_zero()
+
+
 def test_grouped_query_and_alibi_through_a_split_kernel():
     import oracle
 

@@ -1,6 +1,6 @@
 // pa_split.hip — instantiations of the split kernels (pa_split.hpp): one (sequence, head) over several workgroups of one
 // launch, meeting in a caller-owned workspace.  Block size 16, fp16 query and pages.
-// Names: [fp8_]d<head>_x<waves per item>_u<blocks per register group>_nt<non-temporal page loads>.
+// Names: [fp8_]d<head>[_gq4]_x<waves per item>_u<blocks per register group>_nt<non-temporal page loads>.
 // The waves per item are a launch parameter, so the rows of one (head, u, nt) share a kernel.  A workgroup holds the logits
 // and probabilities of ITS waves' blocks only (6 bytes per token / workgroups per item), so max_seq_len is bounded by
 // 27 000 tokens x workgroups per item — where the plain kernels stop at ~27 000 and fall back to one wave per head.
@@ -28,6 +28,12 @@ namespace vmi {
    (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 0, 4, true>},
 #define VMI_ROWS_XG(D, U, NT, VA) VMI_ROW_XG(D, 8, U, NT, VA) VMI_ROW_XG(D, 16, U, NT, VA) VMI_ROW_XG(D, 32, U, NT, VA) VMI_ROW_XG(D, 64, U, NT, VA)
 
+#define VMI_ROW_XG8(D, X, U, NT, VA) /* ... over fp8 E4M3 pages */                                                    \
+  {"fp8_d" #D "_gq4_x" #X "_u" #U "_nt" #NT, D, 16, 1, 4, U, (bool)(NT), 4, false,                                   \
+   (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 1, 4>, 0, 0, 0, 1, true, false, false, false, false, false, X,  \
+   (pa_kernel_t)pa_split_kernel<D, U, (bool)(NT), VA, 1, 4, true>},
+#define VMI_ROWS_XG8(D, U, NT, VA) VMI_ROW_XG8(D, 8, U, NT, VA) VMI_ROW_XG8(D, 16, U, NT, VA) VMI_ROW_XG8(D, 32, U, NT, VA) VMI_ROW_XG8(D, 64, U, NT, VA)
+
 Variant g_split_variants[] = {
     VMI_ROWS_X(64, 1, 0, 2) VMI_ROWS_X(64, 2, 0, 2) VMI_ROWS_X(64, 1, 1, 1) VMI_ROWS_X(64, 2, 1, 1)
     VMI_ROWS_X(128, 1, 0, 2) VMI_ROWS_X(128, 2, 0, 2) VMI_ROWS_X(128, 1, 1, 1) VMI_ROWS_X(128, 2, 1, 1)
@@ -35,6 +41,8 @@ Variant g_split_variants[] = {
     VMI_ROWS_XG(64, 2, 0, 2) VMI_ROWS_XG(64, 2, 1, 1) VMI_ROWS_XG(128, 1, 0, 2) VMI_ROWS_XG(128, 1, 1, 1) VMI_ROWS_XG(128, 2, 0, 2)
     // fp8 E4M3 pages (any kv_scale): half the bytes per tile, so two / four blocks per register group
     VMI_ROWS_X8(64, 2, 0, 2) VMI_ROWS_X8(64, 4, 0, 2) VMI_ROWS_X8(64, 2, 1, 1) VMI_ROWS_X8(128, 2, 0, 2) VMI_ROWS_X8(128, 2, 1, 1)
+    // ... and grouped-query heads over fp8 pages: the tile decoded once for its four query heads
+    VMI_ROWS_XG8(64, 2, 0, 2) VMI_ROWS_XG8(64, 2, 1, 1) VMI_ROWS_XG8(128, 2, 0, 2) VMI_ROWS_XG8(128, 2, 1, 1)
 };
 const int g_split_nvariants = (int)(sizeof(g_split_variants) / sizeof(g_split_variants[0]));
 

@@ -140,17 +140,18 @@ __global__ void __launch_bounds__(256, split_wgs_per_cu(D, HPT, ROUNDS)) pa_spli
   // lane & 15 = head; products of fp16 operands are exact in fp32 and the accumulation is fp32: the reference's arithmetic up to
   // summation order (as in pa_v1_kernel's grouped-query kernels, pa_kernel.hpp QK_MFMA).
   constexpr bool QKM = HPT > 1;
-  static_assert(!(QKM && F8), "grouped-query split kernels: 16-bit pages");
   float slope[QKM ? 1 : HPT];
   u32x4 qreg[QKM ? 1 : HPT][NL][QW];
-  u32x4 qB[QKM ? NL : 1];
+  u32x4 qB[QKM ? NL : 1][QKM ? QW : 1];   // (fp8 pages: a K unit is 16 dims = two 8-dim operands)
   if constexpr (QKM) {
     const int n = lane & 15;
     const bool has = n < HPT;
     const h16* qp = p.q + (int64_t)seq * p.q_stride + (int64_t)(head0 + (has ? n : 0)) * D;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < NL; ++i) qB[i] = has ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * 8) : zero4;
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+      for (int qw = 0; qw < QW; ++qw) qB[i][qw] = has ? *reinterpret_cast<const u32x4*>(qp + (CPL * i + c4) * EPU + 8 * qw) : zero4;
     slope[0] = (has && p.alibi) ? p.alibi[head0 + n] : 0.f;   // of head (lane & 15)
   } else {
 #pragma unroll
@@ -233,7 +234,16 @@ __global__ void __launch_bounds__(256, split_wgs_per_cu(D, HPT, ROUNDS)) pa_spli
             f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NL; ++i)
-              d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, r[j][i]), __builtin_bit_cast(h16x8, qB[i]), d4, 0, 0, 0);
+            {
+              if constexpr (F8) {  // the unit's 16 bytes -> half(float(fp8) * kv_scale), two 8-dim operands
+                const u32x4 k0 = deq8<false>(r[j][i][0], r[j][i][1], p.kv_scale);
+                const u32x4 k1 = deq8<false>(r[j][i][2], r[j][i][3], p.kv_scale);
+                d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, k0), __builtin_bit_cast(h16x8, qB[i][0]), d4, 0, 0, 0);
+                d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, k1), __builtin_bit_cast(h16x8, qB[i][QW - 1]), d4, 0, 0, 0);
+              } else {
+                d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, r[j][i]), __builtin_bit_cast(h16x8, qB[i][0]), d4, 0, 0, 0);
+              }
+            }
             // C/D layout: column = lane & 15 (head), rows 4 * (lane >> 4) + reg (tokens of this block)
             const int tok4 = (w + idx * NWe) * BS + 4 * c4;
             f32x4 lg4;

@@ -881,7 +881,7 @@ static int pick_split(int num_seqs, int num_heads, int head_size, int block_size
     // CUs / 2 query heads on (batch 4 x 8192: 43 -> 35 us; batch 8 x 4096 / 8192, where the first form no longer fits: 64 / 164
     // -> 34 / 58), up to CUs / 2 such items.
     big = max_seq_len >= R.split_gqa_min_tokens;
-    if (qpk % 4 == 0 && !f8 && units * 2 >= (long)g_cus) {
+    if (qpk % 4 == 0 && f8 != 2 && units * 2 >= (long)g_cus) {   // (fp8 E4M3 pages too: r05q_split_gq4_fp8_rocprof.json)
       hpt = 4;
       few = (units / 4) * 2 <= (long)g_cus;
       if ((units / 4) * 4 > (long)g_cus) big = max_seq_len >= 2 * R.split_gqa_min_tokens;   // (128 such items at 1024 tokens: 23.9 against 22.9 us)
@@ -927,8 +927,8 @@ static int pick_split(int num_seqs, int num_heads, int head_size, int block_size
   //  32 / 8 x 128, batch 4 x 8192 tokens 43.2 us with temporal loads, 62.8 with non-temporal ones)
   const int nt = (kv_bytes > R.nt_kv_bytes && !(qpk > 1 && hpt == 1)) ? 1 : 0;
   if (hpt > 1) {
-    int vg = find_split(head_size, xw, head_size == 64 ? 2 : 1, nt, 0, hpt);
-    if (!vg) vg = find_split(head_size, xw, head_size == 64 ? 1 : 2, nt, 0, hpt);
+    int vg = find_split(head_size, xw, (head_size == 64 || f8) ? 2 : 1, nt, f8, hpt);
+    if (!vg) vg = find_split(head_size, xw, head_size == 64 ? 1 : 2, nt, f8, hpt);
     return vg;
   }
   int v = f8 ? find_split(head_size, xw, 4, nt, f8) : 0;   // (fp8 pages, half-size tiles: four blocks per group 3 - 5 % ahead of two)
