@@ -32,7 +32,7 @@ for seed in range(first, first + n_cases):
     fast = bool(rng.integers(0, 2))
     qpk = H // hkv
     prefix = {"f16": f"d{D}_gq", "bf16": f"bf16_d{D}_gq", "fp8": f"fp8_d{D}_bs16_gq"}[kind]
-    cands = [i + 1 for i, n in enumerate(names) if n.startswith(prefix) and T._gq_ok(n, qpk)]
+    cands = [i + 1 for i, n in enumerate(names) if n.startswith(prefix) and T._gq_ok(n, qpk) and "_x" not in n]   # (split kernels: soak_split.py)
     vid = int(rng.choice(cands)) if (cands and rng.integers(0, 2)) else 0
     alibi = (rng.uniform(0.0, 0.3, H)).astype(np.float32) if rng.integers(0, 3) == 0 else None
     what = f"seed {seed}: {kind} S{S} H{H}/{hkv} D{D} top {top} fast={fast} alibi={alibi is not None}"

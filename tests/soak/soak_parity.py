@@ -41,6 +41,7 @@ for seed in range(first, first + n_cases):
         cands = [i + 1 for i, n in enumerate(names)
                  if n.startswith(tag) and "LOADSONLY" not in n and (bs != 16 or "_bs" not in n) and
                  "_pvm" not in n and      # opt-in kernels: tests/soak/soak_gqa.py, north-star bound
+                 "_x" not in n and        # split kernels (no fused-append twin, need the workspace): tests/soak/soak_split.py
                  ("_gq" not in n or (H // hkv) % int(n.split("_gq")[1].split("_")[0]) == 0)]
         vid = int(rng.choice(cands)) if (cands and rng.integers(0, 2)) else 0
         msl = int(max(lens.max(), 1)) + int(rng.integers(0, 40))
