@@ -111,3 +111,29 @@ def test_batch_at_and_above_the_ranking_limit_keeps_its_fraction(batch, ragged, 
     assert "q_d64" not in label, f"batch {batch}: the balanced kernel would serve {batch} sequences unranked; picked {label}"
     assert frac >= floor, (f"batch {batch} ragged={ragged}: {us:.1f} us = {frac:.3f} of the 8 TB/s HBM roofline "
                            f"(floor {floor}); kernel: {label}")
+
+
+# Round 5: the split kernels' regimes.  Floors 15 - 25 % off the measured figures (event pairs read 3 - 4 us
+# above rocprofv3 at these sizes): few sequences x long contexts (batch 1 x 16384 tokens: 18 - 19 us by rocprofv3 against 53 without
+# a workspace — asserted as a ratio on the same box), grouped-query heads, and contexts past the plain kernels' LDS in rounds
+# (batch 48 x 32768 tokens: 0.835 of the roofline; the one-wave fallback it replaces ran 0.13).
+@pytest.mark.parametrize("name,kernel,floor", [("long_b1", "_x", None), ("long_gqa", "_gq4_x", None), ("long_32k", "_x", 0.70)])
+def test_split_kernels_keep_their_measured_gain(name, kernel, floor):
+    from vllmini_amd import ops
+
+    if torch.cuda.get_device_properties(0).multi_processor_count < 200:
+        pytest.skip("the figures are stated for a whole MI355X (256 CUs)")
+    us, nbytes, label = _median_attention_us(name, n=24, warm=10)
+    assert kernel in label, f"{name}: the default entry picked {label}"
+    if floor is not None:
+        frac = nbytes / (us * 1e-6) / HBM_PEAK
+        assert frac >= floor, f"{name}: {us:.1f} us = {frac:.3f} of the 8 TB/s HBM roofline (floor {floor}); kernel: {label}"
+        return
+    prev = ops.set_workspace_enabled(False)
+    try:
+        plain_us, _, plain_label = _median_attention_us(name, n=24, warm=10)
+    finally:
+        ops.set_workspace_enabled(prev)
+    assert "_x" not in plain_label
+    assert us * 1.5 <= plain_us, (f"{name}: {label} {us:.1f} us with a workspace, {plain_label} {plain_us:.1f} us without "
+                                  f"(measured 2.9 x / 4.2 x)")

@@ -395,6 +395,39 @@ def test_a_poisoned_workspace_is_healed_by_the_reset_entry():
     assert ops.workspace_status(0) == 0
 
 
+def test_a_launch_in_rounds_replays_from_a_graph():
+    """The rounds twin keeps its per-place round counts in the workspace and zeroes them at the end: a captured launch of more
+    items than are resident replays with the same bits as the eager launch, every time."""
+    from vllmini_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(4242)
+    S, H, D = 40, 12, 64
+    lens = rng.integers(1, 700, S).tolist()
+    case = make_case(rng, S, H, D, lens)
+    t = _upload(case, dev)
+    vid = {n: i + 1 for i, n in enumerate(ops.variant_names())}["d64_x64_u2_nt0"]      # 480 items x 16 workgroups: ten rounds
+    eager = _launch(case, t, vid)
+    assert_close(eager.cpu().numpy(), run_model(case), "rounds, eager")
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    out = torch.full((S, H, D), float("nan"), dtype=torch.float16, device=dev)
+    with torch.cuda.stream(side):
+        _launch(case, t, vid, out=out)             # (this stream's workspace exists before the capture)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            _launch(case, t, vid, out=out)
+            _launch(case, t, vid, out=out)
+        for _ in range(3):
+            out.fill_(float("nan"))
+            g.replay()
+            side.synchronize()
+            assert torch.equal(out.view(torch.int16), eager.view(torch.int16))
+    torch.cuda.current_stream(dev).wait_stream(side)
+    assert ops.workspace_status(0, side.cuda_stream) == 0
+
+
 def test_graph_replay_two_streams_and_two_host_threads():
     from vllmini_amd import ops
 
