@@ -23,6 +23,15 @@
 // its upper word is never zero once written).  Every spin is bounded: a poll that gives up sets status[0] and the
 // launch finishes with wrong numbers instead of hanging the device.
 //
+// Items.  One query head of one sequence, or — grouped-query attention, HPT = 4 — four query heads of ONE KV head: every
+// K / V tile of a wave's blocks is loaded (over fp8 pages: decoded) once for the four, q.K^T of a block on the matrix cores,
+// every head with its own granule, probabilities and partial row.  Pages: fp16, or fp8 E4M3 (F8 = 1).
+//
+// Rounds.  The waiting is safe when every workgroup of the launch is on the chip.  A launch of more workgroups than are
+// resident (launch bounds, LDS) or than the workspace has words for runs the ROUNDS = true twin of the kernel on a grid of
+// whole items that IS resident: a workgroup serves grid-strided items, an item's workgroups always together; the workspace
+// is then indexed by the place in the grid, two halves alternating by round (the loop at the end of the kernel).
+//
 // The workspace belongs to the caller (ownership row: "if a split-KV path needs scratch, the
 // Python wrapper allocates it with torch on the same stream"); the library retains nothing.  Layout: pa_split_layout().
 #pragma once
@@ -32,9 +41,9 @@
 namespace vmi {
 
 struct PASplit {
-  unsigned long long* slots;  // [items][nw]      {float max, float exp_sum} granules; 0 = not published yet
-  float* partials;            // [items][nw / wpg][D]  fp32 partial outputs of the item's workgroups
-  unsigned int* counters;     // [items]          arrivals of the item's workgroups; back to 0 when the item is done
+  unsigned long long* slots;  // [items][HPT][nw] {float max, float exp_sum} granules; 0 = not published yet  (in rounds: [2][places] for [items])
+  float* partials;            // [items][nw / wpg][HPT * D]  fp32 partial outputs of the item's workgroups
+  unsigned int* counters;     // [items]          arrivals of the item's workgroups; back to 0 when the item is done; [4096 + 2 * place + parity]: rounds finished
   unsigned int* status;       // [0]: number of polls that gave up (must stay 0)
   int32_t nw;                 // waves per item (<= 256, a multiple of the waves per workgroup)
   int32_t wtok;               // logits per wave held in LDS: 16 * max(8, ceil(ceil(max_seq_len / 16) / nw)) (split_wtok)
