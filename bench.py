@@ -93,6 +93,8 @@ def build_parser():
     ap.add_argument("--e2e-context", type=int, default=1008, help="context length the e2e sequences start at")
     ap.add_argument("--e2e-ragged", action="store_true", help="e2e with contexts ~ U{16..e2e-context} instead of equal ones")
     ap.add_argument("--e2e-eager", action="store_true", help="e2e: plain launches instead of hipGraph replay")
+    ap.add_argument("--e2e-torch-layers", action="store_true",
+                    help="e2e: the block's linear layers as torch modules instead of csrc/gpt2_layer.hip")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline call pair: no sub-records, no CPU baseline (what the rocprofv3 passes run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -561,7 +563,7 @@ def cpu_baseline(wl, budget_s: float):
 # ---- end to end (GPT-2 small over the batched harness) ----------------------------------------------------------------
 
 def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragged=False, eager=False,
-                ctx0=1008, operator_share=True):
+                ctx0=1008, operator_share=True, native_layers=True):
     """GPT-2 small, `batch` sequences per GPU at ~seq_len context, one token per sequence per step,
     through vllmini_amd.gpt2_decode (hipGraph replay of the whole step).  KV is synthetic: pages are
     filled with random fp16 and sequences are registered at the target context length."""
@@ -593,7 +595,7 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
     ctxs = np.random.default_rng(100 + rank).integers(16, ctx0 + 1, cfg.batch) if ragged else [ctx0] * cfg.batch
     for s in range(cfg.batch):
         pool.allocate_for_prefill(s, int(ctxs[s]))   # bookkeeping only: the pages already hold synthetic KV
-    dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, fused_append=fused)
+    dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, fused_append=fused, native_layers=native_layers)
     ids = list(range(cfg.batch))
     tok = torch.randint(0, dims.vocab_size, (cfg.batch,), device=dev, generator=g)
 
@@ -619,11 +621,15 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     note = ("12 x (c_attn, paged_attention_v1_append [fused], c_proj, MLP) + lm_head, hipGraph replay, greedy" if fused else
             "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy")
+    note += ("; the block's linear layers on this build's kernels (ln_1 + c_attn, c_proj + residual, ln_2 + c_fc + GELU, "
+             "mlp.c_proj + residual: four launches, csrc/gpt2_layer.hip)" if native_layers else
+             "; the block's linear layers as torch modules (layer_norm, F.linear -> hipBLASLt, gelu, add: eleven launches)")
     res = {"metric": "gpt2_small_decode_tokens_per_sec_end_to_end", "value": cfg.batch * world * args.steps / elapsed,
            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3,
            "context": f"U{{16..{ctx0}}} (mean {float(np.mean(ctxs)):.0f})" if ragged else ctx0, "batch_per_gpu": cfg.batch,
            "data": "synthetic KV + random-init GPT-2 small weights", "dtype": "f16", "kv_cache_dtype": kv,
+           "layers": "native" if native_layers else "torch_modules",
            "note": note.replace("hipGraph replay", "plain launches" if eager else "hipGraph replay")}
     if operator_share and not fused:
         # the two operators alone on the decoder's own buffers: the 12 layers' call pairs back to back (the tables,
@@ -659,12 +665,13 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
 
 def run_e2e(args, cfg, dist, rank, world, dev):
     res = e2e_measure(args, cfg, dist, rank, world, dev, kv=args.kv, fused=args.e2e_fused, ragged=args.e2e_ragged,
-                      eager=args.e2e_eager, ctx0=args.e2e_context)
+                      eager=args.e2e_eager, ctx0=args.e2e_context, native_layers=not args.e2e_torch_layers)
     if rank == 0:
         print(json.dumps(res), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
         name = "e2e_ragged.json" if args.e2e_ragged else "e2e_fused.json" if args.e2e_fused else \
             {"fp8": "e2e_fp8.json", "fp8_e5m2": "e2e_fp8_e5m2.json"}.get(args.kv, "e2e.json")
+        name = name.replace(".json", "_torch_layers.json") if args.e2e_torch_layers else name
         with open(os.path.join(REPO, "gpurun_out", name), "w") as f:
             json.dump(res, f, indent=1)
 
@@ -1118,6 +1125,9 @@ def main(argv=None):
         # identical, tests/test_parity_gpu.py): the reference surface stays the pair, the harness may use what is faster
         resf = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, fused=True, operator_share=False)
         line["e2e_step"]["fused_append"] = {k: resf[k] for k in ("value", "unit", "ms_per_step", "note")}
+        # ... and with the block's linear layers left to the torch modules (rounds 1 - 4's harness), for the comparison
+        rest = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, native_layers=False)
+        line["e2e_step"]["torch_module_layers"] = {k: rest[k] for k in ("value", "unit", "ms_per_step", "note")}
     if plain and not args.no_long and args.config == "cfg3" and not args.variant and dist is None:
         line["long_context_step"] = long_context_record(args, dev)
     if dist is not None:

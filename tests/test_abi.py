@@ -36,7 +36,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert os.path.exists(path)
     lib = ctypes.CDLL(path)
     assert sorted(os.path.basename(h) for h in glob.glob(os.path.join(REPO, "include", "*.h"))) == \
-        ["vmi_paged_attention.h", "vmi_paged_attention_diag.h", "vmi_paged_attention_extras.h"]
+        ["vmi_gpt2_layer.h", "vmi_paged_attention.h", "vmi_paged_attention_diag.h", "vmi_paged_attention_extras.h"]
     declared = _declared_symbols()
     assert {"vmi_paged_attention_v1_f16", "vmi_reshape_and_cache_f16", "vmi_last_error_string",
             "vmi_abi_version"} <= set(declared)
@@ -59,7 +59,7 @@ def test_libraries_export_the_c_abi_and_nothing_else_that_can_be_called():
     from vllmini_amd import build
 
     build.build()
-    for path in (build.LIB_PATH, build.EXTRAS_LIB_PATH, build.DIAG_LIB_PATH):
+    for path in (build.LIB_PATH, build.EXTRAS_LIB_PATH, build.DIAG_LIB_PATH, build.LAYER_LIB_PATH):
         if not os.path.exists(path):
             continue
         r = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True)

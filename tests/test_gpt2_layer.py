@@ -1,0 +1,220 @@
+"""The decode harness's own library (include/vmi_gpt2_layer.h): CPU checks of its C-ABI, GPU checks of
+the linear-layer kernels against a torch fp32 restatement of the module chain they replace (vllmini/model/gpt2.py:14-15,
+117-128, 130-135) with the chain's own rounding points, and of the harness that runs on them."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(REPO, "include", "vmi_gpt2_layer.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vmi_gpt2_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_layer_library_exports_its_header_and_nothing_else():
+    from vllmini_amd import build, gpt2_layer
+
+    path = build.build_layer()
+    declared = _declared()
+    assert "vmi_gpt2_linear_f16" in declared and set(declared) == set(gpt2_layer.SIGNATURES)
+    r = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True)
+    funcs = {ln.split()[-1] for ln in r.stdout.splitlines() if ln.strip() and ln.split()[-2] in "TtWw"}
+    assert funcs == set(declared), funcs ^ set(declared)
+    lib = gpt2_layer.load()
+    assert lib.vmi_gpt2_layer_abi_version() == gpt2_layer.ABI_VERSION == 1
+    assert lib.vmi_gpt2_layer_target_arch() == b"gfx950"
+
+
+def test_layer_entry_refuses_bad_arguments_without_touching_a_device():
+    from vllmini_amd import gpt2_layer
+
+    lib = gpt2_layer.load()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf) // 16 * 16 + 16
+    call = lambda x, w, y, M, N, K, epi, res=None: lib.vmi_gpt2_linear_f16(x, K, w, None, None, None, 0.0, res, N, y, N, M, N, K,  # noqa: E731
+                                                                           epi, 0, 0, None)
+    assert call(None, p, p, 1, 16, 32, 0) == 1                      # null x
+    assert call(p, p, p, 1, 16, 32, 3) == 1                         # unknown epilogue
+    assert call(p, p, p, 1, 16, 32, 2) == 1                         # residual epilogue without a residual
+    assert b"residual" in lib.vmi_gpt2_layer_last_error()
+    assert call(p, p, p, 1, 16, 48, 0) == 2                         # K % 32
+    assert call(p, p, p, 1, 24, 32, 0) == 2                         # N % 16
+    assert call(p, p, p, 1, 16, 4640, 0) == 2                       # row tile past a CU's LDS
+    assert b"K % 32" in lib.vmi_gpt2_layer_last_error()
+    assert not gpt2_layer.supports(4, 24, 32) and gpt2_layer.supports(4, 384, 128)
+    assert gpt2_layer.kernel_name(4, 64, 2080, True) is None and gpt2_layer.kernel_name(4, 64, 2080, False) is not None
+
+
+def test_layer_picks_for_the_gpt2_small_decode_step():
+    """The four launches of a layer at batch 256: 32-row tiles where that leaves workgroups for most of the chip, 16-row
+    tiles otherwise, the K range of a slab over two waves from 48 k-steps on."""
+    from vllmini_amd import gpt2_layer as gl
+
+    assert gl.kernel_name(256, 2304, 768, True, gl.EPI_BIAS) == "bm32_nw4_ks1_r2_ln_bias"
+    assert gl.kernel_name(256, 768, 768, False, gl.EPI_BIAS_RESIDUAL) == "bm16_nw4_ks1_r2_residual"
+    assert gl.kernel_name(256, 3072, 768, True, gl.EPI_BIAS_GELU) == "bm32_nw4_ks1_r2_ln_gelu"
+    assert gl.kernel_name(256, 768, 3072, False, gl.EPI_BIAS_RESIDUAL) == "bm16_nw4_ks2_r4_residual"
+    assert gl.kernel_name(3, 384, 128, True, gl.EPI_BIAS) == "bm16_nw4_ks1_r2_ln_bias"
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+
+def _chain(x, w, b, ln=None, gelu=False, residual=None):
+    """The torch module chain in fp32 with ITS rounding points: layer_norm -> half, linear (fp32 sums) + bias -> half,
+    GELU (erf) -> half | residual add -> half."""
+    xf = x.float()
+    if ln is not None:
+        xf = F.layer_norm(xf, (x.shape[1],), ln[0].float(), ln[1].float(), ln[2]).half().float()
+    y = xf.double() @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    y = y.float().half()
+    if gelu:
+        y = F.gelu(y.float()).half()
+    if residual is not None:
+        y = (residual.float() + y.float()).half()
+    return y
+
+
+def _close(got, ref, what):
+    g, r = got.float().cpu().numpy().astype(np.float64), ref.float().cpu().numpy().astype(np.float64)
+    assert np.isfinite(g).all(), what
+    # fp32 sums in another order may cross a rounding boundary of the half output: one half ulp of the value (2^-10 relative),
+    # twice over for the second rounding of the GELU / residual epilogues
+    tol = 2e-3 * np.abs(r) + 2e-3 * max(1e-3, np.abs(r).max()) * 0.25 + 1e-4
+    bad = np.abs(g - r) > tol
+    assert not bad.any(), (what, int(bad.sum()), float(np.abs(g - r).max()))
+
+
+SHAPES = [  # (N, K, ln, epi)    GPT-2 small's four layers, the tiny fixture's, and shapes that leave partial tiles
+    (2304, 768, True, "bias"), (768, 768, False, "res"), (3072, 768, True, "gelu"), (768, 3072, False, "res"),
+    (384, 128, True, "bias"), (128, 128, False, "res"), (512, 128, True, "gelu"), (128, 512, False, "res"),
+    (80, 96, True, "gelu"), (16, 32, False, "bias"), (208, 1568, False, "res"), (2320, 800, True, "bias"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 5, 16, 33, 100, 256, 300])
+def test_linear_kernels_match_the_module_chain(M):
+    from vllmini_amd import gpt2_layer as gl
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(M)
+    for N, K, ln, epi in SHAPES:
+        x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).half().to(dev)
+        w = (torch.randn(N, K, generator=g) * (0.6 / K ** 0.5)).half().to(dev)
+        b = (torch.randn(N, generator=g) * 0.1).half().to(dev)
+        lnp = ((1 + 0.2 * torch.randn(K, generator=g)).half().to(dev), (0.1 * torch.randn(K, generator=g)).half().to(dev), 1e-5) \
+            if ln else None
+        res = torch.randn(M, N, generator=g).half().to(dev) if epi == "res" else None
+        got = gl.linear(x, w, b, ln=lnp, gelu=epi == "gelu", residual=res)
+        ref = _chain(x, w, b, lnp, epi == "gelu", res)
+        _close(got, ref, (M, N, K, ln, epi, gl.kernel_name(M, N, K, ln)))
+        # the packed weight form holds the same values in another order: the same sums in the same order, the same bits
+        assert torch.equal(gl.linear(x, gl.pack_weight(w), b, ln=lnp, gelu=epi == "gelu", residual=res), got), (M, N, K)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_linear_layout_is_not_transposed_anywhere():
+    """x = one-hot rows and a weight whose entry names its (n, k): every output element must be the entry its row's hot k and
+    its column n select — a swapped row/column map of the MFMA result, or a k-group permutation, cannot pass."""
+    from vllmini_amd import gpt2_layer as gl
+
+    dev = torch.device("cuda:0")
+    for M, N, K in ((48, 64, 64), (256, 768, 3072), (40, 2304, 768)):
+        hot = (torch.arange(M) * 37 + 5) % K
+        x = torch.zeros(M, K, dtype=torch.float16)
+        x[torch.arange(M), hot] = 1
+        n, k = torch.meshgrid(torch.arange(N), torch.arange(K), indexing="ij")
+        w = (((n * 7 + k * 13) % 1024).float() / 64 - 8).half()       # exactly representable, asymmetric in (n, k)
+        got = gl.linear(x.to(dev), w.to(dev), None).cpu()
+        assert torch.equal(got, w[:, hot].t().contiguous()), (M, N, K)
+        assert torch.equal(gl.linear(x.to(dev), gl.pack_weight(w.to(dev)), None).cpu(), got), (M, N, K)
+
+
+@pytest.mark.gpu
+def test_linear_in_place_residual_strided_input_no_bias_and_graph_replay():
+    from vllmini_amd import gpt2_layer as gl
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, E = 64, 768
+    qkv = torch.randn(M, 3 * E, generator=g).half().to(dev)
+    w = (torch.randn(E, E, generator=g) * 0.02).half().to(dev)
+    b = (torch.randn(E, generator=g) * 0.1).half().to(dev)
+    x0 = torch.randn(M, E, generator=g).half().to(dev)
+    xs = qkv[:, E:2 * E]                                  # rows 3E apart
+    ref = _chain(xs, w, b, residual=x0)
+    x = x0.clone()
+    assert gl.linear(xs, w, b, residual=x, out=x) is x    # out aliases the residual
+    _close(x, ref, "in place")
+    _close(gl.linear(xs, w, None), _chain(xs, w, None), "no bias")
+    with pytest.raises(RuntimeError, match="alternative"):
+        gl.linear(xs, w, b, gelu=True, residual=x0)
+    with pytest.raises(RuntimeError, match="K % 32"):
+        gl.linear(qkv[:, :48], w[:, :48].contiguous(), b)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gl.linear(x0.cpu(), w.cpu(), b.cpu())
+    # captured in a hipGraph: replays give the eager bits
+    s = torch.cuda.Stream(dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    y = torch.empty(M, E, dtype=torch.float16, device=dev)
+    with torch.cuda.stream(s):
+        gl.linear(xs, w, b, residual=x0, out=y)
+    torch.cuda.current_stream(dev).wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        gl.linear(xs, w, b, residual=x0, out=y)
+    y.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, x)
+
+
+@pytest.mark.gpu
+def test_gpt2_small_decode_on_native_layers_tracks_the_torch_modules():
+    """GPT-2 small, random weights, 24 sequences: the step on the native layer kernels against the same step on torch modules
+    (same pools, same tokens): logits agree to fp16 GEMM rounding, the argmax wherever the top-2 gap is not tiny; and the
+    hipGraph replay of the native step gives the eager native bits."""
+    from vllmini_amd.gpt2_decode import GPT2Dims, GPT2PagedDecoder, random_state_dict
+    from vllmini_amd.kv_pool import PagedKVPool
+
+    dev = torch.device("cuda:0")
+    dims = GPT2Dims()
+    sd = random_state_dict(dims, dev, seed=1)
+    B = 24
+
+    def make(native):
+        pool = PagedKVPool(B * dims.n_layer * 4 + 8, dims.n_head, dims.head_size, 16, 5, dims.n_layer, device=dev, max_seqs=B)
+        dec = GPT2PagedDecoder(dims, sd, pool, native_layers=native)
+        for s in range(B):
+            dec.prefill(s, [(7 * s + j) % dims.vocab_size for j in range(1 + s % 13)])
+        return dec
+
+    nat, ref, rep = make(True), make(False), make(True)
+    assert nat.native_layers and not ref.native_layers
+    rng = np.random.default_rng(0)
+    ids = list(range(B))
+    for step in range(6):
+        toks = rng.integers(0, dims.vocab_size, B).tolist()
+        a = nat.decode(ids, toks).float()
+        b = ref.decode(ids, toks).float()
+        c = rep.decode(ids, toks, use_graph=True).float()
+        assert torch.equal(a, c)
+        err = (a - b).abs().max().item()
+        assert err <= 2e-2 + 1e-2 * b.abs().max().item(), err
+        top2 = b.topk(2, dim=1).values
+        decisive = (top2[:, 0] - top2[:, 1]) > 5e-2
+        assert (a.argmax(1) == b.argmax(1))[decisive].all()

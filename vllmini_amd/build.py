@@ -79,6 +79,10 @@ LIB_NAME = "libvmi_paged_attention.so"
 LIB_PATH = os.path.join(OUT_DIR, LIB_NAME)
 DIAG_LIB_PATH = os.path.join(OUT_DIR, "libvmi_paged_attention_diag.so")
 EXTRAS_LIB_PATH = os.path.join(OUT_DIR, "libvmi_paged_attention_extras.so")
+# the decode harness's own library (include/vmi_gpt2_layer.h): the GPT-2 block's linear layers — one unit, no shared objects,
+# not part of the operators' boundary; loaded by vllmini_amd/gpt2_layer.py only
+SRC_LAYER = os.path.join(CSRC, "gpt2_layer.hip")
+LAYER_LIB_PATH = os.path.join(OUT_DIR, "libvmi_gpt2_layer.so")
 
 ARCH = "gfx950"
 # -ffp-contract=off: the fp16 p*v products must be rounded before the fp16 adds (reference
@@ -188,6 +192,28 @@ def _link(objs, lib: str, verbose: bool) -> None:
     os.replace(tmp, lib)
 
 
+def layer_is_stale() -> bool:
+    if not os.path.exists(LAYER_LIB_PATH):
+        return True
+    t = os.path.getmtime(LAYER_LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in (SRC_LAYER, os.path.join(INCLUDE, "vmi_gpt2_layer.h")))
+
+
+def build_layer(force: bool = False, verbose: bool = False) -> str:
+    """libvmi_gpt2_layer.so: one translation unit, compiled and linked in one hipcc call (~20 s)."""
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if force or layer_is_stale():
+        tmp = LAYER_LIB_PATH + ".tmp"
+        cmd = [_hipcc(), *[f for f in HIPCC_FLAGS if f != "-ffp-contract=off"], "-shared", SRC_LAYER, "-o", tmp]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({proc.returncode}): {' '.join(cmd)}\n{proc.stdout}\n{proc.stderr}")
+        os.replace(tmp, LAYER_LIB_PATH)
+    return LAYER_LIB_PATH
+
+
 def _have_objects() -> bool:
     return os.path.isdir(OUT_DIR) and any(f.endswith(".o") for f in os.listdir(OUT_DIR))
 
@@ -200,6 +226,7 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False, extras
     A tree that holds current libraries but NO objects — the GPU box: objects do not travel (.gpurunignore) — is
     complete as it is: nothing is recompiled there."""
     os.makedirs(OUT_DIR, exist_ok=True)
+    build_layer(force, verbose)
     kinds = ["product"] + (["extras"] if (extras or diag) else []) + (["diag"] if diag else [])
     if not force and not _have_objects() and not any(is_stale(k) for k in kinds):
         return _lib_of(kinds[-1])

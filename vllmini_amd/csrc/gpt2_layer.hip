@@ -1,0 +1,424 @@
+// libvmi_gpt2_layer.so — the GPT-2 block's linear layers for the decode harness (include/vmi_gpt2_layer.h).
+//
+// What the reference does here: torch modules — ln_1 -> c_attn, c_proj + residual, ln_2 -> c_fc -> GELU -> c_proj + residual
+// (vllmini/model/gpt2.py:14-15, 117-128, 130-135 and GPT2Block.forward).  Through torch on this GPU that is, per layer of a
+// 256-row decode step, four hipBLASLt launches of 8 - 9 us each for 0.3 - 1.2 GFLOP, two LayerNorm, two add and one GELU
+// launch of ~5 us each: 67 us of launches whose arithmetic and bytes are worth about 3 (profiles/r05u_e2e_native_layers.md).
+//
+// One kernel family, four launches per layer, each one round trip to memory:
+//   * y = epi(LN?(x) . W^T + b), M <= a few hundred rows (the decode batch), W = nn.Linear's [N, K] as stored;
+//   * a workgroup owns BM rows x (16 * NW) columns.  Its BM x K row tile is loaded ONCE into LDS (rows padded by 16 bytes: the
+//     16-lane groups of a ds_read_b128 then cover all 64 banks), LayerNorm runs on it in place (fp32 statistics, two passes,
+//     one wave per row, rounded to half like torch's layer_norm on half input);
+//   * every wave owns 16 output columns: its W rows are the A operand of v_mfma_f32_16x16x32_f16 exactly as they lie in
+//     memory (lane = kgroup * 16 + row holds 8 consecutive k of one row = one 16-byte load), streamed straight into
+//     registers, two chunks of 12 k-steps in flight — for K = 768 the whole weight slab is requested before the row tile
+//     arrives; the row tile's fragments (B operand, same 16-byte shape) come from LDS;
+//   * KS > 1: the K range of a column slab is split over KS waves, partial tiles meet in LDS and are added in a fixed order;
+//   * D[row = column n][col = row m]: a lane ends with 4 consecutive columns of one output row -> bias, GELU or the residual
+//     add on 8-byte vectors, one 8-byte store.
+// The weights of a GPT-2 small layer are 14 MB and stay in the 256 MiB Infinity Cache between tokens; the row tiles are L2 hits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "vmi_gpt2_layer.h"
+
+namespace vmi_layer {
+
+using h16 = _Float16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct LinearParams {
+  const h16* x;
+  int64_t ldx;
+  const h16* w;
+  const h16* bias;
+  const h16* gamma;
+  const h16* beta;
+  float eps;
+  const h16* res;
+  int64_t ldr;
+  h16* y;
+  int64_t ldy;
+  int M, N, K;
+  int w_packed;   // 0: nn.Linear rows [N, K]; 1: MFMA tiles [N / 16][K / 32][64 lanes][8] (vmi_gpt2_layer.h)
+};
+
+constexpr int CH = 12;    // k-steps (of 32) per weight chunk: 48 VGPRs
+constexpr int XU = 12;    // 16-byte units of the row tile a thread requests at once (GPT-2 small: all of its share)
+
+__device__ __forceinline__ void load_w(u32x4 (&dst)[CH], const h16* wrow, int wstep, int ksb, int ks1) {
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int k = ksb + j;   // wave-uniform
+    if (k < ks1) dst[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)k * wstep);
+  }
+}
+
+template <int MT>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MT], const u32x4 (&wf)[CH], const h16* xa, int ldxs, int ksb, int ks1) {
+  if (ksb + CH <= ks1) {   // a whole chunk: straight-line code, the LDS reads run ahead of the matrix pipe
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const h16x8 xf = *reinterpret_cast<const h16x8*>(xa + (int64_t)mi * 16 * ldxs + (ksb + j) * 32);
+        acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wf[j]), xf, acc[mi], 0, 0, 0);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int k = ksb + j;
+    if (k < ks1) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const h16x8 xf = *reinterpret_cast<const h16x8*>(xa + (int64_t)mi * 16 * ldxs + k * 32);
+        acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wf[j]), xf, acc[mi], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// two elements of a row through LayerNorm's affine form: t = x * rstd - mean * rstd in fp32 straight from the half (v_fma_mix_f32),
+// y = t * gamma + beta in fp32 written as a half (v_fma_mixlo / mixhi_f16: one rounding, to nearest even) — 2 instructions per
+// element where conversions + fp32 math take 7
+__device__ __forceinline__ uint32_t ln_pair(uint32_t x2, uint32_t g2, uint32_t b2, float rstd, float nmr) {
+  float t0, t1;
+  uint32_t y;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(x2), "v"(rstd), "v"(nmr));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(x2), "v"(rstd), "v"(nmr));
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(y) : "v"(t0), "v"(g2), "v"(b2));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "+v"(y) : "v"(t1), "v"(g2), "v"(b2));
+  return y;
+}
+
+// s += x, q += x * x for the two halves of a dword, fp32 sums (v_dot2_f32_f16 would take half the instructions, but its sums
+// came out ~10 % off the fp32 ones on this data — measured, not used)
+__device__ __forceinline__ void ln_stats_pair(uint32_t x2, float& s, float& q) {
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(x2));
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s) : "v"(x2));
+  asm("v_fma_mix_f32 %0, %1, %1, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(q) : "v"(x2));
+  asm("v_fma_mix_f32 %0, %1, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(q) : "v"(x2));
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {   // over the LPR consecutive lanes that share a row
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Order of the memory requests (they complete in order, so what is needed first is asked for first): the row tile, weight
+// chunk 0, [tile to LDS], weight chunks 1 .. NBUF - 1, [LayerNorm], the ring of chunks.  For K = 768 (NBUF = 2) and for
+// mlp.c_proj's K = 3072 over two waves (NBUF = 4) everything a wave will ever read is in flight before its first MFMA.
+template <int BM, int NW, int KS, int NBUF, bool LN, int EPI>
+__global__ __launch_bounds__(NW* KS * 64) void linear_kernel(const LinearParams p) {
+  constexpr int T = NW * KS * 64, MT = BM / 16, LPR = T / BM;   // LPR lanes share a row of the tile (load, LayerNorm)
+  static_assert(LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "a row's lanes lie inside one wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  h16* xs = reinterpret_cast<h16*>(smem);
+  const int ldxs = p.K + 8, upr = p.K >> 3;
+  h16* gb = xs + (size_t)BM * ldxs;                                      // LN: gamma [K], beta [K]
+  float* red = reinterpret_cast<float*>(gb + (LN ? 2 * p.K : 0));       // [(KS - 1)][NW][MT][64][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nw = wave % NW, ks = wave / NW;
+  const int NB = (p.N + 16 * NW - 1) / (16 * NW);
+  const int nb = blockIdx.x % NB, mb = blockIdx.x / NB;
+  const int m0 = mb * BM, n0 = (nb * NW + nw) * 16;
+  const int nks = p.K >> 5;
+  const int ks_per = (nks + KS - 1) / KS, ks0 = ks * ks_per, ks1 = min(nks, ks0 + ks_per);
+  const int kc = lane >> 4, r16 = lane & 15;
+  const bool nvalid = n0 < p.N;   // N % 16 == 0: a slab is wholly inside or wholly outside
+
+  // 1. LayerNorm's gamma and beta (on their way into LDS: 2 * K / 8 units <= 2 * T, checked on the host), then the row
+  //    tile: BM x K halves, rows past M as zeros; LPR consecutive lanes walk one row
+  u32x4 gv[2];
+  if constexpr (LN) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + i * T;
+      gv[i] = u32x4{0u, 0u, 0u, 0u};
+      if (u < 2 * upr) gv[i] = *reinterpret_cast<const u32x4*>((u < upr ? p.gamma + u * 8 : p.beta + (u - upr) * 8));
+    }
+  }
+  const int xrow = tid / LPR, xj = tid % LPR;
+  const bool xin = m0 + xrow < p.M;
+  const h16* xsrc = p.x + (int64_t)(m0 + (xin ? xrow : 0)) * p.ldx;
+  h16* xdst = xs + (int64_t)xrow * ldxs;
+  u32x4 xv[XU];
+#pragma unroll
+  for (int i = 0; i < XU; ++i) {
+    const int u = xj + i * LPR;
+    xv[i] = u32x4{0u, 0u, 0u, 0u};
+    if (xin && u < upr) xv[i] = *reinterpret_cast<const u32x4*>(xsrc + u * 8);
+  }
+  // 2. the weight slab of this wave, chunk 0
+  // (rows as stored: lane (kc, r) reads 16 bytes of row n0 + r, a k-step is 32 elements on; packed tiles: a k-step of a
+  //  16-column slab is 1 KiB in lane order — one contiguous KiB per wave load instead of sixteen 64-byte pieces)
+  const int wstep = p.w_packed ? 512 : 32;
+  const h16* wrow = !nvalid ? p.w : p.w_packed ? p.w + ((int64_t)(n0 >> 4) * nks * 64 + lane) * 8
+                                               : p.w + (int64_t)(n0 + r16) * p.K + 8 * kc;
+  u32x4 wb[NBUF][CH];
+#pragma unroll
+  for (int b = 0; b < NBUF; ++b)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) wb[b][j] = u32x4{0u, 0u, 0u, 0u};
+  if (nvalid) load_w(wb[0], wrow, wstep, ks0, ks1);
+  // residual values of this lane's outputs: asked for now, used in the epilogue
+  const int n = n0 + 4 * kc;
+  h16x4 rr[MT];
+  if constexpr (EPI == VMI_LAYER_EPI_BIAS_RESIDUAL) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int m = m0 + mi * 16 + r16;
+      rr[mi] = h16x4{0, 0, 0, 0};
+      if (nvalid && m < p.M) rr[mi] = *reinterpret_cast<const h16x4*>(p.res + (int64_t)m * p.ldr + n);
+    }
+  }
+  if constexpr (!LN) {
+    // 3. tile to LDS (the few shapes whose rows are longer than XU * LPR units finish them here, one more round trip each)
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      const int u = xj + i * LPR;
+      if (u < upr) *reinterpret_cast<u32x4*>(xdst + u * 8) = xv[i];
+    }
+    for (int ub = XU * LPR; ub < upr; ub += LPR) {
+      const int u = ub + xj;
+      if (u < upr) *reinterpret_cast<u32x4*>(xdst + u * 8) = xin ? *reinterpret_cast<const u32x4*>(xsrc + u * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    // 4. the other chunks of the ring
+    if (nvalid) {
+#pragma unroll
+      for (int b = 1; b < NBUF; ++b) load_w(wb[b], wrow, wstep, ks0 + b * CH, ks1);
+    }
+    __syncthreads();
+  } else {
+    // 3. LayerNorm on the values as they sit in registers (a row's K <= XU * LPR * 8, checked on the host): the LPR lanes of a
+    //    row add up the sum and the sum of squares (fp32; var = E[x^2] - mean^2), gamma / beta come back from LDS, and the tile is written ONCE,
+    //    normalised: y = (x - mean) * rstd * gamma + beta rounded to half — torch's layer_norm on half input
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + i * T;
+      if (u < 2 * upr) *reinterpret_cast<u32x4*>(gb + u * 8) = gv[i];
+    }
+    const float inv_k = 1.f / (float)p.K;
+    float s = 0.f, q = 0.f;   // sum and sum of squares in fp32, each element straight from its half: v_fma_mix_f32
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {   // (units past the row are zeros)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ln_stats_pair(xv[i][e], s, q);
+    }
+    const float mean = group_sum<LPR>(s) * inv_k;
+    const float var = fmaxf(group_sum<LPR>(q) * inv_k - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + p.eps), nmr = -mean * rstd;
+    // 4. the other chunks of the ring
+    if (nvalid) {
+#pragma unroll
+      for (int b = 1; b < NBUF; ++b) load_w(wb[b], wrow, wstep, ks0 + b * CH, ks1);
+    }
+    __syncthreads();   // gamma / beta are in LDS
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      const int u = xj + i * LPR;
+      if (u < upr) {
+        const u32x4 g = *reinterpret_cast<const u32x4*>(gb + u * 8);
+        const u32x4 b = *reinterpret_cast<const u32x4*>(gb + p.K + u * 8);
+        u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ln_pair(xv[i][e], g[e], b[e], rstd, nmr);
+        *reinterpret_cast<u32x4*>(xdst + u * 8) = v;
+      }
+    }
+    __syncthreads();
+  }
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (nvalid) {
+    const h16* xa = xs + (int64_t)r16 * ldxs + 8 * kc;
+    for (int ksb = ks0; ksb < ks1; ksb += NBUF * CH) {
+#pragma unroll
+      for (int b = 0; b < NBUF; ++b) {
+        mma_chunk<MT>(acc, wb[b], xa, ldxs, ksb + b * CH, ks1);
+        if (ksb + (b + NBUF) * CH < ks1) load_w(wb[b], wrow, wstep, ksb + (b + NBUF) * CH, ks1);
+      }
+    }
+  }
+
+  if constexpr (KS > 1) {
+    if (ks > 0) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+        *reinterpret_cast<f32x4*>(red + ((((int64_t)(ks - 1) * NW + nw) * MT + mi) * 64 + lane) * 4) = acc[mi];
+    }
+    __syncthreads();
+    if (ks > 0) return;
+#pragma unroll
+    for (int s = 1; s < KS; ++s)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((((int64_t)(s - 1) * NW + nw) * MT + mi) * 64 + lane) * 4);
+        acc[mi] += o;
+      }
+  }
+  if (!nvalid) return;
+
+  // D[row = 4 * kc + r -> column n][col = r16 -> row m]
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr) {
+    const h16x4 b = *reinterpret_cast<const h16x4*>(p.bias + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = (float)b[r];
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int m = m0 + mi * 16 + r16;
+    if (m >= p.M) continue;
+    h16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (h16)(acc[mi][r] + bias[r]);   // the linear layer's own half output
+    if constexpr (EPI == VMI_LAYER_EPI_BIAS_GELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = (float)o[r];
+        o[r] = (h16)(0.5f * v * (1.f + erff(v * 0.70710678118654752440f)));
+      }
+    } else if constexpr (EPI == VMI_LAYER_EPI_BIAS_RESIDUAL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (h16)((float)rr[mi][r] + (float)o[r]);
+    }
+    *reinterpret_cast<h16x4*>(p.y + (int64_t)m * p.ldy + n) = o;
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+
+static thread_local std::string g_err;
+
+struct Shape {
+  int bm, nw, ks, nbuf;
+};
+
+constexpr int LDS_PER_CU = 160 * 1024;
+constexpr int MAX_K = 4608;
+constexpr int MAX_K_LN = 2048;   // gamma and beta ride into LDS with two 16-byte units per thread of a 256-thread workgroup
+
+// BM = 32 while three such tiles fit a CU's LDS side by side AND the launch still has workgroups for most of the chip;
+// otherwise BM = 16 (twice the workgroups); the K range of a slab is split over two waves from 48 k-steps on.
+static bool pick(int M, int N, int K, bool ln, Shape* s) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (N & 15) || K > (ln ? MAX_K_LN : MAX_K)) return false;
+  const int nb = (N + 63) / 64;
+  // (behind a LayerNorm a row's K must sit in the registers of its lanes: 12 units x T / BM lanes -> K <= 768 at BM = 32,
+  //  1536 at BM = 16, 3072 with the K range over two waves)
+  const bool fits32 = 3 * 32 * (K + 8) * 2 <= LDS_PER_CU && !(ln && K > 768);
+  const int wgs32 = ((M + 31) / 32) * nb;
+  s->bm = (M > 16 && fits32 && wgs32 >= 200) ? 32 : 16;
+  s->nw = 4;
+  s->ks = (s->bm == 16 && K >= 1536) ? 2 : 1;
+  // the ring: two weight chunks (24 k-steps) per wave, four where a wave has more to read and the registers to hold them
+  s->nbuf = (!ln && s->ks == 2 && (K / 32 + 1) / 2 > 2 * CH) ? 4 : 2;   // (behind a LayerNorm the row's values hold those registers)
+  return true;
+}
+
+static size_t lds_bytes(const Shape& s, int K, bool ln) {
+  return (size_t)s.bm * (K + 8) * 2 + (ln ? (size_t)4 * K : 0) + (size_t)(s.ks - 1) * s.nw * (s.bm / 16) * 64 * 16;
+}
+
+template <int BM, int NW, int KS, int NBUF, bool LN, int EPI>
+static int launch(const LinearParams& p, const Shape& s, hipStream_t stream) {
+  const size_t lds = lds_bytes(s, p.K, LN);
+  auto* fn = linear_kernel<BM, NW, KS, NBUF, LN, EPI>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      g_err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e);
+      return VMI_LAYER_E_HIP;
+    }
+  }
+  const int nb = (p.N + 16 * NW - 1) / (16 * NW), mbs = (p.M + BM - 1) / BM;
+  hipLaunchKernelGGL(fn, dim3(nb * mbs), dim3(NW * KS * 64), lds, stream, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_err = std::string("launch: ") + hipGetErrorString(e);
+    return VMI_LAYER_E_HIP;
+  }
+  return VMI_LAYER_OK;
+}
+
+template <int BM, int NW, int KS, int NBUF>
+static int launch_le(const LinearParams& p, const Shape& s, bool ln, int epi, hipStream_t stream) {
+  switch ((ln ? 3 : 0) + epi) {
+    case 0: return launch<BM, NW, KS, NBUF, false, 0>(p, s, stream);
+    case 1: return launch<BM, NW, KS, NBUF, false, 1>(p, s, stream);
+    case 2: return launch<BM, NW, KS, NBUF, false, 2>(p, s, stream);
+    case 3: return launch<BM, NW, KS, NBUF, true, 0>(p, s, stream);
+    case 4: return launch<BM, NW, KS, NBUF, true, 1>(p, s, stream);
+    default: return launch<BM, NW, KS, NBUF, true, 2>(p, s, stream);
+  }
+}
+
+}  // namespace vmi_layer
+
+extern "C" {
+
+int vmi_gpt2_linear_f16(const void* x, int64_t ldx, const void* w, const void* bias, const void* ln_gamma, const void* ln_beta,
+                        float ln_eps, const void* residual, int64_t ldr, void* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
+                        int32_t epilogue, int32_t w_layout, int32_t device, void* stream) {
+  using namespace vmi_layer;
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || epilogue < 0 || epilogue > 2 || w_layout < 0 || w_layout > 1 || (!ln_gamma) != (!ln_beta) ||
+      (epilogue == VMI_LAYER_EPI_BIAS_RESIDUAL && !residual)) {
+    g_err = "vmi_gpt2_linear_f16: null pointer, non-positive size, unknown epilogue or a residual epilogue without a residual";
+    return VMI_LAYER_E_ARG;
+  }
+  const bool ln = ln_gamma != nullptr;
+  Shape s;
+  if (!pick(M, N, K, ln, &s) || (ldx & 7) || (ldy & 3) || (epilogue == VMI_LAYER_EPI_BIAS_RESIDUAL && (ldr & 3)) ||
+      ((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 7)) {
+    g_err = "vmi_gpt2_linear_f16: needs K % 32 == 0, N % 16 == 0, K <= 4608 (2048 behind a LayerNorm), 16-byte aligned rows of x and w, 8-byte aligned rows of y";
+    return VMI_LAYER_E_SHAPE;
+  }
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess || (prev != device && hipSetDevice(device) != hipSuccess)) {
+    g_err = "vmi_gpt2_linear_f16: hipSetDevice failed";
+    return VMI_LAYER_E_HIP;
+  }
+  LinearParams p{static_cast<const h16*>(x), ldx, static_cast<const h16*>(w), static_cast<const h16*>(bias),
+                 static_cast<const h16*>(ln_gamma), static_cast<const h16*>(ln_beta), ln_eps,
+                 static_cast<const h16*>(residual), ldr, static_cast<h16*>(y), ldy, M, N, K, w_layout};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc;
+  if (s.bm == 32)   // (three 32-row tiles side by side in LDS means K <= 845: never with a split K range)
+    rc = launch_le<32, 4, 1, 2>(p, s, ln, epilogue, st);
+  else if (s.ks == 1)
+    rc = launch_le<16, 4, 1, 2>(p, s, ln, epilogue, st);
+  else
+    rc = s.nbuf == 2 ? launch_le<16, 4, 2, 2>(p, s, ln, epilogue, st) : launch_le<16, 4, 2, 4>(p, s, ln, epilogue, st);
+  if (prev != device) (void)hipSetDevice(prev);
+  return rc;
+}
+
+const char* vmi_gpt2_linear_kernel_name(int32_t M, int32_t N, int32_t K, int32_t has_ln, int32_t epilogue) {
+  using namespace vmi_layer;
+  static thread_local std::string name;
+  Shape s;
+  if (!pick(M, N, K, has_ln != 0, &s) || epilogue < 0 || epilogue > 2) return nullptr;
+  static const char* epi[] = {"bias", "gelu", "residual"};
+  name = "bm" + std::to_string(s.bm) + "_nw" + std::to_string(s.nw) + "_ks" + std::to_string(s.ks) + "_r" + std::to_string(s.nbuf) + (has_ln ? "_ln_" : "_") +
+         epi[epilogue];
+  return name.c_str();
+}
+
+const char* vmi_gpt2_layer_last_error(void) { return vmi_layer::g_err.c_str(); }
+int32_t vmi_gpt2_layer_abi_version(void) { return VMI_GPT2_LAYER_ABI_VERSION; }
+const char* vmi_gpt2_layer_target_arch(void) { return "gfx950"; }
+
+}  // extern "C"

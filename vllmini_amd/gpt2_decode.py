@@ -10,8 +10,11 @@ for what the operators are actually batched over:
     bookkeeping (kv_pool.PagedKVPool.decode_step_batch) with a single upload;
   * q/k/v are strided views of the fused c_attn output (row stride 3*hidden), exactly the views
     the reference hands to the ops (gpt2.py:35-41);
-  * everything around the two ops is plain torch (F.linear -> hipBLASLt, layer_norm, gelu):
-    library GEMMs, not part of the hot path.
+  * around the two ops a decode step runs the block's linear layers on this build's own gfx950 kernels
+    (`native_layers`, vllmini_amd/gpt2_layer.py -> csrc/gpt2_layer.hip): LayerNorm + c_attn, c_proj + residual,
+    LayerNorm + c_fc + GELU, mlp.c_proj + residual — four launches per layer where the torch modules take eleven
+    (67 -> 23 us per layer at batch 256).  `native_layers=False` is the torch-module chain (F.linear -> hipBLASLt,
+    layer_norm, gelu), which prefill, the embeddings and lm_head always use.
 
 `reference_off_by_one=True` reproduces the reference caller's seq_lens (length BEFORE the new
 token, scheduler.py:96, so the newest token is not attended); the default attends to it.
@@ -29,7 +32,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import cache_ops, ops
+from . import cache_ops, gpt2_layer, ops
 from .kv_pool import PagedKVPool
 
 
@@ -81,7 +84,7 @@ class GPT2PagedDecoder:
     """Prefill + batched decode of GPT-2 over a PagedKVPool, calling the two hot-path ops."""
 
     def __init__(self, dims: GPT2Dims, state_dict: Dict[str, torch.Tensor], pool: PagedKVPool,
-                 reference_off_by_one: bool = False, fused_append: bool = False):
+                 reference_off_by_one: bool = False, fused_append: bool = False, native_layers: Optional[bool] = None):
         assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
         assert pool.head_size == dims.head_size
         self.dims, self.sd, self.pool = dims, state_dict, pool
@@ -101,6 +104,24 @@ class GPT2PagedDecoder:
             raise ValueError("fused_append writes at position seq_lens-1; reference_off_by_one passes seq_lens-1 "
                              "as the length, so the two cannot be combined")
         self.fused_append = fused_append
+        # native_layers: None = wherever they apply (a HIP device, float16 weights, hidden size a multiple of 32); True insists
+        # (RuntimeError otherwise); False = the torch modules.  The library is loaded HERE: a missing one fails in the constructor.
+        E = dims.n_embd
+        can = pool.device.type == "cuda" and wdt == torch.float16 and E % 32 == 0 and 4 * E <= 4608
+        if native_layers and not can:
+            raise RuntimeError("native_layers needs a HIP device, float16 weights and a hidden size that is a multiple of 32 "
+                               f"(<= 1152); got {pool.device}, {wdt}, {E}")
+        self.native_layers = can if native_layers is None else bool(native_layers)
+        self._packed: Dict[str, gpt2_layer.PackedWeight] = {}
+        if self.native_layers:
+            gpt2_layer.load()
+            # the block weights once more as the MFMA tiles the kernels stream (include/vmi_gpt2_layer.h, w_layout 1): weights
+            # are static, a wave's load of a k-step becomes one contiguous KiB (mlp.c_proj 15.0 -> 8.2 us at batch 256);
+            # the state dict keeps the reference's nn.Linear layout for prefill and for loading checkpoints
+            for i in range(dims.n_layer):
+                for name in ("attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):
+                    key = f"transformer.h.{i}.{name}.weight"
+                    self._packed[key] = gpt2_layer.pack_weight(state_dict[key])
         self.scale = dims.head_size ** -0.5                    # gpt2.py:13
         self.device = pool.device
         self.max_seq_len = pool.max_blocks_per_seq * pool.block_size   # capacity, like scheduler.py:97
@@ -155,9 +176,15 @@ class GPT2PagedDecoder:
         d, pool = self.dims, self.pool
         B = st["input_ids"].shape[0]
         x = self.sd["transformer.wte.weight"][st["input_ids"]] + self.sd["transformer.wpe.weight"][st["position_ids"]]
+        nat, sd, E, pw = self.native_layers, self.sd, d.n_embd, self._packed
         for i in range(d.n_layer):
             p = f"transformer.h.{i}."
-            q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)
+            if nat:      # ln_1 + c_attn in one launch; q/k/v are the same 3E-strided views (gpt2.py:35-41)
+                qkv = gpt2_layer.linear(x, pw[p + "attn.c_attn.weight"], sd[p + "attn.c_attn.bias"],
+                                        ln=(sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], d.layer_norm_epsilon))
+                q, k, v = (qkv[:, j * E:(j + 1) * E].view(B, d.n_head, d.head_size) for j in range(3))
+            else:
+                q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)
             out = torch.empty((B, d.n_head, d.head_size), dtype=q.dtype, device=q.device)   # empty_like(q) is contiguous, gpt2.py:93
             var = st.get("variant", 0)   # work decomposition chosen on the host from the batch's lengths (decode())
             if self.fused_append:
@@ -171,8 +198,14 @@ class GPT2PagedDecoder:
                                        st["seq_lens"], pool.block_size, self.max_seq_len, None,
                                        pool.kv_cache_dtype, pool.kv_scale, 0, 0, 1, 1, 0,
                                        _variant=var)
-            x = x + F.linear(out.view(B, d.n_embd), self.sd[p + "attn.c_proj.weight"], self.sd[p + "attn.c_proj.bias"])
-            x = x + self._mlp(self._ln(x, p + "ln_2"), p)
+            if nat:      # c_proj + residual; ln_2 + c_fc + GELU; mlp.c_proj + residual (x is updated in place)
+                gpt2_layer.linear(out.view(B, E), pw[p + "attn.c_proj.weight"], sd[p + "attn.c_proj.bias"], residual=x, out=x)
+                h = gpt2_layer.linear(x, pw[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], gelu=True,
+                                      ln=(sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], d.layer_norm_epsilon))
+                gpt2_layer.linear(h, pw[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"], residual=x, out=x)
+            else:
+                x = x + F.linear(out.view(B, d.n_embd), self.sd[p + "attn.c_proj.weight"], self.sd[p + "attn.c_proj.bias"])
+                x = x + self._mlp(self._ln(x, p + "ln_2"), p)
         return F.linear(self._ln(x, "transformer.ln_f"), self.sd["lm_head.weight"])   # [B, V]
 
     def _ensure_static(self, B: int) -> dict:

@@ -1,0 +1,132 @@
+"""The GPT-2 block's linear layers for the decode harness, on libvmi_gpt2_layer.so (include/vmi_gpt2_layer.h).
+
+Counterpart of the torch modules around the reference's call pair — ln_1 -> c_attn, c_proj + residual,
+ln_2 -> c_fc -> GELU -> c_proj + residual (vllmini/model/gpt2.py:14-15, 117-128, 130-135, GPT2Block.forward): one
+hand-written gfx950 kernel family (csrc/gpt2_layer.hip) that runs each linear layer of a decode step — LayerNorm in front,
+bias / GELU / residual add behind — as ONE launch.  `linear()` is the only operation; it has no torch fallback: a missing
+library or an unsupported shape raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional, Tuple
+
+import torch
+
+from . import build as _build
+
+ABI_VERSION = 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
+
+_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+SIGNATURES = {
+    "vmi_gpt2_linear_f16": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _i64, _vp, _i64,
+                                           _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vmi_gpt2_linear_kernel_name": (ctypes.c_char_p, [_i32, _i32, _i32, _i32, _i32]),
+    "vmi_gpt2_layer_last_error": (ctypes.c_char_p, []),
+    "vmi_gpt2_layer_abi_version": (_i32, []),
+    "vmi_gpt2_layer_target_arch": (ctypes.c_char_p, []),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class LayerLibraryError(RuntimeError):
+    """libvmi_gpt2_layer.so is missing / stale / does not match the header."""
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                path = _build.LAYER_LIB_PATH
+                if not os.path.exists(path):
+                    raise LayerLibraryError(f"{path} not found: build it with `python -m vllmini_amd.build` "
+                                            "(or __graft_entry__.build()).  The native layers have no torch fallback; "
+                                            "GPT2PagedDecoder(native_layers=False) is the torch-module harness.")
+                try:
+                    lib = ctypes.CDLL(path)
+                except OSError as e:
+                    raise LayerLibraryError(f"cannot load {path}: {e}") from e
+                for name, (restype, argtypes) in SIGNATURES.items():
+                    try:
+                        fn = getattr(lib, name)
+                    except AttributeError as e:
+                        raise LayerLibraryError(f"{path} does not export {name}") from e
+                    fn.restype, fn.argtypes = restype, argtypes
+                if lib.vmi_gpt2_layer_abi_version() != ABI_VERSION:
+                    raise LayerLibraryError(f"{path}: ABI {lib.vmi_gpt2_layer_abi_version()}, expected {ABI_VERSION}")
+                _lib = lib
+    return _lib
+
+
+def supports(M: int, N: int, K: int) -> bool:
+    """Whether linear() takes this shape (K % 32 == 0, N % 16 == 0, K <= 4608)."""
+    return load().vmi_gpt2_linear_kernel_name(M, N, K, 0, 0) is not None
+
+
+def kernel_name(M: int, N: int, K: int, ln: bool = False, epilogue: int = EPI_BIAS) -> Optional[str]:
+    s = load().vmi_gpt2_linear_kernel_name(M, N, K, int(ln), epilogue)
+    return s.decode() if s else None
+
+
+class PackedWeight:
+    """An nn.Linear weight [N, K] re-laid as the MFMA tiles the kernels read (include/vmi_gpt2_layer.h, w_layout 1):
+    tile[s][t][kc * 16 + r][e] = w[16 s + r][32 t + 8 kc + e].  Weights are static, so the harness packs each once."""
+
+    def __init__(self, weight: torch.Tensor):
+        N, K = weight.shape
+        if N % 16 or K % 32 or weight.dtype != torch.float16:
+            raise RuntimeError("pack_weight: half [N, K] with N % 16 == 0 and K % 32 == 0")
+        self.shape = (N, K)
+        self.tiles = weight.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def pack_weight(weight: torch.Tensor) -> PackedWeight:
+    return PackedWeight(weight)
+
+
+def linear(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, *,
+           ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, gelu: bool = False,
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epilogue(LN?(x) @ weight.T + bias): x [M, K] half (last dim contiguous), weight [N, K] half contiguous
+    (nn.Linear layout) or its pack_weight() form, ln = (gamma, beta, eps) for a LayerNorm over K in front, gelu / residual [M, N] behind (not both).
+    `out` may be `residual` itself.  Launches on torch's current stream; never synchronises."""
+    lib = load()
+    packed = isinstance(weight, PackedWeight)
+    wshape = weight.shape
+    if packed:
+        weight = weight.tiles
+    if x.device.type != "cuda":
+        raise RuntimeError("gpt2_layer.linear: there is no CPU path")
+    if x.dtype != torch.float16 or weight.dtype != torch.float16:
+        raise RuntimeError("gpt2_layer.linear: float16 tensors only")
+    if gelu and residual is not None:
+        raise RuntimeError("gpt2_layer.linear: gelu and residual are alternative epilogues")
+    if x.dim() != 2 or len(wshape) != 2 or x.shape[1] != wshape[1] or x.stride(1) != 1 or not weight.is_contiguous():
+        raise RuntimeError("gpt2_layer.linear: x [M, K] with unit stride in K, weight [N, K] contiguous")
+    M, K = x.shape
+    N = wshape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    if out.shape != (M, N) or out.stride(1) != 1 or out.dtype != torch.float16:
+        raise RuntimeError("gpt2_layer.linear: out [M, N] half with unit stride in N")
+    for t, what in ((bias, "bias"), (ln[0] if ln else None, "ln gamma"), (ln[1] if ln else None, "ln beta")):
+        if t is not None and (t.dtype != torch.float16 or not t.is_contiguous() or t.device != x.device):
+            raise RuntimeError(f"gpt2_layer.linear: {what} must be a contiguous half tensor on x's device")
+    if residual is not None and (residual.shape != (M, N) or residual.stride(1) != 1 or residual.dtype != torch.float16):
+        raise RuntimeError("gpt2_layer.linear: residual [M, N] half with unit stride in N")
+    epi = EPI_BIAS_GELU if gelu else EPI_BIAS_RESIDUAL if residual is not None else EPI_BIAS
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    rc = lib.vmi_gpt2_linear_f16(x.data_ptr(), x.stride(0), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 ln[0].data_ptr() if ln else None, ln[1].data_ptr() if ln else None,
+                                 float(ln[2]) if ln else 0.0, residual.data_ptr() if residual is not None else None,
+                                 residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
+                                 M, N, K, epi, int(packed), x.device.index or 0, stream)
+    if rc != 0:
+        raise RuntimeError(lib.vmi_gpt2_layer_last_error().decode("utf-8", "replace"))
+    return out
