@@ -7,6 +7,8 @@
 #   make diag       ... and the diagnostic library (the extras library under -DVMI_DIAG: include/vmi_paged_attention_diag.h's
 #                   entries, the "loads only" variants, the LDS-staging experiment); it shares every object -DVMI_DIAG
 #                   does not change
+#   make layer      libvmi_gpt2_layer.so (include/vmi_gpt2_layer.h): the decode harness's own library — the GPT-2 block's
+#                   linear layers; one unit, part of `make` / `all`
 HIPCC  ?= hipcc
 ARCH   ?= gfx950
 # -ffp-contract=off: the fp16 p*v products are rounded before the fp16 adds (the reference's rounding points)
@@ -28,7 +30,15 @@ EXTRAS_LIB := $(OUTDIR)/libvmi_paged_attention_extras.so
 DIAG_LIB := $(OUTDIR)/libvmi_paged_attention_diag.so
 DEPS   := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/vmi_paged_attention.h include/vmi_paged_attention_extras.h
 
-all: $(LIB) oracle
+LAYER_LIB := $(OUTDIR)/libvmi_gpt2_layer.so
+
+all: $(LIB) $(LAYER_LIB) oracle
+
+layer: $(LAYER_LIB)
+
+$(LAYER_LIB): $(CSRC)/gpt2_layer.hip include/vmi_gpt2_layer.h
+	mkdir -p $(OUTDIR)
+	$(HIPCC) $(filter-out -ffp-contract=off,$(FLAGS)) -shared $< -o $@
 
 extras: $(LIB) $(EXTRAS_LIB)
 

@@ -63,15 +63,23 @@ __device__ __forceinline__ void load_w(u32x4 (&dst)[CH], const h16* wrow, int ws
 
 template <int MT>
 __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[MT], const u32x4 (&wf)[CH], const h16* xa, int ldxs, int ksb, int ks1) {
-  if (ksb + CH <= ks1) {   // a whole chunk: straight-line code, the LDS reads run ahead of the matrix pipe
+  if (ksb + CH <= ks1) {   // a whole chunk: straight-line code, the row tile's fragments read PD k-steps ahead of the matrix pipe
+    constexpr int PD = 4;  // (left to itself the scheduler keeps ONE step of distance: an LDS round trip per MFMA pair)
+    h16x8 xf[PD][MT];
+#pragma unroll
+    for (int j = 0; j < PD; ++j)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) xf[j][mi] = *reinterpret_cast<const h16x8*>(xa + (int64_t)mi * 16 * ldxs + (ksb + j) * 32);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
-        const h16x8 xf = *reinterpret_cast<const h16x8*>(xa + (int64_t)mi * 16 * ldxs + (ksb + j) * 32);
-        acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wf[j]), xf, acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wf[j]), xf[j % PD][mi], acc[mi], 0, 0, 0);
+        if (j + PD < CH) xf[j % PD][mi] = *reinterpret_cast<const h16x8*>(xa + (int64_t)mi * 16 * ldxs + (ksb + j + PD) * 32);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     return;
   }
 #pragma unroll
@@ -109,10 +117,20 @@ __device__ __forceinline__ void ln_stats_pair(uint32_t x2, float& s, float& q) {
   asm("v_fma_mix_f32 %0, %1, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(q) : "v"(x2));
 }
 
+// sum over the LPR consecutive lanes that share a row: inside a row of 16 lanes on the DPP cross-lane paths (quad permutes, then
+// the half-row and row mirrors: each a VALU operand modifier, no LDS round trip), beyond that through ds_bpermute
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {   // over the LPR consecutive lanes that share a row
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (LPR >= 2) v += dpp_get<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (LPR >= 4) v += dpp_get<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 8) v += dpp_get<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of each 8
+  if constexpr (LPR >= 16) v += dpp_get<0x140>(v);  // row_mirror: lane i <-> 15 - i of each 16
 #pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 16; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -356,6 +374,14 @@ static int launch(const LinearParams& p, const Shape& s, hipStream_t stream) {
 
 template <int BM, int NW, int KS, int NBUF>
 static int launch_le(const LinearParams& p, const Shape& s, bool ln, int epi, hipStream_t stream) {
+  if constexpr (NBUF > 2) {   // (the four-chunk ring is picked for shapes without a LayerNorm only: no such kernels are built)
+    if (ln) return VMI_LAYER_E_SHAPE;
+    switch (epi) {
+      case 0: return launch<BM, NW, KS, NBUF, false, 0>(p, s, stream);
+      case 1: return launch<BM, NW, KS, NBUF, false, 1>(p, s, stream);
+      default: return launch<BM, NW, KS, NBUF, false, 2>(p, s, stream);
+    }
+  } else
   switch ((ln ? 3 : 0) + epi) {
     case 0: return launch<BM, NW, KS, NBUF, false, 0>(p, s, stream);
     case 1: return launch<BM, NW, KS, NBUF, false, 1>(p, s, stream);
