@@ -83,6 +83,8 @@ def random_state_dict(dims: GPT2Dims, device, dtype=torch.float16, seed: int = 0
 class GPT2PagedDecoder:
     """Prefill + batched decode of GPT-2 over a PagedKVPool, calling the two hot-path ops."""
 
+    NATIVE_LAYERS_MAX_BATCH = 512    # larger steps run the block's linear layers as torch modules (real GEMMs by then)
+
     def __init__(self, dims: GPT2Dims, state_dict: Dict[str, torch.Tensor], pool: PagedKVPool,
                  reference_off_by_one: bool = False, fused_append: bool = False, native_layers: Optional[bool] = None):
         assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
@@ -176,7 +178,9 @@ class GPT2PagedDecoder:
         d, pool = self.dims, self.pool
         B = st["input_ids"].shape[0]
         x = self.sd["transformer.wte.weight"][st["input_ids"]] + self.sd["transformer.wpe.weight"][st["position_ids"]]
-        nat, sd, E, pw = self.native_layers, self.sd, d.n_embd, self._packed
+        # (the kernels are built for a decode batch: ahead of the torch modules from 1 to 256 rows — 23 - 31 us per layer against
+        #  32 - 43 — level at 512, behind beyond: profiles/r05u_gpt2_layer_probe_batches.json)
+        nat, sd, E, pw = self.native_layers and B <= self.NATIVE_LAYERS_MAX_BATCH, self.sd, d.n_embd, self._packed
         for i in range(d.n_layer):
             p = f"transformer.h.{i}."
             if nat:      # ln_1 + c_attn in one launch; q/k/v are the same 3E-strided views (gpt2.py:35-41)
