@@ -49,6 +49,7 @@ Diagnostic modes (--sweep, --diag, --matrix) live in scripts/bench_diag.py.
 from __future__ import annotations
 
 import argparse
+import dataclasses
 import json
 import os
 import socket
@@ -824,7 +825,6 @@ def strong_n1_record(args, dev):
     """The N = 1 anchor of the STRONG-scaling curve (BASELINE.md §2 last row): all 2048 sequences of BASELINE
     configs[4] on one GPU, pool = max(65536, what two disjoint table sets need) blocks.  2048 = QSORT_MAX, the most sequences
     the balanced kernel ranks (pa_queue.hpp); the default entry's pick is reported."""
-    import dataclasses
     from vllmini_amd import ops
     c5 = CONFIGS["cfg5"]
     b_ = 2048
@@ -879,7 +879,6 @@ def main(argv=None):
         if args.scaling == "strong":
             # total batch 2048 whatever N; N = 1 needs 2 x 131072 blocks for two disjoint table sets,
             # more than the stated 65536 -> the pool is max(65536, needed)
-            import dataclasses
             total = 2048
             if total % world:
                 raise SystemExit(f"--scaling strong: {total} sequences do not divide over {world} GPUs")
@@ -892,11 +891,9 @@ def main(argv=None):
     if args.pv_mfma:
         ops.set_pv_mfma(True)
     if args.kv_heads:
-        import dataclasses
         args.no_cpu_baseline = True      # the eager CPU baseline is written for the multi-head BASELINE configs
         cfg = dataclasses.replace(cfg, name=f"{cfg.name}_kv{args.kv_heads}", num_kv_heads=args.kv_heads)
     if args.batch or args.seq_len:
-        import dataclasses
         b_ = args.batch or cfg.batch
         l_ = args.seq_len or cfg.seq_len
         per = -(-l_ // cfg.block_size)
@@ -1133,6 +1130,14 @@ def main(argv=None):
         rest = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, native_layers=False)
         line["e2e_step"]["torch_module_layers"] = {k: rest[k] for k in ("value", "unit", "ms_per_step", "note")}
         line["e2e_step"]["steps"], line["e2e_step"]["warmup"] = args.steps, args.warmup
+        if dist is None:
+            # the regime the reference's scheduler runs (one sequence per step, scheduler.py:60): a token's latency
+            b1 = dataclasses.replace(e2e_cfg, batch=1)
+            r1 = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False)
+            r1t = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, native_layers=False)
+            line["e2e_step"]["batch_1"] = {"us_per_token": r1["ms_per_step"] * 1e3, "tokens_per_s": r1["value"],
+                                           "torch_module_layers_us_per_token": r1t["ms_per_step"] * 1e3,
+                                           "note": "ONE sequence at the same context, the whole token from one hipGraph"}
         args = args_main
     if plain and not args.no_long and args.config == "cfg3" and not args.variant and dist is None:
         line["long_context_step"] = long_context_record(args, dev)
