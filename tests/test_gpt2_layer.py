@@ -66,6 +66,10 @@ def test_layer_picks_for_the_gpt2_small_decode_step():
     assert gl.kernel_name(256, 3072, 768, True, gl.EPI_BIAS_GELU) == "bm32_nw4_ks1_r2_ln_gelu"
     assert gl.kernel_name(256, 768, 3072, False, gl.EPI_BIAS_RESIDUAL) == "bm16_nw4_ks2_r4_residual"
     assert gl.kernel_name(3, 384, 128, True, gl.EPI_BIAS) == "bm16_nw4_ks1_r2_ln_bias"
+    # few rows (one sequence per step) x a long K: 16-column workgroups with the K range over their four waves
+    assert gl.kernel_name(1, 768, 3072, False, gl.EPI_BIAS_RESIDUAL) == "bm16_nw1_ks4_r2_residual"
+    assert gl.kernel_name(64, 768, 3072, False, gl.EPI_BIAS_RESIDUAL) == "bm16_nw1_ks4_r2_residual"
+    assert gl.kernel_name(64, 768, 768, False, gl.EPI_BIAS_RESIDUAL) == "bm16_nw4_ks1_r2_residual"
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
@@ -100,7 +104,7 @@ def _close(got, ref, what):
 SHAPES = [  # (N, K, ln, epi)    GPT-2 small's four layers, the tiny fixture's, and shapes that leave partial tiles
     (2304, 768, True, "bias"), (768, 768, False, "res"), (3072, 768, True, "gelu"), (768, 3072, False, "res"),
     (384, 128, True, "bias"), (128, 128, False, "res"), (512, 128, True, "gelu"), (128, 512, False, "res"),
-    (80, 96, True, "gelu"), (16, 32, False, "bias"), (208, 1568, False, "res"), (2320, 800, True, "bias"),
+    (80, 96, True, "gelu"), (128, 2048, False, "gelu"), (16, 32, False, "bias"), (208, 1568, False, "res"), (2320, 800, True, "bias"),
 ]
 
 

@@ -344,6 +344,16 @@ static bool pick(int M, int N, int K, bool ln, Shape* s) {
   s->ks = (s->bm == 16 && K >= 1536) ? 2 : 1;
   // the ring: two weight chunks (24 k-steps) per wave, four where a wave has more to read and the registers to hold them
   s->nbuf = (!ln && s->ks == 2 && (K / 32 + 1) / 2 > 2 * CH) ? 4 : 2;   // (behind a LayerNorm the row's values hold those registers)
+  // few rows (one sequence per step is the reference scheduler's regime) x a long K: 64-column workgroups would be N / 64 per
+  // row block — 12 for mlp.c_proj — and a dozen CUs would stream the whole 4.7 MB.  There a workgroup owns 16 columns and its
+  // four waves a quarter of K each: four times the workgroups, a quarter of the bytes per CU (batch 1: 7.4 -> 6.5 us).  At
+  // K = 768 the same split was measured behind (the extra meeting in LDS costs more than the thinner stream saves: c_attn
+  // 5.5 -> 6.0, c_proj 4.3 -> 5.0 us) and is not used.
+  if (s->bm == 16 && ((M + 15) / 16) * nb < 96 && K >= 1536 && !ln) {
+    s->nw = 1;
+    s->ks = 4;
+    s->nbuf = 2;
+  }
   return true;
 }
 
@@ -424,6 +434,8 @@ int vmi_gpt2_linear_f16(const void* x, int64_t ldx, const void* w, const void* b
   int rc;
   if (s.bm == 32)   // (three 32-row tiles side by side in LDS means K <= 845: never with a split K range)
     rc = launch_le<32, 4, 1, 2>(p, s, ln, epilogue, st);
+  else if (s.nw == 1)
+    rc = launch_le<16, 1, 4, 2>(p, s, ln, epilogue, st);
   else if (s.ks == 1)
     rc = launch_le<16, 4, 1, 2>(p, s, ln, epilogue, st);
   else
