@@ -94,6 +94,8 @@ def build_parser():
     ap.add_argument("--e2e-context", type=int, default=1008, help="context length the e2e sequences start at")
     ap.add_argument("--e2e-ragged", action="store_true", help="e2e with contexts ~ U{16..e2e-context} instead of equal ones")
     ap.add_argument("--e2e-eager", action="store_true", help="e2e: plain launches instead of hipGraph replay")
+    ap.add_argument("--e2e-scatter-in-c-attn", action="store_true",
+                    help="e2e: the q/k/v projection writes k and v into the paged cache itself (no reshape_and_cache launch)")
     ap.add_argument("--e2e-torch-layers", action="store_true",
                     help="e2e: the block's linear layers as torch modules instead of csrc/gpt2_layer.hip")
     ap.add_argument("--headline-only", action="store_true",
@@ -564,7 +566,7 @@ def cpu_baseline(wl, budget_s: float):
 # ---- end to end (GPT-2 small over the batched harness) ----------------------------------------------------------------
 
 def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragged=False, eager=False,
-                ctx0=1008, operator_share=True, native_layers=True):
+                ctx0=1008, operator_share=True, native_layers=True, scatter_in_c_attn=False):
     """GPT-2 small, `batch` sequences per GPU at ~seq_len context, one token per sequence per step,
     through vllmini_amd.gpt2_decode (hipGraph replay of the whole step).  KV is synthetic: pages are
     filled with random fp16 and sequences are registered at the target context length."""
@@ -596,7 +598,8 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
     ctxs = np.random.default_rng(100 + rank).integers(16, ctx0 + 1, cfg.batch) if ragged else [ctx0] * cfg.batch
     for s in range(cfg.batch):
         pool.allocate_for_prefill(s, int(ctxs[s]))   # bookkeeping only: the pages already hold synthetic KV
-    dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, fused_append=fused, native_layers=native_layers)
+    dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, fused_append=fused, native_layers=native_layers,
+                           scatter_in_c_attn=scatter_in_c_attn)
     ids = list(range(cfg.batch))
     tok = torch.randint(0, dims.vocab_size, (cfg.batch,), device=dev, generator=g)
 
@@ -622,6 +625,8 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     note = ("12 x (c_attn, paged_attention_v1_append [fused], c_proj, MLP) + lm_head, hipGraph replay, greedy" if fused else
             "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy")
+    if scatter_in_c_attn:
+        note = note.replace("c_attn, reshape_and_cache, paged_attention_v1", "c_attn [writes k, v into the cache itself], paged_attention_v1")
     note += ("; the block's linear layers on this build's kernels (ln_1 + c_attn, c_proj + residual, ln_2 + c_fc + GELU, "
              "mlp.c_proj + residual: four launches, csrc/gpt2_layer.hip)" if native_layers else
              "; the block's linear layers as torch modules (layer_norm, F.linear -> hipBLASLt, gelu, add: eleven launches)")
@@ -666,7 +671,8 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
 
 def run_e2e(args, cfg, dist, rank, world, dev):
     res = e2e_measure(args, cfg, dist, rank, world, dev, kv=args.kv, fused=args.e2e_fused, ragged=args.e2e_ragged,
-                      eager=args.e2e_eager, ctx0=args.e2e_context, native_layers=not args.e2e_torch_layers)
+                      eager=args.e2e_eager, ctx0=args.e2e_context, native_layers=not args.e2e_torch_layers,
+                      scatter_in_c_attn=args.e2e_scatter_in_c_attn)
     if rank == 0:
         print(json.dumps(res), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
@@ -1126,6 +1132,10 @@ def main(argv=None):
         # identical, tests/test_parity_gpu.py): the reference surface stays the pair, the harness may use what is faster
         resf = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, fused=True, operator_share=False)
         line["e2e_step"]["fused_append"] = {k: resf[k] for k in ("value", "unit", "ms_per_step", "note")}
+        # ... or with reshape_and_cache's copy done by the q / k / v projection's epilogue (bit-identical too): the plain attention
+        # kernels, one launch fewer per layer
+        ress = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, scatter_in_c_attn=True)
+        line["e2e_step"]["scatter_in_c_attn"] = {k: ress[k] for k in ("value", "unit", "ms_per_step", "note")}
         # ... and with the block's linear layers left to the torch modules (rounds 1 - 4's harness), for the comparison
         rest = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, native_layers=False)
         line["e2e_step"]["torch_module_layers"] = {k: rest[k] for k in ("value", "unit", "ms_per_step", "note")}
@@ -1134,8 +1144,10 @@ def main(argv=None):
             # the regime the reference's scheduler runs (one sequence per step, scheduler.py:60): a token's latency
             b1 = dataclasses.replace(e2e_cfg, batch=1)
             r1 = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False)
+            r1s = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, scatter_in_c_attn=True)
             r1t = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, native_layers=False)
             line["e2e_step"]["batch_1"] = {"us_per_token": r1["ms_per_step"] * 1e3, "tokens_per_s": r1["value"],
+                                           "scatter_in_c_attn_us_per_token": r1s["ms_per_step"] * 1e3,
                                            "torch_module_layers_us_per_token": r1t["ms_per_step"] * 1e3,
                                            "note": "ONE sequence at the same context, the whole token from one hipGraph"}
         args = args_main

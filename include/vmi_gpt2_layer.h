@@ -38,7 +38,8 @@ enum {
   VMI_LAYER_E_HIP = 3          /* a HIP call failed (text in vmi_gpt2_layer_last_error) */
 };
 
-enum { VMI_LAYER_EPI_BIAS = 0, VMI_LAYER_EPI_BIAS_GELU = 1, VMI_LAYER_EPI_BIAS_RESIDUAL = 2 };
+enum { VMI_LAYER_EPI_BIAS = 0, VMI_LAYER_EPI_BIAS_GELU = 1, VMI_LAYER_EPI_BIAS_RESIDUAL = 2,
+       VMI_LAYER_EPI_BIAS_KV_CACHE = 3 /* vmi_gpt2_linear_qkv_cache_f16 only */ };
 
 /* y[M, N] = epilogue( LN?(x)[M, K] . w[N, K]^T + bias[N] ).
  *   x          half [M, K], row stride ldx elements (rows need 16-byte alignment: ldx % 8 == 0)
@@ -56,6 +57,19 @@ VMI_LAYER_API int vmi_gpt2_linear_f16(const void* x, int64_t ldx, const void* w,
                                       const void* ln_beta, float ln_eps, const void* residual, int64_t ldr, void* y,
                                       int64_t ldy, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t w_layout,
                                       int32_t device, void* stream);
+
+/* The q / k / v projection with reshape_and_cache's copy done by the producer: qkv[M, 3E] = LN?(x) . w[3E, K]^T + bias as
+ * above (E = num_heads * head_size), and for every row m with slot_mapping[m] >= 0 its k and v columns ALSO go to the paged
+ * cache at that slot — key_cache[blk, h, d / 8, off, d % 8], value_cache[blk, h, d, off], blk = slot / block_size,
+ * off = slot % block_size: the bytes cache_ops.reshape_and_cache (ext/cache_kernels.cu:152-207) would write from the k / v
+ * views of qkv, one launch earlier.  float16 caches only (kv_cache_dtype "auto", x = 8); kv_block_stride / kv_head_stride in
+ * elements, applied to both caches as the reference does (attention_kernels.cu:706-707).  head_size % 16 == 0. */
+VMI_LAYER_API int vmi_gpt2_linear_qkv_cache_f16(const void* x, int64_t ldx, const void* w, const void* bias, const void* ln_gamma,
+                                                const void* ln_beta, float ln_eps, void* qkv, int64_t ldy, int32_t M, int32_t K,
+                                                int32_t w_layout, void* key_cache, void* value_cache,
+                                                const int64_t* slot_mapping, int32_t num_heads, int32_t head_size,
+                                                int32_t block_size, int64_t kv_block_stride, int64_t kv_head_stride,
+                                                int32_t device, void* stream);
 
 /* The kernel vmi_gpt2_linear_f16 would launch for this shape ("bm32_nw4_ks1_r2_ln_gelu"), for records; NULL if refused. */
 VMI_LAYER_API const char* vmi_gpt2_linear_kernel_name(int32_t M, int32_t N, int32_t K, int32_t has_ln, int32_t epilogue);

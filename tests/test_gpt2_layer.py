@@ -222,3 +222,74 @@ def test_gpt2_small_decode_on_native_layers_tracks_the_torch_modules():
         top2 = b.topk(2, dim=1).values
         decisive = (top2[:, 0] - top2[:, 1]) > 5e-2
         assert (a.argmax(1) == b.argmax(1))[decisive].all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,H,D,BS", [(1, 12, 64, 16), (37, 12, 64, 16), (256, 12, 64, 16), (20, 2, 64, 16), (9, 4, 128, 8)])
+def test_qkv_projection_with_the_cache_write_leaves_reshape_and_caches_bytes(M, H, D, BS):
+    """vmi_gpt2_linear_qkv_cache_f16 = linear() + cache_ops.reshape_and_cache on its k / v views: the same qkv bits, the same
+    cache bytes (rows with a negative slot skipped, everything else in the caches untouched)."""
+    from vllmini_amd import cache_ops, gpt2_layer as gl
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(M + D)
+    E = H * D
+    K = E
+    NB = max(4, (M + BS - 1) // BS * 3)
+    x = torch.randn(M, K, generator=g).half().to(dev)
+    w = (torch.randn(3 * E, K, generator=g) * (0.6 / K ** 0.5)).half().to(dev)
+    b = (torch.randn(3 * E, generator=g) * 0.1).half().to(dev)
+    lnp = ((1 + 0.2 * torch.randn(K, generator=g)).half().to(dev), (0.1 * torch.randn(K, generator=g)).half().to(dev), 1e-5)
+    kc0 = torch.randn(NB, H, D // 8, BS, 8, generator=g).half().to(dev)
+    vc0 = torch.randn(NB, H, D, BS, generator=g).half().to(dev)
+    slots = torch.randperm(NB * BS, generator=g)[:M].to(torch.int64)
+    if M > 4:
+        slots[3] = -1
+    slots = slots.to(dev)
+    for weight in (w, gl.pack_weight(w)):
+        ref_qkv = gl.linear(x, weight, b, ln=lnp)
+        kr, vr = kc0.clone(), vc0.clone()
+        k, v = (ref_qkv[:, j * E:(j + 1) * E].view(M, H, D) for j in (1, 2))
+        cache_ops.reshape_and_cache(k, v, kr, vr, slots, "auto", 1.0)
+        kg, vg = kc0.clone(), vc0.clone()
+        got = gl.linear_qkv_cache(x, weight, b, kg, vg, slots, H, ln=lnp)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref_qkv)
+        assert torch.equal(kg.view(torch.int16), kr.view(torch.int16)) and torch.equal(vg.view(torch.int16), vr.view(torch.int16))
+        assert not torch.equal(kg, kc0)
+    with pytest.raises(RuntimeError, match="float16 caches"):
+        gl.linear_qkv_cache(x, w, b, kc0.to(torch.uint8), vc0.to(torch.uint8), slots, H, ln=lnp)
+
+
+@pytest.mark.gpu
+def test_decoder_with_the_scatter_in_c_attn_is_bit_identical_to_the_call_pair(golden_dir):
+    """The harness with reshape_and_cache's copy folded into the q / k / v projection: same logits, same caches, bit for bit,
+    as with the reference's call pair — eager and replayed from a hipGraph."""
+    from vllmini_amd.gpt2_decode import GPT2Dims, GPT2PagedDecoder, random_state_dict
+    from vllmini_amd.kv_pool import PagedKVPool
+
+    dev = torch.device("cuda:0")
+    dims = GPT2Dims()
+    sd = random_state_dict(dims, dev, seed=2)
+    B = 9
+
+    def make(scatter):
+        pool = PagedKVPool(B * dims.n_layer * 4 + 8, dims.n_head, dims.head_size, 16, 5, dims.n_layer, device=dev, max_seqs=B)
+        dec = GPT2PagedDecoder(dims, sd, pool, scatter_in_c_attn=scatter)
+        for s in range(B):
+            dec.prefill(s, [(11 * s + j) % dims.vocab_size for j in range(1 + (5 * s) % 17)])
+        return dec
+
+    pair, scat, scat_g = make(False), make(True), make(True)
+    rng = np.random.default_rng(1)
+    ids = list(range(B))
+    for step in range(8):
+        toks = rng.integers(0, dims.vocab_size, B).tolist()
+        a = pair.decode(ids, toks)
+        b = scat.decode(ids, toks)
+        c = scat_g.decode(ids, toks, use_graph=True)
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(pair.pool.key_cache, scat.pool.key_cache) and torch.equal(pair.pool.value_cache, scat.pool.value_cache)
+    assert torch.equal(pair.pool.key_cache, scat_g.pool.key_cache)
+    with pytest.raises(ValueError, match="scatter_in_c_attn"):
+        GPT2PagedDecoder(dims, sd, pair.pool, scatter_in_c_attn=True, fused_append=True)

@@ -47,6 +47,12 @@ struct LinearParams {
   h16* y;
   int64_t ldy;
   int M, N, K;
+  // EPI 3 (the q / k / v projection): columns [E, 2E) and [2E, 3E) of a row also go to the paged cache at the row's slot
+  const int64_t* slots;
+  h16* kcache;
+  h16* vcache;
+  int64_t kv_bstride, kv_hstride;
+  int qdim, hsize, bs;
   int w_packed;   // 0: nn.Linear rows [N, K]; 1: MFMA tiles [N / 16][K / 32][64 lanes][8] (vmi_gpt2_layer.h)
 };
 
@@ -315,6 +321,29 @@ __global__ __launch_bounds__(NW* KS * 64) void linear_kernel(const LinearParams 
       for (int r = 0; r < 4; ++r) o[r] = (h16)((float)rr[mi][r] + (float)o[r]);
     }
     *reinterpret_cast<h16x4*>(p.y + (int64_t)m * p.ldy + n) = o;
+    if constexpr (EPI == VMI_LAYER_EPI_BIAS_KV_CACHE) {
+      // reshape_and_cache's copy (cache_kernels.cu:172-199) done by the producer: K[blk, h, d / 8, off, d % 8], V[blk, h, d, off];
+      // a slab of 16 columns lies inside one of q | k | v and inside one head (E and head_size are multiples of 16)
+      const int part = n0 / p.qdim;   // wave-uniform
+      if (part > 0) {
+        const int64_t slot = p.slots[m];
+        if (slot >= 0) {              // (a negative slot is a padded token: skipped, cache_kernels.cu:165-169)
+          const int64_t blk = slot / p.bs;
+          const int off = (int)(slot - blk * p.bs);
+          const int c = n - part * p.qdim, hh = c / p.hsize, d = c - hh * p.hsize;
+          const int64_t base = blk * p.kv_bstride + (int64_t)hh * p.kv_hstride;
+          if (part == 1) {
+            // (non-temporal, like the scatter kernel's stores: a token's 2-byte V pieces dirty one 128-byte line each, and lines
+            //  left dirty in L2 are written back under the attention launch that follows — profiles/r02b_call_pair_aftermath.md)
+            __builtin_nontemporal_store(o, reinterpret_cast<h16x4*>(p.kcache + base + (int64_t)(d >> 3) * p.bs * 8 + off * 8 + (d & 7)));
+          } else {
+            h16* dst = p.vcache + base + (int64_t)d * p.bs + off;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(o[r], dst + (int64_t)r * p.bs);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -385,20 +414,22 @@ static int launch(const LinearParams& p, const Shape& s, hipStream_t stream) {
 template <int BM, int NW, int KS, int NBUF>
 static int launch_le(const LinearParams& p, const Shape& s, bool ln, int epi, hipStream_t stream) {
   if constexpr (NBUF > 2) {   // (the four-chunk ring is picked for shapes without a LayerNorm only: no such kernels are built)
-    if (ln) return VMI_LAYER_E_SHAPE;
+    if (ln || epi > 2) return VMI_LAYER_E_SHAPE;
     switch (epi) {
       case 0: return launch<BM, NW, KS, NBUF, false, 0>(p, s, stream);
       case 1: return launch<BM, NW, KS, NBUF, false, 1>(p, s, stream);
       default: return launch<BM, NW, KS, NBUF, false, 2>(p, s, stream);
     }
   } else
-  switch ((ln ? 3 : 0) + epi) {
+  switch ((ln ? 4 : 0) + epi) {
     case 0: return launch<BM, NW, KS, NBUF, false, 0>(p, s, stream);
     case 1: return launch<BM, NW, KS, NBUF, false, 1>(p, s, stream);
     case 2: return launch<BM, NW, KS, NBUF, false, 2>(p, s, stream);
-    case 3: return launch<BM, NW, KS, NBUF, true, 0>(p, s, stream);
-    case 4: return launch<BM, NW, KS, NBUF, true, 1>(p, s, stream);
-    default: return launch<BM, NW, KS, NBUF, true, 2>(p, s, stream);
+    case 3: return launch<BM, NW, KS, NBUF, false, 3>(p, s, stream);
+    case 4: return launch<BM, NW, KS, NBUF, true, 0>(p, s, stream);
+    case 5: return launch<BM, NW, KS, NBUF, true, 1>(p, s, stream);
+    case 6: return launch<BM, NW, KS, NBUF, true, 2>(p, s, stream);
+    default: return launch<BM, NW, KS, NBUF, true, 3>(p, s, stream);
   }
 }
 
@@ -406,31 +437,35 @@ static int launch_le(const LinearParams& p, const Shape& s, bool ln, int epi, hi
 
 extern "C" {
 
-int vmi_gpt2_linear_f16(const void* x, int64_t ldx, const void* w, const void* bias, const void* ln_gamma, const void* ln_beta,
-                        float ln_eps, const void* residual, int64_t ldr, void* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
-                        int32_t epilogue, int32_t w_layout, int32_t device, void* stream) {
+static int linear_common(const char* who, const void* x, int64_t ldx, const void* w, const void* bias, const void* ln_gamma,
+                         const void* ln_beta, float ln_eps, const void* residual, int64_t ldr, void* y, int64_t ldy, int32_t M,
+                         int32_t N, int32_t K, int32_t epilogue, int32_t w_layout, const int64_t* slots, void* kcache,
+                         void* vcache, int64_t kv_bstride, int64_t kv_hstride, int qdim, int hsize, int bs, int32_t device,
+                         void* stream) {
   using namespace vmi_layer;
-  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || epilogue < 0 || epilogue > 2 || w_layout < 0 || w_layout > 1 || (!ln_gamma) != (!ln_beta) ||
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || epilogue < 0 || epilogue > 3 || w_layout < 0 || w_layout > 1 || (!ln_gamma) != (!ln_beta) ||
       (epilogue == VMI_LAYER_EPI_BIAS_RESIDUAL && !residual)) {
-    g_err = "vmi_gpt2_linear_f16: null pointer, non-positive size, unknown epilogue or a residual epilogue without a residual";
+    g_err = std::string(who) + ": null pointer, non-positive size, unknown epilogue or a residual epilogue without a residual";
     return VMI_LAYER_E_ARG;
   }
   const bool ln = ln_gamma != nullptr;
   Shape s;
   if (!pick(M, N, K, ln, &s) || (ldx & 7) || (ldy & 3) || (epilogue == VMI_LAYER_EPI_BIAS_RESIDUAL && (ldr & 3)) ||
       ((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 7)) {
-    g_err = "vmi_gpt2_linear_f16: needs K % 32 == 0, N % 16 == 0, K <= 4608 (2048 behind a LayerNorm), 16-byte aligned rows of x and w, 8-byte aligned rows of y";
+    g_err = std::string(who) + ": needs K % 32 == 0, N % 16 == 0, K <= 4608 (2048 behind a LayerNorm), 16-byte aligned rows of x and w, 8-byte aligned rows of y";
     return VMI_LAYER_E_SHAPE;
   }
   int prev = -1;
   if (hipGetDevice(&prev) != hipSuccess || (prev != device && hipSetDevice(device) != hipSuccess)) {
-    g_err = "vmi_gpt2_linear_f16: hipSetDevice failed";
+    g_err = std::string(who) + ": hipSetDevice failed";
     return VMI_LAYER_E_HIP;
   }
   LinearParams p{static_cast<const h16*>(x), ldx, static_cast<const h16*>(w), static_cast<const h16*>(bias),
                  static_cast<const h16*>(ln_gamma), static_cast<const h16*>(ln_beta), ln_eps,
-                 static_cast<const h16*>(residual), ldr, static_cast<h16*>(y), ldy, M, N, K, w_layout};
+                 static_cast<const h16*>(residual), ldr, static_cast<h16*>(y), ldy, M, N, K,
+                 slots, static_cast<h16*>(kcache), static_cast<h16*>(vcache), kv_bstride, kv_hstride, qdim, hsize, bs, w_layout};
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (epilogue == VMI_LAYER_EPI_BIAS_KV_CACHE) s.nbuf = 2;   // (the four-chunk ring is built for bias / GELU / residual only)
   int rc;
   if (s.bm == 32)   // (three 32-row tiles side by side in LDS means K <= 845: never with a split K range)
     rc = launch_le<32, 4, 1, 2>(p, s, ln, epilogue, st);
@@ -444,12 +479,39 @@ int vmi_gpt2_linear_f16(const void* x, int64_t ldx, const void* w, const void* b
   return rc;
 }
 
+int vmi_gpt2_linear_f16(const void* x, int64_t ldx, const void* w, const void* bias, const void* ln_gamma, const void* ln_beta,
+                        float ln_eps, const void* residual, int64_t ldr, void* y, int64_t ldy, int32_t M, int32_t N, int32_t K,
+                        int32_t epilogue, int32_t w_layout, int32_t device, void* stream) {
+  if (epilogue == VMI_LAYER_EPI_BIAS_KV_CACHE) {
+    vmi_layer::g_err = "vmi_gpt2_linear_f16: the cache epilogue has its own entry, vmi_gpt2_linear_qkv_cache_f16";
+    return VMI_LAYER_E_ARG;
+  }
+  return linear_common("vmi_gpt2_linear_f16", x, ldx, w, bias, ln_gamma, ln_beta, ln_eps, residual, ldr, y, ldy, M, N, K, epilogue,
+                       w_layout, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, device, stream);
+}
+
+int vmi_gpt2_linear_qkv_cache_f16(const void* x, int64_t ldx, const void* w, const void* bias, const void* ln_gamma,
+                                  const void* ln_beta, float ln_eps, void* qkv, int64_t ldy, int32_t M, int32_t K,
+                                  int32_t w_layout, void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                                  int32_t num_heads, int32_t head_size, int32_t block_size, int64_t kv_block_stride,
+                                  int64_t kv_head_stride, int32_t device, void* stream) {
+  const int64_t E = (int64_t)num_heads * head_size;
+  if (!key_cache || !value_cache || !slot_mapping || num_heads <= 0 || head_size <= 0 || block_size <= 0 || (head_size & 15) ||
+      kv_block_stride <= 0 || kv_head_stride <= 0 || E > (1 << 20)) {
+    vmi_layer::g_err = "vmi_gpt2_linear_qkv_cache_f16: null cache / slot pointer, or a head size that is not a multiple of 16";
+    return VMI_LAYER_E_ARG;
+  }
+  return linear_common("vmi_gpt2_linear_qkv_cache_f16", x, ldx, w, bias, ln_gamma, ln_beta, ln_eps, nullptr, 0, qkv, ldy, M,
+                       (int32_t)(3 * E), K, VMI_LAYER_EPI_BIAS_KV_CACHE, w_layout, slot_mapping, key_cache, value_cache,
+                       kv_block_stride, kv_head_stride, (int)E, head_size, block_size, device, stream);
+}
+
 const char* vmi_gpt2_linear_kernel_name(int32_t M, int32_t N, int32_t K, int32_t has_ln, int32_t epilogue) {
   using namespace vmi_layer;
   static thread_local std::string name;
   Shape s;
-  if (!pick(M, N, K, has_ln != 0, &s) || epilogue < 0 || epilogue > 2) return nullptr;
-  static const char* epi[] = {"bias", "gelu", "residual"};
+  if (!pick(M, N, K, has_ln != 0, &s) || epilogue < 0 || epilogue > 3) return nullptr;
+  static const char* epi[] = {"bias", "gelu", "residual", "kvcache"};
   name = "bm" + std::to_string(s.bm) + "_nw" + std::to_string(s.nw) + "_ks" + std::to_string(s.ks) + "_r" + std::to_string(s.nbuf) + (has_ln ? "_ln_" : "_") +
          epi[epilogue];
   return name.c_str();

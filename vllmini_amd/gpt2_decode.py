@@ -86,7 +86,8 @@ class GPT2PagedDecoder:
     NATIVE_LAYERS_MAX_BATCH = 512    # larger steps run the block's linear layers as torch modules (real GEMMs by then)
 
     def __init__(self, dims: GPT2Dims, state_dict: Dict[str, torch.Tensor], pool: PagedKVPool,
-                 reference_off_by_one: bool = False, fused_append: bool = False, native_layers: Optional[bool] = None):
+                 reference_off_by_one: bool = False, fused_append: bool = False, native_layers: Optional[bool] = None,
+                 scatter_in_c_attn: bool = False):
         assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
         assert pool.head_size == dims.head_size
         self.dims, self.sd, self.pool = dims, state_dict, pool
@@ -114,6 +115,12 @@ class GPT2PagedDecoder:
             raise RuntimeError("native_layers needs a HIP device, float16 weights and a hidden size that is a multiple of 32 "
                                f"(<= 1152); got {pool.device}, {wdt}, {E}")
         self.native_layers = can if native_layers is None else bool(native_layers)
+        # scatter_in_c_attn: the q / k / v projection writes k and v into the paged cache itself (gpt2_layer.linear_qkv_cache:
+        # reshape_and_cache's copy in the producer's epilogue, bit-identical caches) — the step runs paged_attention_v1 alone,
+        # one launch fewer per layer than the reference's call pair and on the plain attention kernels (unlike fused_append)
+        if scatter_in_c_attn and (not self.native_layers or fused_append or pool.kv_cache_dtype != "auto"):
+            raise ValueError("scatter_in_c_attn needs native_layers, float16 pages and the two-op attention (not fused_append)")
+        self.scatter_in_c_attn = scatter_in_c_attn
         self._packed: Dict[str, gpt2_layer.PackedWeight] = {}
         if self.native_layers:
             gpt2_layer.load()
@@ -183,7 +190,13 @@ class GPT2PagedDecoder:
         nat, sd, E, pw = self.native_layers and B <= self.NATIVE_LAYERS_MAX_BATCH, self.sd, d.n_embd, self._packed
         for i in range(d.n_layer):
             p = f"transformer.h.{i}."
-            if nat:      # ln_1 + c_attn in one launch; q/k/v are the same 3E-strided views (gpt2.py:35-41)
+            scat = nat and self.scatter_in_c_attn
+            if scat:     # ln_1 + c_attn + the cache write of k and v in one launch
+                qkv = gpt2_layer.linear_qkv_cache(x, pw[p + "attn.c_attn.weight"], sd[p + "attn.c_attn.bias"], pool.key_cache,
+                                                  pool.value_cache, st["slots"][i], d.n_head,
+                                                  ln=(sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], d.layer_norm_epsilon))
+                q, k, v = (qkv[:, j * E:(j + 1) * E].view(B, d.n_head, d.head_size) for j in range(3))
+            elif nat:    # ln_1 + c_attn in one launch; q/k/v are the same 3E-strided views (gpt2.py:35-41)
                 qkv = gpt2_layer.linear(x, pw[p + "attn.c_attn.weight"], sd[p + "attn.c_attn.bias"],
                                         ln=(sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], d.layer_norm_epsilon))
                 q, k, v = (qkv[:, j * E:(j + 1) * E].view(B, d.n_head, d.head_size) for j in range(3))
@@ -196,8 +209,9 @@ class GPT2PagedDecoder:
                                               st["tables"][i], st["seq_lens"], pool.block_size, self.max_seq_len,
                                               _variant=var)
             else:
-                cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i],
-                                            pool.kv_cache_dtype, pool.kv_scale)                            # gpt2.py:44
+                if not scat:
+                    cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i],
+                                                pool.kv_cache_dtype, pool.kv_scale)                        # gpt2.py:44
                 ops.paged_attention_v1(out, q, pool.key_cache, pool.value_cache, d.n_head, self.scale, st["tables"][i],
                                        st["seq_lens"], pool.block_size, self.max_seq_len, None,
                                        pool.kv_cache_dtype, pool.kv_scale, 0, 0, 1, 1, 0,

@@ -18,12 +18,14 @@ import torch
 from . import build as _build
 
 ABI_VERSION = 1
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, EPI_BIAS_KV_CACHE = 0, 1, 2, 3
 
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
 SIGNATURES = {
     "vmi_gpt2_linear_f16": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _i64, _vp, _i64,
                                            _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vmi_gpt2_linear_qkv_cache_f16": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _i64, _i32, _i32, _i32,
+                                                     _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
     "vmi_gpt2_linear_kernel_name": (ctypes.c_char_p, [_i32, _i32, _i32, _i32, _i32]),
     "vmi_gpt2_layer_last_error": (ctypes.c_char_p, []),
     "vmi_gpt2_layer_abi_version": (_i32, []),
@@ -127,6 +129,52 @@ def linear(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, *,
                                  float(ln[2]) if ln else 0.0, residual.data_ptr() if residual is not None else None,
                                  residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
                                  M, N, K, epi, int(packed), x.device.index or 0, stream)
+    if rc != 0:
+        raise RuntimeError(lib.vmi_gpt2_layer_last_error().decode("utf-8", "replace"))
+    return out
+
+
+def linear_qkv_cache(x: torch.Tensor, weight, bias: Optional[torch.Tensor], key_cache: torch.Tensor, value_cache: torch.Tensor,
+                     slot_mapping: torch.Tensor, num_heads: int, *, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The q / k / v projection with cache_ops.reshape_and_cache's copy done by the producing kernel: returns qkv [M, 3E] and
+    writes every row's k and v into the float16 paged caches at slot_mapping[m] (rows with a negative slot are skipped) — the
+    same bytes the reference's call (gpt2.py:44, 81-89) writes from the k / v views of qkv, one launch earlier."""
+    lib = load()
+    packed = isinstance(weight, PackedWeight)
+    wshape = weight.shape
+    if packed:
+        weight = weight.tiles
+    if x.device.type != "cuda":
+        raise RuntimeError("gpt2_layer.linear_qkv_cache: there is no CPU path")
+    M, K = x.shape
+    N = wshape[0]
+    E = N // 3
+    if N != 3 * E or E % num_heads or x.dtype != torch.float16 or weight.dtype != torch.float16 or x.stride(1) != 1 \
+            or wshape[1] != K or not weight.is_contiguous():
+        raise RuntimeError("gpt2_layer.linear_qkv_cache: x [M, K] half, weight [3E, K] half contiguous, E = heads * head_size")
+    D = E // num_heads
+    if key_cache.dtype != torch.float16 or value_cache.dtype != torch.float16 or key_cache.dim() != 5 or value_cache.dim() != 4 \
+            or key_cache.shape[4] != 8 or key_cache.shape[1] != num_heads or key_cache.shape[2] * 8 != D \
+            or value_cache.shape[1:3] != (num_heads, D) or key_cache.shape[3] != value_cache.shape[3] \
+            or not key_cache[0].is_contiguous() or not value_cache[0].is_contiguous() \
+            or key_cache.stride(0) != value_cache.stride(0):
+        raise RuntimeError("gpt2_layer.linear_qkv_cache: float16 caches in the reference layout [NB, H, D/8, bs, 8] / [NB, H, D, bs]")
+    if slot_mapping.dtype != torch.int64 or slot_mapping.shape != (M,) or not slot_mapping.is_contiguous():
+        raise RuntimeError("gpt2_layer.linear_qkv_cache: slot_mapping int64 [M]")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    if out.shape != (M, N) or out.stride(1) != 1 or out.dtype != torch.float16:
+        raise RuntimeError("gpt2_layer.linear_qkv_cache: out [M, 3E] half with unit stride in N")
+    for t, what in ((bias, "bias"), (ln[0] if ln else None, "ln gamma"), (ln[1] if ln else None, "ln beta")):
+        if t is not None and (t.dtype != torch.float16 or not t.is_contiguous() or t.device != x.device):
+            raise RuntimeError(f"gpt2_layer.linear_qkv_cache: {what} must be a contiguous half tensor on x's device")
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    rc = lib.vmi_gpt2_linear_qkv_cache_f16(x.data_ptr(), x.stride(0), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           ln[0].data_ptr() if ln else None, ln[1].data_ptr() if ln else None,
+                                           float(ln[2]) if ln else 0.0, out.data_ptr(), out.stride(0), M, K, int(packed),
+                                           key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr(), num_heads, D,
+                                           key_cache.shape[3], key_cache.stride(0), key_cache.stride(1), x.device.index or 0, stream)
     if rc != 0:
         raise RuntimeError(lib.vmi_gpt2_layer_last_error().decode("utf-8", "replace"))
     return out
