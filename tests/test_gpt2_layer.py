@@ -293,3 +293,34 @@ def test_decoder_with_the_scatter_in_c_attn_is_bit_identical_to_the_call_pair(go
     assert torch.equal(pair.pool.key_cache, scat_g.pool.key_cache)
     with pytest.raises(ValueError, match="scatter_in_c_attn"):
         GPT2PagedDecoder(dims, sd, pair.pool, scatter_in_c_attn=True, fused_append=True)
+
+
+@pytest.mark.gpu
+def test_linear_kernels_over_random_shapes():
+    """Every pick — 32 / 16-row tiles, K over one, two or four waves, two- and four-chunk rings, partial chunks, partial row and
+    column tiles — on 80 random (M, N, K, LayerNorm, epilogue) against the module chain, plain and packed weights."""
+    from vllmini_amd import gpt2_layer as gl
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    seen = set()
+    for case in range(80):
+        M = int(rng.choice([1, 2, 7, 16, 17, 31, 32, 33, 63, 64, 100, 129, 255, 256, 257, 400, 600]))
+        N = 16 * int(rng.integers(1, 200))
+        ln = bool(rng.integers(0, 2))
+        K = 32 * int(rng.integers(1, (2048 if ln else 4608) // 32 + 1))
+        epi = ["bias", "gelu", "res"][int(rng.integers(0, 3))]
+        x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).half().to(dev)
+        w = (torch.randn(N, K, generator=g) * (0.6 / K ** 0.5)).half().to(dev)
+        b = (torch.randn(N, generator=g) * 0.1).half().to(dev) if rng.integers(0, 4) else None
+        lnp = ((1 + 0.2 * torch.randn(K, generator=g)).half().to(dev), (0.1 * torch.randn(K, generator=g)).half().to(dev), 1e-5) \
+            if ln else None
+        res = torch.randn(M, N, generator=g).half().to(dev) if epi == "res" else None
+        name = gl.kernel_name(M, N, K, ln)
+        seen.add(name.rsplit("_", 1)[0])
+        got = gl.linear(x, w, b, ln=lnp, gelu=epi == "gelu", residual=res)
+        _close(got, _chain(x, w, b, lnp, epi == "gelu", res), (case, M, N, K, ln, epi, name))
+        assert torch.equal(gl.linear(x, gl.pack_weight(w), b, ln=lnp, gelu=epi == "gelu", residual=res), got), (case, M, N, K)
+    torch.cuda.synchronize()
+    assert len(seen) >= 6, seen      # the draw reached most of the kernel family
