@@ -52,7 +52,7 @@ struct LinearParams {
   h16* kcache;
   h16* vcache;
   int64_t kv_bstride, kv_hstride;
-  int qdim, hsize, bs;
+  int qdim, hsize, bs, bs_shift;
   int w_packed;   // 0: nn.Linear rows [N, K]; 1: MFMA tiles [N / 16][K / 32][64 lanes][8] (vmi_gpt2_layer.h)
 };
 
@@ -156,7 +156,10 @@ __global__ __launch_bounds__(NW* KS * 64) void linear_kernel(const LinearParams 
   const int nw = wave % NW, ks = wave / NW;
   const int NB = (p.N + 16 * NW - 1) / (16 * NW);
   const int nb = blockIdx.x % NB, mb = blockIdx.x / NB;
-  const int m0 = mb * BM, n0 = (nb * NW + nw) * 16;
+  // (the cache epilogue deals a workgroup's waves to slabs N / NW apart, one each of q | q,k | k,v | v: the value cache's
+  //  scattered two-byte pieces then leave through every CU's store path, not through the third of the workgroups that would
+  //  hold the v columns — the projection with the cache write 18.2 -> see profiles/r05u_e2e_native_layers.md §3b)
+  const int m0 = mb * BM, n0 = (EPI == VMI_LAYER_EPI_BIAS_KV_CACHE ? nw * NB + nb : nb * NW + nw) * 16;
   const int nks = p.K >> 5;
   const int ks_per = (nks + KS - 1) / KS, ks0 = ks * ks_per, ks1 = min(nks, ks0 + ks_per);
   const int kc = lane >> 4, r16 = lane & 15;
@@ -205,6 +208,17 @@ __global__ __launch_bounds__(NW* KS * 64) void linear_kernel(const LinearParams 
       const int m = m0 + mi * 16 + r16;
       rr[mi] = h16x4{0, 0, 0, 0};
       if (nvalid && m < p.M) rr[mi] = *reinterpret_cast<const h16x4*>(p.res + (int64_t)m * p.ldr + n);
+    }
+  }
+  // EPI 3: the rows' cache slots too — a load in the epilogue would wait for the stores in front of it (loads and stores share
+  // vmcnt), one acknowledged round trip per row block
+  int64_t slot[MT];
+  if constexpr (EPI == VMI_LAYER_EPI_BIAS_KV_CACHE) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int m = m0 + mi * 16 + r16;
+      slot[mi] = -1;
+      if (nvalid && n0 >= p.qdim && m < p.M) slot[mi] = p.slots[m];
     }
   }
   if constexpr (!LN) {
@@ -326,11 +340,10 @@ __global__ __launch_bounds__(NW* KS * 64) void linear_kernel(const LinearParams 
       // a slab of 16 columns lies inside one of q | k | v and inside one head (E and head_size are multiples of 16)
       const int part = n0 / p.qdim;   // wave-uniform
       if (part > 0) {
-        const int64_t slot = p.slots[m];
-        if (slot >= 0) {              // (a negative slot is a padded token: skipped, cache_kernels.cu:165-169)
-          const int64_t blk = slot / p.bs;
-          const int off = (int)(slot - blk * p.bs);
-          const int c = n - part * p.qdim, hh = c / p.hsize, d = c - hh * p.hsize;
+        if (slot[mi] >= 0) {          // (a negative slot is a padded token: skipped, cache_kernels.cu:165-169)
+          const int64_t blk = slot[mi] >> p.bs_shift;     // block sizes are powers of two (8 / 16 / 32)
+          const int off = (int)(slot[mi] & (p.bs - 1));
+          const int c0 = n0 - part * p.qdim, hh = c0 / p.hsize, d = c0 - hh * p.hsize + 4 * kc;   // (hh: wave-uniform)
           const int64_t base = blk * p.kv_bstride + (int64_t)hh * p.kv_hstride;
           if (part == 1) {
             // (non-temporal, like the scatter kernel's stores: a token's 2-byte V pieces dirty one 128-byte line each, and lines
@@ -463,7 +476,7 @@ static int linear_common(const char* who, const void* x, int64_t ldx, const void
   LinearParams p{static_cast<const h16*>(x), ldx, static_cast<const h16*>(w), static_cast<const h16*>(bias),
                  static_cast<const h16*>(ln_gamma), static_cast<const h16*>(ln_beta), ln_eps,
                  static_cast<const h16*>(residual), ldr, static_cast<h16*>(y), ldy, M, N, K,
-                 slots, static_cast<h16*>(kcache), static_cast<h16*>(vcache), kv_bstride, kv_hstride, qdim, hsize, bs, w_layout};
+                 slots, static_cast<h16*>(kcache), static_cast<h16*>(vcache), kv_bstride, kv_hstride, qdim, hsize, bs, bs > 0 ? __builtin_ctz(bs) : 0, w_layout};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (epilogue == VMI_LAYER_EPI_BIAS_KV_CACHE) s.nbuf = 2;   // (the four-chunk ring is built for bias / GELU / residual only)
   int rc;
@@ -497,8 +510,9 @@ int vmi_gpt2_linear_qkv_cache_f16(const void* x, int64_t ldx, const void* w, con
                                   int64_t kv_head_stride, int32_t device, void* stream) {
   const int64_t E = (int64_t)num_heads * head_size;
   if (!key_cache || !value_cache || !slot_mapping || num_heads <= 0 || head_size <= 0 || block_size <= 0 || (head_size & 15) ||
+      (block_size & (block_size - 1)) ||
       kv_block_stride <= 0 || kv_head_stride <= 0 || E > (1 << 20)) {
-    vmi_layer::g_err = "vmi_gpt2_linear_qkv_cache_f16: null cache / slot pointer, or a head size that is not a multiple of 16";
+    vmi_layer::g_err = "vmi_gpt2_linear_qkv_cache_f16: null cache / slot pointer, a head size that is not a multiple of 16 or a block size that is not a power of two";
     return VMI_LAYER_E_ARG;
   }
   return linear_common("vmi_gpt2_linear_qkv_cache_f16", x, ldx, w, bias, ln_gamma, ln_beta, ln_eps, nullptr, 0, qkv, ldy, M,
