@@ -167,6 +167,8 @@ def test_linear_in_place_residual_strided_input_no_bias_and_graph_replay():
     _close(gl.linear(xs, w, None), _chain(xs, w, None), "no bias")
     with pytest.raises(RuntimeError, match="alternative"):
         gl.linear(xs, w, b, gelu=True, residual=x0)
+    with pytest.raises(RuntimeError, match="must not alias x"):
+        gl.linear(x0, w, b, out=x0)
     with pytest.raises(RuntimeError, match="K % 32"):
         gl.linear(qkv[:, :48], w[:, :48].contiguous(), b)
     with pytest.raises(RuntimeError, match="no CPU path"):

@@ -117,6 +117,9 @@ def linear(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, *,
         out = torch.empty((M, N), dtype=torch.float16, device=x.device)
     if out.shape != (M, N) or out.stride(1) != 1 or out.dtype != torch.float16:
         raise RuntimeError("gpt2_layer.linear: out [M, N] half with unit stride in N")
+    if out.data_ptr() == x.data_ptr():
+        # a workgroup stores its columns of `out` while others still read the rows of `x`: only the RESIDUAL may alias out
+        raise RuntimeError("gpt2_layer.linear: out must not alias x (out may alias the residual)")
     for t, what in ((bias, "bias"), (ln[0] if ln else None, "ln gamma"), (ln[1] if ln else None, "ln beta")):
         if t is not None and (t.dtype != torch.float16 or not t.is_contiguous() or t.device != x.device):
             raise RuntimeError(f"gpt2_layer.linear: {what} must be a contiguous half tensor on x's device")
