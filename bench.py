@@ -611,7 +611,7 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
     def step(i):
         nonlocal tok
         logits = dec.decode(ids, tok, use_graph=not eager)
-        tok = logits.argmax(-1)                       # greedy: stays on the device, no host sync
+        tok = dec.greedy(logits)                      # greedy: stays on the device, no host sync
         if dist is not None:
             k = i & 1
             if works[k] is not None:

@@ -71,6 +71,14 @@ VMI_LAYER_API int vmi_gpt2_linear_qkv_cache_f16(const void* x, int64_t ldx, cons
                                                 int32_t block_size, int64_t kv_block_stride, int64_t kv_head_stride,
                                                 int32_t device, void* stream);
 
+/* The two ends of a decode step.  out[t, :] = wte[input_ids[t], :] + wpe[position_ids[t], :] (one launch for torch's two gathers
+ * and an add; hidden % 8 == 0) — and greedy sampling: out[r] = the index of the first maximum of logits[r, 0:vocab]
+ * (torch.argmax's tie rule; row stride ld elements, any alignment). */
+VMI_LAYER_API int vmi_gpt2_embed_f16(const int64_t* input_ids, const int64_t* position_ids, const void* wte, const void* wpe,
+                                     void* out, int32_t num_tokens, int32_t hidden, int32_t device, void* stream);
+VMI_LAYER_API int vmi_gpt2_argmax_f16(const void* logits, int64_t ld, int32_t num_rows, int32_t vocab, int64_t* out,
+                                      int32_t device, void* stream);
+
 /* The kernel vmi_gpt2_linear_f16 would launch for this shape ("bm32_nw4_ks1_r2_ln_gelu"), for records; NULL if refused. */
 VMI_LAYER_API const char* vmi_gpt2_linear_kernel_name(int32_t M, int32_t N, int32_t K, int32_t has_ln, int32_t epilogue);
 

@@ -326,3 +326,34 @@ def test_linear_kernels_over_random_shapes():
         assert torch.equal(gl.linear(x, gl.pack_weight(w), b, ln=lnp, gelu=epi == "gelu", residual=res), got), (case, M, N, K)
     torch.cuda.synchronize()
     assert len(seen) >= 6, seen      # the draw reached most of the kernel family
+
+
+@pytest.mark.gpu
+def test_embed_and_argmax_equal_torch():
+    from vllmini_amd import gpt2_layer as gl
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(9)
+    V, P, E = 50257, 1024, 768
+    wte = torch.randn(V, E, generator=g).half().to(dev)
+    wpe = torch.randn(P, E, generator=g).half().to(dev)
+    for T in (1, 5, 256):
+        ids = torch.randint(0, V, (T,), generator=g).to(dev)
+        pos = torch.randint(0, P, (T,), generator=g).to(dev)
+        assert torch.equal(gl.embed(ids, pos, wte, wpe), wte[ids] + wpe[pos])
+    # argmax: rows of 50 257 halves start at every alignment; ties go to the first maximum; a row slice of a wider tensor
+    for B in (1, 3, 9, 256):
+        logits = torch.randn(B, V, generator=g).half().to(dev)
+        assert torch.equal(gl.argmax(logits), logits.argmax(-1))
+    tie = torch.zeros(4, V, dtype=torch.float16, device=dev)
+    tie[0, 777] = tie[0, 40000] = 3.0
+    tie[1, V - 1] = 1.0
+    tie[2, 0] = tie[2, 1] = 2.0
+    tie[3] = -5.0
+    assert gl.argmax(tie).tolist() == [777, V - 1, 0, 0]
+    wide = torch.randn(6, V + 37, generator=g).half().to(dev)
+    assert torch.equal(gl.argmax(wide[:, 5:5 + 1000]), wide[:, 5:5 + 1000].argmax(-1))
+    small = torch.randn(7, 13, generator=g).half().to(dev)
+    assert torch.equal(gl.argmax(small), small.argmax(-1))
+    with pytest.raises(RuntimeError, match="half logits"):
+        gl.argmax(logits.float())

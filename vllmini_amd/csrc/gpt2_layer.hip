@@ -360,6 +360,75 @@ __global__ __launch_bounds__(NW* KS * 64) void linear_kernel(const LinearParams 
   }
 }
 
+// ---- the two ends of a decode step: token + position embedding, greedy argmax --------------------------------------------------
+
+// out[b, :] = wte[ids[b], :] + wpe[pos[b], :] (gpt2.py:183-233: inputs_embeds + position_embeds; half + half rounded once)
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos,
+                                                    const h16* __restrict__ wte, const h16* __restrict__ wpe, h16* __restrict__ out,
+                                                    int E) {
+  const int b = blockIdx.x;
+  const h16* t = wte + ids[b] * (int64_t)E;
+  const h16* q = wpe + pos[b] * (int64_t)E;
+  h16* o = out + (int64_t)b * E;
+  for (int u = threadIdx.x; u < (E >> 3); u += 256) {
+    const h16x8 a = *reinterpret_cast<const h16x8*>(t + u * 8), c = *reinterpret_cast<const h16x8*>(q + u * 8);
+    h16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (h16)((float)a[e] + (float)c[e]);
+    *reinterpret_cast<h16x8*>(o + u * 8) = r;
+  }
+}
+
+// out[b] = index of the first maximum of logits[b, 0:V] (torch.argmax's tie rule); one workgroup per row, 16-byte loads from the
+// first aligned element on (rows of 50 257 halves start at odd addresses)
+__device__ __forceinline__ void amax_take(float v, int i, float& best, int& at) {
+  if (v > best || (v == best && i < at)) {
+    best = v;
+    at = i;
+  }
+}
+__global__ __launch_bounds__(1024) void argmax_kernel(const h16* __restrict__ logits, int64_t ld, int V, int64_t* __restrict__ out) {
+  __shared__ float sb[16];
+  __shared__ int si[16];
+  const h16* row = logits + (int64_t)blockIdx.x * ld;
+  const int tid = threadIdx.x;
+  float best = -INFINITY;
+  int at = 0x7fffffff;
+  const int head = (int)(((16 - ((uintptr_t)row & 15)) & 15) >> 1);   // elements in front of the first 16-byte boundary
+  const int a0 = head < V ? head : V;
+  if (tid < a0) amax_take((float)row[tid], tid, best, at);
+  const int nvec = (V - a0) >> 3;
+  for (int u = tid; u < nvec; u += 1024) {
+    const h16x8 v = *reinterpret_cast<const h16x8*>(row + a0 + u * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax_take((float)v[e], a0 + u * 8 + e, best, at);
+  }
+  const int t0 = a0 + nvec * 8;
+  if (t0 + tid < V) amax_take((float)row[t0 + tid], t0 + tid, best, at);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(at, o, 64);
+    amax_take(ob, oi, best, at);
+  }
+  if ((tid & 63) == 0) {
+    sb[tid >> 6] = best;
+    si[tid >> 6] = at;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    best = tid < 16 ? sb[tid] : -INFINITY;
+    at = tid < 16 ? si[tid] : 0x7fffffff;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(at, o, 64);
+      amax_take(ob, oi, best, at);
+    }
+    if (tid == 0) out[blockIdx.x] = at == 0x7fffffff ? 0 : at;
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
@@ -518,6 +587,53 @@ int vmi_gpt2_linear_qkv_cache_f16(const void* x, int64_t ldx, const void* w, con
   return linear_common("vmi_gpt2_linear_qkv_cache_f16", x, ldx, w, bias, ln_gamma, ln_beta, ln_eps, nullptr, 0, qkv, ldy, M,
                        (int32_t)(3 * E), K, VMI_LAYER_EPI_BIAS_KV_CACHE, w_layout, slot_mapping, key_cache, value_cache,
                        kv_block_stride, kv_head_stride, (int)E, head_size, block_size, device, stream);
+}
+
+static int with_device(const char* who, int32_t device, int* prev) {
+  if (hipGetDevice(prev) != hipSuccess || (*prev != device && hipSetDevice(device) != hipSuccess)) {
+    vmi_layer::g_err = std::string(who) + ": hipSetDevice failed";
+    return VMI_LAYER_E_HIP;
+  }
+  return VMI_LAYER_OK;
+}
+
+static int after_launch(const char* who, int prev, int32_t device) {
+  const hipError_t e = hipGetLastError();
+  if (prev != device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    vmi_layer::g_err = std::string(who) + ": " + hipGetErrorString(e);
+    return VMI_LAYER_E_HIP;
+  }
+  return VMI_LAYER_OK;
+}
+
+int vmi_gpt2_embed_f16(const int64_t* input_ids, const int64_t* position_ids, const void* wte, const void* wpe, void* out,
+                       int32_t num_tokens, int32_t hidden, int32_t device, void* stream) {
+  using namespace vmi_layer;
+  if (!input_ids || !position_ids || !wte || !wpe || !out || num_tokens <= 0 || hidden <= 0 || (hidden & 7) ||
+      ((uintptr_t)wte & 15) || ((uintptr_t)wpe & 15) || ((uintptr_t)out & 15)) {
+    g_err = "vmi_gpt2_embed_f16: null pointer, or a hidden size / table address that is not a multiple of 8 halves / 16 bytes";
+    return VMI_LAYER_E_ARG;
+  }
+  int prev = -1;
+  if (int rc = with_device("vmi_gpt2_embed_f16", device, &prev)) return rc;
+  hipLaunchKernelGGL(embed_kernel, dim3(num_tokens), dim3(256), 0, static_cast<hipStream_t>(stream), input_ids, position_ids,
+                     static_cast<const h16*>(wte), static_cast<const h16*>(wpe), static_cast<h16*>(out), hidden);
+  return after_launch("vmi_gpt2_embed_f16", prev, device);
+}
+
+int vmi_gpt2_argmax_f16(const void* logits, int64_t ld, int32_t num_rows, int32_t vocab, int64_t* out, int32_t device,
+                        void* stream) {
+  using namespace vmi_layer;
+  if (!logits || !out || num_rows <= 0 || vocab <= 0 || ld < vocab) {
+    g_err = "vmi_gpt2_argmax_f16: null pointer or non-positive size";
+    return VMI_LAYER_E_ARG;
+  }
+  int prev = -1;
+  if (int rc = with_device("vmi_gpt2_argmax_f16", device, &prev)) return rc;
+  hipLaunchKernelGGL(argmax_kernel, dim3(num_rows), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const h16*>(logits), ld, vocab, out);
+  return after_launch("vmi_gpt2_argmax_f16", prev, device);
 }
 
 const char* vmi_gpt2_linear_kernel_name(int32_t M, int32_t N, int32_t K, int32_t has_ln, int32_t epilogue) {

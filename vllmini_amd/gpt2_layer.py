@@ -26,6 +26,8 @@ SIGNATURES = {
                                            _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vmi_gpt2_linear_qkv_cache_f16": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _i64, _i32, _i32, _i32,
                                                      _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
+    "vmi_gpt2_embed_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vmi_gpt2_argmax_f16": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "vmi_gpt2_linear_kernel_name": (ctypes.c_char_p, [_i32, _i32, _i32, _i32, _i32]),
     "vmi_gpt2_layer_last_error": (ctypes.c_char_p, []),
     "vmi_gpt2_layer_abi_version": (_i32, []),
@@ -180,4 +182,42 @@ def linear_qkv_cache(x: torch.Tensor, weight, bias: Optional[torch.Tensor], key_
                                            key_cache.shape[3], key_cache.stride(0), key_cache.stride(1), x.device.index or 0, stream)
     if rc != 0:
         raise RuntimeError(lib.vmi_gpt2_layer_last_error().decode("utf-8", "replace"))
+    return out
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(load().vmi_gpt2_layer_last_error().decode("utf-8", "replace"))
+
+
+def embed(input_ids: torch.Tensor, position_ids: torch.Tensor, wte: torch.Tensor, wpe: torch.Tensor,
+          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """wte[input_ids] + wpe[position_ids] in one launch (gpt2.py: inputs_embeds + position_embeds): int64 ids [T], half tables."""
+    lib = load()
+    T, E = input_ids.shape[0], wte.shape[1]
+    if input_ids.device.type != "cuda":
+        raise RuntimeError("gpt2_layer.embed: there is no CPU path")
+    if input_ids.dtype != torch.int64 or position_ids.dtype != torch.int64 or position_ids.shape != (T,) \
+            or not input_ids.is_contiguous() or not position_ids.is_contiguous() or wte.dtype != torch.float16 \
+            or wpe.dtype != torch.float16 or wpe.shape[1] != E or not wte.is_contiguous() or not wpe.is_contiguous():
+        raise RuntimeError("gpt2_layer.embed: int64 ids / positions [T], contiguous half tables [V, E] / [P, E]")
+    if out is None:
+        out = torch.empty((T, E), dtype=torch.float16, device=wte.device)
+    _check(lib.vmi_gpt2_embed_f16(input_ids.data_ptr(), position_ids.data_ptr(), wte.data_ptr(), wpe.data_ptr(), out.data_ptr(),
+                                  T, E, wte.device.index or 0, torch.cuda.current_stream(wte.device).cuda_stream))
+    return out
+
+
+def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch.argmax(logits, -1) for half logits [B, V] (first maximum on ties), one workgroup per row."""
+    lib = load()
+    if logits.device.type != "cuda":
+        raise RuntimeError("gpt2_layer.argmax: there is no CPU path")
+    if logits.dim() != 2 or logits.dtype != torch.float16 or logits.stride(1) != 1:
+        raise RuntimeError("gpt2_layer.argmax: half logits [B, V] with unit stride in V")
+    B, V = logits.shape
+    if out is None:
+        out = torch.empty((B,), dtype=torch.int64, device=logits.device)
+    _check(lib.vmi_gpt2_argmax_f16(logits.data_ptr(), logits.stride(0), B, V, out.data_ptr(), logits.device.index or 0,
+                                   torch.cuda.current_stream(logits.device).cuda_stream))
     return out
