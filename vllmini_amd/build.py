@@ -202,6 +202,8 @@ def layer_is_stale() -> bool:
 def build_layer(force: bool = False, verbose: bool = False) -> str:
     """libvmi_gpt2_layer.so: one translation unit, compiled and linked in one hipcc call (~20 s)."""
     os.makedirs(OUT_DIR, exist_ok=True)
+    if not force and os.path.exists(LAYER_LIB_PATH) and not _have_objects():
+        return LAYER_LIB_PATH      # a tree with libraries and no objects is the GPU box: complete as it is (see build())
     if force or layer_is_stale():
         tmp = LAYER_LIB_PATH + ".tmp"
         cmd = [_hipcc(), *[f for f in HIPCC_FLAGS if f != "-ffp-contract=off"], "-shared", SRC_LAYER, "-o", tmp]
