@@ -357,3 +357,42 @@ def test_embed_and_argmax_equal_torch():
     assert torch.equal(gl.argmax(small), small.argmax(-1))
     with pytest.raises(RuntimeError, match="half logits"):
         gl.argmax(logits.float())
+
+
+@pytest.mark.gpu
+def test_graph_replay_across_a_pick_threshold_keeps_one_graph_per_launch_geometry():
+    """32 sequences whose contexts grow from 505 to 520 tokens cross a threshold of the attention pick (the variant id is baked
+    into a captured step): the harness keeps ONE graph per variant and switches between them — never a capture in the middle of
+    a run once both exist — and the replayed logits are the eager ones."""
+    from vllmini_amd.gpt2_decode import GPT2Dims, GPT2PagedDecoder, random_state_dict
+    from vllmini_amd.kv_pool import PagedKVPool
+
+    dev = torch.device("cuda:0")
+    dims = GPT2Dims(n_layer=2)
+    sd = random_state_dict(dims, dev, seed=4)
+    B, ctx = 32, 505
+
+    def make():
+        pool = PagedKVPool(B * dims.n_layer * 34 + 8, dims.n_head, dims.head_size, 16, 35, dims.n_layer, device=dev, max_seqs=B,
+                           multi_block_prefill=True)
+        dec = GPT2PagedDecoder(dims, sd, pool)
+        for s in range(B):
+            dec.prefill(s, [(3 * s + j) % dims.vocab_size for j in range(ctx)])
+        return dec
+
+    eager, graph = make(), make()
+    rng = np.random.default_rng(2)
+    ids = list(range(B))
+    variants = []
+    for step in range(15):
+        toks = rng.integers(0, dims.vocab_size, B).tolist()
+        a = eager.decode(ids, toks)
+        b = graph.decode(ids, toks, use_graph=True)
+        variants.append(graph._static["variant"])
+        assert torch.equal(a, b), step
+    assert len(set(variants)) == len(graph._graph)
+    captured = dict(graph._graph)
+    for step in range(3):      # more steps on variants already seen: the same graph objects, nothing captured
+        toks = rng.integers(0, dims.vocab_size, B).tolist()
+        assert torch.equal(eager.decode(ids, toks), graph.decode(ids, toks, use_graph=True))
+    assert all(graph._graph[v][0] is captured[v][0] for v in captured)
