@@ -1132,10 +1132,6 @@ def main(argv=None):
         # identical, tests/test_parity_gpu.py): the reference surface stays the pair, the harness may use what is faster
         resf = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, fused=True, operator_share=False)
         line["e2e_step"]["fused_append"] = {k: resf[k] for k in ("value", "unit", "ms_per_step", "note")}
-        # ... or with reshape_and_cache's copy done by the q / k / v projection's epilogue (bit-identical too): the plain attention
-        # kernels, one launch fewer per layer
-        ress = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, scatter_in_c_attn=True)
-        line["e2e_step"]["scatter_in_c_attn"] = {k: ress[k] for k in ("value", "unit", "ms_per_step", "note")}
         # ... and with the block's linear layers left to the torch modules (rounds 1 - 4's harness), for the comparison
         rest = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, native_layers=False)
         line["e2e_step"]["torch_module_layers"] = {k: rest[k] for k in ("value", "unit", "ms_per_step", "note")}
@@ -1150,6 +1146,13 @@ def main(argv=None):
                                            "scatter_in_c_attn_us_per_token": r1s["ms_per_step"] * 1e3,
                                            "torch_module_layers_us_per_token": r1t["ms_per_step"] * 1e3,
                                            "note": "ONE sequence at the same context, the whole token from one hipGraph"}
+            # BASELINE configs[1] as a decode step: batch 32 at ~512 tokens (the pool's contexts start 24 tokens short of it)
+            c2 = dataclasses.replace(e2e_cfg, batch=32)
+            r2 = e2e_measure(args, c2, dist, rank, world, dev, ctx0=480, operator_share=False)
+            r2t = e2e_measure(args, c2, dist, rank, world, dev, ctx0=480, operator_share=False, native_layers=False)
+            line["e2e_step"]["cfg2_shape"] = {"batch": 32, "context": 480, "tokens_per_s": r2["value"],
+                                              "us_per_token": r2["ms_per_step"] * 1e3,
+                                              "torch_module_layers_us_per_token": r2t["ms_per_step"] * 1e3}
         args = args_main
     if plain and not args.no_long and args.config == "cfg3" and not args.variant and dist is None:
         line["long_context_step"] = long_context_record(args, dev)
