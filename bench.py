@@ -96,6 +96,8 @@ def build_parser():
     ap.add_argument("--e2e-eager", action="store_true", help="e2e: plain launches instead of hipGraph replay")
     ap.add_argument("--e2e-scatter-in-c-attn", action="store_true",
                     help="e2e: the q/k/v projection writes k and v into the paged cache itself (no reshape_and_cache launch)")
+    ap.add_argument("--e2e-sampler", default="greedy", choices=("greedy", "top_k", "top_k_torch"),
+                    help="e2e: how the next token is chosen (top_k = scheduler.py:144-153 in one launch; top_k_torch = the torch chain)")
     ap.add_argument("--e2e-torch-layers", action="store_true",
                     help="e2e: the block's linear layers as torch modules instead of csrc/gpt2_layer.hip")
     ap.add_argument("--headline-only", action="store_true",
@@ -566,13 +568,13 @@ def cpu_baseline(wl, budget_s: float):
 # ---- end to end (GPT-2 small over the batched harness) ----------------------------------------------------------------
 
 def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragged=False, eager=False,
-                ctx0=1008, operator_share=True, native_layers=True, scatter_in_c_attn=False):
+                ctx0=1008, operator_share=True, native_layers=True, scatter_in_c_attn=False, sampler="greedy"):
     """GPT-2 small, `batch` sequences per GPU at ~seq_len context, one token per sequence per step,
     through vllmini_amd.gpt2_decode (hipGraph replay of the whole step).  KV is synthetic: pages are
     filled with random fp16 and sequences are registered at the target context length."""
     import numpy as np
 
-    from vllmini_amd import cache_ops, ops
+    from vllmini_amd import cache_ops, gpt2_layer, ops
     from vllmini_amd.gpt2_decode import GPT2Dims, GPT2PagedDecoder, random_state_dict
     from vllmini_amd.kv_pool import PagedKVPool
 
@@ -611,7 +613,13 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
     def step(i):
         nonlocal tok
         logits = dec.decode(ids, tok, use_graph=not eager)
-        tok = dec.greedy(logits)                      # greedy: stays on the device, no host sync
+        if sampler == "greedy":
+            tok = dec.greedy(logits)                  # stays on the device, no host sync
+        elif sampler == "top_k":                      # the reference's sampling (scheduler.py:144-153), one launch of this build
+            tok = gpt2_layer.sample_top_k(logits, 50, 1.0, generator=g)
+        else:                                         # ... as the torch chain the reference spells out
+            vals, idx = torch.topk(logits.float(), 50, dim=-1)
+            tok = idx.gather(-1, torch.multinomial(torch.softmax(vals, -1), 1, generator=g)).squeeze(-1)
         if dist is not None:
             k = i & 1
             if works[k] is not None:
@@ -672,7 +680,7 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
 def run_e2e(args, cfg, dist, rank, world, dev):
     res = e2e_measure(args, cfg, dist, rank, world, dev, kv=args.kv, fused=args.e2e_fused, ragged=args.e2e_ragged,
                       eager=args.e2e_eager, ctx0=args.e2e_context, native_layers=not args.e2e_torch_layers,
-                      scatter_in_c_attn=args.e2e_scatter_in_c_attn)
+                      scatter_in_c_attn=args.e2e_scatter_in_c_attn, sampler=args.e2e_sampler)
     if rank == 0:
         print(json.dumps(res), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
@@ -1141,11 +1149,16 @@ def main(argv=None):
             b1 = dataclasses.replace(e2e_cfg, batch=1)
             r1 = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False)
             r1s = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, scatter_in_c_attn=True)
+            r1k = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, sampler="top_k")
+            r1kt = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, sampler="top_k_torch")
             r1t = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, native_layers=False)
             line["e2e_step"]["batch_1"] = {"us_per_token": r1["ms_per_step"] * 1e3, "tokens_per_s": r1["value"],
                                            "scatter_in_c_attn_us_per_token": r1s["ms_per_step"] * 1e3,
                                            "torch_module_layers_us_per_token": r1t["ms_per_step"] * 1e3,
-                                           "note": "ONE sequence at the same context, the whole token from one hipGraph"}
+                                           "top_k_50_sampling_us_per_token": r1k["ms_per_step"] * 1e3,
+                                           "top_k_50_sampling_torch_chain_us_per_token": r1kt["ms_per_step"] * 1e3,
+                                           "note": "ONE sequence at the same context, the whole token from one hipGraph; greedy "
+                                                   "unless named; top_k_50 = the reference's sampling (scheduler.py:144-153)"}
             # BASELINE configs[1] as a decode step: batch 32 at ~512 tokens (the pool's contexts start 24 tokens short of it)
             c2 = dataclasses.replace(e2e_cfg, batch=32)
             r2 = e2e_measure(args, c2, dist, rank, world, dev, ctx0=480, operator_share=False)

@@ -79,6 +79,13 @@ VMI_LAYER_API int vmi_gpt2_embed_f16(const int64_t* input_ids, const int64_t* po
 VMI_LAYER_API int vmi_gpt2_argmax_f16(const void* logits, int64_t ld, int32_t num_rows, int32_t vocab, int64_t* out,
                                       int32_t device, void* stream);
 
+/* Scheduler.sample_next_token (vllmini/scheduler.py:144-153: logits / temperature, top-k, softmax, one multinomial draw) for a
+ * batch of rows in one launch: out[r] = the index drawn from softmax(top_k largest of logits[r, :] / temperature), the draw made by
+ * inverse CDF over those top_k in descending order (ties: smaller index first) at uniform[r] in [0, 1) — the caller's random
+ * numbers, e.g. torch.rand(num_rows, generator=...), so the generator and its state stay the caller's.  vocab <= 65536, top_k <= 64. */
+VMI_LAYER_API int vmi_gpt2_sample_top_k_f16(const void* logits, int64_t ld, int32_t num_rows, int32_t vocab, int32_t top_k,
+                                            float temperature, const float* uniform, int64_t* out, int32_t device, void* stream);
+
 /* The kernel vmi_gpt2_linear_f16 would launch for this shape ("bm32_nw4_ks1_r2_ln_gelu"), for records; NULL if refused. */
 VMI_LAYER_API const char* vmi_gpt2_linear_kernel_name(int32_t M, int32_t N, int32_t K, int32_t has_ln, int32_t epilogue);
 

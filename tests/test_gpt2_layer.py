@@ -396,3 +396,54 @@ def test_graph_replay_across_a_pick_threshold_keeps_one_graph_per_launch_geometr
         toks = rng.integers(0, dims.vocab_size, B).tolist()
         assert torch.equal(eager.decode(ids, toks), graph.decode(ids, toks, use_graph=True))
     assert all(graph._graph[v][0] is captured[v][0] for v in captured)
+
+
+@pytest.mark.gpu
+def test_top_k_sampling_kernel_draws_from_the_reference_distribution():
+    """vmi_gpt2_sample_top_k_f16 against the torch chain the reference spells out (scheduler.py:144-153): the k survivors are
+    torch.topk's, the draw at a given uniform number is the inverse CDF over their softmax in descending order, ties go to the
+    smaller index, rows of equal logits (the block-wide path) work, and the frequencies of many draws match the probabilities."""
+    from vllmini_amd import gpt2_layer as gl
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    V = 50257
+    for B, k, temp in ((1, 50, 1.0), (7, 50, 0.7), (256, 50, 1.0), (5, 1, 1.0), (4, 64, 1.3), (3, 13, 1.0)):
+        logits = (torch.randn(B, V, generator=g) * 2).half().to(dev)
+        vals, idx = torch.topk(logits.float() / temp, k, dim=-1)
+        cdf = torch.softmax(vals, -1).double().cumsum(-1)
+        for u in (0.0, 0.173, 0.5, 0.9371, 0.999999):
+            uu = torch.full((B,), u, dtype=torch.float32, device=dev)
+            got = gl.sample_top_k(logits, k, temp, uniform=uu)
+            j = (cdf >= u * cdf[:, -1:]).int().argmax(-1)                       # first survivor whose cumulative mass reaches u
+            want = idx.gather(-1, j[:, None]).squeeze(-1)
+            # (a draw that sits within float rounding of a CDF step may land on the neighbour: compare there by mass)
+            bad = got != want
+            if bad.any():
+                pos = (idx == got[:, None]).int().argmax(-1)
+                assert ((idx == got[:, None]).any(-1))[bad].all()
+                near = (cdf.gather(-1, pos[:, None]).squeeze(-1) - u * cdf[:, -1]).abs() < 1e-5
+                near |= (cdf.gather(-1, (pos - 1).clamp(min=0)[:, None]).squeeze(-1) - u * cdf[:, -1]).abs() < 1e-5
+                assert near[bad].all(), (B, k, u)
+    # ties: equal logits everywhere -> the k smallest indices, equal mass each; a few equal maxima -> smaller index first
+    flat = torch.zeros(3, V, dtype=torch.float16, device=dev)
+    for u, want in ((0.0, 0), (0.51, 25), (0.999, 49)):
+        assert gl.sample_top_k(flat, 50, 1.0, uniform=torch.full((3,), u, device=dev)).tolist() == [want] * 3
+    peaks = torch.full((2, V), -4.0, dtype=torch.float16, device=dev)
+    peaks[:, 40000] = peaks[:, 123] = peaks[:, 9999] = 6.0
+    assert gl.sample_top_k(peaks, 3, 1.0, uniform=torch.tensor([0.1, 0.5], device=dev)).tolist() == [123, 9999]
+    small = torch.randn(4, 37, generator=g).half().to(dev)           # fewer columns than threads, top_k larger than the row
+    got = gl.sample_top_k(small, 50, 1.0, uniform=torch.zeros(4, device=dev))
+    assert torch.equal(got, small.argmax(-1))
+    # frequencies: 20 000 draws of one row against its top-8 probabilities
+    row = (torch.randn(1, V, generator=g) * 3).half().to(dev)
+    vals, idx = torch.topk(row.float(), 8, dim=-1)
+    p = torch.softmax(vals, -1)[0].cpu().numpy()
+    gen = torch.Generator(device=dev).manual_seed(3)
+    draws = gl.sample_top_k(row.expand(20000, V).contiguous(), 8, 1.0, generator=gen).cpu().numpy()
+    freq = np.array([(draws == int(i)).mean() for i in idx[0].cpu().numpy()])
+    assert abs(freq.sum() - 1) < 1e-9 and np.abs(freq - p).max() < 0.012, (freq, p)
+    # the scheduler's sampler takes this path for the decoder's half logits
+    from vllmini_amd.scheduler import sample_top_k
+    out = sample_top_k(row.expand(64, V).contiguous(), generator=torch.Generator(device=dev).manual_seed(1))
+    assert out.dtype == torch.int64 and set(out.tolist()) <= set(torch.topk(row.float(), 50).indices[0].tolist())

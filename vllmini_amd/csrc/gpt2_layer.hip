@@ -429,6 +429,159 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const h16* __restrict__ lo
   }
 }
 
+// ---- top-k sampling (Scheduler.sample_next_token, scheduler.py:144-153: logits / temperature -> top-k 50 -> softmax -> one draw) ---
+//
+// torch does this as topk (a radix select over 50 257 values) + softmax + multinomial + gather: 127 us for one row, 309 us for
+// 256 — a quarter of a one-sequence token.  Here one 1024-thread workgroup per row keeps the row in registers as unique 32-bit
+// keys (order-preserving half bits << 16 | 65535 - index: larger key = larger logit, ties to the smaller index) and never sorts
+// it: (1) every thread's maximum goes to LDS and ONE wave finds the k-th largest of those 1024 — a lower bound of the row's k-th
+// largest value; (2) the few hundred elements at or above it are compacted into LDS; (3) one wave finds the exact k-th largest
+// key among them by bisection on the key, ranks the k survivors, and (4) draws from their softmax by inverse CDF with a uniform
+// number the caller supplies (so the generator stays torch's).  Rows whose candidates overflow the LDS list (thousands of equal
+// logits) take a block-wide bisection instead: slower, same answer.
+constexpr int SK_T = 1024, SK_PER = 64, SK_CAP = 512, SK_KMAX = 64;   // (a row of N(0, s) logits leaves ~50 - 60 candidates)
+
+__device__ __forceinline__ uint32_t sk_key(h16 v, int idx) {
+  const uint16_t b = __builtin_bit_cast(uint16_t, v);
+  const uint16_t k = (b & 0x8000u) ? (uint16_t)~b : (uint16_t)(b | 0x8000u);
+  return ((uint32_t)k << 16) | (uint32_t)(65535 - idx);
+}
+__device__ __forceinline__ float sk_value(uint32_t key) {
+  const uint16_t k = (uint16_t)(key >> 16);
+  const uint16_t b = (k & 0x8000u) ? (uint16_t)(k & 0x7fffu) : (uint16_t)~k;
+  return (float)__builtin_bit_cast(h16, b);
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(SK_T) void sample_top_k_kernel(const h16* __restrict__ logits, int64_t ld, int V, int top_k,
+                                                            float inv_temperature, const float* __restrict__ uniform,
+                                                            int64_t* __restrict__ out) {
+  __shared__ uint32_t tmax_s[SK_T];
+  __shared__ uint32_t cand[SK_CAP];
+  __shared__ uint32_t sel[SK_KMAX], sorted[SK_KMAX];
+  __shared__ int cnt_s, wcount[SK_T / 64];
+  __shared__ uint32_t bound_s;
+  const h16* row = logits + (int64_t)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = min(min(top_k, SK_KMAX), V);
+  uint32_t keys[SK_PER];
+  uint32_t tmax = 0;
+#pragma unroll
+  for (int i = 0; i < SK_PER; ++i) {
+    const int idx = tid + i * SK_T;
+    keys[i] = idx < V ? sk_key(row[idx], idx) : 0u;   // (0 is below every real key)
+    tmax = max(tmax, keys[i]);
+  }
+  tmax_s[tid] = tmax;
+  if (tid == 0) cnt_s = 0;
+  __syncthreads();
+  // (1) wave 0: the k-th largest of the 1024 thread maxima (V < 1024: fewer are real, zeros fill up and the bound is 0)
+  if (wave == 0) {
+    uint32_t m[SK_T / 64];
+#pragma unroll
+    for (int j = 0; j < SK_T / 64; ++j) m[j] = tmax_s[lane + j * 64];
+    // largest VALUE (upper 16 key bits) v with count(m >= v << 16) >= k — a bound needs no more; counts by ballot + scalar popcount
+    uint32_t lo = 0, hi = 0xffffu;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < SK_T / 64; ++j) c += __builtin_popcountll(__ballot((m[j] >> 16) >= mid));
+      if (c >= k) lo = mid; else hi = mid - 1;
+    }
+    lo <<= 16;
+    if (lane == 0) bound_s = lo;
+  }
+  __syncthreads();
+  const uint32_t bound = bound_s;
+  // (2) everything at or above the bound into the LDS list
+#pragma unroll
+  for (int i = 0; i < SK_PER; ++i) {
+    if (keys[i] >= bound && keys[i] != 0u) {
+      const int pos = atomicAdd(&cnt_s, 1);
+      if (pos < SK_CAP) cand[pos] = keys[i];
+    }
+  }
+  __syncthreads();
+  const int n = cnt_s;
+  uint32_t thr;
+  if (n <= SK_CAP) {
+    // (3) wave 0: the exact k-th largest key of the list by bisection (keys are unique: exactly k keys are >= it)
+    if (wave != 0) return;
+    uint32_t c[SK_CAP / 64];
+#pragma unroll
+    for (int j = 0; j < SK_CAP / 64; ++j) c[j] = lane + j * 64 < n ? cand[lane + j * 64] : 0u;
+    const int nl = (n + 63) >> 6;
+    uint32_t lo = bound, hi = 0xffffffffu;
+    while (lo < hi) {
+      const uint32_t mid = lo + (uint32_t)(((uint64_t)hi - lo + 1) >> 1);
+      int cc = 0;
+#pragma unroll
+      for (int j = 0; j < SK_CAP / 64; ++j)
+        if (j < nl) cc += __builtin_popcountll(__ballot(c[j] >= mid));
+      if (cc >= k) lo = mid; else hi = mid - 1;
+    }
+    thr = lo;
+    // the k survivors into sel[] (any order)
+    if (lane == 0) cnt_s = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < SK_CAP / 64; ++j)
+      if (j < nl && c[j] >= thr && c[j] != 0u) sel[atomicAdd(&cnt_s, 1)] = c[j];
+  } else {
+    // thousands of candidates (long runs of equal logits): block-wide bisection over the keys in registers
+    uint32_t lo = bound, hi = 0xffffffffu;
+    while (lo < hi) {
+      const uint32_t mid = lo + (uint32_t)(((uint64_t)hi - lo + 1) >> 1);
+      int cc = 0;
+#pragma unroll
+      for (int i = 0; i < SK_PER; ++i) cc += keys[i] >= mid;
+      cc = wave_sum_i(cc);
+      __syncthreads();
+      if (lane == 0) wcount[wave] = cc;
+      __syncthreads();
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < SK_T / 64; ++w) tot += wcount[w];
+      if (tot >= k) lo = mid; else hi = mid - 1;
+    }
+    thr = lo;
+    __syncthreads();
+    if (tid == 0) cnt_s = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SK_PER; ++i)
+      if (keys[i] >= thr && keys[i] != 0u) sel[atomicAdd(&cnt_s, 1)] = keys[i];
+    __syncthreads();
+    if (wave != 0) return;
+  }
+  // (4) wave 0: rank the k survivors (descending), softmax over their values, inverse CDF
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t mine = lane < k ? sel[lane] : 0u;
+  int rank = 0;
+  for (int j = 0; j < k; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)mine, j) > mine;   // (j is uniform: v_readlane)
+  if (lane < k) sorted[rank] = mine;
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t skey = lane < k ? sorted[lane] : 0u;
+  const float top = sk_value(sorted[0]);
+  const float e = lane < k ? __expf((sk_value(skey) - top) * inv_temperature) : 0.f;
+  float cum = e;   // inclusive scan over the lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float up = __shfl_up(cum, o, 64);
+    if (lane >= o) cum += up;
+  }
+  const float total = __shfl(cum, k - 1, 64);
+  const float target = uniform[blockIdx.x] * total;
+  const uint64_t hit = __ballot(lane < k && cum >= target);
+  const int pick = hit ? __builtin_ctzll(hit) : k - 1;
+  if (lane == pick) out[blockIdx.x] = 65535 - (int)(skey & 0xffffu);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
@@ -634,6 +787,24 @@ int vmi_gpt2_argmax_f16(const void* logits, int64_t ld, int32_t num_rows, int32_
   hipLaunchKernelGGL(argmax_kernel, dim3(num_rows), dim3(1024), 0, static_cast<hipStream_t>(stream),
                      static_cast<const h16*>(logits), ld, vocab, out);
   return after_launch("vmi_gpt2_argmax_f16", prev, device);
+}
+
+int vmi_gpt2_sample_top_k_f16(const void* logits, int64_t ld, int32_t num_rows, int32_t vocab, int32_t top_k, float temperature,
+                              const float* uniform, int64_t* out, int32_t device, void* stream) {
+  using namespace vmi_layer;
+  if (!logits || !uniform || !out || num_rows <= 0 || vocab <= 0 || ld < vocab || top_k <= 0 || !(temperature > 0.f)) {
+    g_err = "vmi_gpt2_sample_top_k_f16: null pointer, non-positive size / top_k / temperature";
+    return VMI_LAYER_E_ARG;
+  }
+  if (vocab > SK_T * SK_PER || top_k > SK_KMAX) {
+    g_err = "vmi_gpt2_sample_top_k_f16: vocab <= 65536 and top_k <= 64";
+    return VMI_LAYER_E_SHAPE;
+  }
+  int prev = -1;
+  if (int rc = with_device("vmi_gpt2_sample_top_k_f16", device, &prev)) return rc;
+  hipLaunchKernelGGL(sample_top_k_kernel, dim3(num_rows), dim3(SK_T), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const h16*>(logits), ld, vocab, top_k, 1.f / temperature, uniform, out);
+  return after_launch("vmi_gpt2_sample_top_k_f16", prev, device);
 }
 
 const char* vmi_gpt2_linear_kernel_name(int32_t M, int32_t N, int32_t K, int32_t has_ln, int32_t epilogue) {

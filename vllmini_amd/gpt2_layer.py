@@ -28,6 +28,7 @@ SIGNATURES = {
                                                      _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
     "vmi_gpt2_embed_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vmi_gpt2_argmax_f16": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
+    "vmi_gpt2_sample_top_k_f16": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i32, ctypes.c_float, _vp, _vp, _i32, _vp]),
     "vmi_gpt2_linear_kernel_name": (ctypes.c_char_p, [_i32, _i32, _i32, _i32, _i32]),
     "vmi_gpt2_layer_last_error": (ctypes.c_char_p, []),
     "vmi_gpt2_layer_abi_version": (_i32, []),
@@ -220,4 +221,26 @@ def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
         out = torch.empty((B,), dtype=torch.int64, device=logits.device)
     _check(lib.vmi_gpt2_argmax_f16(logits.data_ptr(), logits.stride(0), B, V, out.data_ptr(), logits.device.index or 0,
                                    torch.cuda.current_stream(logits.device).cuda_stream))
+    return out
+
+
+def sample_top_k(logits: torch.Tensor, top_k: int = 50, temperature: float = 1.0,
+                 generator: Optional[torch.Generator] = None, uniform: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Scheduler.sample_next_token (scheduler.py:144-153) for a batch in one launch: logits / temperature -> the top_k largest ->
+    softmax -> one draw per row, by inverse CDF over the top_k in descending order at `uniform` (default: torch.rand from
+    `generator`).  Same distribution as topk + softmax + multinomial, not the same stream of draws.  int64 [B]."""
+    lib = load()
+    if logits.device.type != "cuda":
+        raise RuntimeError("gpt2_layer.sample_top_k: there is no CPU path")
+    if logits.dim() != 2 or logits.dtype != torch.float16 or logits.stride(1) != 1:
+        raise RuntimeError("gpt2_layer.sample_top_k: half logits [B, V] with unit stride in V")
+    B, V = logits.shape
+    if uniform is None:
+        uniform = torch.rand(B, device=logits.device, generator=generator)
+    if uniform.dtype != torch.float32 or uniform.shape != (B,) or not uniform.is_contiguous():
+        raise RuntimeError("gpt2_layer.sample_top_k: uniform float32 [B]")
+    out = torch.empty((B,), dtype=torch.int64, device=logits.device)
+    _check(lib.vmi_gpt2_sample_top_k_f16(logits.data_ptr(), logits.stride(0), B, V, min(top_k, V), float(temperature),
+                                         uniform.data_ptr(), out.data_ptr(), logits.device.index or 0,
+                                         torch.cuda.current_stream(logits.device).cuda_stream))
     return out
