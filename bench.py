@@ -1147,7 +1147,7 @@ def main(argv=None):
         if dist is None:
             # the regime the reference's scheduler runs (one sequence per step, scheduler.py:60): a token's latency
             b1 = dataclasses.replace(e2e_cfg, batch=1)
-            r1 = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False)
+            r1 = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False)   # (the call pair)
             r1s = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, scatter_in_c_attn=True)
             r1k = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, sampler="top_k")
             r1kt = e2e_measure(args, b1, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, sampler="top_k_torch")

@@ -84,10 +84,11 @@ class GPT2PagedDecoder:
     """Prefill + batched decode of GPT-2 over a PagedKVPool, calling the two hot-path ops."""
 
     NATIVE_LAYERS_MAX_BATCH = 512    # larger steps run the block's linear layers as torch modules (real GEMMs by then)
+    SCATTER_IN_C_ATTN_MAX_BATCH = 64  # up to here the cache write rides in the q / k / v projection unless the caller says no
 
     def __init__(self, dims: GPT2Dims, state_dict: Dict[str, torch.Tensor], pool: PagedKVPool,
                  reference_off_by_one: bool = False, fused_append: bool = False, native_layers: Optional[bool] = None,
-                 scatter_in_c_attn: bool = False):
+                 scatter_in_c_attn: Optional[bool] = None):
         assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
         assert pool.head_size == dims.head_size
         self.dims, self.sd, self.pool = dims, state_dict, pool
@@ -118,9 +119,14 @@ class GPT2PagedDecoder:
         # scatter_in_c_attn: the q / k / v projection writes k and v into the paged cache itself (gpt2_layer.linear_qkv_cache:
         # reshape_and_cache's copy in the producer's epilogue, bit-identical caches) — the step runs paged_attention_v1 alone,
         # one launch fewer per layer than the reference's call pair and on the plain attention kernels (unlike fused_append)
-        if scatter_in_c_attn and (not self.native_layers or fused_append or pool.kv_cache_dtype != "auto"):
+        # None = where it is a measured win: steps of at most SCATTER_IN_C_ATTN_MAX_BATCH rows (launch-bound: -2 ... -6 % per token
+        # from 1 to 32 sequences, +1 % at 256 where the scattered two-byte V pieces cost more in the projection's tail)
+        can_scatter = self.native_layers and not fused_append and pool.kv_cache_dtype == "auto"
+        if scatter_in_c_attn and not can_scatter:
             raise ValueError("scatter_in_c_attn needs native_layers, float16 pages and the two-op attention (not fused_append)")
-        self.scatter_in_c_attn = scatter_in_c_attn
+        self.scatter_in_c_attn = scatter_in_c_attn if scatter_in_c_attn is not None or not can_scatter else None
+        if not can_scatter:
+            self.scatter_in_c_attn = False
         self._packed: Dict[str, gpt2_layer.PackedWeight] = {}
         if self.native_layers:
             gpt2_layer.load()
@@ -193,7 +199,7 @@ class GPT2PagedDecoder:
             x = sd["transformer.wte.weight"][st["input_ids"]] + sd["transformer.wpe.weight"][st["position_ids"]]
         for i in range(d.n_layer):
             p = f"transformer.h.{i}."
-            scat = nat and self.scatter_in_c_attn
+            scat = nat and (B <= self.SCATTER_IN_C_ATTN_MAX_BATCH if self.scatter_in_c_attn is None else self.scatter_in_c_attn)
             if scat:     # ln_1 + c_attn + the cache write of k and v in one launch
                 qkv = gpt2_layer.linear_qkv_cache(x, pw[p + "attn.c_attn.weight"], sd[p + "attn.c_attn.bias"], pool.key_cache,
                                                   pool.value_cache, st["slots"][i], d.n_head,
