@@ -439,12 +439,20 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const h16* __restrict__ lo
 // key among them by bisection on the key, ranks the k survivors, and (4) draws from their softmax by inverse CDF with a uniform
 // number the caller supplies (so the generator stays torch's).  Rows whose candidates overflow the LDS list (thousands of equal
 // logits) take a block-wide bisection instead: slower, same answer.
-constexpr int SK_T = 1024, SK_PER = 64, SK_CAP = 512, SK_KMAX = 64;   // (a row of N(0, s) logits leaves ~50 - 60 candidates)
+constexpr int SK_T = 1024, SK_UPT = 8, SK_CAP = 512, SK_KMAX = 64;   // (a row of N(0, s) logits leaves ~50 - 60 candidates)
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t sk_key(h16 v, int idx) {
+// two halves of a dword -> two order-preserving 16-bit keys (negative: all bits flipped, else the sign bit set)
+__device__ __forceinline__ uint32_t sk_keys2(uint32_t x) {
+  const uint32_t s = (x >> 15) & 0x00010001u;
+  return x ^ ((s * 0xffffu) | 0x80008000u);
+}
+__device__ __forceinline__ uint32_t sk_max2(uint32_t a, uint32_t b) {   // v_pk_max_u16
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t sk_key16(h16 v) {
   const uint16_t b = __builtin_bit_cast(uint16_t, v);
-  const uint16_t k = (b & 0x8000u) ? (uint16_t)~b : (uint16_t)(b | 0x8000u);
-  return ((uint32_t)k << 16) | (uint32_t)(65535 - idx);
+  return (b & 0x8000u) ? (uint16_t)~b : (uint16_t)(b | 0x8000u);
 }
 __device__ __forceinline__ float sk_value(uint32_t key) {
   const uint16_t k = (uint16_t)(key >> 16);
@@ -457,6 +465,10 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 
+// The row sits in registers as packed 16-bit value keys, eight consecutive elements (one 16-byte load from the first aligned
+// element on) per unit, SK_UPT units per thread; the up to 7 + 7 elements in front of the first and behind the last unit are one
+// extra element of threads 0 .. 13.  A candidate's unique 32-bit key (value key << 16 | 65535 - index: ties to the smaller index)
+// is built only when it is appended.
 __global__ __launch_bounds__(SK_T) void sample_top_k_kernel(const h16* __restrict__ logits, int64_t ld, int V, int top_k,
                                                             float inv_temperature, const float* __restrict__ uniform,
                                                             int64_t* __restrict__ out) {
@@ -468,42 +480,66 @@ __global__ __launch_bounds__(SK_T) void sample_top_k_kernel(const h16* __restric
   const h16* row = logits + (int64_t)blockIdx.x * ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = min(min(top_k, SK_KMAX), V);
-  uint32_t keys[SK_PER];
-  uint32_t tmax = 0;
+  const int head = (int)(((16 - ((uintptr_t)row & 15)) & 15) >> 1);
+  const int a0 = head < V ? head : V, nvec = (V - a0) >> 3, t0 = a0 + nvec * 8, ntail = V - t0;
+  u32x4 kv[SK_UPT];      // packed value keys, 0 where there is no element
+  uint32_t umax[SK_UPT];  // the largest value key of each unit
 #pragma unroll
-  for (int i = 0; i < SK_PER; ++i) {
-    const int idx = tid + i * SK_T;
-    keys[i] = idx < V ? sk_key(row[idx], idx) : 0u;   // (0 is below every real key)
-    tmax = max(tmax, keys[i]);
+  for (int j = 0; j < SK_UPT; ++j) {
+    const int u = tid + j * SK_T;
+    kv[j] = u32x4{0u, 0u, 0u, 0u};
+    if (u < nvec) kv[j] = *reinterpret_cast<const u32x4*>(row + a0 + u * 8);
+  }
+  int xi = -1;            // the extra element of this thread (index), if any
+  if (tid < a0) xi = tid;
+  else if (tid - a0 < ntail) xi = t0 + tid - a0;
+  uint32_t xk = xi >= 0 ? sk_key16(row[xi]) : 0u;
+  uint32_t tmax = xk;
+#pragma unroll
+  for (int j = 0; j < SK_UPT; ++j) {
+    const bool has = tid + j * SK_T < nvec;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) kv[j][e] = has ? sk_keys2(kv[j][e]) : 0u;
+    const uint32_t m2 = sk_max2(sk_max2(kv[j][0], kv[j][1]), sk_max2(kv[j][2], kv[j][3]));
+    umax[j] = max(m2 & 0xffffu, m2 >> 16);
+    tmax = max(tmax, umax[j]);
   }
   tmax_s[tid] = tmax;
   if (tid == 0) cnt_s = 0;
   __syncthreads();
-  // (1) wave 0: the k-th largest of the 1024 thread maxima (V < 1024: fewer are real, zeros fill up and the bound is 0)
+  // (1) wave 0: the k-th largest of the 1024 thread maxima — a lower bound of the row's k-th largest value (counts by ballot +
+  //     scalar popcount: no cross-lane traffic)
   if (wave == 0) {
     uint32_t m[SK_T / 64];
 #pragma unroll
     for (int j = 0; j < SK_T / 64; ++j) m[j] = tmax_s[lane + j * 64];
-    // largest VALUE (upper 16 key bits) v with count(m >= v << 16) >= k — a bound needs no more; counts by ballot + scalar popcount
     uint32_t lo = 0, hi = 0xffffu;
     while (lo < hi) {
       const uint32_t mid = (lo + hi + 1) >> 1;
       int c = 0;
 #pragma unroll
-      for (int j = 0; j < SK_T / 64; ++j) c += __builtin_popcountll(__ballot((m[j] >> 16) >= mid));
+      for (int j = 0; j < SK_T / 64; ++j) c += __builtin_popcountll(__ballot(m[j] >= mid));
       if (c >= k) lo = mid; else hi = mid - 1;
     }
-    lo <<= 16;
     if (lane == 0) bound_s = lo;
   }
   __syncthreads();
-  const uint32_t bound = bound_s;
-  // (2) everything at or above the bound into the LDS list
+  const uint32_t bound = bound_s;   // a VALUE key; 0 only when fewer than k thread maxima are real (V < 1024 or so)
+  // (2) everything at or above the bound into the LDS list, as unique 32-bit keys
+  auto append = [&](uint32_t vkey, int idx) {
+    const int pos = atomicAdd(&cnt_s, 1);
+    if (pos < SK_CAP) cand[pos] = (vkey << 16) | (uint32_t)(65535 - idx);
+  };
+  if (xi >= 0 && xk >= bound) append(xk, xi);
 #pragma unroll
-  for (int i = 0; i < SK_PER; ++i) {
-    if (keys[i] >= bound && keys[i] != 0u) {
-      const int pos = atomicAdd(&cnt_s, 1);
-      if (pos < SK_CAP) cand[pos] = keys[i];
+  for (int j = 0; j < SK_UPT; ++j) {
+    const int u = tid + j * SK_T;
+    if (u < nvec && umax[j] >= bound) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t vk = (kv[j][e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+        if (vk >= bound) append(vk, a0 + u * 8 + e);
+      }
     }
   }
   __syncthreads();
@@ -516,7 +552,7 @@ __global__ __launch_bounds__(SK_T) void sample_top_k_kernel(const h16* __restric
 #pragma unroll
     for (int j = 0; j < SK_CAP / 64; ++j) c[j] = lane + j * 64 < n ? cand[lane + j * 64] : 0u;
     const int nl = (n + 63) >> 6;
-    uint32_t lo = bound, hi = 0xffffffffu;
+    uint32_t lo = bound << 16, hi = 0xffffffffu;
     while (lo < hi) {
       const uint32_t mid = lo + (uint32_t)(((uint64_t)hi - lo + 1) >> 1);
       int cc = 0;
@@ -533,14 +569,26 @@ __global__ __launch_bounds__(SK_T) void sample_top_k_kernel(const h16* __restric
     for (int j = 0; j < SK_CAP / 64; ++j)
       if (j < nl && c[j] >= thr && c[j] != 0u) sel[atomicAdd(&cnt_s, 1)] = c[j];
   } else {
-    // thousands of candidates (long runs of equal logits): block-wide bisection over the keys in registers
-    uint32_t lo = bound, hi = 0xffffffffu;
+    // thousands of candidates (long runs of equal logits): block-wide bisection over the unique keys of everything in registers
+    auto count_ge = [&](uint32_t mid) {
+      int cc = (xi >= 0 && ((xk << 16) | (uint32_t)(65535 - xi)) >= mid) ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < SK_UPT; ++j) {
+        const int u = tid + j * SK_T;
+        if (u < nvec) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t vk = (kv[j][e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+            cc += ((vk << 16) | (uint32_t)(65535 - (a0 + u * 8 + e))) >= mid;
+          }
+        }
+      }
+      return cc;
+    };
+    uint32_t lo = bound << 16, hi = 0xffffffffu;
     while (lo < hi) {
       const uint32_t mid = lo + (uint32_t)(((uint64_t)hi - lo + 1) >> 1);
-      int cc = 0;
-#pragma unroll
-      for (int i = 0; i < SK_PER; ++i) cc += keys[i] >= mid;
-      cc = wave_sum_i(cc);
+      const int cc = wave_sum_i(count_ge(mid));
       __syncthreads();
       if (lane == 0) wcount[wave] = cc;
       __syncthreads();
@@ -553,9 +601,19 @@ __global__ __launch_bounds__(SK_T) void sample_top_k_kernel(const h16* __restric
     __syncthreads();
     if (tid == 0) cnt_s = 0;
     __syncthreads();
+    if (xi >= 0 && ((xk << 16) | (uint32_t)(65535 - xi)) >= thr) sel[atomicAdd(&cnt_s, 1)] = (xk << 16) | (uint32_t)(65535 - xi);
 #pragma unroll
-    for (int i = 0; i < SK_PER; ++i)
-      if (keys[i] >= thr && keys[i] != 0u) sel[atomicAdd(&cnt_s, 1)] = keys[i];
+    for (int j = 0; j < SK_UPT; ++j) {
+      const int u = tid + j * SK_T;
+      if (u < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t vk = (kv[j][e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+          const uint32_t key = (vk << 16) | (uint32_t)(65535 - (a0 + u * 8 + e));
+          if (key >= thr) sel[atomicAdd(&cnt_s, 1)] = key;
+        }
+      }
+    }
     __syncthreads();
     if (wave != 0) return;
   }
@@ -796,7 +854,7 @@ int vmi_gpt2_sample_top_k_f16(const void* logits, int64_t ld, int32_t num_rows, 
     g_err = "vmi_gpt2_sample_top_k_f16: null pointer, non-positive size / top_k / temperature";
     return VMI_LAYER_E_ARG;
   }
-  if (vocab > SK_T * SK_PER || top_k > SK_KMAX) {
+  if (vocab > 65536 || top_k > SK_KMAX) {
     g_err = "vmi_gpt2_sample_top_k_f16: vocab <= 65536 and top_k <= 64";
     return VMI_LAYER_E_SHAPE;
   }
