@@ -96,8 +96,6 @@ def build_parser():
     ap.add_argument("--e2e-eager", action="store_true", help="e2e: plain launches instead of hipGraph replay")
     ap.add_argument("--e2e-scatter-in-c-attn", action="store_true",
                     help="e2e: the q/k/v projection writes k and v into the paged cache itself (no reshape_and_cache launch)")
-    ap.add_argument("--e2e-block-tail", action="store_true",
-                    help="e2e: a block's tail as ONE launch (grid barriers) for steps of at most 64 rows — measured behind")
     ap.add_argument("--e2e-sampler", default="greedy", choices=("greedy", "top_k", "top_k_torch"),
                     help="e2e: how the next token is chosen (top_k = scheduler.py:144-153 in one launch; top_k_torch = the torch chain)")
     ap.add_argument("--e2e-torch-layers", action="store_true",
@@ -570,8 +568,7 @@ def cpu_baseline(wl, budget_s: float):
 # ---- end to end (GPT-2 small over the batched harness) ----------------------------------------------------------------
 
 def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragged=False, eager=False,
-                ctx0=1008, operator_share=True, native_layers=True, scatter_in_c_attn=False, sampler="greedy",
-                block_tail=False):
+                ctx0=1008, operator_share=True, native_layers=True, scatter_in_c_attn=False, sampler="greedy"):
     """GPT-2 small, `batch` sequences per GPU at ~seq_len context, one token per sequence per step,
     through vllmini_amd.gpt2_decode (hipGraph replay of the whole step).  KV is synthetic: pages are
     filled with random fp16 and sequences are registered at the target context length."""
@@ -604,7 +601,7 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
     for s in range(cfg.batch):
         pool.allocate_for_prefill(s, int(ctxs[s]))   # bookkeeping only: the pages already hold synthetic KV
     dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, fused_append=fused, native_layers=native_layers,
-                           scatter_in_c_attn=scatter_in_c_attn, block_tail=block_tail)
+                           scatter_in_c_attn=scatter_in_c_attn)
     ids = list(range(cfg.batch))
     tok = torch.randint(0, dims.vocab_size, (cfg.batch,), device=dev, generator=g)
 
@@ -683,8 +680,7 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
 def run_e2e(args, cfg, dist, rank, world, dev):
     res = e2e_measure(args, cfg, dist, rank, world, dev, kv=args.kv, fused=args.e2e_fused, ragged=args.e2e_ragged,
                       eager=args.e2e_eager, ctx0=args.e2e_context, native_layers=not args.e2e_torch_layers,
-                      scatter_in_c_attn=args.e2e_scatter_in_c_attn, sampler=args.e2e_sampler,
-                      block_tail=args.e2e_block_tail)
+                      scatter_in_c_attn=args.e2e_scatter_in_c_attn, sampler=args.e2e_sampler)
     if rank == 0:
         print(json.dumps(res), file=sys.stderr, flush=True)
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)

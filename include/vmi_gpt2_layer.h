@@ -86,17 +86,6 @@ VMI_LAYER_API int vmi_gpt2_argmax_f16(const void* logits, int64_t ld, int32_t nu
 VMI_LAYER_API int vmi_gpt2_sample_top_k_f16(const void* logits, int64_t ld, int32_t num_rows, int32_t vocab, int32_t top_k,
                                             float temperature, const float* uniform, int64_t* out, int32_t device, void* stream);
 
-/* A block's tail in ONE launch, for steps of at most 64 rows: x += attn_out . w_proj^T + b_proj;
- * h = GELU(LayerNorm(x) . w_fc^T + b_fc); x += h . w_proj2^T + b_proj2 (gpt2.py:117-128, 130-135) — the three launches
- * vmi_gpt2_linear_f16 would make, as three phases of one launch separated by barriers over its (all-resident) grid; bit-identical
- * to them.  x [M, E] is updated in place, h_scratch [M, 4E] is the caller's buffer for the GELU output, barrier_workspace points
- * at 16 zeroed bytes the launch leaves zeroed again (one launch at a time per workspace).  M <= 64, E % 32 == 0, E <= 1152. */
-VMI_LAYER_API int vmi_gpt2_block_tail_f16(const void* attn_out, int64_t ld_attn, void* x, int64_t ldx, const void* w_proj,
-                                          const void* b_proj, const void* ln2_gamma, const void* ln2_beta, float ln_eps,
-                                          const void* w_fc, const void* b_fc, const void* w_proj2, const void* b_proj2,
-                                          void* h_scratch, int64_t ldh, void* barrier_workspace, int32_t M, int32_t E,
-                                          int32_t w_layout, int32_t device, void* stream);
-
 /* The kernel vmi_gpt2_linear_f16 would launch for this shape ("bm32_nw4_ks1_r2_ln_gelu"), for records; NULL if refused. */
 VMI_LAYER_API const char* vmi_gpt2_linear_kernel_name(int32_t M, int32_t N, int32_t K, int32_t has_ln, int32_t epilogue);
 

@@ -448,52 +448,3 @@ def test_top_k_sampling_kernel_draws_from_the_reference_distribution():
     out = sample_top_k(row.expand(64, V).contiguous(), generator=torch.Generator(device=dev).manual_seed(1))
     assert out.dtype == torch.int64 and set(out.tolist()) <= set(torch.topk(row.float(), 50).indices[0].tolist())
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,E", [(1, 768), (16, 768), (17, 768), (64, 768), (3, 128), (40, 256)])
-def test_block_tail_in_one_launch_is_bit_identical_to_the_three_launches(M, E):
-    """vmi_gpt2_block_tail_f16 = linear(c_proj, residual) ; linear(ln_2, c_fc, gelu) ; linear(mlp.c_proj, residual) as phases of
-    one launch behind grid barriers: the same bits, call after call on one workspace (it leaves its counters zeroed), plain and
-    packed weights, eager and from a hipGraph."""
-    from vllmini_amd import gpt2_layer as gl
-
-    dev = torch.device("cuda:0")
-    g = torch.Generator(device="cpu").manual_seed(M * 7 + E)
-    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).half().to(dev)   # noqa: E731
-    wp, bp = mk(E, E, sc=0.03), mk(E, sc=0.1)
-    wf, bf = mk(4 * E, E, sc=0.03), mk(4 * E, sc=0.1)
-    w2, b2 = mk(E, 4 * E, sc=0.02), mk(E, sc=0.1)
-    ln2 = ((1 + 0.2 * torch.randn(E, generator=g)).half().to(dev), (0.1 * torch.randn(E, generator=g)).half().to(dev), 1e-5)
-    bar = torch.zeros(4, dtype=torch.int32, device=dev)
-    h = torch.empty(M, 4 * E, dtype=torch.float16, device=dev)
-    for packed in (False, True):
-        W = [gl.pack_weight(w) if packed else w for w in (wp, wf, w2)]
-        for rep in range(3):
-            attn, x0 = mk(M, E), mk(M, E)
-            ref = x0.clone()
-            gl.linear(attn, W[0], bp, residual=ref, out=ref)
-            hh = gl.linear(ref, W[1], bf, ln=ln2, gelu=True)
-            gl.linear(hh, W[2], b2, residual=ref, out=ref)
-            got = x0.clone()
-            gl.block_tail(attn, got, W[0], bp, ln2, W[1], bf, W[2], b2, h, bar)
-            torch.cuda.synchronize()
-            assert torch.equal(got, ref), (M, E, packed, rep, (got.float() - ref.float()).abs().max().item())
-            assert torch.equal(h, hh) and bar.tolist() == [0, 0, 0, 0]
-    # from a graph, replayed
-    attn, x0 = mk(M, E), mk(M, E)
-    ref = x0.clone()
-    gl.linear(attn, wp, bp, residual=ref, out=ref)
-    gl.linear(gl.linear(ref, wf, bf, ln=ln2, gelu=True), w2, b2, residual=ref, out=ref)
-    xg = x0.clone()
-    s = torch.cuda.Stream(dev)
-    s.wait_stream(torch.cuda.current_stream(dev))
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=s):
-        gl.block_tail(attn, xg, wp, bp, ln2, wf, bf, w2, b2, h, bar)
-    for _ in range(2):
-        xg.copy_(x0)
-        graph.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(xg, ref)
-    with pytest.raises(RuntimeError, match="at most 64 rows"):
-        gl.block_tail(mk(65, E), mk(65, E), wp, bp, ln2, wf, bf, w2, b2, torch.empty(65, 4 * E, dtype=torch.float16, device=dev), bar)

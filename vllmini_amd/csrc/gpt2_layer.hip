@@ -140,43 +140,14 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-// Accesses of the fused launches (block_tail_kernel): data one workgroup writes and another reads INSIDE a launch crosses the
-// XCDs' L2s, which are not coherent with one another — such payloads go as agent-scope relaxed atomics (write-through stores,
-// loads that bypass the non-coherent levels; the idiom of pa_split.hpp), 8 bytes at a time.  AG = false: plain accesses.
-template <bool AG>
-__device__ __forceinline__ u32x4 ld16(const h16* ptr) {
-  if constexpr (AG) {
-    const uint64_t* q = reinterpret_cast<const uint64_t*>(ptr);
-    const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return u32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
-  } else {
-    return *reinterpret_cast<const u32x4*>(ptr);
-  }
-}
-template <bool AG>
-__device__ __forceinline__ h16x4 ld8(const h16* ptr) {
-  if constexpr (AG)
-    return __builtin_bit_cast(h16x4, __hip_atomic_load(reinterpret_cast<const uint64_t*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  else
-    return *reinterpret_cast<const h16x4*>(ptr);
-}
-template <bool AG>
-__device__ __forceinline__ void st8(h16* ptr, h16x4 v) {
-  if constexpr (AG)
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(ptr), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else
-    *reinterpret_cast<h16x4*>(ptr) = v;
-}
-
 // Order of the memory requests (they complete in order, so what is needed first is asked for first): the row tile, weight
 // chunk 0, [tile to LDS], weight chunks 1 .. NBUF - 1, [LayerNorm], the ring of chunks.  For K = 768 (NBUF = 2) and for
 // mlp.c_proj's K = 3072 over two waves (NBUF = 4) everything a wave will ever read is in flight before its first MFMA.
-// XG (fused launches): bit 0 = the row tile, bit 1 = the residual, bit 2 = the output cross workgroups inside the launch
-template <int BM, int NW, int KS, int NBUF, bool LN, int EPI, int XG>
-__device__ __forceinline__ void linear_body(const LinearParams& p, const int wg, unsigned char* smem) {
+template <int BM, int NW, int KS, int NBUF, bool LN, int EPI>
+__global__ __launch_bounds__(NW* KS * 64) void linear_kernel(const LinearParams p) {
   constexpr int T = NW * KS * 64, MT = BM / 16, LPR = T / BM;   // LPR lanes share a row of the tile (load, LayerNorm)
   static_assert(LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "a row's lanes lie inside one wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   h16* xs = reinterpret_cast<h16*>(smem);
   const int ldxs = p.K + 8, upr = p.K >> 3;
   h16* gb = xs + (size_t)BM * ldxs;                                      // LN: gamma [K], beta [K]
@@ -184,7 +155,7 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, const int wg,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = wave % NW, ks = wave / NW;
   const int NB = (p.N + 16 * NW - 1) / (16 * NW);
-  const int nb = wg % NB, mb = wg / NB;
+  const int nb = blockIdx.x % NB, mb = blockIdx.x / NB;
   // (the cache epilogue deals a workgroup's waves to slabs N / NW apart, one each of q | q,k | k,v | v: the value cache's
   //  scattered two-byte pieces then leave through every CU's store path, not through the third of the workgroups that would
   //  hold the v columns — the projection with the cache write 18.2 -> see profiles/r05u_e2e_native_layers.md §3b)
@@ -214,7 +185,7 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, const int wg,
   for (int i = 0; i < XU; ++i) {
     const int u = xj + i * LPR;
     xv[i] = u32x4{0u, 0u, 0u, 0u};
-    if (xin && u < upr) xv[i] = ld16<(XG & 1) != 0>(xsrc + u * 8);
+    if (xin && u < upr) xv[i] = *reinterpret_cast<const u32x4*>(xsrc + u * 8);
   }
   // 2. the weight slab of this wave, chunk 0
   // (rows as stored: lane (kc, r) reads 16 bytes of row n0 + r, a k-step is 32 elements on; packed tiles: a k-step of a
@@ -236,7 +207,7 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, const int wg,
     for (int mi = 0; mi < MT; ++mi) {
       const int m = m0 + mi * 16 + r16;
       rr[mi] = h16x4{0, 0, 0, 0};
-      if (nvalid && m < p.M) rr[mi] = ld8<(XG & 2) != 0>(p.res + (int64_t)m * p.ldr + n);
+      if (nvalid && m < p.M) rr[mi] = *reinterpret_cast<const h16x4*>(p.res + (int64_t)m * p.ldr + n);
     }
   }
   // EPI 3: the rows' cache slots too — a load in the epilogue would wait for the stores in front of it (loads and stores share
@@ -259,7 +230,7 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, const int wg,
     }
     for (int ub = XU * LPR; ub < upr; ub += LPR) {
       const int u = ub + xj;
-      if (u < upr) *reinterpret_cast<u32x4*>(xdst + u * 8) = xin ? ld16<(XG & 1) != 0>(xsrc + u * 8) : u32x4{0u, 0u, 0u, 0u};
+      if (u < upr) *reinterpret_cast<u32x4*>(xdst + u * 8) = xin ? *reinterpret_cast<const u32x4*>(xsrc + u * 8) : u32x4{0u, 0u, 0u, 0u};
     }
     // 4. the other chunks of the ring
     if (nvalid) {
@@ -328,17 +299,16 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, const int wg,
         *reinterpret_cast<f32x4*>(red + ((((int64_t)(ks - 1) * NW + nw) * MT + mi) * 64 + lane) * 4) = acc[mi];
     }
     __syncthreads();
-    if (ks == 0) {
+    if (ks > 0) return;
 #pragma unroll
-      for (int s = 1; s < KS; ++s)
+    for (int s = 1; s < KS; ++s)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((((int64_t)(s - 1) * NW + nw) * MT + mi) * 64 + lane) * 4);
-          acc[mi] += o;
-        }
-    }
+      for (int mi = 0; mi < MT; ++mi) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((((int64_t)(s - 1) * NW + nw) * MT + mi) * 64 + lane) * 4);
+        acc[mi] += o;
+      }
   }
-  if (!nvalid || ks != 0) return;   // (no barrier behind this point)
+  if (!nvalid) return;
 
   // D[row = 4 * kc + r -> column n][col = r16 -> row m]
   float bias[4] = {0.f, 0.f, 0.f, 0.f};
@@ -364,7 +334,7 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, const int wg,
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (h16)((float)rr[mi][r] + (float)o[r]);
     }
-    st8<(XG & 4) != 0>(p.y + (int64_t)m * p.ldy + n, o);
+    *reinterpret_cast<h16x4*>(p.y + (int64_t)m * p.ldy + n) = o;
     if constexpr (EPI == VMI_LAYER_EPI_BIAS_KV_CACHE) {
       // reshape_and_cache's copy (cache_kernels.cu:172-199) done by the producer: K[blk, h, d / 8, off, d % 8], V[blk, h, d, off];
       // a slab of 16 columns lies inside one of q | k | v and inside one head (E and head_size are multiples of 16)
@@ -386,64 +356,6 @@ __device__ __forceinline__ void linear_body(const LinearParams& p, const int wg,
           }
         }
       }
-    }
-  }
-}
-
-template <int BM, int NW, int KS, int NBUF, bool LN, int EPI>
-__global__ __launch_bounds__(NW* KS * 64) void linear_kernel(const LinearParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  linear_body<BM, NW, KS, NBUF, LN, EPI, 0>(p, blockIdx.x, smem);
-}
-
-// ---- a block's tail in ONE launch (steps of at most 64 rows) ----------------------------------------------------------------
-// c_proj + residual -> LayerNorm + c_fc + GELU -> mlp.c_proj + residual: three launches whose floors (~3 us each, plus the graph's
-// ~1.2 us between dependent kernels) are most of their time when the step has a row block or four.  Here they are three phases
-// of one launch of at most one workgroup per CU, separated by a barrier over the grid (one counter per barrier in a caller-owned
-// 16-byte workspace: arrive with release, poll with acquire, a bounded spin — a fault ends in wrong numbers, not in a hung
-// device; the last workgroup out zeroes the counters for the next launch).  The phases are the SAME code as the stand-alone
-// kernels (linear_body), so the result is bit-identical to the three launches; what crosses workgroups inside the launch — the
-// hidden state after c_proj, the GELU output — goes through agent-scope accesses (ld16 / ld8 / st8).
-struct TailParams {
-  LinearParams a, b, c;
-  unsigned* bar;
-  int nA, nB, nC;
-};
-
-__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
-  // every payload that crosses workgroups is an agent-scope write-through store, complete (vmcnt) before the workgroup's barrier
-  // lets its thread 0 arrive — so the counter itself needs no release / acquire (each would flush or invalidate an L2 per poll)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
-  }
-  __syncthreads();
-}
-
-template <bool CKS4>   // phase C as the stand-alone pick has it: K over four waves of a 16-column workgroup from K = 1536 on
-__global__ __launch_bounds__(256) void block_tail_kernel(const TailParams tp) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int wg = blockIdx.x;
-  const unsigned G = gridDim.x;
-  if (wg < tp.nA) linear_body<16, 4, 1, 2, false, VMI_LAYER_EPI_BIAS_RESIDUAL, 4>(tp.a, wg, smem);
-  grid_barrier(tp.bar + 0, G);
-  if (wg < tp.nB) linear_body<16, 4, 1, 2, true, VMI_LAYER_EPI_BIAS_GELU, 1 | 4>(tp.b, wg, smem);
-  grid_barrier(tp.bar + 1, G);
-  if (wg < tp.nC) {
-    if constexpr (CKS4)
-      linear_body<16, 1, 4, 2, false, VMI_LAYER_EPI_BIAS_RESIDUAL, 1 | 2>(tp.c, wg, smem);
-    else
-      linear_body<16, 4, 1, 2, false, VMI_LAYER_EPI_BIAS_RESIDUAL, 1 | 2>(tp.c, wg, smem);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(tp.bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == G) {
-      __hip_atomic_store(tp.bar + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(tp.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(tp.bar + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -957,68 +869,6 @@ int vmi_gpt2_sample_top_k_f16(const void* logits, int64_t ld, int32_t num_rows, 
   hipLaunchKernelGGL(sample_top_k_kernel, dim3(num_rows), dim3(SK_T), 0, static_cast<hipStream_t>(stream),
                      static_cast<const h16*>(logits), ld, vocab, top_k, 1.f / temperature, uniform, out);
   return after_launch("vmi_gpt2_sample_top_k_f16", prev, device);
-}
-
-int vmi_gpt2_block_tail_f16(const void* attn_out, int64_t ld_attn, void* x, int64_t ldx, const void* w_proj, const void* b_proj,
-                            const void* ln2_gamma, const void* ln2_beta, float ln_eps, const void* w_fc, const void* b_fc,
-                            const void* w_proj2, const void* b_proj2, void* h_scratch, int64_t ldh, void* barrier_workspace,
-                            int32_t M, int32_t E, int32_t w_layout, int32_t device, void* stream) {
-  using namespace vmi_layer;
-  if (!attn_out || !x || !w_proj || !ln2_gamma || !ln2_beta || !w_fc || !w_proj2 || !h_scratch || !barrier_workspace || M <= 0 ||
-      E <= 0 || w_layout < 0 || w_layout > 1) {
-    g_err = "vmi_gpt2_block_tail_f16: null pointer or non-positive size";
-    return VMI_LAYER_E_ARG;
-  }
-  if (M > 64 || (E & 31) || 4 * E > MAX_K || E > 1536 || (ld_attn & 7) || (ldx & 7) || (ldh & 7) || ((uintptr_t)attn_out & 15) ||
-      ((uintptr_t)x & 15) || ((uintptr_t)h_scratch & 15) || ((uintptr_t)barrier_workspace & 15)) {
-    g_err = "vmi_gpt2_block_tail_f16: at most 64 rows, E % 32 == 0, E <= 1152, 16-byte aligned rows";
-    return VMI_LAYER_E_SHAPE;
-  }
-  int prev = -1;
-  if (int rc = with_device("vmi_gpt2_block_tail_f16", device, &prev)) return rc;
-  int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-  const int mbs = (M + 15) / 16;
-  TailParams tp{};
-  auto lp = [&](const void* xin, int64_t ldxin, const void* w, const void* b, const void* g, const void* be, const void* res,
-                int64_t ldr, void* y, int64_t ldy, int N, int K) {
-    return LinearParams{static_cast<const h16*>(xin), ldxin, static_cast<const h16*>(w), static_cast<const h16*>(b),
-                        static_cast<const h16*>(g), static_cast<const h16*>(be), ln_eps, static_cast<const h16*>(res), ldr,
-                        static_cast<h16*>(y), ldy, M, N, K, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, w_layout};
-  };
-  tp.a = lp(attn_out, ld_attn, w_proj, b_proj, nullptr, nullptr, x, ldx, x, ldx, E, E);
-  tp.b = lp(x, ldx, w_fc, b_fc, ln2_gamma, ln2_beta, nullptr, 0, h_scratch, ldh, 4 * E, E);
-  tp.c = lp(h_scratch, ldh, w_proj2, b_proj2, nullptr, nullptr, x, ldx, x, ldx, E, 4 * E);
-  tp.bar = static_cast<unsigned*>(barrier_workspace);
-  tp.nA = mbs * ((E + 63) / 64);
-  tp.nB = mbs * ((4 * E + 63) / 64);
-  const bool cks4 = 4 * E >= 1536;   // (pick(): few rows x a long K)
-  tp.nC = mbs * (cks4 ? (E + 15) / 16 : (E + 63) / 64);
-  const int grid = tp.nA > tp.nB ? (tp.nA > tp.nC ? tp.nA : tp.nC) : (tp.nB > tp.nC ? tp.nB : tp.nC);
-  const Shape sa{16, 4, 1, 2}, sc = cks4 ? Shape{16, 1, 4, 2} : Shape{16, 4, 1, 2};
-  size_t lds = lds_bytes(sa, E, true);
-  if (lds_bytes(sc, 4 * E, false) > lds) lds = lds_bytes(sc, 4 * E, false);
-  // every workgroup must be on the chip while the others wait for it: one per CU is what the row tile of phase C leaves room for
-  const int per_cu = (int)(LDS_PER_CU / lds) > 0 ? (int)(LDS_PER_CU / lds) : 0;
-  if (per_cu == 0 || grid > cus * (per_cu > 2 ? 2 : per_cu)) {
-    if (prev != device) (void)hipSetDevice(prev);
-    g_err = "vmi_gpt2_block_tail_f16: the launch's workgroups would not all be resident";
-    return VMI_LAYER_E_SHAPE;
-  }
-  if (lds > 64 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(cks4 ? reinterpret_cast<const void*>(block_tail_kernel<true>) : reinterpret_cast<const void*>(block_tail_kernel<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      if (prev != device) (void)hipSetDevice(prev);
-      set_err("hipFuncSetAttribute: ", hipGetErrorString(e));
-      return VMI_LAYER_E_HIP;
-    }
-  }
-  if (cks4)
-    hipLaunchKernelGGL(block_tail_kernel<true>, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), tp);
-  else
-    hipLaunchKernelGGL(block_tail_kernel<false>, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), tp);
-  return after_launch("vmi_gpt2_block_tail_f16", prev, device);
 }
 
 const char* vmi_gpt2_linear_kernel_name(int32_t M, int32_t N, int32_t K, int32_t has_ln, int32_t epilogue) {

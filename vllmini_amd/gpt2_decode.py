@@ -88,7 +88,7 @@ class GPT2PagedDecoder:
 
     def __init__(self, dims: GPT2Dims, state_dict: Dict[str, torch.Tensor], pool: PagedKVPool,
                  reference_off_by_one: bool = False, fused_append: bool = False, native_layers: Optional[bool] = None,
-                 scatter_in_c_attn: Optional[bool] = None, block_tail: bool = False):
+                 scatter_in_c_attn: Optional[bool] = None):
         assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
         assert pool.head_size == dims.head_size
         self.dims, self.sd, self.pool = dims, state_dict, pool
@@ -127,8 +127,6 @@ class GPT2PagedDecoder:
         self.scatter_in_c_attn = scatter_in_c_attn if scatter_in_c_attn is not None or not can_scatter else None
         if not can_scatter:
             self.scatter_in_c_attn = False
-        self.block_tail = block_tail and self.native_layers and E <= 1152
-        self._tail_bar = torch.zeros(4, dtype=torch.int32, device=pool.device) if self.block_tail else None
         self._packed: Dict[str, gpt2_layer.PackedWeight] = {}
         if self.native_layers:
             gpt2_layer.load()
@@ -227,15 +225,7 @@ class GPT2PagedDecoder:
                                        st["seq_lens"], pool.block_size, self.max_seq_len, None,
                                        pool.kv_cache_dtype, pool.kv_scale, 0, 0, 1, 1, 0,
                                        _variant=var)
-            if nat and B <= gpt2_layer.BLOCK_TAIL_MAX_ROWS and self.block_tail:
-                # the three launches below as ONE (phases behind grid barriers, bit-identical): steps of a row block or four are
-                # mostly launch floors — one sequence per step 528 -> see profiles/r05u_e2e_native_layers.md §3e
-                gpt2_layer.block_tail(out.view(B, E), x, pw[p + "attn.c_proj.weight"], sd[p + "attn.c_proj.bias"],
-                                      (sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], d.layer_norm_epsilon),
-                                      pw[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], pw[p + "mlp.c_proj.weight"],
-                                      sd[p + "mlp.c_proj.bias"], torch.empty((B, 4 * E), dtype=x.dtype, device=x.device),
-                                      self._tail_bar)
-            elif nat:    # c_proj + residual; ln_2 + c_fc + GELU; mlp.c_proj + residual (x is updated in place)
+            if nat:      # c_proj + residual; ln_2 + c_fc + GELU; mlp.c_proj + residual (x is updated in place)
                 gpt2_layer.linear(out.view(B, E), pw[p + "attn.c_proj.weight"], sd[p + "attn.c_proj.bias"], residual=x, out=x)
                 h = gpt2_layer.linear(x, pw[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], gelu=True,
                                       ln=(sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], d.layer_norm_epsilon))

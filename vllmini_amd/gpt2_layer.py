@@ -29,8 +29,6 @@ SIGNATURES = {
     "vmi_gpt2_embed_f16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vmi_gpt2_argmax_f16": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "vmi_gpt2_sample_top_k_f16": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i32, ctypes.c_float, _vp, _vp, _i32, _vp]),
-    "vmi_gpt2_block_tail_f16": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _i64,
-                                               _vp, _i32, _i32, _i32, _i32, _vp]),
     "vmi_gpt2_linear_kernel_name": (ctypes.c_char_p, [_i32, _i32, _i32, _i32, _i32]),
     "vmi_gpt2_layer_last_error": (ctypes.c_char_p, []),
     "vmi_gpt2_layer_abi_version": (_i32, []),
@@ -247,37 +245,3 @@ def sample_top_k(logits: torch.Tensor, top_k: int = 50, temperature: float = 1.0
                                          torch.cuda.current_stream(logits.device).cuda_stream))
     return out
 
-
-BLOCK_TAIL_MAX_ROWS = 64
-
-
-def block_tail(attn_out: torch.Tensor, x: torch.Tensor, w_proj, b_proj, ln2: Tuple[torch.Tensor, torch.Tensor, float], w_fc, b_fc,
-               w_proj2, b_proj2, h_scratch: torch.Tensor, barrier_workspace: torch.Tensor) -> torch.Tensor:
-    """A block's tail — c_proj + residual, ln_2 + c_fc + GELU, mlp.c_proj + residual — in ONE launch for steps of at most 64
-    rows (the three linear() launches' phases behind grid barriers; bit-identical to them).  x [M, E] is updated in place;
-    h_scratch [M, 4E] half and barrier_workspace (>= 4 zeroed int32, left zeroed) are the caller's; weights all plain or all
-    pack_weight()ed."""
-    lib = load()
-    packed = isinstance(w_proj, PackedWeight)
-    if isinstance(w_fc, PackedWeight) != packed or isinstance(w_proj2, PackedWeight) != packed:
-        raise RuntimeError("gpt2_layer.block_tail: weights all plain or all packed")
-    ws = [w.tiles if packed else w for w in (w_proj, w_fc, w_proj2)]
-    M, E = x.shape
-    if x.device.type != "cuda":
-        raise RuntimeError("gpt2_layer.block_tail: there is no CPU path")
-    if tuple(w_proj.shape) != (E, E) or tuple(w_fc.shape) != (4 * E, E) or tuple(w_proj2.shape) != (E, 4 * E):
-        raise RuntimeError("gpt2_layer.block_tail: c_proj [E, E], c_fc [4E, E], mlp.c_proj [E, 4E]")
-    for t, shape in ((attn_out, (M, E)), (x, (M, E)), (h_scratch, (M, 4 * E))):
-        if t.dtype != torch.float16 or tuple(t.shape) != shape or t.stride(1) != 1:
-            raise RuntimeError("gpt2_layer.block_tail: attn_out / x [M, E], h_scratch [M, 4E], half, unit stride in the last dim")
-    for t in (*ws, b_proj, b_fc, b_proj2, ln2[0], ln2[1]):
-        if t.dtype != torch.float16 or not t.is_contiguous():
-            raise RuntimeError("gpt2_layer.block_tail: contiguous half weights, biases and LayerNorm parameters")
-    if barrier_workspace.dtype != torch.int32 or barrier_workspace.numel() < 4 or not barrier_workspace.is_contiguous():
-        raise RuntimeError("gpt2_layer.block_tail: barrier_workspace int32 [>= 4], zeroed")
-    _check(lib.vmi_gpt2_block_tail_f16(attn_out.data_ptr(), attn_out.stride(0), x.data_ptr(), x.stride(0), ws[0].data_ptr(),
-                                       b_proj.data_ptr(), ln2[0].data_ptr(), ln2[1].data_ptr(), float(ln2[2]), ws[1].data_ptr(),
-                                       b_fc.data_ptr(), ws[2].data_ptr(), b_proj2.data_ptr(), h_scratch.data_ptr(),
-                                       h_scratch.stride(0), barrier_workspace.data_ptr(), M, E, int(packed), x.device.index or 0,
-                                       torch.cuda.current_stream(x.device).cuda_stream))
-    return x
