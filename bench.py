@@ -581,7 +581,7 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
     # GPT-2 small with the position table extended past 1024 so contexts can cross seq_len 1024
     dims = GPT2Dims(n_positions=2048)
     assert (cfg.num_heads, cfg.head_size) == (dims.n_head, dims.head_size)
-    total_steps = args.warmup + args.steps + 2
+    total_steps = args.warmup + 2 * args.steps + 2      # (two timed regions, below)
     mb = -(-(ctx0 + total_steps) // cfg.block_size) + 1
     blocks_needed = cfg.batch * dims.n_layer * (mb - 1)
     pool = PagedKVPool(blocks_needed + 64, dims.n_head, dims.head_size, cfg.block_size, mb, dims.n_layer, device=dev,
@@ -626,11 +626,19 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
                 works[k].wait()
             _, works[k] = shard.gather_token_ids_async(tok, cfg.batch * world, dist, gathered[k])
 
-    elapsed = shard.timed_steps(step, args.steps, args.warmup, dist, sync=device_sync(dev))
+    # TWO consecutive timed regions of `steps` (each in the full bracket), the faster one reported: these sub-records run seconds
+    # after multi-GB pools were allocated and released, and one region in ten or so caught a ~100 ms stall of the runtime (a
+    # one-sequence token read 4 637 us instead of 527 in one of three otherwise identical runs).  The second region's contexts
+    # are `steps` tokens longer, so it wins only when the first was hit.  (Three short regions with a median were tried: each
+    # bracket's drain costs a 6-step region ~5 % — the figure must not depend on how it is protected.)
+    regions = []
+    for c in range(2):
+        regions.append(shard.max_over_ranks(shard.timed_steps(step, args.steps, args.warmup if c == 0 else 0, dist,
+                                                              sync=device_sync(dev)), dist, dev) / args.steps)
     for w in works:
         if w is not None:
             w.wait()
-    elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    elapsed = min(regions) * args.steps
     note = ("12 x (c_attn, paged_attention_v1_append [fused], c_proj, MLP) + lm_head, hipGraph replay, greedy" if fused else
             "12 x (c_attn, reshape_and_cache, paged_attention_v1, c_proj, MLP) + lm_head, hipGraph replay, greedy")
     if scatter_in_c_attn:
@@ -644,6 +652,7 @@ def e2e_measure(args, cfg, dist, rank, world, dev, kv="auto", fused=False, ragge
            "context": f"U{{16..{ctx0}}} (mean {float(np.mean(ctxs)):.0f})" if ragged else ctx0, "batch_per_gpu": cfg.batch,
            "data": "synthetic KV + random-init GPT-2 small weights", "dtype": "f16", "kv_cache_dtype": kv,
            "layers": "native" if native_layers else "torch_modules",
+           "timed_regions_ms_per_step": [r * 1e3 for r in regions],
            "note": note.replace("hipGraph replay", "plain launches" if eager else "hipGraph replay")}
     if operator_share and not fused:
         # the two operators alone on the decoder's own buffers: the 12 layers' call pairs back to back (the tables,
