@@ -35,7 +35,7 @@ def sample_top_k(logits: torch.Tensor, top_k: int = 50, temperature: float = 1.0
                  generator: Optional[torch.Generator] = None) -> torch.Tensor:
     """Batched form of Scheduler.sample_next_token (scheduler.py:144-153): [B, V] -> [B] int64.  Half logits on a HIP device
     (what the decoder hands over) are drawn by ONE launch of this build's kernel — the same distribution, the uniform numbers
-    from the same torch generator (vllmini_amd/gpt2_layer.py sample_top_k: 127 / 309 us -> ~8 for 1 / 256 rows); anything else
+    from the same torch generator (vllmini_amd/gpt2_layer.py sample_top_k: 127 / 309 us -> 14 for 1 / 256 rows); anything else
     takes the torch chain the reference spells out."""
     if logits.is_cuda and logits.dtype == torch.float16 and logits.dim() == 2 and logits.stride(1) == 1 \
             and logits.shape[1] <= 65536 and top_k <= 64 and (generator is None or generator.device.type == "cuda"):
