@@ -1152,6 +1152,12 @@ def main(argv=None):
         # ... and with the block's linear layers left to the torch modules (rounds 1 - 4's harness), for the comparison
         rest = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, native_layers=False)
         line["e2e_step"]["torch_module_layers"] = {k: rest[k] for k in ("value", "unit", "ms_per_step", "note")}
+        # ... and with the reference's sampling (scheduler.py:144-153: top-k 50, one multinomial draw) in place of the argmax:
+        # one launch of this build against the torch chain (topk, softmax, multinomial, gather)
+        resk = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, sampler="top_k")
+        reskt = e2e_measure(args, e2e_cfg, dist, rank, world, dev, ctx0=args.e2e_context, operator_share=False, sampler="top_k_torch")
+        line["e2e_step"]["top_k_50_sampling"] = {"value": resk["value"], "unit": "tokens/s", "ms_per_step": resk["ms_per_step"],
+                                                 "torch_chain_ms_per_step": reskt["ms_per_step"]}
         line["e2e_step"]["steps"], line["e2e_step"]["warmup"] = args.steps, args.warmup
         if dist is None:
             # the regime the reference's scheduler runs (one sequence per step, scheduler.py:60): a token's latency
