@@ -83,7 +83,7 @@ def build_parser():
     ap.add_argument("--kv-heads", type=int, default=0,
                     help="grouped-query attention: num_kv_heads < num_heads (diagnostic; BASELINE configs are multi-head)")
     ap.add_argument("--seq-len", type=int, default=0, help="override the config's seq_len (diagnostic sweeps)")
-    ap.add_argument("--op", default="v1", choices=["v1", "v2", "fused"],
+    ap.add_argument("--op", default="v1", choices=["v1", "v2", "fused", "newest"],
                     help="attention operator in the step: paged_attention_v1 (headline) or the split-KV paged_attention_v2")
     ap.add_argument("--variant", type=int, default=0, help="force a kernel work decomposition (0 = heuristic)")
     ap.add_argument("--variant-name", default="", help="the same by kernel name (ops.variant_names())")
@@ -275,9 +275,11 @@ def attend(wl, out, t, variant, op="v1"):
     from vllmini_amd import ops
 
     c = wl.cfg
-    if op == "fused":   # reshape_and_cache + paged_attention_v1 in one launch (extension, include/vmi_paged_attention.h)
+    if op in ("fused", "newest"):   # reshape_and_cache + paged_attention_v1 in one launch (extension, include/vmi_paged_attention.h)
+        # ("newest": the same attention — the newest token read from this step's rows — WITHOUT the cache write)
         ops.paged_attention_v1_append(out, wl.query, wl.key, wl.value, wl.key_cache, wl.value_cache, c.kv_heads,
-                                      wl.scale, wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, _variant=variant)
+                                      wl.scale, wl.tables[t], wl.seq_lens, c.block_size, c.seq_len, _variant=variant,
+                                      write_cache=op == "fused")
         return
     if op == "v1":
         ops.paged_attention_v1(out, wl.query, wl.key_cache, wl.value_cache, c.kv_heads, wl.scale,
@@ -302,7 +304,7 @@ def scatter(wl, t, op="v1"):
 
     if NOOP_RESHAPE is not None:
         NOOP_RESHAPE.fill_(1.0)
-    elif op != "fused" and not SKIP_RESHAPE:
+    elif op not in ("fused", "newest") and not SKIP_RESHAPE:
         cache_ops.reshape_and_cache(wl.key, wl.value, wl.key_cache, wl.value_cache,
                                     wl.slots[(t + 1) % len(wl.tables) if RESHAPE_OTHER else t], KV_DTYPE, 1.0)
 

@@ -45,7 +45,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define VMI_ABI_VERSION 21
+#define VMI_ABI_VERSION 22
 
 /* validation codes (positive); HIP runtime errors are returned negated */
 enum {
@@ -281,7 +281,8 @@ int vmi_paged_attention_v1_last_partner(void);
 
 /*
  * 1 when `variant` can serve a launch with this max_seq_len (its logits rows fit the 160 KiB of LDS) and, with
- * for_append != 0, has a fused-append twin; 0 otherwise.  For callers that pick a variant from what they know about
+ * for_append = 1, has a fused-append twin (for_append = 2: a form for vmi_paged_attention_v1_newest_f16, the fused append
+ * without the cache write — the fused-append twins and the balanced kernels' append-read form); 0 otherwise.  For callers that pick a variant from what they know about
  * the batch (the pick functions above take the batch's longest length) but launch with a larger max_seq_len — the
  * capacity of the pool, as the reference's scheduler does (vllmini/scheduler.py:97): an explicit `variant` that does not
  * fit is an error (VMI_E_MAX_SEQ_LEN), variant 0 falls back by itself.
@@ -362,6 +363,37 @@ int vmi_copy_blocks(void* const* key_cache_ptrs, void* const* value_cache_ptrs, 
  */
 int vmi_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_host, int32_t num_pairs,
                     int64_t block_bytes, int32_t kind, int32_t device, void* stream);
+
+/*
+ * paged_attention_v1 over the cache PLUS this step's rows (extension): the arguments and the attention of
+ * vmi_paged_attention_v1_append_f16 — the token at position seq_lens[i]-1 is taken from key / value, whatever the cache
+ * holds in its slot — WITHOUT the cache write.  The caller stores the rows itself, any time before the next token's
+ * attention of the same layer: the 12 layers of a GPT-2 token need ONE vmi_reshape_and_cache_f16 over [layers * num_seqs]
+ * rows (the reference's pool is shared by all layers, vllmini/kv_cache.py:13-14) instead of one per layer in front of each
+ * attention (vllmini/model/gpt2.py:44).  `out` is bit-identical to the call pair's.  Caches are not touched.
+ */
+int vmi_paged_attention_v1_newest_f16(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
+    int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+    int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    int32_t device, void* stream,
+    const void* key, const void* value, int64_t key_stride, int64_t value_stride, int32_t variant);
+
+/*
+ * The pool's preemption move (extension; counterpart of BlockManager.swap_to_cpu / swap_from_cpu,
+ * vllmini/block_manager.py:70-87, which the reference runs as one copy per block, cache_kernels.cu:56-62): ONE launch on
+ * `stream` moves block_mapping[i] = (src block, dst block) of BOTH caches for every i.
+ *   src_key / src_value, dst_key / dst_value   DEVICE-ACCESSIBLE pointers: device memory or pinned (mapped) host memory —
+ *                                              the GPU reads / writes host pages directly, no staging copy
+ *   block_mapping                              device-accessible int64 [num_pairs, 2]
+ *   block_bytes                                bytes of one block of one cache; a multiple of 16
+ * The bytes moved are exactly vmi_swap_blocks' (tests/test_parity_gpu.py); asynchronous, never synchronises.
+ */
+int vmi_swap_blocks_batched(const void* src_key, const void* src_value, void* dst_key, void* dst_value,
+                            const int64_t* block_mapping, int32_t num_pairs, int64_t block_bytes,
+                            int32_t device, void* stream);
 
 /*
  * 0 for the product library, 1 for the diagnostic build (-DVMI_DIAG: adds the entries of vmi_paged_attention_diag.h, the

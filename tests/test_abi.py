@@ -45,7 +45,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in vllmini_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
     typed = _lib.load()
-    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 21
+    assert typed.vmi_abi_version() == _lib.ABI_VERSION == 22
     assert typed.vmi_target_arch() == b"gfx950"
     assert typed.vmi_is_diag_build() == 0 and typed.vmi_has_extras() == 0
 

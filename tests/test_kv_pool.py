@@ -96,9 +96,50 @@ def test_batched_decode_equals_per_sequence_reference_order():
         assert len(owned) == len(set(owned)) and not set(owned) & set(a.free_blocks)
 
 
+def test_swap_out_and_in_keep_the_sequence_and_move_it_to_new_blocks():
+    """BlockManager.swap_to_cpu / swap_from_cpu (block_manager.py:70-87) on the bookkeeping: the blocks return to the free
+    list, the host pool holds as many, and the sequence comes back on OTHER blocks with the same shape of table — the next
+    decode steps then produce the slots an undisturbed twin produces, block ids renamed."""
+    kw = dict(num_blocks=40, num_heads=2, head_size=64, block_size=16, max_blocks_per_seq=6, num_layers=3,
+              device="cpu", allocate_tensors=False)
+    a, twin = PagedKVPool(host_blocks=16, **kw), PagedKVPool(**kw)
+    for p in (a, twin):
+        p.allocate_for_prefill(1, 20)          # 2 blocks per layer
+        p.allocate_for_prefill(2, 5)
+        for _ in range(14):
+            p.decode_step_batch([1, 2])
+    before = a.table(1)
+    n = a.swap_out(1)
+    assert n == 3 * 3 and 1 not in a.allocated_blocks and 1 in a.swapped and len(a._host_free) == 16 - n
+    assert a.blocks_of(1) == n and not a.swap_in(99)                            # :76-77
+    with pytest.raises(ValueError):
+        a.swap_out(1)                                                           # kv_cache.py:50-51
+    a.allocate_for_prefill(3, 16 * 5)                                           # takes 15 of the free blocks
+    a.free_blocks, keep = a.free_blocks[:4], a.free_blocks[4:]
+    assert not a.swap_in(1) and 1 in a.swapped                                  # not enough free blocks: False (:86-87)
+    a.free_blocks += keep
+    assert a.swap_in(1) and 1 not in a.swapped and len(a._host_free) == 16
+    after = a.table(1)
+    assert np.array_equal(after >= 0, before >= 0)            # the same shape of table, other blocks
+    assert a.seq_len(1) == twin.seq_len(1)
+    rename = {int(o): int(nw) for o, nw in zip(before[before >= 0], after[after >= 0])}
+    for _ in range(20):
+        ta, sa, la = a.decode_step_batch([1])
+        tt, st, lt = twin.decode_step_batch([1])
+        assert np.array_equal(la, lt) and np.array_equal(ta >= 0, tt >= 0)
+        # same offsets inside the blocks; blocks known before the swap are the renamed ones
+        assert np.array_equal(sa % 16, st % 16)
+        for l in range(3):
+            if int(st[l, 0] // 16) in rename:
+                assert int(sa[l, 0] // 16) == rename[int(st[l, 0] // 16)]
+    owned = [b for s in a.allocated_blocks for b in a.allocated_blocks[s]]
+    assert len(owned) == len(set(owned)) and not set(owned) & set(a.free_blocks)
+    assert a.swap_stats["blocks_out"] == a.swap_stats["blocks_in"] == n
+
+
 def test_reference_limits_raise():
     pool = PagedKVPool(num_blocks=5, num_heads=2, head_size=64, block_size=16, max_blocks_per_seq=2, num_layers=2,
-                       device="cpu", allocate_tensors=False)
+                       device="cpu", allocate_tensors=False, multi_block_prefill=False)   # (the reference's limit, pinned)
     with pytest.raises(RuntimeError, match="single block per layer"):
         pool.allocate_for_prefill(1, 17)                                   # kv_cache.py:25-35 latent limit
     pool.allocate_for_prefill(1, 16)

@@ -19,9 +19,11 @@ V, EOS = 97, 96
 class FakeDecoder:
     """next-token logits are a pure function of (last token, position): one-hot at (7*tok + pos) % 97."""
 
-    def __init__(self, num_blocks=64, layers=2, max_blocks_per_seq=8):
-        self.pool = PagedKVPool(num_blocks, 2, 64, 16, max_blocks_per_seq, layers, device="cpu", allocate_tensors=False)
+    def __init__(self, num_blocks=64, layers=2, max_blocks_per_seq=8, host_blocks=0):
+        self.pool = PagedKVPool(num_blocks, 2, 64, 16, max_blocks_per_seq, layers, device="cpu", allocate_tensors=False,
+                                host_blocks=host_blocks)
         self.decode_calls = []
+        self.prefill_batches = []
 
     @staticmethod
     def _logits(tok, pos):
@@ -32,6 +34,10 @@ class FakeDecoder:
     def prefill(self, seq_id, ids):
         self.pool.allocate_for_prefill(seq_id, len(ids))
         return self._logits(ids[-1], len(ids) - 1)
+
+    def prefill_batch(self, seq_ids, prompts):
+        self.prefill_batches.append(list(seq_ids))
+        return torch.stack([self.prefill(s, p) for s, p in zip(seq_ids, prompts)])
 
     def decode(self, seq_ids, tokens):
         pos = [self.pool.seq_len(s) for s in seq_ids]
@@ -87,10 +93,59 @@ def test_max_length_and_eos_end_sequences():
     assert not sch.active
 
 
-def test_out_of_blocks_evicts_youngest_other_sequence():
-    # 2 layers, 16-token blocks: each sequence needs 2 blocks at prefill and 2 more at token 17
+def test_out_of_blocks_preempts_youngest_and_resumes_it_with_the_same_tokens():
+    """The pool cannot hold four sequences past 16 tokens: the youngest are swapped out (block_manager.py:70-73), come back
+    oldest first when there is room (:75-87), and EVERY sequence ends with the tokens of an unconstrained run."""
     dec = FakeDecoder(num_blocks=10, layers=2)
     sch = BatchScheduler(dec, max_length=40, eos_token_id=EOS, sampler=sample_greedy)
+    ids = [sch.add_sequence([3 + i] * 15) for i in range(4)]      # 8 blocks used, 2 free
+    sch.run()
+    assert not sch.evicted and sch.stats["preemptions"] >= 2 and sch.stats["resumes"] == sch.stats["preemptions"]
+    assert all(sch.sequences[s] == _expected([3 + s] * 15, 40) for s in ids)
+    assert not sch.active and not sch.swapped and not sch.last_logits and not dec.pool.swapped
+    assert sorted(dec.pool.free_blocks) == list(range(10)) and sorted(dec.pool._host_free) == list(range(dec.pool.host_blocks))
+    st = dec.pool.swap_stats
+    assert st["swap_outs"] == st["swap_ins"] == sch.stats["preemptions"] and st["blocks_out"] == st["blocks_in"] > 0
+    # the youngest went first (scheduler.py:117-130) and a preempted sequence never ran while an older one waited on the host
+    first_victim_gone = next(i for i, c in enumerate(dec.decode_calls) if ids[-1] not in c)
+    assert all(ids[-1] in c for c in dec.decode_calls[:first_victim_gone])
+    assert all(ids[0] in c for c in dec.decode_calls[: 40 - 15])  # the oldest never left
+
+
+def test_full_host_pool_falls_back_to_dropping_like_the_reference():
+    dec = FakeDecoder(num_blocks=10, layers=2, host_blocks=2)       # room for ONE preempted 15-token sequence
+    sch = BatchScheduler(dec, max_length=40, eos_token_id=EOS, sampler=sample_greedy)
+    ids = [sch.add_sequence([3 + i] * 15) for i in range(4)]
+    sch.run()
+    assert sch.stats["preemptions"] >= 1 and sch.evicted and sch.stats["dropped"] == len(sch.evicted)
+    done = [s for s in ids if s not in sch.evicted]
+    assert done and all(sch.sequences[s] == _expected([3 + s] * 15, 40) for s in done)
+    assert sorted(dec.pool.free_blocks) == list(range(10)) and sorted(dec.pool._host_free) == [0, 1]
+
+
+def test_submitted_requests_are_admitted_in_groups_and_refill_the_batch():
+    """submit() queues; step() prefills as many queued prompts as fit — ONE prefill_batch call — and refills the batch as
+    sequences end; per-request max_new_tokens; prompts longer than a block (multi-block prefill is the pool's default)."""
+    dec = FakeDecoder(num_blocks=64, layers=2, max_blocks_per_seq=8)
+    sch = BatchScheduler(dec, max_length=100, eos_token_id=EOS, max_batch=3, sampler=sample_greedy, record_latency=True)
+    prompts = [[5 + i] * (3 + 7 * i) for i in range(7)]             # 3 ... 45 tokens
+    new = [4, 9, 2, 6, 1, 5, 3]
+    ids = [sch.submit(p, max_new_tokens=k) for p, k in zip(prompts, new)]
+    assert not sch.active and len(sch.waiting) == 7
+    sch.run()
+    for sid, p, k in zip(ids, prompts, new):
+        assert sch.sequences[sid] == _expected(p, len(p) + k)[: len(p) + k]
+    assert dec.prefill_batches and dec.prefill_batches[0] == ids[:3]            # the first three together, in arrival order
+    assert max(len(c) for c in dec.decode_calls) == 3 and sch.stats["admitted"] == 7
+    assert sum(len(c) for c in dec.decode_calls) == sum(new) == sch.stats["decode_rows"]
+    assert len(sch.first_token_s) == 7 and sum(len(a) for a in sch.token_latency_s) == sum(new)
+    assert sorted(dec.pool.free_blocks) == list(range(64)) and not sch.pending()
+
+
+def test_out_of_blocks_drop_mode_is_the_reference_behaviour():
+    # 2 layers, 16-token blocks: each sequence needs 2 blocks at prefill and 2 more at token 17
+    dec = FakeDecoder(num_blocks=10, layers=2)
+    sch = BatchScheduler(dec, max_length=40, eos_token_id=EOS, sampler=sample_greedy, preempt="drop")
     ids = [sch.add_sequence([3 + i] * 15) for i in range(4)]      # 8 blocks used, 2 free
     sch.run()
     assert sch.evicted, "pool of 10 blocks cannot hold four sequences past 16 tokens"

@@ -41,6 +41,7 @@ SIGNATURES = {
     "vmi_paged_attention_v1_workspace_reset": (ctypes.c_int, [_c_void_p, _i64, _i32, _c_void_p]),
     "vmi_paged_attention_v1_pick_variant_ws": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "vmi_paged_attention_v1_append_f16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
+    "vmi_paged_attention_v1_newest_f16": (ctypes.c_int, list(_PA_ARGS) + [_c_void_p, _c_void_p, _i64, _i64, _i32]),
     "vmi_paged_attention_v1_fp8": (ctypes.c_int, list(_PA_ARGS) + [_f32, _i32]),
     "vmi_paged_attention_v1_fp8_ws": (ctypes.c_int, list(_PA_ARGS) + [_f32, _c_void_p, _i64, _i32]),
     "vmi_paged_attention_v2_fp8": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p] + list(_PA_ARGS) + [_f32, _i32]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "vmi_paged_attention_v2_variant_name": (ctypes.c_char_p, [_i32]),
     "vmi_copy_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _i32, _c_void_p, _i32, _i64, _i32, _c_void_p]),
     "vmi_swap_blocks": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i32, _i64, _i32, _i32, _c_void_p]),
+    "vmi_swap_blocks_batched": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _i64, _i32, _c_void_p]),
     "vmi_is_diag_build": (ctypes.c_int, []),
     "vmi_has_extras": (ctypes.c_int, []),
     "vmi_reshape_and_cache_f16": (ctypes.c_int, [
@@ -109,7 +111,7 @@ DIAG_SIGNATURES = {
     "vmi_debug_set_split_flags": (ctypes.c_int, [_i32]),
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _lock = threading.Lock()
 _product = None      # libvmi_paged_attention.so

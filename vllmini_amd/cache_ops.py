@@ -19,7 +19,7 @@ import torch
 from . import _lib
 from .ops import _check_device, _raise_native, reshape_and_cache  # noqa: F401
 
-__all__ = ["reshape_and_cache", "reshape_and_cache_flash", "swap_blocks", "copy_blocks", "convert_fp8"]
+__all__ = ["reshape_and_cache", "reshape_and_cache_flash", "swap_blocks", "swap_blocks_batched", "copy_blocks", "convert_fp8"]
 
 
 def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
@@ -85,6 +85,51 @@ def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tenso
     rc = _lib.load().vmi_swap_blocks(src.data_ptr(), dst.data_ptr(), bm.data_ptr(), int(bm.shape[0]), block_bytes,
                                      kind, dev.index if dev.index is not None else torch.cuda.current_device(),
                                      torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        _raise_native(rc)
+    return None
+
+
+def swap_blocks_batched(src_key: torch.Tensor, src_value: torch.Tensor, dst_key: torch.Tensor, dst_value: torch.Tensor,
+                        block_mapping: torch.Tensor) -> None:
+    """dst_key[m[i,1]] = src_key[m[i,0]] and dst_value[m[i,1]] = src_value[m[i,0]] for every row of `block_mapping` in ONE
+    launch on the current stream (include/vmi_paged_attention.h: vmi_swap_blocks_batched) — the pool's preemption move,
+    counterpart of BlockManager.swap_to_cpu / swap_from_cpu (vllmini/block_manager.py:70-87), which the reference runs as one
+    copy per block (cache_kernels.cu:56-62).  Each side is a pair of HIP device tensors or a pair of PINNED host tensors (the
+    GPU addresses those pages directly); block_mapping int64 [n, 2], CPU or device.  The bytes moved are swap_blocks'."""
+    if block_mapping.dim() != 2 or block_mapping.shape[1] != 2 or block_mapping.dtype != torch.int64:
+        raise RuntimeError("block_mapping must be an int64 [num_pairs, 2] tensor")
+    devs = [t.device for t in (src_key, src_value, dst_key, dst_value) if t.is_cuda]
+    if not devs:
+        raise RuntimeError("Invalid device combination")                                 # cache_kernels.cu:39
+    dev = devs[0]
+    for name, t in (("src_key", src_key), ("src_value", src_value), ("dst_key", dst_key), ("dst_value", dst_value)):
+        if t.is_cuda:
+            if t.device != dev:
+                raise RuntimeError("src and dst must be on the same GPU")                # :30-31
+        elif not t.is_pinned():
+            raise RuntimeError(f"swap_blocks_batched: {name} is host memory that is not pinned (the GPU moves the blocks itself)")
+        if not t.is_contiguous():
+            raise RuntimeError(f"swap_blocks_batched: {name} must be contiguous")
+    if src_key.is_cuda != src_value.is_cuda or dst_key.is_cuda != dst_value.is_cuda:
+        raise RuntimeError("swap_blocks_batched: the key and value cache of a side must live in the same memory")
+    block_bytes = src_key.element_size() * src_key[0].numel()
+    for t in (src_value, dst_key, dst_value):
+        if t.element_size() * t[0].numel() != block_bytes:
+            raise RuntimeError("swap_blocks_batched: all four caches must have the same block size in bytes")
+    n = int(block_mapping.shape[0])
+    if n == 0:
+        return None
+    bm_host = block_mapping if not block_mapping.is_cuda else None
+    if bm_host is not None:
+        if int(bm_host[:, 0].max()) >= min(src_key.shape[0], src_value.shape[0]) or \
+                int(bm_host[:, 1].max()) >= min(dst_key.shape[0], dst_value.shape[0]) or int(bm_host.min()) < 0:
+            raise RuntimeError("swap_blocks_batched: block number out of range")
+    bm = block_mapping.contiguous().to(dev)
+    rc = _lib.load().vmi_swap_blocks_batched(src_key.data_ptr(), src_value.data_ptr(), dst_key.data_ptr(), dst_value.data_ptr(),
+                                             bm.data_ptr(), n, block_bytes,
+                                             dev.index if dev.index is not None else torch.cuda.current_device(),
+                                             torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         _raise_native(rc)
     return None

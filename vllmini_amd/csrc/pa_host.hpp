@@ -46,7 +46,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache, const void
                  int32_t device, void* stream, int32_t variant, bool bf = false, bool append = false,
                  const void* key = nullptr, const void* value = nullptr, int64_t key_stride = 0, int64_t value_stride = 0,
                  int f8 = 0, float kv_scale = 1.0f, const int32_t* bsp = nullptr, void* workspace = nullptr,
-                 int64_t workspace_bytes = 0);
+                 int64_t workspace_bytes = 0, bool append_no_write = false);
 int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* query, const void* key_cache,
                  const void* value_cache, int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
                  float scale, const int32_t* block_tables, const int32_t* seq_lens, int32_t block_size,

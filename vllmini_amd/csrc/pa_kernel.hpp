@@ -353,6 +353,9 @@ struct PAParams {
   // q_flags = test / experiment knobs, 0 = automatic
   int32_t num_seqs;
   int32_t q_flags;
+  // fused append: bit 0 = do NOT store the rows (vmi_paged_attention_v1_newest_*: the attention takes the newest token from
+  // key / value, the caller writes the cache itself — e.g. one reshape_and_cache for all the layers of a token)
+  int32_t app_flags;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -1302,12 +1305,12 @@ __global__ void __launch_bounds__(HPW* WPH * 64, (UMAX > 0 && WPH == 1) ? 3 : 1)
   // acknowledgement); a writer wave per workgroup +18 us and writer workgroups +10 us (writes into the middle of
   // the read stream); here +5 us (pieces) / +3 us (whole tiles, non-temporal).
   if constexpr (APP_TILE) {
-    if (own_last) {
+    if (own_last && !(p.app_flags & 1)) {
       store_tile(const_cast<h16*>(p.kc), klast);
       store_tile(const_cast<h16*>(p.vc), vlast);
     }
   } else if constexpr (APP) {
-    if (sub == 0 && lbA < p.max_blocks_per_seq) {
+    if (sub == 0 && lbA < p.max_blocks_per_seq && !(p.app_flags & 1)) {
       const int64_t phys = bt[lbA];
 #pragma unroll
       for (int hh = 0; hh < HPT; ++hh) {
@@ -1421,6 +1424,7 @@ struct Variant {
   int XW;            // split kernels (pa_split.hpp): waves per (sequence, head), spread over XW / WPH workgroups that meet in a
                      //   caller-owned workspace; 0 = not a split kernel.  fn is a pa_split_kernel_t there
   pa_kernel_t fn_rounds;  // split kernels: the same kernel serving more items than are resident in rounds (nullptr: none)
+  pa_kernel_t fn_app;     // balanced kernels: the append-read form of the same kernel (pa_queue.hpp APP; nullptr: none)
 };
 
 typedef void (*pa_reduce_t)(h16*, const float*, const float*, const h16*, const int32_t*, int);

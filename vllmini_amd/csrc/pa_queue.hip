@@ -6,6 +6,10 @@ namespace vmi {
 
 #define VMI_ROW_Q(NAME, D, BF, US, UQ, UT)                                                                        \
   {NAME, D, 16, 4, 1, US, true, 1, BF, (pa_kernel_t)pa_q_kernel<D, BF, true, US, UQ, 0, false, UT>, 0, 0, 0, 0, false, false, false, true},
+// ... with its append-read form (vmi_paged_attention_v1_newest_f16 on a full chip: pa_queue.hpp APP)
+#define VMI_ROW_QA(NAME, D, BF, US, UQ, UT)                                                                       \
+  {NAME, D, 16, 4, 1, US, true, 1, BF, (pa_kernel_t)pa_q_kernel<D, BF, true, US, UQ, 0, false, UT>, 0, 0, 0, 0, false, false, false, true, \
+   false, false, 0, nullptr, (pa_kernel_t)pa_q_kernel<D, BF, true, US, UQ, 0, false, UT, true>},
 #define VMI_ROW_Q8(NAME, D, US, UQ, F8, UT) /* fp8 pages (1 = E4M3, 2 = E5M2), float16 query, kv_scale 1 */        \
   {NAME, D, 16, 4, 1, US, true, 1, false, (pa_kernel_t)pa_q_kernel<D, false, true, US, UQ, F8, false, UT>, 0, 0, 0, F8, false, false, false, true},
 #define VMI_ROW_Q8M(NAME, D, US, UQ, F8, UT) /* ... with q.K^T of the K pass on the matrix cores (pa_queue.hpp, KM) */ \
@@ -17,7 +21,7 @@ namespace vmi {
 //  profiles/r03c_heavy_tailed_batches.md)
 Variant g_queue_variants[] = {
     // head size 64: one block per group when every item has its own wave, two when workers run items in turn
-    VMI_ROW_Q("q_d64_s1q2", 64, false, 1, 2, 2)
+    VMI_ROW_QA("q_d64_s1q2", 64, false, 1, 2, 2)
 #ifdef VMI_EXTRAS   // (bfloat16 / E5M2 rows: libvmi_paged_attention_extras.so only — this unit is compiled once for each library)
     VMI_ROW_Q("bf16_q_d64_s1q2", 64, true, 1, 2, 2)
 #endif

@@ -90,7 +90,7 @@ constexpr int QF_NOSTATS = 1 << 14;  // experiment: do not read the lengths at a
 #ifdef VMI_DIAG
 extern __device__ uint64_t* g_wave_timeline;  // [gridDim.x * 4][4]: start, end (100 MHz ticks), HW_ID, XCC_ID; nullptr = off
 #endif
-template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1>
+template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1, bool APP = false>
 // (second launch bound = minimum waves per SIMD: 3 workgroups of 4 waves per CU must all be resident in mode S, i.e.
 //  <= 168 VGPRs; head size 128 — twice the registers per block — runs 2 workgroups per CU, 256 VGPRs)
 #ifdef VMI_DIAG
@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
   static_assert((D * BS / EPU) % 64 == 0 && NL >= 1, "a tile must fill whole 1-KiB loads");
   static_assert(!(F8 && BF), "fp8 pages: float16 query only in these kernels");
   static_assert(!(KM && BF), "KM is built for float16 operands");
+  static_assert(!(APP && (F8 || KM)), "the fused append is built for 16-bit pages");
   constexpr int UPR = BS / EPU;  // V: 16-B units per dim row
   constexpr int RPL = 64 / UPR;  // V: rows per load
   constexpr int QW = F8 ? 2 : 1;  // 16-byte pieces of q facing one K unit
@@ -159,6 +160,20 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     const int s0 = nat_ok ? w_nat / H : 0;
     meta_issue(cur, s0, nat_ok ? w_nat - s0 * H : 0, 1, 0);
   }
+  // ---- APP ("append-read": vmi_paged_attention_v1_newest_f16 on a full chip).  The attention takes the token at position
+  //      L-1 from this step's key / value rows (PAParams key / value) instead of the cache: an item's K tile of block
+  //      (L-1)/16 is loaded with the lanes of token (L-1)%16 pointed at the key row (no register, no extra request), its V
+  //      tile gets the token's element of each dim row patched in before the first V product.  Whatever the page holds in
+  //      that slot — old bytes, or the row if it was stored already — is never used, so `out` is bit-identical to
+  //      reshape_and_cache + paged_attention_v1 and the cache write is free to happen LATER: the caller stores a token's
+  //      rows of ALL layers with one reshape_and_cache (GPT2PagedDecoder(deferred_scatter=True)).  The patch costs
+  //      nothing: cfg3 120.7 us with it, 121.3 without (profiles/r06_append_read.md).
+  //      The WRITE was tried inside this kernel and is not built: stores at the START of the launch (requested with the
+  //      first metadata, issued behind the first page request) +20 us — 73 728 partial lines leave L2 into the middle of
+  //      the read stream; as each wave's LAST act +7 us on equal lengths and +9 on ragged ones — more than the stand-alone
+  //      reshape_and_cache launch costs in front of the attention (6.1 us); on a second stream beside the attention the
+  //      pair runs 140 us instead of 127 (cross-stream dependencies: scripts/overlap_scatter_probe.py).  The writing
+  //      entry (vmi_paged_attention_v1_append_f16) therefore stays with pa_v1_kernel's whole-tile stores (+3 us). ----
   const int flags = p.q_flags;
   // ... and so is the item that would be this wave's FIRST as a solo worker of mode Q: item <worker index>, in INDEX order
   // (see "first round" below) — two waves per workgroup ask for a table slice and a q they may not need.
@@ -343,9 +358,21 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
     f32x2_t qf[(F8 && !KM) ? NL : 1][8];  // fp8 pages: q as fp32 pairs (v_pk_fma_f32 against the decoded bytes)
     float slope = 0.f;
     uint16_t* outp = nullptr;
+    // APP: where the item's newest token lives (block lbA, offset offA; lbA = -1: nowhere) and the rows it comes from
+    int lbA = -1, offA = 0, aseq = 0, akvh = 0;
+    uint32_t vnew[APP ? NL : 1];
+    auto key_row_of = [&](int seq_, int kvh_) -> const char* {  // this lane's 16-B chunk of load 0 (load i: + 64 * i bytes)
+      return reinterpret_cast<const char*>(p.key + (int64_t)seq_ * p.key_stride + (int64_t)kvh_ * D) + c4 * 16;
+    };
 
     auto adopt = [&](const Meta& m) {  // make m the current item
       L = __builtin_amdgcn_readfirstlane(m.L);
+      if constexpr (APP) {
+        lbA = L >= 1 ? (L - 1) / BS : -1;  // (of the FULL length: a truncated item never meets its newest token)
+        offA = L >= 1 ? (L - 1) % BS : 0;
+        aseq = m.seq;
+        akvh = m.head / qpk;
+      }
       L = L > p.lpad ? p.lpad : L;  // seq_len > max_seq_len: truncated to the LDS that was reserved
       nblk = (L + BS - 1) / BS;
       nmy = nblk > sub ? (nblk - sub + T - 1) / T : 0;
@@ -383,8 +410,9 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       }
     };
     static_assert(64 % UU == 0, "a register group must not straddle two table slices");
-    auto load_group = [&](u32x4(&r)[UU][NL], const h16* cache_, int g) {
-      const char* cache = reinterpret_cast<const char*>(cache_);
+    auto load_group = [&](u32x4(&r)[UU][NL], auto ktag, int g) {  // ktag: std::true_type = the K cache, false_type = V
+      constexpr bool ISK = decltype(ktag)::value;
+      const char* cache = reinterpret_cast<const char*>(ISK ? p.kc : p.vc);
       table_for(g);
 #pragma unroll
       for (int j = 0; j < UU; ++j) {
@@ -392,10 +420,20 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
         idx = idx < nmy ? idx : nmy - 1;  // padding slots re-read my last block (never out of bounds)
         const int64_t phys = __builtin_amdgcn_readlane(bt_reg, idx & 63);
         const char* blk = cache + phys * p.kv_block_stride * ES + hoff;
+        if constexpr (APP && ISK) {
+          if (sub + idx * T == lbA) {  // wave-uniform: the block of the newest token — its lanes read the key row
+            const char* kr = key_row_of(aseq, akvh);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(tk == offA ? kr + i * 64 : blk + i * 1024);
+            continue;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < NL; ++i) r[j][i] = ld16<NT>(blk + i * 1024);
       }
     };
+    constexpr std::true_type KC{};
+    constexpr std::false_type VC{};
 
     float qk_max;
     auto compute_k = [&](u32x4(&r)[UU][NL], int g) {
@@ -450,6 +488,19 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
           const int b = sub + idx * T;
           const int token0 = b * BS + hf * EPU;
           const bool last = (b == nblk - 1);
+          if constexpr (APP && MASK) {  // the newest token lives in the sequence's last block: final group only
+            if (b == lbA && hf == (offA >> 3)) {
+              const int e = offA & 7;
+#pragma unroll
+              for (int i = 0; i < NL; ++i)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                  const uint32_t old = r[j][i][w];
+                  const uint32_t patched = (e & 1) ? ((old & 0x0000ffffu) | (vnew[i] << 16)) : ((old & 0xffff0000u) | vnew[i]);
+                  r[j][i][w] = ((e >> 1) == w) ? patched : old;
+                }
+            }
+          }
           PV8<BF> pv;
           pv.load(*reinterpret_cast<const u32x4_alias*>(pr + token0));
           if constexpr (F8) {  // a unit is 16 tokens: two 8-token groups, each with its own probability vector
@@ -479,11 +530,21 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       const int nmy2 = nb2 > sub ? (nb2 - sub + T - 1) / T : 0;
       if (nmy2 <= 0) return;
       const int64_t hoff2 = ((int64_t)(m.head / qpk) * p.kv_head_stride + lane * EPU) * ES;
+      const int lf2 = __builtin_amdgcn_readfirstlane(m.L);
+      const int lbA2 = (APP && lf2 >= 1) ? (lf2 - 1) / BS : -1, offA2 = (lf2 - 1) & (BS - 1);
 #pragma unroll
       for (int j = 0; j < UU; ++j) {
         const int idx = j < nmy2 ? j : nmy2 - 1;
         const int64_t phys = __builtin_amdgcn_readlane(m.bt, idx);
         const char* blk = reinterpret_cast<const char*>(p.kc) + phys * p.kv_block_stride * ES + hoff2;
+        if constexpr (APP) {
+          if (sub + idx * T == lbA2) {
+            const char* kr = key_row_of(m.seq, m.head / qpk);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) rn[j][i] = ld16<NT>(tk == offA2 ? kr + i * 64 : blk + i * 1024);
+            continue;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < NL; ++i) rn[j][i] = ld16<NT>(blk + i * 1024);
       }
@@ -491,7 +552,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
 
     // ---- first item: its metadata was requested above ----
     adopt(first);
-    if (nmy > 0) load_group(rn, p.kc, 0);
+    if (nmy > 0) load_group(rn, KC, 0);
     int round = 0;  // items this worker has finished
 
     for (;;) {
@@ -513,7 +574,7 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
         if (!has_next) break;
         if constexpr (QMODE) {
           adopt(nxt);
-          if (nmy > 0) load_group(rn, p.kc, 0);
+          if (nmy > 0) load_group(rn, KC, 0);
           ++round;
         }
         continue;
@@ -528,36 +589,43 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
       // =========================== K pass: logits -> LDS, running max ========================
       // group 0 is in rn (requested during the previous item); the rest ping-pongs between ra and rb
       if (ngroups == 1) {
-        load_group(ra, p.vc, 0);  // one group in all: K and V cost one round trip between them
+        load_group(ra, VC, 0);  // one group in all: K and V cost one round trip between them
         compute_k(rn, 0);
       } else if (ngroups > 1) {
         // The V pass starts BEFORE the K pass ends: its first group (the LAST one: the block reshape_and_cache has just
         // written is requested early, profiles/r01o_call_pair_gap.md) goes into rn — free since group 0 was consumed —
         // ahead of the final K computation, the second one right behind it, so two groups stay in flight across the
         // K -> V change and the softmax instead of the queue running empty there.
-        load_group(ra, p.kc, 1);
+        load_group(ra, KC, 1);
         compute_k(rn, 0);
         // (written out as a two-step loop plus its two possible tails: folding the tails into the loop with
         //  conditional loads was tried for code size and made the register allocator spill 600 bytes per lane)
         int g = 1;
         for (; g + 2 < ngroups; g += 2) {
-          load_group(rb, p.kc, g + 1);
+          load_group(rb, KC, g + 1);
           compute_k(ra, g);
-          load_group(ra, p.kc, g + 2);
+          load_group(ra, KC, g + 2);
           compute_k(rb, g + 1);
         }
         if (g + 2 == ngroups) {
-          load_group(rb, p.kc, g + 1);
+          load_group(rb, KC, g + 1);
           compute_k(ra, g);
-          load_group(rn, p.vc, lastg);
+          load_group(rn, VC, lastg);
           compute_k(rb, g + 1);
         } else {
-          load_group(rn, p.vc, lastg);
+          load_group(rn, VC, lastg);
           compute_k(ra, g);
         }
-        load_group(ra, p.vc, lastg - 1);
+        load_group(ra, VC, lastg - 1);
       }
       fetch_next();  // the next item's table slice, length and q are requested
+      if constexpr (APP) {  // ... and the newest token's V elements of my dim rows, by the wave that owns its block
+        if (lbA >= 0 && lbA < nblk && (lbA % T) == sub) {
+          const h16* vr = p.value + (int64_t)aseq * p.value_stride + (int64_t)akvh * D;
+#pragma unroll
+          for (int i = 0; i < NL; ++i) vnew[i] = (uint32_t)__builtin_bit_cast(uint16_t, vr[RPL * i + rowl]);
+        }
+      }
 
       // =========================== softmax over the logits in LDS ============================
       float inv_sum;
@@ -621,13 +689,13 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
         if constexpr (QMODE) prefetch_next(nxt, has_next);
         int s = 1;  // step s = group lastg - s; odd steps in ra, even steps in rb
         for (; s + 2 < ngroups; s += 2) {
-          load_group(rb, p.vc, lastg - (s + 1));
+          load_group(rb, VC, lastg - (s + 1));
           compute_v(std::false_type{}, ra, lastg - s);
-          load_group(ra, p.vc, lastg - (s + 2));
+          load_group(ra, VC, lastg - (s + 2));
           compute_v(std::false_type{}, rb, lastg - (s + 1));
         }
         if (s + 2 == ngroups) {
-          load_group(rb, p.vc, lastg - (s + 1));
+          load_group(rb, VC, lastg - (s + 1));
           compute_v(std::false_type{}, ra, lastg - s);
           compute_v(std::false_type{}, rb, lastg - (s + 1));
         } else {
@@ -798,10 +866,10 @@ __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ?
 #ifdef VMI_DIAG
 // The diagnostic flavour of the kernel: the same body, bracketed by two reads of the constant 100 MHz clock, one record per
 // wave (vmi_diag_set_wave_timeline).  A wave that retires early in mode Q records when it left.
-template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1>
+template <int D, bool BF, bool NT, int US, int UQ, int F8 = 0, bool KM = false, int UT = 1, bool APP = false>
 __global__ void __launch_bounds__(256, (US >= 4 || (UQ >= 4 && !F8) || D > 64) ? 2 : 3) pa_q_kernel(const PAParams p) {
   const uint64_t t0 = wall_clock64();
-  pa_q_body<D, BF, NT, US, UQ, F8, KM, UT>(p);
+  pa_q_body<D, BF, NT, US, UQ, F8, KM, UT, APP>(p);
   uint64_t* tl = g_wave_timeline;
   if (tl && (threadIdx.x & 63) == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the wave's stores have left

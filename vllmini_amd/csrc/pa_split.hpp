@@ -119,6 +119,10 @@ __global__ void __launch_bounds__(256, split_wgs_per_cu(D, HPT, ROUNDS)) pa_spli
   // alternating by round (see the loop at the end).
   const int total = items * G;
   constexpr bool looped = ROUNDS;   // (a kernel of its own: the loop costs the one-round kernels registers)
+  // A poll that gives up (SPLIT_SPIN_LIMIT: co-residency violated — another kernel holds the CUs, two split launches share a
+  // workspace, dispatch out of order) must not pass unnoticed: besides the count in status[0] the item's softmax sum becomes
+  // NaN, so every output element of the item is NaN (the launch used to finish with plausible wrong numbers).
+  bool poisoned = false;
   auto process = [&](int vb, int wsi) {
   int item, g;
   if (sp.flags & SPF_GMAJOR) {
@@ -365,8 +369,9 @@ __global__ void __launch_bounds__(256, split_wgs_per_cu(D, HPT, ROUNDS)) pa_spli
             ok = ok && (x[hh][q] >> 32) != 0ull;
           }
         if (__all(ok)) break;
-        if (spins >= SPLIT_SPIN_LIMIT) {  // never on a healthy launch; finish with wrong numbers rather than hang the device
+        if (spins >= SPLIT_SPIN_LIMIT) {  // never on a healthy launch; finish — with NaN outputs — rather than hang the device
           if (lane == 0) atomicAdd(sp.status, 1u);
+          poisoned = true;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -387,6 +392,10 @@ __global__ void __launch_bounds__(256, split_wgs_per_cu(D, HPT, ROUNDS)) pa_spli
         for (int q = 0; q < SPL; ++q) sloc += sj[q] * __expf(mj[q] - M[hh]);
         S[hh] = wave_sum(sloc);  // the same values in the same lanes in every wave of the item: one S for all
       }
+    }
+    if (poisoned) {
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) S[hh] = __builtin_nanf("");
     }
     VMI_SSTAMP(5);
 
@@ -580,6 +589,7 @@ __global__ void __launch_bounds__(256, split_wgs_per_cu(D, HPT, ROUNDS)) pa_spli
         while (__hip_atomic_load(done + (round & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G * (round >> 1)) {
           if (++spins >= SPLIT_SPIN_LIMIT) {
             if (lane == 0) atomicAdd(sp.status, 1u);
+            poisoned = true;   // (this round's item, and every later one of this workgroup, comes out as NaN)
             break;
           }
           __builtin_amdgcn_s_sleep(1);

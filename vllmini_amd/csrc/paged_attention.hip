@@ -284,6 +284,34 @@ __global__ void __launch_bounds__(256)
   for (int64_t i = threadIdx.x; i < n16; i += 256) vd[i] = vs[i];  // :87-91
 }
 
+// ----------------------------------------------------------------------------------------
+// swap_blocks, batched: the pool's preemption move (reference BlockManager.swap_to_cpu / swap_from_cpu,
+// vllmini/block_manager.py:70-87, over cache_kernels.cu:24-63's one memcpy per block).  A preempted sequence of
+// 1 000 tokens owns 12 x 63 blocks in each cache: 1 512 memcpys of 24 KiB (~6 ms of host calls for 36 MB).  Here ONE
+// launch moves every pair of BOTH caches; either side may be pinned host memory, which the GPU addresses directly
+// (the stores / loads cross PCIe as full 64-lane x 16-B bursts), so the host's cost is one launch whatever the length.
+// grid = (pairs, 2): y = 0 the K cache, 1 the V cache; 256 threads, 16-B moves.
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    swap_blocks_kernel(const uint8_t* __restrict__ src_k, const uint8_t* __restrict__ src_v, uint8_t* __restrict__ dst_k,
+                       uint8_t* __restrict__ dst_v, const int64_t* __restrict__ block_mapping, int64_t block_bytes) {
+  const int64_t pair = blockIdx.x;
+  const int64_t so = block_mapping[2 * pair] * block_bytes;
+  const int64_t doff = block_mapping[2 * pair + 1] * block_bytes;
+  const u32x4* s = reinterpret_cast<const u32x4*>((blockIdx.y ? src_v : src_k) + so);
+  u32x4* d = reinterpret_cast<u32x4*>((blockIdx.y ? dst_v : dst_k) + doff);
+  const int64_t n16 = block_bytes >> 4;
+  int64_t i = threadIdx.x;
+  for (; i + 768 < n16; i += 1024) {  // four requests in flight per lane: a PCIe round trip is microseconds
+    const u32x4 a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
+    d[i] = a;
+    d[i + 256] = b;
+    d[i + 512] = c;
+    d[i + 768] = e;
+  }
+  for (; i < n16; i += 256) d[i] = s[i];
+}
+
 #ifdef VMI_DIAG   // the diagnostic library only (build.py --diag): not in the product .so
 // ----------------------------------------------------------------------------------------
 // diagnostics (not part of the reference surface): what read bandwidth does this box give a
@@ -1000,6 +1028,19 @@ static Variant* app_variant_v1(int id) {
     return &g_app_bf16_variants[id - 1 - g_ncore - g_extra_nvariants_v1];
   return nullptr;  // fp8-cache variants have no fused-append twin
 }
+// ... or, for the append-read entry (no cache write), a balanced kernel's APP form (pa_queue.hpp): launched through fn_app
+static Variant* app_read_variant_v1(int id) {
+  if (Variant* v = app_variant_v1(id)) return v;
+  if (id >= 1 && id <= nvariants_v1() && variant_v1(id).QUEUE && variant_v1(id).fn_app) return &variant_v1(id);
+  return nullptr;
+}
+// is there a balanced kernel with a fused-append form for this head size?
+static bool balanced_append_built(int head_size, bool bf) {
+  for (int i = 0; i < g_queue_nvariants; ++i)
+    if (g_queue_variants[i].fn_app && g_queue_variants[i].D == head_size && g_queue_variants[i].BF == bf && !g_queue_variants[i].F8)
+      return true;
+  return false;
+}
 
 // ---- block-sparse attention (blocksparse_vert_stride > 1): kernels of their own (pa_variants_sparse*.hip) ----
 // bsp = {tp_rank, local_blocks, vert_stride, blocksparse_block_size, head_sliding_step}
@@ -1044,7 +1085,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
                         int64_t kv_head_stride, int32_t device, void* stream, int32_t variant,
                         bool bf, bool append, const void* key, const void* value, int64_t key_stride,
                         int64_t value_stride, int f8, float kv_scale, const int32_t* bsp, void* workspace,
-                        int64_t workspace_bytes) {
+                        int64_t workspace_bytes, bool append_no_write) {
   // (an EMPTY batch — num_seqs == 0: the per-sequence tensors have no storage, torch hands out null data pointers — is
   //  a no-op below, not an error; the caches must exist either way)
   if (!key_cache || !value_cache || (num_seqs != 0 && (!out || !query || !block_tables || !seq_lens)))
@@ -1099,10 +1140,11 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   } else if (variant == 0) {
     picked = true;
     variant = pick_variant_gqa(num_seqs, num_heads, num_heads / num_kv_heads, head_size, block_size, max_seq_len, bf, f8);
-    if (!variant || (append && !app_variant_v1(variant)))
+    if (!variant || (append && !(append_no_write ? app_read_variant_v1(variant) : app_variant_v1(variant))))
       variant = f8 ? pick_variant_fp8(num_seqs, num_heads, head_size, block_size, max_seq_len, 0, bf, f8,
                                       kv_scale == 1.0f && !append)
-                   : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, 0, !append);
+                   : pick_variant(num_seqs, num_heads, head_size, block_size, max_seq_len, bf, 0,
+                                  !append || (append_no_write && balanced_append_built(head_size, bf)));
     variant = fit_lds(variant, head_size, block_size, lpad, bf, f8);
   }
   const bool have_ws = workspace != nullptr && aligned16(workspace) &&
@@ -1113,7 +1155,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   }
   if (!sparse_v && (variant < 1 || variant > nvariants_v1()))
     return fail(VMI_E_VARIANT, "paged_attention_v1: unknown variant %d", variant);
-  Variant* vp = sparse_v ? sparse_v : (append ? app_variant_v1(variant) : &variant_v1(variant));
+  Variant* vp = sparse_v ? sparse_v : (append ? (append_no_write ? app_read_variant_v1(variant) : app_variant_v1(variant)) : &variant_v1(variant));
   if (!vp) return fail(VMI_E_VARIANT, "paged_attention_v1_append: variant %d (%s) has no fused-append twin", variant,
                        variant_v1(variant).name);
   Variant& v = *vp;
@@ -1137,9 +1179,10 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   if (v.STAGE && (append || bsp || (f8 && kv_scale != 1.0f)))
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (LDS-staging experiment) takes fp16 pages or fp8 E4M3 "
                 "pages with kv_scale 1, without the fused append or block-sparse attention", v.name);
-  if (v.QUEUE && (append || bsp || (f8 && kv_scale != 1.0f)))
+  if (v.QUEUE && ((append && !(v.fn_app && append_no_write)) || bsp || (f8 && kv_scale != 1.0f)))
     return fail(VMI_E_VARIANT, "paged_attention_v1: variant %s (balanced kernel) takes fp16 / bf16 pages, or fp8 pages "
-                "with kv_scale 1, without the fused append or block-sparse attention", v.name);
+                "with kv_scale 1, without block-sparse attention%s", v.name,
+                append ? "; of the fused append it has the append-read form only (vmi_paged_attention_v1_newest_f16)" : "");
   if (v.QUEUE && (int64_t)num_seqs * num_heads > 0x7fffffff)
     return fail(VMI_E_SHAPE, "paged_attention_v1: num_seqs * num_heads = %lld items exceed 2^31",
                 (long long)num_seqs * num_heads);
@@ -1215,6 +1258,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   fill_sparse(p, bsp);
   p.num_seqs = num_seqs;
   p.q_flags = 0;
+  p.app_flags = (append && append_no_write) ? 1 : 0;
   g_last_variant = sparse_v ? 0 : variant;
   g_last_partner = 0;
 
@@ -1223,7 +1267,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
   auto launch_balanced = [&](Variant& q, int gate) -> int {
     const size_t qlds = variant_lds_bytes(q, lpad);
     if (qlds > 48 * 1024) {
-      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(q.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(append ? q.fn_app : q.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
       if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
     const int cus = device_cus(device);
@@ -1232,7 +1276,7 @@ int launch_pa_v1(void* out, const void* query, const void* key_cache,
     const int64_t items = (int64_t)num_seqs * num_heads;
     int64_t g = (int64_t)cus * per_cu;
     if (g * 4 > items) g = (items + 3) / 4;
-    pa_kernel_t fn = q.fn;
+    pa_kernel_t fn = append ? q.fn_app : q.fn;
     PAParams pq = p;
     pq.q_flags = g_queue_flags | gate;
     hipLaunchKernelGGL(fn, dim3((unsigned)g), dim3(256), qlds, static_cast<hipStream_t>(stream), pq);
@@ -1507,6 +1551,7 @@ int launch_pa_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out, c
   p.value_stride = 0;
   p.num_seqs = num_seqs;
   p.q_flags = 0;
+  p.app_flags = 0;
   p.kv_scale = kv_scale;
   fill_sparse(p, bsp);
   dim3 grid((num_heads + v.HPW * v.HPT - 1) / (v.HPW * v.HPT), num_seqs, parts);  // :890
@@ -1664,6 +1709,21 @@ int vmi_paged_attention_v1_append_f16(void* out, const void* query, void* key_ca
                            value_stride);
 }
 
+int vmi_paged_attention_v1_newest_f16(void* out, const void* query, const void* key_cache, const void* value_cache,
+                                      int32_t num_seqs, int32_t num_heads, int32_t head_size,
+                                      int32_t num_kv_heads, float scale, const int32_t* block_tables,
+                                      const int32_t* seq_lens, int32_t block_size, int32_t max_seq_len,
+                                      int32_t max_num_blocks_per_seq, const float* alibi_slopes,
+                                      int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                      int32_t device, void* stream, const void* key, const void* value,
+                                      int64_t key_stride, int64_t value_stride, int32_t variant) {
+  return vmi::launch_pa_v1(out, query, key_cache, value_cache, num_seqs, num_heads, head_size,
+                           num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+                           kv_head_stride, device, stream, variant, false, true, key, value, key_stride,
+                           value_stride, 0, 1.0f, nullptr, nullptr, 0, true);
+}
+
 int vmi_paged_attention_v1_fp8(void* out, const void* query, const void* key_cache, const void* value_cache,
                                int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t num_kv_heads,
                                float scale, const int32_t* block_tables, const int32_t* seq_lens,
@@ -1765,7 +1825,7 @@ int vmi_is_diag_build(void) {
 
 int vmi_paged_attention_v1_variant_fits(int32_t variant, int32_t max_seq_len, int32_t for_append) {
   if (variant < 1 || variant > vmi::nvariants_v1() || max_seq_len < 0) return 0;
-  if (for_append && !vmi::app_variant_v1(variant)) return 0;
+  if (for_append && !(for_append == 2 ? vmi::app_read_variant_v1(variant) : vmi::app_variant_v1(variant))) return 0;
   const int lpad = ((max_seq_len + 31) / 32) * 32;
   return vmi::variant_lds_bytes(vmi::variant_v1(variant), lpad) <= (size_t)160 * 1024 ? 1 : 0;
 }
@@ -1955,6 +2015,28 @@ int vmi_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_hos
     e = hipMemcpyAsync(d + doff, s + so, (size_t)block_bytes, k, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "swap_blocks hipMemcpyAsync");
   }
+  return VMI_OK;
+}
+
+int vmi_swap_blocks_batched(const void* src_key, const void* src_value, void* dst_key, void* dst_value,
+                            const int64_t* block_mapping, int32_t num_pairs, int64_t block_bytes, int32_t device,
+                            void* stream) {
+  using namespace vmi;
+  if (num_pairs < 0 || block_bytes <= 0 || (block_bytes & 15))
+    return fail(VMI_E_SHAPE, "swap_blocks_batched: bad sizes (pairs=%d block_bytes=%lld)", num_pairs, (long long)block_bytes);
+  if (num_pairs == 0) return VMI_OK;
+  if (!src_key || !src_value || !dst_key || !dst_value || !block_mapping)
+    return fail(VMI_E_NULL_POINTER, "swap_blocks_batched: NULL pointer");
+  if (!aligned16(src_key) || !aligned16(src_value) || !aligned16(dst_key) || !aligned16(dst_value))
+    return fail(VMI_E_ALIGNMENT, "swap_blocks_batched: cache pointers must be 16-byte aligned");
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipLaunchKernelGGL(swap_blocks_kernel, dim3(num_pairs, 2), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint8_t*>(src_key), static_cast<const uint8_t*>(src_value),
+                     static_cast<uint8_t*>(dst_key), static_cast<uint8_t*>(dst_value), block_mapping, block_bytes);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "swap_blocks_batched launch");
   return VMI_OK;
 }
 

@@ -88,7 +88,7 @@ class GPT2PagedDecoder:
 
     def __init__(self, dims: GPT2Dims, state_dict: Dict[str, torch.Tensor], pool: PagedKVPool,
                  reference_off_by_one: bool = False, fused_append: bool = False, native_layers: Optional[bool] = None,
-                 scatter_in_c_attn: Optional[bool] = None):
+                 scatter_in_c_attn: Optional[bool] = None, deferred_scatter: bool = False, pad_batch_to: int = 0):
         assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
         assert pool.head_size == dims.head_size
         self.dims, self.sd, self.pool = dims, state_dict, pool
@@ -108,6 +108,14 @@ class GPT2PagedDecoder:
             raise ValueError("fused_append writes at position seq_lens-1; reference_off_by_one passes seq_lens-1 "
                              "as the length, so the two cannot be combined")
         self.fused_append = fused_append
+        # deferred_scatter (round 6): every layer's attention takes the newest token from this step's k / v rows themselves
+        # (ops.paged_attention_v1_append(write_cache=False): the append-read kernels, bit-identical `out`) and the token's
+        # n_layer x B rows go into the cache with ONE reshape_and_cache at the end of the step — the pool is shared by all
+        # layers (kv_cache.py:13-14), so the op takes them as [n_layer * B] rows with their [n_layer * B] slots — instead of
+        # one launch in front of every attention (gpt2.py:44).  Same caches, same logits as the call pair.
+        if deferred_scatter and (fused_append or reference_off_by_one or pool.kv_cache_dtype != "auto"):
+            raise ValueError("deferred_scatter is built for float16 pages, the two-op step and seq_lens that count the new token")
+        self.deferred_scatter = deferred_scatter
         # native_layers: None = wherever they apply (a HIP device, float16 weights, hidden size a multiple of 32); True insists
         # (RuntimeError otherwise); False = the torch modules.  The library is loaded HERE: a missing one fails in the constructor.
         E = dims.n_embd
@@ -121,7 +129,7 @@ class GPT2PagedDecoder:
         # one launch fewer per layer than the reference's call pair and on the plain attention kernels (unlike fused_append)
         # None = where it is a measured win: steps of at most SCATTER_IN_C_ATTN_MAX_BATCH rows (launch-bound: -2 ... -6 % per token
         # from 1 to 32 sequences, +1 % at 256 where the scattered two-byte V pieces cost more in the projection's tail)
-        can_scatter = self.native_layers and not fused_append and pool.kv_cache_dtype == "auto"
+        can_scatter = self.native_layers and not fused_append and not deferred_scatter and pool.kv_cache_dtype == "auto"
         if scatter_in_c_attn and not can_scatter:
             raise ValueError("scatter_in_c_attn needs native_layers, float16 pages and the two-op attention (not fused_append)")
         self.scatter_in_c_attn = scatter_in_c_attn if scatter_in_c_attn is not None or not can_scatter else None
@@ -140,8 +148,10 @@ class GPT2PagedDecoder:
         self.scale = dims.head_size ** -0.5                    # gpt2.py:13
         self.device = pool.device
         self.max_seq_len = pool.max_blocks_per_seq * pool.block_size   # capacity, like scheduler.py:97
-        self._static: Optional[dict] = None
-        self._graph = None
+        self._static: Optional[dict] = None        # the static buffers of the batch size used last (see _ensure_static)
+        self._sets: Dict[int, dict] = {}
+        self._cur: Optional[dict] = None
+        self.pad_batch_to = int(pad_batch_to)      # decode steps are laid out for the next multiple of this many rows (0: as they come)
 
     # ---- pieces shared by prefill and decode --------------------------------------------------------
     def _ln(self, x, prefix):
@@ -184,6 +194,72 @@ class GPT2PagedDecoder:
         x = self._ln(x[-1:], "transformer.ln_f")
         return F.linear(x, self.sd["lm_head.weight"])[0]
 
+    PREFILL_SCORE_BYTES = 256 << 20   # a prefill_batch call pads its prompts to [n, H, T, T] scores: at most this many bytes
+
+    @torch.no_grad()
+    def prefill_batch(self, seq_ids: Sequence[int], prompts: Sequence[Sequence[int]]) -> torch.Tensor:
+        """Admission of several prompts in ONE pass (round 6): the prompts' tokens run through the block's layers as one
+        packed [sum T, E] matrix, every layer writes ALL their K / V rows with one reshape_and_cache (concatenated slots —
+        the op is batched over tokens, cache_kernels.cu:219-260), and the causal attention (eager, as the reference's
+        prefill: gpt2.py:46-58, 71-78) runs on the prompts padded to the longest, [n, H, T, T] scores at a time.
+        Returns the last-token logits [n, V]; per sequence the same arithmetic as prefill() up to GEMM tiling."""
+        n = len(seq_ids)
+        lens = [len(p) for p in prompts]
+        if n == 0:
+            return torch.empty((0, self.dims.vocab_size), dtype=torch.float16, device=self.device)
+        d, pool, dev = self.dims, self.pool, self.device
+        H, D, E = d.n_head, d.head_size, d.n_embd
+        done = []
+        try:
+            slots = []
+            for sid, T in zip(seq_ids, lens):
+                slots.append(pool.allocate_for_prefill(sid, T)[1])          # [layers, T]
+                done.append(sid)
+        except RuntimeError:
+            for sid in done:       # all or nothing: the caller retries with a smaller group
+                pool.free(sid)
+            raise
+        slots_dev = torch.from_numpy(np.ascontiguousarray(np.concatenate(slots, axis=1))).to(dev)     # [layers, sum T]
+        ids = torch.as_tensor([t for p in prompts for t in p], dtype=torch.long, device=dev)
+        starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        pos = torch.from_numpy(np.concatenate([np.arange(T, dtype=np.int64) for T in lens])).to(dev)
+        x = self.sd["transformer.wte.weight"][ids] + self.sd["transformer.wpe.weight"][pos]
+        # groups of prompts whose padded scores fit the budget, longest first inside the call's own order
+        groups, cur, cur_T = [], [], 0
+        for i in range(n):
+            T = max(cur_T, lens[i])
+            if cur and (len(cur) + 1) * H * T * T * 2 > self.PREFILL_SCORE_BYTES:
+                groups.append(cur)
+                cur, T = [], lens[i]
+            cur.append(i)
+            cur_T = T
+        groups.append(cur)
+        plans = []
+        for g in groups:
+            T = max(lens[i] for i in g)
+            idx = np.zeros((len(g), T), dtype=np.int64)                      # packed row of (prompt, position); pads -> row 0
+            valid = np.zeros((len(g), T), dtype=bool)
+            for r, i in enumerate(g):
+                idx[r, : lens[i]] = starts[i] + np.arange(lens[i])
+                valid[r, : lens[i]] = True
+            mask = torch.triu(torch.full((T, T), float("-inf"), dtype=x.dtype, device=dev), diagonal=1)
+            plans.append((torch.from_numpy(idx).to(dev), torch.from_numpy(valid).to(dev),
+                          torch.from_numpy(idx[valid]).to(dev), mask))
+        for i in range(d.n_layer):
+            p = f"transformer.h.{i}."
+            q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)                                       # [sum T, H, D] views
+            cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, slots_dev[i], pool.kv_cache_dtype, pool.kv_scale)
+            a = torch.empty((x.shape[0], E), dtype=x.dtype, device=dev)
+            for idx, valid, rows, mask in plans:
+                qh, kh, vh = (t[idx].transpose(1, 2) for t in (q, k, v))                          # [g, H, T, D]
+                w = torch.matmul(qh, kh.transpose(-1, -2)) * self.scale + mask                    # gpt2.py:72-74
+                o = torch.matmul(F.softmax(w, dim=-1), vh)                                        # gpt2.py:76-78
+                a[rows] = o.transpose(1, 2).reshape(idx.shape[0], idx.shape[1], E)[valid]
+            x = x + F.linear(a, self.sd[p + "attn.c_proj.weight"], self.sd[p + "attn.c_proj.bias"])
+            x = x + self._mlp(self._ln(x, p + "ln_2"), p)
+        last = torch.from_numpy(starts[1:] - 1).to(dev)
+        return F.linear(self._ln(x[last], "transformer.ln_f"), self.sd["lm_head.weight"])
+
     # ---- batched decode -------------------------------------------------------------------------------
     def _forward_decode(self, st: dict) -> torch.Tensor:
         """One decode step for B sequences from static device buffers (graph-capturable: no allocation
@@ -207,16 +283,20 @@ class GPT2PagedDecoder:
                 q, k, v = (qkv[:, j * E:(j + 1) * E].view(B, d.n_head, d.head_size) for j in range(3))
             elif nat:    # ln_1 + c_attn in one launch; q/k/v are the same 3E-strided views (gpt2.py:35-41)
                 qkv = gpt2_layer.linear(x, pw[p + "attn.c_attn.weight"], sd[p + "attn.c_attn.bias"],
-                                        ln=(sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], d.layer_norm_epsilon))
+                                        ln=(sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], d.layer_norm_epsilon),
+                                        out=st["qkv_all"][i] if self.deferred_scatter else None)   # (kept until the step's one scatter)
                 q, k, v = (qkv[:, j * E:(j + 1) * E].view(B, d.n_head, d.head_size) for j in range(3))
             else:
                 q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)
+                if self.deferred_scatter:
+                    st["qkv_all"][i].copy_(torch.cat([q.reshape(B, E), k.reshape(B, E), v.reshape(B, E)], dim=1))
+                    q, k, v = (st["qkv_all"][i][:, j * E:(j + 1) * E].view(B, d.n_head, d.head_size) for j in range(3))
             out = torch.empty((B, d.n_head, d.head_size), dtype=q.dtype, device=q.device)   # empty_like(q) is contiguous, gpt2.py:93
             var = st.get("variant", 0)   # work decomposition chosen on the host from the batch's lengths (decode())
-            if self.fused_append:
+            if self.fused_append or self.deferred_scatter:
                 ops.paged_attention_v1_append(out, q, k, v, pool.key_cache, pool.value_cache, d.n_head, self.scale,
                                               st["tables"][i], st["seq_lens"], pool.block_size, self.max_seq_len,
-                                              _variant=var)
+                                              _variant=var, write_cache=not self.deferred_scatter)
             else:
                 if not scat:
                     cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, st["slots"][i],
@@ -233,10 +313,19 @@ class GPT2PagedDecoder:
             else:
                 x = x + F.linear(out.view(B, d.n_embd), self.sd[p + "attn.c_proj.weight"], self.sd[p + "attn.c_proj.bias"])
                 x = x + self._mlp(self._ln(x, p + "ln_2"), p)
+        if self.deferred_scatter:    # the token's n_layer x B rows of k and v, one launch (the pool is shared by the layers)
+            qa = st["qkv_all"]
+            rows = qa.view(d.n_layer * B, 3 * E)     # [n_layer * B] rows of stride 3E: k and v are strided views, as per layer
+            cache_ops.reshape_and_cache(rows[:, E:2 * E].view(d.n_layer * B, d.n_head, d.head_size),
+                                        rows[:, 2 * E:].view(d.n_layer * B, d.n_head, d.head_size),
+                                        pool.key_cache, pool.value_cache, st["slots"].view(-1), pool.kv_cache_dtype, pool.kv_scale)
         return F.linear(self._ln(x, "transformer.ln_f"), self.sd["lm_head.weight"])   # [B, V]
 
     def _ensure_static(self, B: int) -> dict:
-        if self._static is None or self._static["input_ids"].shape[0] != B:
+        """The static device buffers, pinned staging buffers and captured graphs of batch size B (kept per size: a serving
+        batch moves between a few padded sizes, and a graph must not be captured again every time it comes back to one)."""
+        cur = self._sets.get(B)
+        if cur is None:
             L, MB, dev = self.dims.n_layer, self.pool.max_blocks_per_seq, self.device
             # tables, slots, lengths and positions live in ONE device buffer (8-byte aligned sections, typed views): a step
             # uploads them with one copy instead of four (4 x ~4 us of copy kernels per token: 3 % of a batch-1 token)
@@ -251,66 +340,102 @@ class GPT2PagedDecoder:
             def views(buf):
                 return {name: buf[offs[name][0]:offs[name][0] + offs[name][1]].view(dt).view(shape) for name, shape, dt in sections}
 
-            self._meta = torch.zeros(total, dtype=torch.uint8, device=dev)
-            self._static = {"input_ids": torch.zeros(B, dtype=torch.long, device=dev), **views(self._meta)}
-            self._static["tables"].fill_(-1)
-            self._graph = None
+            meta = torch.zeros(total, dtype=torch.uint8, device=dev)
+            static = {"input_ids": torch.zeros(B, dtype=torch.long, device=dev), **views(meta)}
+            if self.deferred_scatter:
+                static["qkv_all"] = torch.empty((L, B, 3 * self.dims.n_embd), dtype=torch.float16, device=dev)
+            static["tables"].fill_(-1)
+            cur = {"static": static, "meta": meta, "graphs": {}, "stage": None}
             # Two PINNED host staging buffers: an upload from pageable memory is staged synchronously by the
             # runtime behind everything already queued on the stream, which serialises host and GPU (the fp8 step, 1.7 ms
             # of GPU work, ran 3.06 ms that way).  From pinned memory the copy is truly asynchronous and the host
             # prepares step i+1 while the GPU runs step i; a buffer is reused only after its own copy has executed.
-            self._stage = None
             if dev.type == "cuda":
-                self._stage_buf = [torch.empty(total, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-                self._stage = [{k: v.numpy() for k, v in views(b).items()} for b in self._stage_buf]
-                self._stage_ev = [None, None]
-                self._stage_i = 0
+                cur["stage_buf"] = [torch.empty(total, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+                cur["stage"] = [{k: v.numpy() for k, v in views(b).items()} for b in cur["stage_buf"]]
+                cur["stage_ev"] = [None, None]
+                cur["stage_i"] = 0
+            self._sets[B] = cur
+        self._cur = cur
+        self._static = cur["static"]
         return self._static
 
+    @property
+    def _graph(self) -> Optional[dict]:
+        """variant id -> (graph, static output) of the batch size used last."""
+        return None if self._cur is None else self._cur["graphs"]
+
+    def _padded(self, B: int) -> int:
+        m = self.pad_batch_to
+        return B if not m or B % m == 0 else (B // m + 1) * m
+
     def stage_step(self, seq_ids: Sequence[int], input_ids) -> dict:
-        """Host bookkeeping for one step + ONE upload of all of it into the static device buffers."""
+        """Host bookkeeping for one step + ONE upload of all of it into the static device buffers.  With pad_batch_to the
+        step is laid out for the next multiple of it: the padding rows are empty sequences (length 0: the attention writes
+        zeros; slot -1: reshape_and_cache skips the row, cache_kernels.cu:165-169) that cost a row of the linear layers each
+        and keep the launch geometry — hence the captured graph — one of a few."""
         B = len(seq_ids)
-        st = self._ensure_static(B)
+        Bp = self._padded(B)
+        st = self._ensure_static(Bp)
+        cur = self._cur
         positions = np.fromiter((self.pool.seq_len(s) for s in seq_ids), dtype=np.int64, count=B)  # scheduler.py:81
         tables, slots, ctx = self.pool.decode_step_batch(seq_ids)
         lens = ctx - 1 if self.reference_off_by_one else ctx
         host = {"tables": tables, "slots": slots, "seq_lens": lens.astype(np.int32), "position_ids": positions}
-        if self._stage is None:
+        if cur["stage"] is None:
             for k, a in host.items():
-                st[k].copy_(torch.from_numpy(np.ascontiguousarray(a)), non_blocking=True)
+                dst = st[k][:, :B] if k in ("tables", "slots") else st[k][:B]
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(a)), non_blocking=True)
+                if Bp > B:
+                    pad = st[k][:, B:] if k in ("tables", "slots") else st[k][B:]
+                    pad.fill_(-1 if k in ("tables", "slots") else 0)
         else:
-            i = self._stage_i
-            if self._stage_ev[i] is not None:
-                self._stage_ev[i].synchronize()          # this set's previous uploads have run
-            for k, a in host.items():
-                self._stage[i][k][...] = a
-            self._meta.copy_(self._stage_buf[i], non_blocking=True)
+            i = cur["stage_i"]
+            if cur["stage_ev"][i] is not None:
+                cur["stage_ev"][i].synchronize()          # this set's previous uploads have run
+            sg = cur["stage"][i]
+            sg["tables"][:, :B] = tables
+            sg["slots"][:, :B] = slots
+            sg["seq_lens"][:B] = host["seq_lens"]
+            sg["position_ids"][:B] = positions
+            if Bp > B:
+                sg["tables"][:, B:] = -1
+                sg["slots"][:, B:] = -1
+                sg["seq_lens"][B:] = 0
+                sg["position_ids"][B:] = 0
+            cur["meta"].copy_(cur["stage_buf"][i], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._stage_ev[i] = ev
-            self._stage_i = i ^ 1
+            cur["stage_ev"][i] = ev
+            cur["stage_i"] = i ^ 1
         # the lengths are known here on the host: let the library's heuristic see the batch's true longest and mean
         # length (a ragged batch gets the many-waves-per-head decomposition, vmi_paged_attention_v1_pick_variant_hint)
-        st["variant"] = ops.pick_variant(B, self.dims.n_head, self.dims.head_size, max(int(lens.max()), 1),
-                                         self.pool.block_size, mean_seq_len=max(int(lens.mean()), 1),
+        st["variant"] = ops.pick_variant(Bp, self.dims.n_head, self.dims.head_size, max(int(lens.max()), 1),
+                                         self.pool.block_size, mean_seq_len=max(int(lens.sum()) // Bp, 1),
                                          bf16=self.pool.key_cache.dtype == torch.bfloat16,
                                          fp8={"auto": False, "fp8_e5m2": "e5m2"}.get(self.pool.kv_cache_dtype, True))
         # few sequences x long contexts: with the wrapper's workspace the library spreads a head over several workgroups
         # (ops.pick_variant(workspace=True) names a split kernel, "_x<waves>", exactly where the default entry would run one)
-        if st["variant"] and not self.fused_append and self.pool.kv_cache_dtype == "auto" and \
-                self.pool.key_cache.dtype == torch.float16:
-            ws_pick = ops.pick_variant(B, self.dims.n_head, self.dims.head_size, max(int(lens.max()), 1),
+        # (only when the launch WILL carry a workspace: the wrapper's switch is on and one exists for this stream — none is
+        #  created under stream capture — else the split id would fail with VMI_E_WORKSPACE; ADVICE r05)
+        if st["variant"] and not self.fused_append and not self.deferred_scatter and self.pool.kv_cache_dtype == "auto" and \
+                self.pool.key_cache.dtype == torch.float16 and ops._ws_enabled and self.device.type == "cuda" and \
+                ops.workspace_for(self.device.index if self.device.index is not None else torch.cuda.current_device()) is not None:
+            ws_pick = ops.pick_variant(Bp, self.dims.n_head, self.dims.head_size, max(int(lens.max()), 1),
                                        self.pool.block_size, workspace=True)
-            if ws_pick and "_x" in ops.variant_names()[ws_pick - 1]:
+            if ws_pick and ops.is_split(ws_pick):
                 st["variant"] = ws_pick
         # ... but the launch reserves LDS for self.max_seq_len (the pool's capacity, as the reference's scheduler passes
         # it, scheduler.py:97) and may be the fused append: a hinted variant that cannot serve that is dropped
-        if not ops.variant_fits(st["variant"], self.max_seq_len, for_append=self.fused_append):
+        if not ops.variant_fits(st["variant"], self.max_seq_len,
+                                for_append="read" if self.deferred_scatter else self.fused_append):
             st["variant"] = 0
+        ids_dst = st["input_ids"][:B]
         if isinstance(input_ids, torch.Tensor):
-            st["input_ids"].copy_(input_ids.to(torch.long), non_blocking=True)
+            ids_dst.copy_(input_ids.to(torch.long), non_blocking=True)
         else:
-            st["input_ids"].copy_(torch.as_tensor(list(input_ids), dtype=torch.long), non_blocking=True)
+            ids_dst.copy_(torch.as_tensor(list(input_ids), dtype=torch.long), non_blocking=True)
+        st["rows"] = B
         return st
 
     @torch.no_grad()
@@ -318,14 +443,15 @@ class GPT2PagedDecoder:
         """Feed one token per sequence; returns logits [B, V].  With use_graph the step's ~150 kernel
         launches are replayed from one hipGraph (captured on first use for this batch size)."""
         st = self.stage_step(seq_ids, input_ids)
+        B = st["rows"]
         if not use_graph:
-            return self._forward_decode(st)
+            out = self._forward_decode(st)
+            return out if out.shape[0] == B else out[:B]
         # one captured graph per launch geometry (the variant is baked into a capture): a batch whose contexts grow across a
         # pick threshold — 512 tokens at batch 32, say — switches graphs instead of capturing again in the middle of a run
         # (a re-capture costs milliseconds: the step before 1 051 us per token, after 624)
-        if self._graph is None:
-            self._graph = {}
-        hit = self._graph.get(st["variant"])
+        graphs = self._cur["graphs"]
+        hit = graphs.get(st["variant"])
         if hit is None:
             s = torch.cuda.Stream(self.device)
             s.wait_stream(torch.cuda.current_stream(self.device))
@@ -335,9 +461,9 @@ class GPT2PagedDecoder:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=s):   # (the warm-up's stream: its paged_attention_v1 workspace exists)
                 out = self._forward_decode(st)
-            hit = self._graph[st["variant"]] = (graph, out)
+            hit = graphs[st["variant"]] = (graph, out)
         hit[0].replay()
-        return hit[1]
+        return hit[1] if hit[1].shape[0] == B else hit[1][:B]
 
     def greedy(self, logits: torch.Tensor) -> torch.Tensor:
         """argmax over the vocabulary, on the device (int64 [B]); with the native layers one workgroup per row instead of

@@ -6,6 +6,7 @@ Reference:
     KVCache.append_block          vllmini/kv_cache.py:56-73    pop(0) from the free list into the first -1 entry
     KVCache.free                  vllmini/kv_cache.py:81-86    blocks appended back to the free list
     BlockManager.decode_step      vllmini/block_manager.py:28-63  per layer: slot = last_block*bs + filled; new block when full
+    BlockManager.swap_to_cpu / swap_from_cpu   vllmini/block_manager.py:70-87  a sequence's blocks to host memory and back
 
 The reference keeps one int32 [1, max_blocks] table PER (sequence, layer) on the device and scans
 it element by element (a device->host sync per element, block_manager.py:36-39).  Here the same
@@ -21,9 +22,11 @@ tests/golden/seam_trace.npz); for a batch, new blocks are handed out in the orde
 would use if it stepped the sequences one after the other (sequence-major, then layer).
 
 Reference quirks that are reproduced or flagged, not silently changed:
-  * prefill hands out exactly one block per layer, so prompts longer than block_size are rejected
-    here (the reference would silently write into the next block, which belongs to another layer:
-    kv_cache.py:25-35, SURVEY.md §3B) unless `multi_block_prefill=True` (this build's extension);
+  * the reference's prefill hands out exactly one block per layer and silently writes a longer prompt into the next
+    block, which belongs to another layer (kv_cache.py:25-35).  Here a prompt gets ceil(len / block_size)
+    blocks per layer (`multi_block_prefill=True`, the default since round 6: a serving loop cannot be fed 16-token
+    prompts); up to block_size tokens the blocks, tables and slots are the reference's own (the golden allocator traces
+    replay under either setting).  `multi_block_prefill=False` pins the reference's limit: longer prompts are refused;
   * decode_step needs a trailing -1 in the table to find the last block (block_manager.py:36-39), so a
     sequence can use at most max_blocks_per_seq-1 blocks per layer before the next step fails; that
     raises here (the reference dies with UnboundLocalError);
@@ -42,8 +45,8 @@ X = 8  # halves per 16-byte K chunk (kv_cache.py:13: head_size // 8, ..., 8)
 class PagedKVPool:
     def __init__(self, num_blocks: int, num_heads: int, head_size: int, block_size: int,
                  max_blocks_per_seq: int, num_layers: int, device: torch.device | str = "cuda",
-                 allocate_tensors: bool = True, max_seqs: int = 64, multi_block_prefill: bool = False,
-                 kv_cache_dtype: str = "auto", kv_scale: float = 1.0):
+                 allocate_tensors: bool = True, max_seqs: int = 64, multi_block_prefill: bool = True,
+                 kv_cache_dtype: str = "auto", kv_scale: float = 1.0, host_blocks: int = 0):
         self.num_blocks = num_blocks
         self.num_heads = num_heads
         self.head_size = head_size
@@ -70,6 +73,13 @@ class PagedKVPool:
             self.key_cache = self.value_cache = None
         self.free_blocks: List[int] = list(range(num_blocks))          # kv_cache.py:16, FIFO
         self.allocated_blocks: Dict[int, List[int]] = {}               # kv_cache.py:17
+        # preemption (block_manager.py:15 cpu_cache): a pinned host pool in the SAME block layout, allocated at the first
+        # swap_out; host_blocks = 0 -> as many as the device pool.  swapped[seq_id] = everything needed to put the sequence back
+        self.host_blocks = int(host_blocks) or num_blocks
+        self.host_key_cache = self.host_value_cache = None
+        self._host_free: List[int] = list(range(self.host_blocks))
+        self.swapped: Dict[int, dict] = {}
+        self.swap_stats = {"swap_outs": 0, "swap_ins": 0, "blocks_out": 0, "blocks_in": 0, "bytes_out": 0, "bytes_in": 0}
         self._row_of: Dict[int, int] = {}
         self._free_rows: List[int] = []
         self._rows = 0
@@ -149,6 +159,94 @@ class PagedKVPool:
             self._tables[:, row, :] = -1
             self._nblocks[:, row] = 0
             self._free_rows.append(row)
+
+    # ---- preemption: a sequence's blocks to host memory and back (block_manager.py:70-87) -------------------------------
+    @property
+    def block_bytes(self) -> int:
+        """Bytes of one block of ONE cache (K and V blocks have the same size)."""
+        esz = 1 if self.kv_cache_dtype in ("fp8", "fp8_e4m3", "fp8_e5m2") else 2
+        return self.num_heads * self.head_size * self.block_size * esz
+
+    def _move_blocks(self, to_host: bool, pairs: np.ndarray) -> None:
+        if self.key_cache is None:          # bookkeeping only (CPU tests)
+            return
+        from . import cache_ops
+        if self.host_key_cache is None:     # pinned: the GPU reads / writes these pages directly (one launch per swap)
+            pin = self.device.type == "cuda"
+            self.host_key_cache = torch.empty((self.host_blocks,) + tuple(self.key_cache.shape[1:]),
+                                              dtype=self.key_cache.dtype, pin_memory=pin)
+            self.host_value_cache = torch.empty((self.host_blocks,) + tuple(self.value_cache.shape[1:]),
+                                                dtype=self.value_cache.dtype, pin_memory=pin)
+        dev, host = (self.key_cache, self.value_cache), (self.host_key_cache, self.host_value_cache)
+        src, dst = (dev, host) if to_host else (host, dev)
+        cache_ops.swap_blocks_batched(src[0], src[1], dst[0], dst[1], torch.from_numpy(np.ascontiguousarray(pairs)))
+
+    def swap_out(self, seq_id: int) -> int:
+        """swap_to_cpu (block_manager.py:70-73): copy the sequence's blocks — every layer's — to the host pool, then free
+        them.  ONE launch moves them all (cache_ops.swap_blocks_batched; the reference: one .cpu() gather per cache),
+        asynchronously on the current stream: the freed blocks may be handed out at once, launches that overwrite them
+        queue behind the copy.  Returns the number of blocks moved; RuntimeError when the host pool cannot take them."""
+        if seq_id not in self.allocated_blocks:
+            raise ValueError(f"No KV cache allocated for sequence {seq_id}")            # kv_cache.py:50-51
+        blocks = self.allocated_blocks[seq_id]
+        n = len(blocks)
+        if len(self._host_free) < n:
+            raise RuntimeError(f"Not enough free host blocks to swap out sequence {seq_id} ({n} needed, "
+                               f"{len(self._host_free)} of {self.host_blocks} free)")
+        host = self._host_free[:n]
+        del self._host_free[:n]
+        row = self._row_of[seq_id]
+        self.swapped[seq_id] = {"host": host, "dev": list(blocks), "tables": self._tables[:, row, :].copy(),
+                                "nblocks": self._nblocks[:, row].copy(), "filled": self._filled[:, row].copy(),
+                                "seq_len": int(self._seq_len[row])}
+        self._move_blocks(True, np.stack([np.asarray(blocks, dtype=np.int64), np.asarray(host, dtype=np.int64)], axis=1))
+        self.free(seq_id)
+        st = self.swap_stats
+        st["swap_outs"] += 1
+        st["blocks_out"] += n
+        st["bytes_out"] += 2 * n * self.block_bytes
+        return n
+
+    def swap_in(self, seq_id: int) -> bool:
+        """swap_from_cpu (block_manager.py:75-87): False when the sequence is not swapped out or the pool has not enough
+        free blocks (the reference answers its RuntimeError the same way); else the sequence owns as many NEW blocks
+        (free-list order), its tables name them in the old positions, and the pages are back — bit for bit."""
+        st = self.swapped.get(seq_id)
+        if st is None:
+            return False                                                    # :76-77
+        n = len(st["host"])
+        if len(self.free_blocks) < n:
+            return False                                                    # :86-87
+        new = self._take(n)
+        lut = np.full(self.num_blocks, -1, dtype=np.int32)
+        lut[np.asarray(st["dev"], dtype=np.int64)] = np.asarray(new, dtype=np.int32)
+        row = self._new_row(seq_id)
+        t = st["tables"]
+        self._tables[:, row, :] = np.where(t >= 0, lut[np.maximum(t, 0)], -1)
+        self._nblocks[:, row] = st["nblocks"]
+        self._filled[:, row] = st["filled"]
+        self._seq_len[row] = st["seq_len"]
+        self.allocated_blocks[seq_id] = list(new)
+        self._move_blocks(False, np.stack([np.asarray(st["host"], dtype=np.int64), np.asarray(new, dtype=np.int64)], axis=1))
+        self._host_free.extend(st["host"])
+        del self.swapped[seq_id]
+        ss = self.swap_stats
+        ss["swap_ins"] += 1
+        ss["blocks_in"] += n
+        ss["bytes_in"] += 2 * n * self.block_bytes
+        return True
+
+    def drop_swapped(self, seq_id: int) -> None:
+        """Forget a swapped-out sequence (block_manager.py:65-68: free() also deletes the cpu copy)."""
+        st = self.swapped.pop(seq_id, None)
+        if st is not None:
+            self._host_free.extend(st["host"])
+
+    def blocks_of(self, seq_id: int) -> int:
+        """Blocks a sequence holds on the device, or would need to come back."""
+        if seq_id in self.allocated_blocks:
+            return len(self.allocated_blocks[seq_id])
+        return len(self.swapped[seq_id]["host"])
 
     def seq_len(self, seq_id: int) -> int:
         return int(self._seq_len[self._row_of[seq_id]])

@@ -38,6 +38,8 @@ __all__ = [
     "reset_workspaces",
     "variant_fits",
     "variant_names",
+    "is_split",
+    "check_workspaces",
 ]
 
 _SUPPORTED_KV_CACHE_DTYPES = ("auto",)
@@ -354,6 +356,7 @@ def paged_attention_v1_append(
     kv_scale: float = 1.0,
     *,
     _variant: int = 0,
+    write_cache: bool = True,
 ) -> None:
     """Fused decode step (extension, include/vmi_paged_attention.h: vmi_paged_attention_v1_append_*):
 
@@ -363,6 +366,10 @@ def paged_attention_v1_append(
     in one launch — the pair the reference issues per layer (gpt2.py:87-112).  `seq_lens` already counts this
     step's token (as in gpt2.py:99-104); its slot is derived from the block table, so no slot_mapping is passed.
     Caches and `out` are bit-identical to the two-op sequence (tests/test_parity_gpu.py).
+
+    write_cache=False (vmi_paged_attention_v1_newest_f16): the same attention — the newest token is read from key / value —
+    WITHOUT the cache write; the caller stores the rows later (one reshape_and_cache for all the layers of a token:
+    GPT2PagedDecoder(deferred_scatter=True)).  `out` is unchanged by it, the caches are not touched.
     """
     if _check_kv_cache_dtype(kv_cache_dtype):
         raise RuntimeError("paged_attention_v1_append is not built for an fp8 KV cache")
@@ -379,8 +386,11 @@ def paged_attention_v1_append(
             raise RuntimeError(f"{name} must be [num_seqs, num_kv_heads, head_size], got {tuple(t.shape)}")
         if t.stride(2) != 1 or t.stride(1) != head_size:
             raise RuntimeError(f"{name} must be contiguous in its last two dimensions")
+    if not write_cache and query.dtype != torch.float16:
+        raise RuntimeError("paged_attention_v1_append(write_cache=False) is built for float16 tensors")
     fn = _extras("paged_attention_v1_append over bfloat16 tensors").vmi_paged_attention_v1_append_bf16 \
-        if query.dtype == torch.bfloat16 else _lib.load().vmi_paged_attention_v1_append_f16
+        if query.dtype == torch.bfloat16 else (_lib.load().vmi_paged_attention_v1_append_f16 if write_cache else
+                                               _lib.load().vmi_paged_attention_v1_newest_f16)
     rc = fn(*args, key.data_ptr(), value.data_ptr(), int(key.stride(0)), int(value.stride(0)), int(_variant))
     if rc != 0:
         _raise_native(rc)
@@ -541,10 +551,39 @@ def reshape_and_cache(
 
 # ---- tuning helpers (not part of the reference surface) --------------------------------------
 
+_NAMES: dict = {}     # per loaded library (product / extras / diag have different menus): its variant names, asked for once
+
+
 def variant_names() -> list[str]:
     lib = _lib.load()
-    n = lib.vmi_paged_attention_v1_variant_count()
-    return [lib.vmi_paged_attention_v1_variant_name(i + 1).decode() for i in range(n)]
+    names = _NAMES.get(id(lib))
+    if names is None:   # (~300 ctypes calls: 170 us — a decode step asks every time)
+        n = lib.vmi_paged_attention_v1_variant_count()
+        names = _NAMES[id(lib)] = [lib.vmi_paged_attention_v1_variant_name(i + 1).decode() for i in range(n)]
+    return list(names)
+
+
+def is_split(variant: int) -> bool:
+    """Is `variant` a split kernel (pa_split.hpp: a (sequence, head) spread over several workgroups that meet in a workspace)?"""
+    lib = _lib.load()
+    if id(lib) not in _NAMES:
+        variant_names()
+    names = _NAMES[id(lib)]
+    return 1 <= variant <= len(names) and "_x" in names[variant - 1]
+
+
+def check_workspaces(index: Optional[int] = None) -> None:
+    """Raise if any launch on a cached workspace (of device `index`) gave up waiting for another workgroup (the kernel then
+    wrote NaN rows and counted the event in the workspace's first word).  Synchronises; for sync points: the end of a decode
+    loop, a bench, a test.  Concurrent split launches on ONE workspace — two streams replaying graphs captured on the same
+    side stream — are not supported: the workspace is per (device, stream at call or capture time)."""
+    for (i, st), ws in list(_WS.items()):
+        if index is None or i == index:
+            n = int(ws[:4].view(torch.int32).item())
+            if n:
+                raise RuntimeError(f"paged_attention_v1: {n} poll(s) of a split kernel gave up on the workspace of device {i}, "
+                                   f"stream {st:#x}: its workgroups were not co-resident (another kernel on the CUs, or two "
+                                   "launches sharing the workspace); the affected rows are NaN.  ops.reset_workspaces() clears it")
 
 
 def variant_names_v2() -> list[str]:
@@ -563,10 +602,12 @@ def set_pv_mfma(on: bool) -> bool:
     return bool(_lib.load().vmi_set_pv_mfma(int(bool(on))))
 
 
-def variant_fits(variant: int, max_seq_len: int, for_append: bool = False) -> bool:
-    """Can `variant` (from pick_variant) serve a launch with this max_seq_len — and the fused append, if asked?
+def variant_fits(variant: int, max_seq_len: int, for_append=False) -> bool:
+    """Can `variant` (from pick_variant) serve a launch with this max_seq_len — and the fused append, if asked
+    (for_append=True; "read": its form without the cache write, paged_attention_v1_append(write_cache=False))?
     False -> pass `_variant=0` and let the library choose."""
-    return bool(_lib.load().vmi_paged_attention_v1_variant_fits(int(variant), int(max_seq_len), int(bool(for_append))))
+    mode = 2 if for_append == "read" else int(bool(for_append))
+    return bool(_lib.load().vmi_paged_attention_v1_variant_fits(int(variant), int(max_seq_len), mode))
 
 
 def last_variant() -> int:
