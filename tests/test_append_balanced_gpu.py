@@ -75,7 +75,7 @@ def _check(c, what, variant=0, expect_balanced=True):
         ops.paged_attention_v1_append(out_b, c["q"], c["key"], c["value"], kc_b, vc_b, c["Hkv"], scale, c["tab"], c["lens"], BS,
                                       c["msl"], _variant=variant)
     else:
-        with pytest.raises(RuntimeError, match="append-read form only"):
+        with pytest.raises(RuntimeError, match="no fused-append twin|append-read form only"):
             ops.paged_attention_v1_append(out_b, c["q"], c["key"], c["value"], kc_b, vc_b, c["Hkv"], scale, c["tab"], c["lens"],
                                           BS, c["msl"], _variant=variant)
         ops.paged_attention_v1_append(out_b, c["q"], c["key"], c["value"], kc_b, vc_b, c["Hkv"], scale, c["tab"], c["lens"], BS, c["msl"])
@@ -86,12 +86,12 @@ def _check(c, what, variant=0, expect_balanced=True):
     assert torch.equal(vc_a.view(i16), vc_b.view(i16)), f"{what}: value cache differs"
     live = (c["lens"] > 0)
     assert torch.isfinite(out_n[live].float()).all(), f"{what}: non-finite"
-    for name, o in (("append-read", out_n),) + ((("fused", out_b),) if not expect_balanced or True else ()):
+    for name, o in (("append-read", out_n), ("fused", out_b)):
         same = torch.equal(out_a.view(i16), o.view(i16))
         if name == "fused" and expect_balanced and not same:
-            # the writing entry runs another work decomposition than the pair on a full chip: fp32 summation order, <= 1 fp16 ulp
+            # the writing entry runs another work decomposition than the pair on a full chip: fp32 summation order
             d = (out_a.float() - o.float()).abs()
-            assert float((d / out_a.float().abs().clamp_min(2.0 ** -10)).max()) <= 2.0 ** -9, f"{what}: fused differs by more than an ulp"
+            assert float(d.max()) <= 1e-3, f"{what}: fused differs by {float(d.max()):.3e}"
             continue
         assert same, f"{what}: {name} out differs, max {float((out_a.float() - o.float()).abs().max()):.3e} in " \
                      f"{int((out_a.view(i16) != o.view(i16)).any(-1).any(-1).sum())} sequences"

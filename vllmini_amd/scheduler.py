@@ -77,7 +77,7 @@ class BatchScheduler:
     def __init__(self, decoder, max_length: int, eos_token_id: int, max_batch: int = 256,
                  sampler: Callable[..., torch.Tensor] = sample_top_k, use_graph: bool = False,
                  generator: Optional[torch.Generator] = None, preempt: str = "swap", record_latency: bool = False,
-                 max_prefill_tokens: int = 8192):
+                 max_prefill_tokens: int = 8192, admit_every: int = 1, headroom_blocks: Optional[int] = None):
         self.decoder = decoder
         # a sequence may grow to max_length tokens; the pool's table must hold them (the reference crashes at that
         # point, block_manager.py:41-63 — here ONE such sequence would abort the step of every sequence in its batch)
@@ -96,6 +96,14 @@ class BatchScheduler:
         self.generator = generator
         self.preempt = preempt if hasattr(pool, "swap_out") else "drop"
         self.max_prefill_tokens = max_prefill_tokens
+        # queued requests are admitted every `admit_every` decode steps (or when nothing runs): 1 = at once, as the reference
+        # prefills on arrival; larger = fewer, larger prefill calls (a prefill call is ~300 launches whatever it carries,
+        # and at 2 sequences ending per step the slots and blocks of 16 steps make one call of ~32 prompts)
+        self.admit_every = max(1, int(admit_every))
+        self._last_admit_step = -(1 << 30)
+        # blocks kept free per running sequence when a newcomer is let in (None: one per layer — a sequence's next block
+        # boundary; 0: a prompt is admitted whenever it fits and growth is paid for by preemption, the reference's way)
+        self.headroom_blocks = headroom_blocks
         self._ids = itertools.count()
         self.active: Dict[int, int] = {}                     # seq_id -> arrival index   (active_sequences, :17)
         self.last_logits: Dict[int, torch.Tensor] = {}       # :18 — of the sequences that were NOT in the last decode call
@@ -111,7 +119,7 @@ class BatchScheduler:
         self._lb_pos: Dict[int, int] = {}
         self._lb_logits: Optional[torch.Tensor] = None
         self.stats = {"preemptions": 0, "resumes": 0, "dropped": 0, "admitted": 0, "prefill_calls": 0, "decode_rows": 0,
-                      "host_s": 0.0, "wait_s": 0.0}
+                      "host_s": 0.0, "wait_s": 0.0, "admit_s": 0.0}
         self.record_latency = record_latency
         self._t_last: Dict[int, float] = {}
         self.token_latency_s: List[np.ndarray] = []          # per step: seconds since each stepped sequence's previous token
@@ -209,7 +217,8 @@ class BatchScheduler:
     def _headroom(self, extra_running: int = 0) -> int:
         """Blocks the running sequences may ask for before a newcomer's first block boundary: one per layer each."""
         pool = self.decoder.pool
-        return getattr(pool, "num_layers", 1) * (len(self.active) + extra_running)
+        per = getattr(pool, "num_layers", 1) if self.headroom_blocks is None else self.headroom_blocks
+        return per * (len(self.active) + extra_running)
 
     def _resume(self) -> None:
         """Swapped-out sequences come back oldest first, while a batch slot is free and the pool holds their blocks plus
@@ -235,6 +244,8 @@ class BatchScheduler:
         their prompt's blocks plus the running sequences' headroom — as many as fit, through ONE prefill call."""
         if not self.waiting or self.swapped:
             return
+        if self.active and self.steps - self._last_admit_step < self.admit_every:
+            return
         pool = self.decoder.pool
         L, bs = getattr(pool, "num_layers", 1), getattr(pool, "block_size", 16)
         free = len(pool.free_blocks) - self._headroom()
@@ -252,6 +263,7 @@ class BatchScheduler:
             group.append(self.waiting.popleft())
         if not group:
             return
+        self._last_admit_step = self.steps
         if len(group) > 1 and hasattr(self.decoder, "prefill_batch"):
             logits = self.decoder.prefill_batch([g[0] for g in group], [g[1] for g in group])
             self.stats["prefill_calls"] += 1
@@ -266,8 +278,32 @@ class BatchScheduler:
     def _batch_logits(self, batch: List[int]) -> torch.Tensor:
         if batch == self._lb_ids and self._lb_logits is not None and not any(s in self.last_logits for s in batch):
             return self._lb_logits
-        rows = [self.last_logits[s] if s in self.last_logits else self._lb_logits[self._lb_pos[s]] for s in batch]
-        return torch.stack(rows)
+        # the members of the last call come out of its tensor with ONE gather; only newcomers (prefilled, resumed) are single rows
+        pos = [-1 if s in self.last_logits else self._lb_pos.get(s, -1) for s in batch]
+        new = [i for i, p in enumerate(pos) if p < 0]
+        if len(new) == len(batch):
+            return torch.stack([self.last_logits[s] for s in batch])
+        lb = self._lb_logits
+        if not new:
+            return lb.index_select(0, self._index(pos, lb.device))
+        # newcomers' rows ride at the end of the gather's source: one index_select over [last call's rows ; newcomers' rows]
+        src = torch.cat([lb, torch.stack([self.last_logits[batch[i]] for i in new]).to(lb.dtype)])
+        n0, k = lb.shape[0], 0
+        for i in new:
+            pos[i] = n0 + k
+            k += 1
+        return src.index_select(0, self._index(pos, lb.device))
+
+    def _index(self, pos: List[int], device) -> torch.Tensor:
+        """A row-index vector on `device`; on a GPU through a pinned buffer (torch.tensor(list, device=) stages synchronously:
+        120 us a step).  One buffer is enough: step() waits for this step's ids, queued behind the copy, before the next call."""
+        if device.type != "cuda":
+            return torch.tensor(pos, dtype=torch.long)
+        if getattr(self, "_idx_pin", None) is None or self._idx_pin.numel() < len(pos):
+            self._idx_pin = torch.empty(max(len(pos), 2 * self.max_batch), dtype=torch.int64, pin_memory=True)
+            self._idx_np = self._idx_pin.numpy()
+        self._idx_np[: len(pos)] = pos
+        return self._idx_pin[: len(pos)].to(device, non_blocking=True)
 
     def _tokens_to_host(self, tokens: torch.Tensor):
         """The sampled ids on their way to the host, requested NOW — ahead of the decode launches — and read after them."""
@@ -290,7 +326,11 @@ class BatchScheduler:
         if self.swapped:
             self._resume()
         if self.waiting:
+            ta = time.perf_counter()
             self._admit()
+            ta = time.perf_counter() - ta
+            self.stats["admit_s"] += ta
+            t0 += ta                                   # (prefill calls are accounted apart from the decode step's host time)
         batch = sorted(self.active, key=self.active.get)[: self.max_batch]      # oldest first (PriorityQueue, :16)
         if not batch:
             return []
