@@ -19,7 +19,7 @@ CORE_UNITS := paged_attention pa_variants_extra pa_append_core pa_append_extra p
 ABSENT_UNITS := pa_extras_absent
 EXTRAS_UNITS := pa_variants_bf16 pa_append_bf16 pa_variants_fp8_bf16 pa_variants_fp8_e5m2 pa_variants_fp8_e5m2_bf16 \
           pa_variants_sparse pa_variants_sparse_bf16 pa_f32 pa_extras_cache pa_extras_abi
-DIAG_UNITS := paged_attention pa_append_core pa_queue pa_split pa_stage
+DIAG_UNITS := paged_attention pa_append_core pa_variants_fp8 pa_queue pa_split pa_stage
 # pa_queue.hip holds its bfloat16 / E5M2 rows behind -DVMI_EXTRAS: one object for the product, one for the other two
 OBJS   := $(CORE_UNITS:%=$(OUTDIR)/%.hip.o) $(ABSENT_UNITS:%=$(OUTDIR)/%.hip.o)
 EXTRAS_OBJS := $(filter-out $(OUTDIR)/pa_queue.hip.o,$(CORE_UNITS:%=$(OUTDIR)/%.hip.o)) $(OUTDIR)/pa_queue.hip.extras.o \

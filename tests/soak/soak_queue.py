@@ -87,7 +87,7 @@ for seed in range(first, first + n_cases):
         lib.vmi_debug_set_queue_flags(0)
         return out
 
-    plain = attend(names["fp8_d64_bs16_h1_w1_u1_nt1" if f8 else f"d{D}_h1_w1_u1_nt1"], 0)
+    plain = attend(names["fp8_d64_bs16_h1_w1_u2_nt1" if f8 else f"d{D}_h1_w1_u1_nt1"], 0)
     # ((seed // 3) % 3 == 0: the default fp8 kernel, K pass on the matrix cores — single-wave modes bit-identical to EACH OTHER, all
     #  modes within the tolerance of the plain kernel; the VALU forms are bit-identical to the plain kernel as well)
     qn = names[("fp8_q_d64_s2q4m", "fp8_q_d64_s2q4", "fp8_q_d64_s1q2")[(seed // 3) % 3] if f8 else (f"q_d{D}_s1q2" if D == 64 else f"q_d{D}_s1q1")]

@@ -1,4 +1,4 @@
-"""Guard of the work-decomposition heuristic: in nine cells that span its regimes the DEFAULT pick must stay within 8 % of the
+"""Guard of the work-decomposition heuristic: in nine cells that span its regimes the DEFAULT pick must stay within 5 % of the
 best of a handful of named kernels — so that a kernel or threshold change that silently invalidates the offline sweeps
 (profiles/r04_pick_generalisation.md, r04_underfilled_chip.md, r05_split_kernels.md) fails a test instead.
 
@@ -16,7 +16,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOLERANCE = 1.08
+TOLERANCE = 1.05     # (round 6: 8 % -> 5 %; the widest margin measured over two passes of all cells is 2.5 %)
 PER_GRAPH = 12
 
 # name, batch, heads, head_size, seq_len, ragged, candidates
@@ -83,7 +83,7 @@ def _graph_us(wl, out, vid, dev):
 
 
 @pytest.mark.parametrize("cell", CELLS, ids=[c[0] for c in CELLS])
-def test_default_pick_is_within_8_percent_of_the_best_named_kernel(cell):
+def test_default_pick_is_within_5_percent_of_the_best_named_kernel(cell):
     from vllmini_amd import ops
     from vllmini_amd.workload import CONFIGS, make_workload
 
@@ -97,11 +97,18 @@ def test_default_pick_is_within_8_percent_of_the_best_named_kernel(cell):
                               num_blocks=2 * batch * per + 8, num_kv_heads=kv_heads)
     wl = make_workload(cfg, dev, seed=21, table_sets=2, ragged=ragged)
     out = torch.empty((batch, heads, head_size), dtype=torch.float16, device=dev)
+    from vllmini_amd import _lib
+
     ids = {n: i + 1 for i, n in enumerate(ops.variant_names())}
     default_a, label = _graph_us(wl, out, 0, dev)
     times = {}
     for c in candidates:
-        times[c] = min(_graph_us(wl, out, ids[c], dev)[0] for _ in range(2))
+        if c in ids:
+            times[c] = min(_graph_us(wl, out, ids[c], dev)[0] for _ in range(2))
+        else:   # a comparison point no pick rule returns: the diagnostic library holds it (same sources, same kernel)
+            with _lib.use_diag():
+                vid = ops.variant_names().index(c) + 1
+                times[c] = min(_graph_us(wl, out, vid, dev)[0] for _ in range(2))
     default_b, _ = _graph_us(wl, out, 0, dev)
     default = min(default_a, default_b)
     best_name = min(times, key=times.get)

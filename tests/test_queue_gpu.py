@@ -392,7 +392,7 @@ def test_default_entry_more_items_than_resident_waves_is_several_waves_per_head(
     assert ops.last_launch_label() == ("fp8_d64_bs16_h1_w4_u2_nt1" if f8 else "d64_h1_w8_u1_nt1")
     assert torch.isfinite(got).all()
     assert torch.equal(got, attend())
-    plain = attend(names["fp8_d64_bs16_h1_w1_u1_nt1" if f8 else "d64_h4_w1_u1_nt1"])
+    plain = attend(names["fp8_d64_bs16_h1_w1_u2_nt1" if f8 else "d64_h4_w1_u1_nt1"])
     assert float((got.float() - plain.float()).abs().max()) <= 1e-3 * (2.0 if f8 else 1.0)
     idx = np.unique(np.r_[0, 1, B // 2, B - 2, B - 1])
     tab_dev = wl.tables[0][torch.from_numpy(idx).to(dev)][:, : cfg.blocks_per_seq].clamp(min=0)
@@ -618,7 +618,7 @@ def test_default_entry_over_fp8_pages_between_half_a_chip_and_a_full_one(B, ragg
     got = attend()
     assert ops.last_launch_label() == kernel
     assert torch.isfinite(got).all() and torch.equal(got, attend())
-    plain = attend(names["fp8_d64_bs16_h1_w1_u1_nt1"])    # (the "m" kernel's q.K^T runs on the matrix cores: other fp32 summation
+    plain = attend(names["fp8_d64_bs16_h1_w1_u2_nt1"])    # (the "m" kernel's q.K^T runs on the matrix cores: other fp32 summation
     assert float((got.float() - plain.float()).abs().max()) <= 2e-3    #  order than the plain kernel's, same tolerance)
     idx = np.unique(np.r_[0, 1, B // 2, B - 1, int(np.argmax(lens)), int(np.argmin(lens))])
     tab_dev = wl.tables[0][torch.from_numpy(idx).to(dev)][:, : cfg.blocks_per_seq].clamp(min=0)

@@ -107,7 +107,7 @@ def test_more_items_than_are_resident_go_in_rounds(D):
     t = _upload(case, dev)
     ref = run_model(case)
     sub = 2                                                   # 24 items: resident for every width
-    for name in (f"d{D}_x8_u2_nt0", f"d{D}_x32_u1_nt1", f"d{D}_x128_u2_nt0", f"d{D}_x256_u1_nt0"):
+    for name in (f"d{D}_x8_u2_nt0", f"d{D}_x32_u2_nt1", f"d{D}_x128_u2_nt0", f"d{D}_x256_u2_nt0"):
         x = int(name.split("_x")[1].split("_")[0])
         if S * H * (x // 4) <= 3 * 256:
             continue                                          # (would not need rounds)
@@ -278,7 +278,7 @@ def test_grouped_query_and_alibi_through_a_split_kernel():
     slopes = (0.5 ** np.arange(1, 9)).astype(np.float32)
     from vllmini_amd import ops
 
-    vid = dict((n, i) for i, n in _split_names(64))["d64_x8_u1_nt0"]
+    vid = dict((n, i) for i, n in _split_names(64))["d64_x8_u2_nt0"]
     out = torch.full((4, 8, 64), float("nan"), dtype=torch.float16, device=dev)
     ops.paged_attention_v1(out, t["q"], t["kc"], t["vc"], 2, case["scale"], t["tab"], t["lens"], 16, t["msl"],
                            torch.from_numpy(slopes).to(dev), "auto", 1.0, 0, 0, 1, 1, 0, _variant=vid)
@@ -363,7 +363,7 @@ def test_a_workspace_is_reused_across_many_launches_and_shapes_and_results_do_no
     first = {}
     for rep in range(30):
         for k, (c, t, ref) in enumerate(cases):
-            for name in ("d64_x8_u1_nt0", "d64_x16_u1_nt0"):
+            for name in ("d64_x8_u2_nt0", "d64_x16_u2_nt0"):
                 got = _launch(c, t, names[name])
                 if rep == 0:
                     assert_close(got.cpu().numpy(), ref, f"{name} case {k}")
@@ -383,7 +383,7 @@ def test_a_poisoned_workspace_is_healed_by_the_reset_entry():
     case = make_case(rng, 4, 12, 64, [700, 512, 64, 1000])
     t = _upload(case, dev)
     ref = run_model(case)
-    vid = dict((n, i) for i, n in _split_names(64))["d64_x16_u1_nt0"]
+    vid = dict((n, i) for i, n in _split_names(64))["d64_x16_u2_nt0"]
     assert_close(_launch(case, t, vid).cpu().numpy(), ref, "clean")
     ws = ops.workspace_for(0, create=False)
     ws[256: 256 + 64].fill_(3)                    # arrival counters of the first items: "killed mid-flight"
@@ -436,7 +436,7 @@ def test_graph_replay_two_streams_and_two_host_threads():
     case = make_case(rng, 6, 12, 64, [1024, 999, 512, 100, 17, 640])
     t = _upload(case, dev)
     ref = run_model(case)
-    vid = dict((n, i) for i, n in _split_names(64))["d64_x16_u1_nt0"]
+    vid = dict((n, i) for i, n in _split_names(64))["d64_x16_u2_nt0"]
 
     # hipGraph: the capture stream's workspace must exist before the capture (nothing is allocated under capture)
     s = torch.cuda.Stream()

@@ -110,9 +110,11 @@ def _launch(case, vid, v2, kvd, kv_scale, bf):
     return out.view(torch.int16).cpu().numpy().view(np.uint16) if bf else out.cpu().numpy()
 
 
-def _walk(names, v2, cases):
+def _walk(names, v2, cases, only=None):
     checked, refused_everywhere, unparsed = 0, [], []
     for vid, name in enumerate(names, start=1):
+        if only is not None and name not in only:
+            continue
         m = NAME.match(name)
         if not m or bool(m["v2"]) != v2:
             unparsed.append(name)
@@ -185,6 +187,24 @@ def test_every_v2_variant_of_the_product_library_is_oracle_checked(extras):
     assert not unparsed, unparsed[:5]
     assert not refused, refused[:5]
     assert checked == len(names)
+
+
+def test_the_diagnostic_library_s_comparison_kernels_are_oracle_checked_too():
+    """Round 6 moved the work decompositions no pick rule returns out of the product menu into the diagnostic library
+    (pa_table_core.inc / pa_table_fp8.inc / pa_split.hip, #ifdef VMI_DIAG): the offline sweeps' comparison points.  They are
+    still kernels of this build — every one of them is run against the oracle here (the "loads only" bandwidth probes and the
+    LDS-staging experiment are the diagnostic library's only kernels that are wrong / unproven by design)."""
+    from vllmini_amd import _lib, ops
+
+    with _lib.use_extras():
+        shipped = set(ops.variant_names())
+    with _lib.use_diag():
+        names = ops.variant_names()
+        only = {n for n in names if n not in shipped and "LOADSONLY" not in n and not n.startswith("stage_")}
+        assert 50 <= len(only) <= 90, len(only)
+        checked, refused, unparsed = _walk(names, False, Cases(), only=only)
+    assert not unparsed and not refused, (unparsed[:5], refused[:5])
+    assert checked == len(only)
 
 
 def test_unknown_variant_ids_are_rejected():

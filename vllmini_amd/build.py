@@ -65,7 +65,7 @@ PRODUCT_UNITS = [(s, "") for s in CORE] + [(SRC_ABSENT, "")]
 EXTRAS_UNITS = [(s, "extras" if s == SRC_QUEUE else "") for s in CORE] + [(s, "") for s in EXTRAS]
 # the diagnostic library: these units are compiled again with -DVMI_DIAG (it changes their variant tables / entries),
 # pa_stage.hip exists only there, every other object is the extras library's
-DIAG_UNITS = [SRC, SRC_APPEND[0], SRC_QUEUE, SRC_SPLIT]
+DIAG_UNITS = [SRC, SRC_APPEND[0], SRC_FP8, SRC_QUEUE, SRC_SPLIT]
 DIAG_ONLY = [SRC_STAGE]
 DIAG_LIB_UNITS = [(s, "diag") if s in DIAG_UNITS else (s, f) for s, f in EXTRAS_UNITS] + [(s, "diag") for s in DIAG_ONLY]
 SOURCES = [*CORE, SRC_ABSENT, *EXTRAS]                        # every unit of the product and extras libraries
