@@ -866,6 +866,12 @@ def standin_main(args, dist, rank, world, dev):
                 w.wait()
         _EXCHANGE["work"] = [None, None]
     per_rank = shard.all_ranks(elapsed / args.steps * 1e3, dist, dev)     # the N > 1 line's per-rank figures, same code path
+    exch_us = None
+    if dist is not None:     # the exchange alone, as the real line reports it (wall clock here: no device events on CPU)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            exchange_tokens(dist, None)
+        exch_us = shard.max_over_ranks((time.perf_counter() - t0) / 20 * 1e6, dist, dev)
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
     placement = shard.gather_objects(_PLACEMENT, dist) if dist is not None else None
     legacy = None
@@ -892,6 +898,8 @@ def standin_main(args, dist, rank, world, dev):
                    "roofline": None, "cpu_baseline": None,
                    "method_version": 3, "timing_bracket": shard.TIMING_BRACKET, "ms_per_step_per_rank": per_rank,
                    "rank_placement": placement, "token_exchange_every_steps": EXCHANGE_EVERY,
+                   "token_exchange_us": exch_us, "rccl_ranks": world if placement is not None else None,
+                   "process_group_backend": "gloo (stand-in)" if placement is not None else None,
                    "legacy_method_step": legacy,
                    "self_launched": os.environ.get("VMI_BENCH_SELF_LAUNCHED") == "1"})
 
@@ -1306,6 +1314,8 @@ def main(argv=None):
                                   "and waited for one token later and before the closing synchronise; token_exchange_us = median "
                                   f"of {args.kernel_samples} BLOCKING exchanges alone, by HIP events")
         line["token_exchange_every_steps"] = EXCHANGE_EVERY
+        line["rccl_ranks"] = dist.get_world_size()          # ranks in the process group (backend "nccl" = RCCL on ROCm)
+        line["process_group_backend"] = dist.get_backend()
         line["rank_placement"] = shard.gather_objects(_PLACEMENT, dist)     # per rank: device uuid / PCI id, NUMA node, bound cores
         # the SAME K steps the way rounds 1-2 measured them: blocking exchange on every step, clock behind the barrier
         l_elapsed = shard.max_over_ranks(time_steps(wl, out, args.steps, args.warmup, args.variant, dist, dev, op=args.op, legacy=True),

@@ -62,6 +62,9 @@ def test_world_8_stand_in_of_the_scaling_curve(scaling, per_rank):
     assert line["token_exchange_every_steps"] == 12
     per = line["ms_per_step_per_rank"]
     assert len(per) == 8 and all(x > 0 for x in per) and max(per) == pytest.approx(line["ms_per_step"])
+    # what the first real 8-GPU line must carry beside `value`: the ranks of the process group, every rank's figure, the
+    # exchange's own duration (the real line: backend nccl = RCCL, per-rank kernel medians too — same keys, same code path)
+    assert line["rccl_ranks"] == 8 and line["token_exchange_us"] > 0 and "gloo" in line["process_group_backend"]
     assert line["value"] == pytest.approx(2048 * 25 / (line["ms_per_step"] * 25 / 1e3), rel=1e-6)
     place = line["rank_placement"]
     assert [p["local_rank"] for p in place] == list(range(8))

@@ -154,7 +154,7 @@ def test_long_contexts_use_every_wave_of_the_widest_split_kernels(D):
     names = dict((n, i) for i, n in _split_names(D))
     first = None
     for x in (64, 128, 256):
-        for u, nt in ((2, 0), (1, 1)):
+        for u, nt in ((2, 0), (2, 1)):
             name = f"d{D}_x{x}_u{u}_nt{nt}"
             got = _launch(case, t, names[name])
             assert_close(got.cpu().numpy(), ref, name)
