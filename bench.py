@@ -747,7 +747,10 @@ def serve_measure(args, dev, rank=0, requests=None, note_extra=""):
     mean_mid = float(np.mean([len(p) + k / 2 for p, k in zip(prompts, new)]))
     want = int(args.serve_pool_frac * args.serve_max_batch * L * (mean_mid / bs + 1))
     nblocks = args.serve_pool_blocks or max(want, L * mb + 64)
-    pool = PagedKVPool(nblocks, dims.n_head, dims.head_size, bs, mb, L, device=dev, max_seqs=args.serve_max_batch + 8)
+    pool = PagedKVPool(nblocks, dims.n_head, dims.head_size, bs, mb, L, device=dev, max_seqs=args.serve_max_batch + 8,
+                       host_blocks=max(nblocks // 4, L * mb))
+    if args.serve_preempt == "swap":
+        pool.reserve_host()          # (the pinned host pool of a server exists before its first request)
     deferred = not args.serve_no_deferred_scatter
     dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, deferred_scatter=deferred,
                            scatter_in_c_attn=None if not deferred else None, pad_batch_to=0 if args.serve_eager else 32)
@@ -1230,10 +1233,10 @@ def main(argv=None):
             int(((wl.seq_lens + cfg.block_size - 1) // cfg.block_size).sum().item()) * 4 + cfg.batch * 4
     achieved = line_bytes / (ks["median"] * 1e-6) / 1e9
     # the variant the library actually launched (it knows the launch's kv_scale, the pick queries do not)
-    vid = args.variant or (ops.last_variant() if args.op in ("v1", "fused") else 0)
+    vid = args.variant or (ops.last_variant() if args.op in ("v1", "fused", "newest") else 0)
     vname = ops.variant_names()[vid - 1] if vid else f"paged_attention_v2 variant {args.variant or 'auto'}"
     traffic, traffic_src = (pmc_traffic(cfg.name + {"auto": "", "fp8": "_fp8", "fp8_e5m2": "_fp8_e5m2"}[args.kv], vname) if args.op == "v1" else
-                            pmc_traffic(cfg.name + "_fused", vname) if args.op == "fused" else (None, None))
+                            pmc_traffic(cfg.name + "_" + args.op, vname) if args.op in ("fused", "newest") else (None, None))
     line = {
         "metric": "decode_tokens_per_sec_paged_attention_v1_per_layer",
         "value": tokens / elapsed,

@@ -4,6 +4,9 @@
 T=${1:-r04z}
 scripts/profile_bench.sh ${T}_cfg3 > /dev/null 2>&1
 scripts/profile_bench.sh ${T}_cfg3_ragged --ragged > /dev/null 2>&1
+scripts/profile_bench.sh ${T}_cfg3_fused --op fused > /dev/null 2>&1                   # reshape_and_cache + attention in one launch
+scripts/profile_bench.sh ${T}_cfg3_newest --op newest > /dev/null 2>&1                 # append-read attention, no cache write (round 6)
+scripts/profile_bench.sh ${T}_cfg3_newest_ragged --op newest --ragged > /dev/null 2>&1
 scripts/profile_bench.sh ${T}_cfg3_fp8 --kv fp8 > /dev/null 2>&1
 scripts/profile_bench.sh ${T}_cfg3_fp8_ragged --kv fp8 --ragged > /dev/null 2>&1
 scripts/profile_bench.sh ${T}_cfg4 --config cfg4 > /dev/null 2>&1
@@ -14,7 +17,7 @@ scripts/profile_bench.sh ${T}_long_b1 --config long_b1 > /dev/null 2>&1         
 scripts/profile_bench.sh ${T}_long_b4 --config long_b4 > /dev/null 2>&1             # batch 4 x 8192 tokens
 scripts/profile_bench.sh ${T}_long_gqa --config long_gqa > /dev/null 2>&1           # batch 4 x 8192 tokens, 32 / 8 heads x 128: four query heads per item
 scripts/profile_bench.sh ${T}_long_32k --config long_32k > /dev/null 2>&1           # batch 48 x 32768 tokens: past the plain kernels' LDS, in rounds
-for c in cfg3 cfg3_ragged cfg3_fp8 cfg3_fp8_ragged cfg4 cfg4_ragged cfg2 cfg5_strong long_b1 long_b4 long_gqa long_32k; do
+for c in cfg3 cfg3_ragged cfg3_fused cfg3_newest cfg3_newest_ragged cfg3_fp8 cfg3_fp8_ragged cfg4 cfg4_ragged cfg2 cfg5_strong long_b1 long_b4 long_gqa long_32k; do
   python - "$T" "$c" <<'PY'
 import json, sys, glob, shutil, os
 t, c = sys.argv[1], sys.argv[2]

@@ -167,16 +167,21 @@ class PagedKVPool:
         esz = 1 if self.kv_cache_dtype in ("fp8", "fp8_e4m3", "fp8_e5m2") else 2
         return self.num_heads * self.head_size * self.block_size * esz
 
-    def _move_blocks(self, to_host: bool, pairs: np.ndarray) -> None:
-        if self.key_cache is None:          # bookkeeping only (CPU tests)
-            return
-        from . import cache_ops
-        if self.host_key_cache is None:     # pinned: the GPU reads / writes these pages directly (one launch per swap)
-            pin = self.device.type == "cuda"
+    def reserve_host(self) -> None:
+        """Allocate the pinned host pool now (else at the first swap_out: pinning host_blocks x 2 x block_bytes takes a
+        fraction of a second per GB — a server does it at start-up, not under its first preemption)."""
+        if self.key_cache is not None and self.host_key_cache is None:
+            pin = self.device.type == "cuda"    # pinned: the GPU reads / writes these pages directly (one launch per swap)
             self.host_key_cache = torch.empty((self.host_blocks,) + tuple(self.key_cache.shape[1:]),
                                               dtype=self.key_cache.dtype, pin_memory=pin)
             self.host_value_cache = torch.empty((self.host_blocks,) + tuple(self.value_cache.shape[1:]),
                                                 dtype=self.value_cache.dtype, pin_memory=pin)
+
+    def _move_blocks(self, to_host: bool, pairs: np.ndarray) -> None:
+        if self.key_cache is None:          # bookkeeping only (CPU tests)
+            return
+        from . import cache_ops
+        self.reserve_host()
         dev, host = (self.key_cache, self.value_cache), (self.host_key_cache, self.host_value_cache)
         src, dst = (dev, host) if to_host else (host, dev)
         cache_ops.swap_blocks_batched(src[0], src[1], dst[0], dst[1], torch.from_numpy(np.ascontiguousarray(pairs)))
