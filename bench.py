@@ -37,6 +37,15 @@ Beside `value` (never as it), each a sub-record of the same line:
                 vllmini_amd.gpt2_decode + kv_pool: decode tokens/s — BASELINE's first metric — and the share of the
                 step spent in the two operators
 
+  deferred_scatter_step   a TOKEN of a 12-layer model on the cfg3 shape (12 disjoint table sets): 12 call pairs against 12 append-read
+                attention launches + ONE reshape_and_cache for the 12 layers' rows, per layer step (round 6, N = 1)
+  serve_step    the continuous-batching scheduler itself (vllmini_amd/scheduler.py over GPT2PagedDecoder): a seeded closed-loop
+                trace of ragged requests, batched admission, refills, preemption by swap — generated tokens/s, per-token latency,
+                occupancy, host us per step beside the GPU wait, swap traffic (`--serve` alone runs the 2048-request trace)
+
+The headline's timed region holds EXACTLY K steps; a region shorter than --min-timed-ms (50) is repeated and the line reports the
+MEDIAN region with every region listed (`ms_per_step_regions`).  The e2e records report the median of three regions.
+
 Multi-GPU: sequences are sharded over ranks as independent KV pools, no collective on the data
 path.  --scaling weak (default): 256 sequences per GPU, pool of 65536 blocks (BASELINE configs[4]); --scaling strong:
 2048 sequences in all, 2048/N per GPU, pool = max(65536, what the batch needs).  For N > 1 the timed region also holds
