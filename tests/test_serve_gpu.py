@@ -155,11 +155,16 @@ def test_scheduler_drop_mode_loses_the_victims_like_the_reference():
     assert sorted(dec.pool.free_blocks) == list(range(3 * 22))
 
 
-def test_prefill_batch_matches_prefill_one_by_one():
+@pytest.mark.parametrize("paged", [True, False], ids=["paged", "eager"])
+def test_prefill_batch_matches_prefill_one_by_one(paged):
+    """prefill_batch — its causal attention as ONE paged_attention_v1 launch over the prompts' positions (paged_prefill, the
+    default on the GPU), or eager on padded groups — against the reference-style prefill of one prompt at a time (eager masked
+    attention, gpt2.py:46-58): same blocks, tables and slots; logits and caches within fp16-GEMM noise; decisive argmaxes equal."""
     rng = np.random.default_rng(5)
     prompts = [rng.integers(0, 500, n).tolist() for n in (1, 16, 17, 3, 90, 33, 64)]
-    _, one = _model(num_blocks=400)
-    _, many = _model(num_blocks=400)
+    _, one = _model(num_blocks=400, paged_prefill=False)
+    _, many = _model(num_blocks=400, paged_prefill=paged)
+    assert many.paged_prefill == paged and (many._prefill_variant() > 0) == paged or not paged
     many.PREFILL_SCORE_BYTES = 3 * 2 * 90 * 90 * 2            # forces several padded groups inside the one call
     ref = torch.stack([one.prefill(i, p) for i, p in enumerate(prompts)])
     got = many.prefill_batch(list(range(len(prompts))), prompts)

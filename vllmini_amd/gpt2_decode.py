@@ -88,7 +88,8 @@ class GPT2PagedDecoder:
 
     def __init__(self, dims: GPT2Dims, state_dict: Dict[str, torch.Tensor], pool: PagedKVPool,
                  reference_off_by_one: bool = False, fused_append: bool = False, native_layers: Optional[bool] = None,
-                 scatter_in_c_attn: Optional[bool] = None, deferred_scatter: bool = False, pad_batch_to: int = 0):
+                 scatter_in_c_attn: Optional[bool] = None, deferred_scatter: bool = False, pad_batch_to: int = 0,
+                 paged_prefill: Optional[bool] = None):
         assert pool.num_layers == dims.n_layer and pool.num_heads == dims.n_head
         assert pool.head_size == dims.head_size
         self.dims, self.sd, self.pool = dims, state_dict, pool
@@ -151,6 +152,11 @@ class GPT2PagedDecoder:
         self._static: Optional[dict] = None        # the static buffers of the batch size used last (see _ensure_static)
         self._sets: Dict[int, dict] = {}
         self._cur: Optional[dict] = None
+        # paged_prefill (round 6): prefill_batch runs its causal attention through paged_attention_v1 itself — every prompt
+        # position is a "sequence" of length position + 1 over its prompt's block table, after the layer's K / V rows are in the
+        # cache — instead of the reference's eager masked attention (gpt2.py:46-58): one launch per layer for all prompts of
+        # the call, and prefill logits with the decode path's own arithmetic.  None = on a HIP device; False = eager.
+        self.paged_prefill = (pool.device.type == "cuda") if paged_prefill is None else bool(paged_prefill)
         self.pad_batch_to = int(pad_batch_to)      # decode steps are laid out for the next multiple of this many rows (0: as they come)
 
     # ---- pieces shared by prefill and decode --------------------------------------------------------
@@ -200,9 +206,12 @@ class GPT2PagedDecoder:
     def prefill_batch(self, seq_ids: Sequence[int], prompts: Sequence[Sequence[int]]) -> torch.Tensor:
         """Admission of several prompts in ONE pass (round 6): the prompts' tokens run through the block's layers as one
         packed [sum T, E] matrix, every layer writes ALL their K / V rows with one reshape_and_cache (concatenated slots —
-        the op is batched over tokens, cache_kernels.cu:219-260), and the causal attention (eager, as the reference's
-        prefill: gpt2.py:46-58, 71-78) runs on the prompts padded to the longest, [n, H, T, T] scores at a time.
-        Returns the last-token logits [n, V]; per sequence the same arithmetic as prefill() up to GEMM tiling."""
+        the op is batched over tokens, cache_kernels.cu:219-260), and the causal attention is ONE paged_attention_v1 launch
+        over sum T "sequences" — position t of a prompt attends to the first t + 1 tokens of that prompt's pages, a ragged
+        batch the balanced kernels are built for (paged_prefill) — or, eager as the reference's prefill (gpt2.py:46-58,
+        71-78), on the prompts padded to the longest, [n, H, T, T] scores at a time.
+        Returns the last-token logits [n, V]; per sequence the arithmetic of prefill() up to GEMM tiling (eager) / of the
+        decode steps that would have produced the same context (paged)."""
         n = len(seq_ids)
         lens = [len(p) for p in prompts]
         if n == 0:
@@ -211,9 +220,11 @@ class GPT2PagedDecoder:
         H, D, E = d.n_head, d.head_size, d.n_embd
         done = []
         try:
-            slots = []
+            slots, tabs = [], []
             for sid, T in zip(seq_ids, lens):
-                slots.append(pool.allocate_for_prefill(sid, T)[1])          # [layers, T]
+                _, sl, tb = pool.allocate_for_prefill(sid, T)                # slots [layers, T], table [layers, MB]
+                slots.append(sl)
+                tabs.append(tb)
                 done.append(sid)
         except RuntimeError:
             for sid in done:       # all or nothing: the caller retries with a smaller group
@@ -224,6 +235,14 @@ class GPT2PagedDecoder:
         starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         pos = torch.from_numpy(np.concatenate([np.arange(T, dtype=np.int64) for T in lens])).to(dev)
         x = self.sd["transformer.wte.weight"][ids] + self.sd["transformer.wpe.weight"][pos]
+        paged = self.paged_prefill
+        if paged:
+            mbe = -(-max(lens) // pool.block_size)
+            seq_of_tok = torch.from_numpy(np.repeat(np.arange(n, dtype=np.int64), lens)).to(dev)
+            tables_seq = torch.from_numpy(np.ascontiguousarray(np.stack(tabs, axis=1)[:, :, :mbe])).to(dev)   # [layers, n, mbe]
+            tables_tok = tables_seq[:, seq_of_tok, :].contiguous()                                              # [layers, sum T, mbe]
+            lens_tok = (pos + 1).to(torch.int32)
+            pvar = self._prefill_variant()
         # groups of prompts whose padded scores fit the budget, longest first inside the call's own order
         groups, cur, cur_T = [], [], 0
         for i in range(n):
@@ -235,7 +254,7 @@ class GPT2PagedDecoder:
             cur_T = T
         groups.append(cur)
         plans = []
-        for g in groups:
+        for g in ([] if paged else groups):
             T = max(lens[i] for i in g)
             idx = np.zeros((len(g), T), dtype=np.int64)                      # packed row of (prompt, position); pads -> row 0
             valid = np.zeros((len(g), T), dtype=bool)
@@ -250,6 +269,10 @@ class GPT2PagedDecoder:
             q, k, v = self._qkv(self._ln(x, p + "ln_1"), p)                                       # [sum T, H, D] views
             cache_ops.reshape_and_cache(k, v, pool.key_cache, pool.value_cache, slots_dev[i], pool.kv_cache_dtype, pool.kv_scale)
             a = torch.empty((x.shape[0], E), dtype=x.dtype, device=dev)
+            if paged:
+                ops.paged_attention_v1(a.view(-1, H, D), q, pool.key_cache, pool.value_cache, H, self.scale, tables_tok[i], lens_tok,
+                                       pool.block_size, mbe * pool.block_size, None, pool.kv_cache_dtype, pool.kv_scale, 0, 0, 1, 1, 0,
+                                       _variant=pvar)
             for idx, valid, rows, mask in plans:
                 qh, kh, vh = (t[idx].transpose(1, 2) for t in (q, k, v))                          # [g, H, T, D]
                 w = torch.matmul(qh, kh.transpose(-1, -2)) * self.scale + mask                    # gpt2.py:72-74
@@ -259,6 +282,23 @@ class GPT2PagedDecoder:
             x = x + self._mlp(self._ln(x, p + "ln_2"), p)
         last = torch.from_numpy(starts[1:] - 1).to(dev)
         return F.linear(self._ln(x[last], "transformer.ln_f"), self.sd["lm_head.weight"])
+
+    def _prefill_variant(self) -> int:
+        """The work decomposition of the prefill launch.  Its "sequences" are the positions of a few prompts: thousands of short
+        items that re-read each other's pages, so what wins is one wave per (position, head) with TEMPORAL page loads, four
+        blocks deep — the prompt's pages stay in L2 (64 prompts U{4..512}: 530 us against 754 for the default pick, which sees
+        10 GB of pages and streams them; 8 prompts 45 against 89: scripts/prefill_attention_variants.py).  0 = the library picks."""
+        if getattr(self, "_pvar", None) is None:
+            self._pvar = 0
+            if self.pool.kv_cache_dtype == "auto" and self.pool.block_size == 16:
+                hpw = 4 if self.dims.n_head % 4 == 0 else 1
+                names = ops.variant_names()
+                for u in (4, 2):
+                    name = f"d{self.dims.head_size}_h{hpw}_w1_u{u}_nt0"
+                    if name in names:
+                        self._pvar = names.index(name) + 1
+                        break
+        return self._pvar
 
     # ---- batched decode -------------------------------------------------------------------------------
     def _forward_decode(self, st: dict) -> torch.Tensor:

@@ -264,7 +264,7 @@ class BatchScheduler:
         if not group:
             return
         self._last_admit_step = self.steps
-        if len(group) > 1 and hasattr(self.decoder, "prefill_batch"):
+        if hasattr(self.decoder, "prefill_batch") and (len(group) > 1 or getattr(self.decoder, "paged_prefill", False)):
             logits = self.decoder.prefill_batch([g[0] for g in group], [g[1] for g in group])
             self.stats["prefill_calls"] += 1
             for i, (sid, ids) in enumerate(group):
