@@ -234,3 +234,50 @@ def test_max_length_beyond_the_block_table_is_refused_up_front():
     BatchScheduler(dec, max_length=48, eos_token_id=EOS)                 # (4 - 1) * 16 tokens: fits
     with pytest.raises(ValueError, match="does not fit"):
         BatchScheduler(dec, max_length=49, eos_token_id=EOS)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_randomised_serving_runs_complete_every_request_with_the_expected_tokens(seed):
+    """Seeded random traces through the serving loop on the stand-in decoder: arrivals between steps (submit and add_sequence
+    mixed), ragged prompts, per-request lengths, pools from roomy to barely enough, host pools from ample to too small,
+    admission cadence 1 ... 8 — whatever is preempted, resumed, or (only when the host pool is full) dropped, every surviving
+    request ends with exactly the tokens of its solo run, and every block — device and host — is back at the end."""
+    rng = np.random.default_rng(1000 + seed)
+    layers = int(rng.integers(1, 4))
+    mbs = 8
+    nblocks = int(rng.integers(layers * mbs + 2, 6 * layers * mbs))
+    ample = 40 * nblocks                                      # (room for every request's pages at once)
+    host = int(rng.choice([ample, ample, layers * 3, layers * mbs]))
+    dec = FakeDecoder(num_blocks=nblocks, layers=layers, max_blocks_per_seq=mbs, host_blocks=host)
+    sch = BatchScheduler(dec, max_length=(mbs - 1) * 16, eos_token_id=EOS, max_batch=int(rng.integers(1, 7)), sampler=sample_greedy,
+                         admit_every=int(rng.integers(1, 9)), headroom_blocks=int(rng.choice([0, layers])) if rng.random() < 0.7 else None,
+                         record_latency=bool(seed % 2))
+    reqs = {}
+    pending = [(rng.integers(1, V - 1, int(rng.integers(1, 60))).tolist(), int(rng.integers(1, 50))) for _ in range(int(rng.integers(3, 25)))]
+    steps = 0
+    while pending or sch.pending():
+        for _ in range(int(rng.integers(0, 4))):
+            if pending:
+                p, k = pending.pop()
+                try:
+                    sid = sch.submit(p, max_new_tokens=k) if rng.random() < 0.7 else sch.add_sequence(p, max_new_tokens=k)
+                except RuntimeError as e:       # add_sequence with nothing left to preempt: the request is refused, nothing leaks
+                    assert "free blocks" in str(e)
+                    continue
+                reqs[sid] = (p, k)
+        sch.step()
+        steps += 1
+        owned = [b for s in dec.pool.allocated_blocks for b in dec.pool.allocated_blocks[s]]
+        assert len(owned) == len(set(owned)) and not set(owned) & set(dec.pool.free_blocks)          # no block owned twice
+        assert set(sch.active) == set(dec.pool.allocated_blocks) and set(sch.swapped) == set(dec.pool.swapped)
+        assert steps < 5000, "the loop does not terminate"
+    assert not sch.active and not sch.swapped and not sch.waiting and not sch.last_logits
+    assert sorted(dec.pool.free_blocks) == list(range(nblocks)) and sorted(dec.pool._host_free) == list(range(dec.pool.host_blocks))
+    cap = (mbs - 1) * 16
+    for sid, (p, k) in reqs.items():
+        want = _expected(p, min(cap, len(p) + k))[: min(cap, len(p) + k)] if len(p) < cap else p
+        if sid in sch.evicted:
+            assert sch.sequences[sid] == want[: len(sch.sequences[sid])] and host < ample   # dropped only when the host pool can fill up
+        else:
+            assert sch.sequences[sid] == want, (sid, len(p), k)
+    assert sch.stats["resumes"] <= sch.stats["preemptions"]
