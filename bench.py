@@ -125,6 +125,7 @@ def build_parser():
                     help="blocks kept free per running sequence at admission (0: a prompt is admitted whenever it fits; growth preempts)")
     ap.add_argument("--serve-pool-frac", type=float, default=0.7, help="pool = this share of what max_batch mid-life sequences hold")
     ap.add_argument("--serve-preempt", default="swap", choices=("swap", "drop"))
+    ap.add_argument("--serve-kv", default="auto", choices=("auto", "fp8"), help="KV pages of the serving run (fp8 = E4M3: the same pool bytes hold twice the tokens)")
     ap.add_argument("--serve-no-deferred-scatter", action="store_true", help="the reference's call pair per layer instead")
     ap.add_argument("--serve-eager", action="store_true", help="plain launches instead of hipGraph replay")
     ap.add_argument("--no-serve", action="store_true", help="skip the extra serving-loop measurement")
@@ -757,10 +758,10 @@ def serve_measure(args, dev, rank=0, requests=None, note_extra=""):
     want = int(args.serve_pool_frac * args.serve_max_batch * L * (mean_mid / bs + 1))
     nblocks = args.serve_pool_blocks or max(want, L * mb + 64)
     pool = PagedKVPool(nblocks, dims.n_head, dims.head_size, bs, mb, L, device=dev, max_seqs=args.serve_max_batch + 8,
-                       host_blocks=max(nblocks // 4, L * mb))
+                       host_blocks=max(nblocks // 4, L * mb), kv_cache_dtype=args.serve_kv)
     if args.serve_preempt == "swap":
         pool.reserve_host()          # (the pinned host pool of a server exists before its first request)
-    deferred = not args.serve_no_deferred_scatter
+    deferred = not args.serve_no_deferred_scatter and args.serve_kv == "auto"      # (the append-read kernels are built for fp16 pages)
     dec = GPT2PagedDecoder(dims, random_state_dict(dims, dev, seed=rank), pool, deferred_scatter=deferred,
                            scatter_in_c_attn=None if not deferred else None, pad_batch_to=0 if args.serve_eager else 32)
     g = torch.Generator(device=dev).manual_seed(5 + rank)
@@ -820,7 +821,7 @@ def serve_measure(args, dev, rank=0, requests=None, note_extra=""):
            "preemptions": st["preemptions"], "resumes": st["resumes"], "dropped": st["dropped"],
            "swap_out_MB": ss["bytes_out"] / 1e6, "swap_in_MB": ss["bytes_in"] / 1e6,
            "pool_blocks": nblocks, "pool_GB": 2 * nblocks * pool.block_bytes / 1e9, "sampler": args.serve_sampler,
-           "preempt": args.serve_preempt, "deferred_scatter": deferred, "graph_replay": not args.serve_eager,
+           "preempt": args.serve_preempt, "kv_cache_dtype": args.serve_kv, "deferred_scatter": deferred, "graph_replay": not args.serve_eager,
            "trace": f"closed loop, all {requests} requests queued at t = 0; prompts U{{4..{args.serve_max_prompt}}} tokens "
                     f"(mean {np.mean([len(p) for p in prompts]):.0f}), outputs geometric (mean {np.mean(new):.0f}), prompt + output "
                     f"<= {max_length}; seed 17",
@@ -1412,12 +1413,24 @@ def main(argv=None):
                                      "kernel issues NO MFMA; the matrix cores are used by the grouped-query kernels only"}
         del wl4, out4
         torch.cuda.empty_cache()
+    def guarded(key, fn):
+        """A sub-record that fails must not take the headline with it (N = 1; with several ranks an exception on one of them
+        would leave the others inside a collective, so there it propagates): the record says what went wrong instead."""
+        if dist is not None:
+            line[key] = fn()
+            return
+        try:
+            line[key] = fn()
+        except Exception as e:       # noqa: BLE001 — reported on the line, never hidden
+            line[key] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            torch.cuda.empty_cache()
+
     if plain and not args.no_cfg2 and args.config == "cfg3" and not args.variant:
-        line["cfg2_step"] = cfg2_record(args, dist, rank, world, dev)
+        guarded("cfg2_step", lambda: cfg2_record(args, dist, rank, world, dev))
     if plain and not args.no_strong and args.config == "cfg3" and not args.variant and dist is None:
-        line["cfg5_strong_n1"] = strong_n1_record(args, dev)
+        guarded("cfg5_strong_n1", lambda: strong_n1_record(args, dev))
     if plain and not args.no_deferred and args.config == "cfg3" and not args.variant and dist is None:
-        line["deferred_scatter_step"] = deferred_scatter_record(args, dev)
+        guarded("deferred_scatter_step", lambda: deferred_scatter_record(args, dev))
     if plain and not args.no_e2e and args.config == "cfg3" and not args.variant:
         # every step appends a token: a long timed region would measure a longer context than the ~1 k the record is quoted on
         # (the default 200 + 20 steps end at 1 230 tokens: +22 % bytes in the last step) — the sub-record runs at most 24 + 6 steps
@@ -1468,10 +1481,10 @@ def main(argv=None):
                                               "torch_module_layers_us_per_token": r2t["ms_per_step"] * 1e3}
         args = args_main
     if plain and not args.no_long and args.config == "cfg3" and not args.variant and dist is None:
-        line["long_context_step"] = long_context_record(args, dev)
+        guarded("long_context_step", lambda: long_context_record(args, dev))
     if plain and not args.no_serve and args.config == "cfg3" and not args.variant and dist is None:
         # the continuous-batching scheduler itself: a bounded trace inside the default run, 2048 with --serve
-        line["serve_step"] = serve_measure(args, dev, rank, requests=min(args.serve_requests, 1024))
+        guarded("serve_step", lambda: serve_measure(args, dev, rank, requests=min(args.serve_requests, 1024)))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

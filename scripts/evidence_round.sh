@@ -12,6 +12,8 @@ python bench.py --scaling strong --config cfg5_strong --headline-only > $O/${T}_
 python bench.py --serve 2> $O/${T}_serve.err; cp $O/serve.json $O/${T}_serve.json
 python bench.py --serve --serve-preempt drop 2> /dev/null; cp $O/serve.json $O/${T}_serve_drop.json
 python bench.py --serve --serve-no-deferred-scatter 2> /dev/null; cp $O/serve.json $O/${T}_serve_call_pair.json
+python bench.py --serve --serve-kv fp8 2> /dev/null; cp $O/serve.json $O/${T}_serve_fp8.json
+python bench.py --serve --serve-pool-frac 1.5 2> /dev/null; cp $O/serve.json $O/${T}_serve_roomy_pool.json
 python - "$T" <<'PY'
 import json, sys
 t = sys.argv[1]
@@ -20,7 +22,7 @@ for n in ("bench_cfg3", "bench_forced_dist_n1", "bench_forced_dist_n1_strong", "
     print(n, l["config"]["workload"][:40], "ms/step %.4f" % l["ms_per_step"], "regions", l.get("timed_regions"), "%.1f ms" % l.get("timed_region_ms", 0),
           "kernel %.2f" % l["paged_attention_v1_us_median"], "frac %.3f" % l["roofline"]["frac"], "traffic", l["roofline"]["traffic"],
           "exch", l.get("token_exchange_us"), "ranks", l.get("rccl_ranks"))
-for n in ("serve", "serve_drop", "serve_call_pair"):
+for n in ("serve", "serve_drop", "serve_call_pair", "serve_fp8", "serve_roomy_pool"):
     s = json.load(open(f"gpurun_out/{t}_{n}.json"))
     print(n, {k: (round(s[k], 1) if isinstance(s[k], float) else s[k]) for k in ("value", "wall_s", "decode_steps", "batch_occupancy", "host_us_per_step", "gpu_wait_us_per_step", "admit_s", "preemptions", "dropped", "swap_out_MB")}, s["token_latency_ms"])
 PY
