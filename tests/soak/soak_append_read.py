@@ -114,9 +114,11 @@ for seed in range(first, first + n_cases):
     ops.paged_attention_v1_append(out_f, q, key, value, kc_f, vc_f, Hkv, scale, tab, lens_d, BS, msl)
     torch.cuda.synchronize()
     live = torch.from_numpy(lens > 0).to(dev)
+    ref_f = out_p[live].float()
+    tol = 2.0 * torch.exp2(torch.floor(torch.log2(ref_f.abs().clamp_min(2.0 ** -14))) - 10.0)      # 2 fp16 ulp at |out|
     if not (torch.equal(kc_f.view(i16), kc_p.view(i16)) and torch.equal(vc_f.view(i16), vc_p.view(i16))
-            and float((out_f[live].float() - out_p[live].float()).abs().max() if bool(live.any()) else 0.0) <= 2.0 ** -9):
-        # (2 fp16 ulp at |out| ~ 1: the fused entry may run another decomposition than the pair — the grouped-query kernels sum
+            and bool(((out_f[live].float() - ref_f).abs() <= torch.clamp_min(tol, 1e-3)).all())):
+        # (max(1e-3, 2 fp16 ulp at |out|) — this step's value rows are N(0, 1), outputs reach 2 - 3: the fused entry may run another decomposition than the pair — the grouped-query kernels sum
         #  q.K^T on the matrix cores — and one flipped fp16 probability of a 2-3-token context moves an output by that much; every
         #  decomposition is pinned to the oracle at that bound by tests/test_parity_gpu.py)
         fails += 1

@@ -105,7 +105,7 @@ for seed in range(first, first + n_cases):
         label = ops.last_launch_label()
         picked[label.split(" ")[0]] = picked.get(label.split(" ")[0], 0) + 1
         again = attend(0)
-        plain = attend(names[("fp8_d%d_bs16_h1_w1_u1_nt1" % D) if f8 else f"d{D}_h1_w1_u1_nt1"])
+        plain = attend(names[("fp8_d%d_bs16_h1_w1_u%d_nt1" % (D, 2 if D == 64 else 1)) if f8 else f"d{D}_h1_w1_u1_nt1"])
     except RuntimeError as e:
         print(f"FAIL {what}: {e}")
         fails += 1
