@@ -142,6 +142,18 @@ def test_submitted_requests_are_admitted_in_groups_and_refill_the_batch():
     assert sorted(dec.pool.free_blocks) == list(range(64)) and not sch.pending()
 
 
+def test_a_request_that_can_never_fit_is_rejected_and_the_loop_goes_on():
+    dec = FakeDecoder(num_blocks=8, layers=2, max_blocks_per_seq=8)                # 8 blocks: a 70-token prompt needs 2 x 5
+    sch = BatchScheduler(dec, max_length=100, eos_token_id=EOS, sampler=sample_greedy)
+    a = sch.submit([3] * 5, max_new_tokens=4)
+    big = sch.submit([7] * 70, max_new_tokens=4)
+    c = sch.submit([9] * 6, max_new_tokens=3)
+    sch.run()
+    assert big in sch.rejected and "free blocks" in sch.rejected[big] and sch.sequences[big] == [7] * 70
+    assert sch.sequences[a] == _expected([3] * 5, 9) and sch.sequences[c] == _expected([9] * 6, 9)
+    assert not sch.pending() and sorted(dec.pool.free_blocks) == list(range(8))
+
+
 def test_out_of_blocks_drop_mode_is_the_reference_behaviour():
     # 2 layers, 16-token blocks: each sequence needs 2 blocks at prefill and 2 more at token 17
     dec = FakeDecoder(num_blocks=10, layers=2)

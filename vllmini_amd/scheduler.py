@@ -113,6 +113,7 @@ class BatchScheduler:
         self.swapped: Dict[int, int] = {}                    # preempted, pages on the host: seq_id -> arrival index
         self.waiting: collections.deque = collections.deque()   # submitted, not prefilled yet: (seq_id, ids)
         self.evicted: List[int] = []                         # dropped for good (the reference's handle_out_of_memory)
+        self.rejected: Dict[int, str] = {}                   # submitted requests that can never fit the pool: seq_id -> why
         self.steps = 0
         # the last decode call's logits stay ONE tensor: a step whose batch is the previous one samples from it directly
         self._lb_ids: List[int] = []
@@ -259,11 +260,26 @@ class BatchScheduler:
             group.append((sid, ids))
             free -= need
             tokens += len(ids)
+        alone = False
         if not group and not self.active and self.waiting:      # nothing runs and the head of the queue does not "fit": try it alone
             group.append(self.waiting.popleft())
+            alone = True
         if not group:
             return
         self._last_admit_step = self.steps
+        try:
+            self._prefill_group(group)
+        except RuntimeError as e:
+            # a request the EMPTY pool cannot hold (more blocks than exist, or a prompt past the block table) can never run: it is
+            # refused — recorded with the reason, its id keeps answering sequences[...] with the prompt — and the loop goes on
+            if not alone or not any(k in str(e) for k in ("free blocks", "blocks per layer", "single block per layer")):
+                raise
+            sid, ids = group[0]
+            self.rejected[sid] = str(e)
+            self.stop_at.pop(sid, None)
+            self._t_submit.pop(sid, None)
+
+    def _prefill_group(self, group) -> None:
         if hasattr(self.decoder, "prefill_batch") and (len(group) > 1 or getattr(self.decoder, "paged_prefill", False)):
             logits = self.decoder.prefill_batch([g[0] for g in group], [g[1] for g in group])
             self.stats["prefill_calls"] += 1
