@@ -142,6 +142,27 @@ def test_submitted_requests_are_admitted_in_groups_and_refill_the_batch():
     assert sorted(dec.pool.free_blocks) == list(range(64)) and not sch.pending()
 
 
+def test_abort_frees_a_request_wherever_it_is():
+    dec = FakeDecoder(num_blocks=10, layers=2)
+    sch = BatchScheduler(dec, max_length=40, eos_token_id=EOS, sampler=sample_greedy)
+    ids = [sch.add_sequence([3 + i] * 15) for i in range(4)]
+    queued = sch.submit([50] * 4, max_new_tokens=5)
+    for _ in range(3):
+        sch.step()                                                # past token 16: the two youngest are swapped out
+    assert len(sch.swapped) == 2 and queued in [w[0] for w in sch.waiting]
+    victim = next(iter(sch.swapped))
+    assert sch.abort(victim) and victim not in sch.swapped and not dec.pool.swapped.get(victim)
+    assert sch.abort(queued) and not sch.waiting and not sch.abort(queued) and not sch.abort(12345)
+    running = next(iter(sch.active))
+    n_before = len(sch.sequences[running])
+    assert sch.abort(running) and running not in sch.active and len(sch.sequences[running]) == n_before
+    sch.run()
+    rest = [s for s in ids if s not in (victim, running)]
+    assert all(sch.sequences[s] == _expected([3 + s] * 15, 40) for s in rest)
+    assert sorted(dec.pool.free_blocks) == list(range(10)) and sorted(dec.pool._host_free) == list(range(dec.pool.host_blocks))
+    assert not sch.pending() and not sch.last_logits
+
+
 def test_a_request_that_can_never_fit_is_rejected_and_the_loop_goes_on():
     dec = FakeDecoder(num_blocks=8, layers=2, max_blocks_per_seq=8)                # 8 blocks: a 70-token prompt needs 2 x 5
     sch = BatchScheduler(dec, max_length=100, eos_token_id=EOS, sampler=sample_greedy)

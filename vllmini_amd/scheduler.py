@@ -166,6 +166,26 @@ class BatchScheduler:
         self.waiting.append((seq_id, ids))
         return seq_id
 
+    def abort(self, seq_id: int) -> bool:
+        """Cancel a request wherever it is — queued, running, or swapped out: its blocks (device or host) are free at once, its
+        tokens so far stay readable in `sequences`.  False if the id is not pending.  (The reference has no cancellation; a
+        serving front end needs one when a client goes away.)"""
+        for i, (sid, _) in enumerate(self.waiting):
+            if sid == seq_id:
+                del self.waiting[i]
+                self.stop_at.pop(seq_id, None)
+                self._t_submit.pop(seq_id, None)
+                return True
+        if seq_id in self.swapped:
+            self.decoder.pool.drop_swapped(seq_id)
+            del self.swapped[seq_id]
+            self._forget(seq_id)
+            return True
+        if seq_id in self.active:
+            self._finish(seq_id)
+            return True
+        return False
+
     # ---- leaving -------------------------------------------------------------------------------------------
     def _forget(self, seq_id: int) -> None:
         self.active.pop(seq_id, None)
