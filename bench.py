@@ -124,6 +124,8 @@ def build_parser():
     ap.add_argument("--serve-headroom", type=int, default=0,
                     help="blocks kept free per running sequence at admission (0: a prompt is admitted whenever it fits; growth preempts)")
     ap.add_argument("--serve-pool-frac", type=float, default=0.7, help="pool = this share of what max_batch mid-life sequences hold")
+    ap.add_argument("--serve-rate", type=float, default=0.0,
+                    help="open loop: Poisson arrivals at this many requests/s (0 = closed loop, every request queued at t = 0)")
     ap.add_argument("--serve-preempt", default="swap", choices=("swap", "drop"))
     ap.add_argument("--serve-kv", default="auto", choices=("auto", "fp8"), help="KV pages of the serving run (fp8 = E4M3: the same pool bytes hold twice the tokens)")
     ap.add_argument("--serve-no-deferred-scatter", action="store_true", help="the reference's call pair per layer instead")
@@ -794,8 +796,25 @@ def serve_measure(args, dev, rank=0, requests=None, note_extra=""):
         return run
     dec.prefill_batch, dec.prefill = timed(real_prefill_batch), timed(real_prefill)
     t0 = time.perf_counter()
-    ids = [sch.submit(p, max_new_tokens=k) for p, k in zip(prompts, new)]
-    steps = sch.run()
+    if args.serve_rate > 0:
+        # OPEN loop: Poisson arrivals at `serve_rate` requests/s (seeded); the scheduler steps whenever something is pending and
+        # sleeps until the next arrival otherwise — latency under a given load instead of the closed loop's saturation throughput
+        arrive = np.cumsum(np.random.default_rng(23 + rank).exponential(1.0 / args.serve_rate, requests))
+        ids, i, steps = [], 0, 0
+        while i < requests or sch.pending():
+            now = time.perf_counter() - t0
+            while i < requests and arrive[i] <= now:
+                ids.append(sch.submit(prompts[i], max_new_tokens=new[i]))
+                i += 1
+            if sch.pending():
+                sch.step()
+                steps += 1
+            else:
+                time.sleep(max(0.0, min(arrive[i] - now, 1e-3)))
+        steps = sch.steps
+    else:
+        ids = [sch.submit(p, max_new_tokens=k) for p, k in zip(prompts, new)]
+        steps = sch.run()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     from vllmini_amd import ops
@@ -822,11 +841,13 @@ def serve_measure(args, dev, rank=0, requests=None, note_extra=""):
            "swap_out_MB": ss["bytes_out"] / 1e6, "swap_in_MB": ss["bytes_in"] / 1e6,
            "pool_blocks": nblocks, "pool_GB": 2 * nblocks * pool.block_bytes / 1e9, "sampler": args.serve_sampler,
            "preempt": args.serve_preempt, "kv_cache_dtype": args.serve_kv, "deferred_scatter": deferred, "graph_replay": not args.serve_eager,
-           "trace": f"closed loop, all {requests} requests queued at t = 0; prompts U{{4..{args.serve_max_prompt}}} tokens "
+           "arrival_rate_per_s": args.serve_rate or None,
+           "trace": (f"open loop, Poisson arrivals at {args.serve_rate:g} requests/s" if args.serve_rate > 0 else
+                     f"closed loop, all {requests} requests queued at t = 0") + f"; {requests} requests; prompts U{{4..{args.serve_max_prompt}}} tokens "
                     f"(mean {np.mean([len(p) for p in prompts]):.0f}), outputs geometric (mean {np.mean(new):.0f}), prompt + output "
                     f"<= {max_length}; seed 17",
-           "note": "BatchScheduler (vllmini_amd/scheduler.py) over GPT2PagedDecoder, random-init GPT-2 small, real prefills (torch "
-                   "eager causal attention, several prompts per call) and decode steps through the paged-attention operators; "
+           "note": "BatchScheduler (vllmini_amd/scheduler.py) over GPT2PagedDecoder, random-init GPT-2 small, real prefills (several "
+                   "prompts per call, their causal attention ONE paged_attention_v1 launch per layer) and decode steps through the operators; "
                    "host_us_per_step = the scheduler's and pool's Python per decode step (bookkeeping, staging, the graph launch) apart "
                    "from gpu_wait_us_per_step, the time it then waits for the sampled ids, and from admit_s, the admission of queued "
                    "requests (prefill_s = the prefill calls in it: host-bound torch launches); all of it is inside wall_s" + note_extra}

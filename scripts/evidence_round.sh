@@ -14,6 +14,7 @@ python bench.py --serve --serve-preempt drop 2> /dev/null; cp $O/serve.json $O/$
 python bench.py --serve --serve-no-deferred-scatter 2> /dev/null; cp $O/serve.json $O/${T}_serve_call_pair.json
 python bench.py --serve --serve-kv fp8 2> /dev/null; cp $O/serve.json $O/${T}_serve_fp8.json
 python bench.py --serve --serve-pool-frac 1.5 2> /dev/null; cp $O/serve.json $O/${T}_serve_roomy_pool.json
+for r in 200 400 600 800; do python bench.py --serve --serve-rate $r --serve-admit-every 4 2> /dev/null; cp $O/serve.json $O/${T}_serve_rate_$r.json; done
 python - "$T" <<'PY'
 import json, sys
 t = sys.argv[1]
